@@ -1,0 +1,126 @@
+/*
+ * spsnet_sa.h -- C ABI of libspsnet_sa.so, the MI355X (gfx950) implementation of the
+ * point-sampling / set-abstraction hot path of SPSNet / IA-SSD.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one `*_kernel_launcher*`
+ * of the reference's `pointnet2_batch_cuda` extension (all paths relative to
+ * pcdet/ops/pointnet2/pointnet2_batch/src/ of the reference) and keeps its argument
+ * order and meaning, with two deliberate changes:
+ *   - a trailing `sps_stream_t` (a hipStream_t; NULL = the legacy default stream the
+ *     reference launches on, sampling_gpu.cu:223);
+ *   - an `int` status (SPS_OK / SPS_ERR_*) instead of fprintf + exit(-1)
+ *     (sampling_gpu.cu:39-43); `sps_last_error()` returns the message.
+ *
+ * Ownership is the reference's: the caller allocates every buffer, including scratch
+ * (`temp` pre-filled with 1e10, ball-query `idx` zeroed, gradient buffers zeroed --
+ * pointnet2_utils.py:25-26,95,218,246).  Nothing is allocated, freed or synchronised
+ * inside these calls, so they are legal inside hipGraph stream capture.  All pointers
+ * are DEVICE pointers to contiguous fp32 / int32 arrays.
+ */
+#ifndef SPSNET_SA_H
+#define SPSNET_SA_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *sps_stream_t; /* hipStream_t */
+
+enum {
+    SPS_OK = 0,
+    SPS_ERR_INVALID = 1, /* bad shape / null pointer / unsupported size */
+    SPS_ERR_LAUNCH = 2   /* hipGetLastError() != hipSuccess after the launch */
+};
+
+/* library identity: SPS_ABI_VERSION this header was written for */
+#define SPS_ABI_VERSION 1
+int sps_abi_version(void);
+/* message of the most recent failing call on this thread ("" if none) */
+const char *sps_last_error(void);
+/* block size the reference would use for an n-point FPS (cuda_utils.h:10-14) */
+int sps_opt_n_threads(int work_size);
+
+/* ---- the 11 functions of pointnet2_batch_cuda (src/pointnet2_api.cpp:10-26) ---------- */
+
+/* farthest_point_sampling_kernel_launcher, sampling_gpu.cu:211-253 / sampling_gpu.h:24-25.
+ * dataset (B,N,3) f32, temp (B,N) f32 in/out (running min distance), idxs (B,M) i32 out. */
+int sps_farthest_point_sampling_kernel_launcher(int b, int n, int m, const float *dataset,
+                                                float *temp, int *idxs, sps_stream_t stream);
+
+/* furthest_point_sampling_with_dist_kernel_launcher, sampling_gpu.cu:374-416 / sampling_gpu.h:30-31.
+ * dataset (B,N,N) f32 pairwise distances. */
+int sps_furthest_point_sampling_with_dist_kernel_launcher(int b, int n, int m, const float *dataset,
+                                                          float *temp, int *idxs, sps_stream_t stream);
+
+/* gather_points_kernel_launcher_fast, sampling_gpu.cu:26-43 / sampling_gpu.h:12-13.
+ * points (B,C,N), idx (B,npoints) -> out (B,C,npoints). */
+int sps_gather_points_kernel_launcher_fast(int b, int c, int n, int npoints, const float *points,
+                                           const int *idx, float *out, sps_stream_t stream);
+
+/* gather_points_grad_kernel_launcher_fast, sampling_gpu.cu:65-83 / sampling_gpu.h:19-20.
+ * grad_points (B,C,N) must be zeroed by the caller; contributions are accumulated. */
+int sps_gather_points_grad_kernel_launcher_fast(int b, int c, int n, int npoints, const float *grad_out,
+                                                const int *idx, float *grad_points, sps_stream_t stream);
+
+/* ball_query_kernel_launcher_fast, ball_query_gpu.cu:48-67 / ball_query_gpu.h:12-13.
+ * new_xyz (B,M,3), xyz (B,N,3) -> idx (B,M,nsample) i32; rows of empty balls are not written. */
+int sps_ball_query_kernel_launcher_fast(int b, int n, int m, float radius, int nsample,
+                                        const float *new_xyz, const float *xyz, int *idx,
+                                        sps_stream_t stream);
+
+/* ball_query_dilated_kernel_launcher_fast, ball_query_gpu.cu:120-139 / ball_query_gpu.h:18-19. */
+int sps_ball_query_dilated_kernel_launcher_fast(int b, int n, int m, float max_radius, float min_radius,
+                                                int nsample, const float *new_xyz, const float *xyz,
+                                                int *idx, sps_stream_t stream);
+
+/* group_points_kernel_launcher_fast, group_points_gpu.cu:74-92 / group_points_gpu.h:13-14.
+ * points (B,C,N), idx (B,npoints,nsample) -> out (B,C,npoints,nsample). */
+int sps_group_points_kernel_launcher_fast(int b, int c, int n, int npoints, int nsample,
+                                          const float *points, const int *idx, float *out,
+                                          sps_stream_t stream);
+
+/* group_points_grad_kernel_launcher_fast, group_points_gpu.cu:33-50 / group_points_gpu.h:19-20. */
+int sps_group_points_grad_kernel_launcher_fast(int b, int c, int n, int npoints, int nsample,
+                                               const float *grad_out, const int *idx, float *grad_points,
+                                               sps_stream_t stream);
+
+/* three_nn_kernel_launcher_fast, interpolate_gpu.cu:61-80.
+ * unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3) f32 (squared), idx (B,n,3) i32. */
+int sps_three_nn_kernel_launcher_fast(int b, int n, int m, const float *unknown, const float *known,
+                                      float *dist2, int *idx, sps_stream_t stream);
+
+/* three_interpolate_kernel_launcher_fast, interpolate_gpu.cu:107-123.
+ * points (B,C,m), idx/weight (B,n,3) -> out (B,C,n). */
+int sps_three_interpolate_kernel_launcher_fast(int b, int c, int m, int n, const float *points,
+                                               const int *idx, const float *weight, float *out,
+                                               sps_stream_t stream);
+
+/* three_interpolate_grad_kernel_launcher_fast, interpolate_gpu.cu:152-168. */
+int sps_three_interpolate_grad_kernel_launcher_fast(int b, int c, int n, int m, const float *grad_out,
+                                                    const int *idx, const float *weight, float *grad_points,
+                                                    sps_stream_t stream);
+
+/* ---- fused entry points for the SA module layer (pointnet2_modules.py) ----------------- */
+
+/* Score + top-k sampler: replaces the max/sigmoid/(mul)/topk/int chain of
+ * pointnet2_modules.py:287-303.  cls (B,N,C) f32 logits; stds (B,N) f32 or NULL.
+ *   stds == NULL : score = sigmoid(max_c cls)                         ('ctr_aware' / 'cls')
+ *   stds != NULL : score = sigmoid(max_c cls) * (1 - sigmoid(stds/8-3))   (SPSNet 'ss'/'sss')
+ * idx (B,K) i32 receives the K best points, score descending, index ascending on ties;
+ * score_out (B,N) f32 (may be NULL) receives the scores.  Requires K <= N <= 16384. */
+int sps_score_topk(int b, int n, int c, int k, const float *cls, const float *stds, int *idx,
+                   float *score_out, sps_stream_t stream);
+
+/* Fused QueryAndGroup (pointnet2_utils.py:299-322): ball query, grouping of xyz (centred
+ * on new_xyz) and of `features`, concatenated along channels, in one pass.
+ * xyz (B,N,3), new_xyz (B,M,3), features (B,C,N) or NULL (C = 0)
+ *   -> idx (B,M,nsample) i32 (required; fully written, zeros for empty balls)
+ *   -> out (B,3+C,M,nsample) f32 when use_xyz != 0, else (B,C,M,nsample). */
+int sps_query_and_group(int b, int n, int m, int c, float radius, int nsample, int use_xyz,
+                        const float *xyz, const float *new_xyz, const float *features, int *idx,
+                        float *out, sps_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPSNET_SA_H */

@@ -1,0 +1,197 @@
+"""numpy/ctypes front-end of the C oracle (oracle/sa_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke() as the checker -- never by the product package.
+
+Each function mirrors one reference kernel (file:line in sa_oracle.c) and, like the
+reference's pybind functions (src/pointnet2_api.cpp:10-26), writes into caller-style
+buffers that it allocates the way pointnet2_utils.py does (temp = 1e10, idx = 0, grads = 0).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libsa_oracle.so")
+_lib = None
+
+_F = ctypes.POINTER(ctypes.c_float)
+_I = ctypes.POINTER(ctypes.c_int)
+
+
+def build(force=False):
+    """Compile sa_oracle.c with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "sa_oracle.c")
+    stale = (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "clean", "all"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.orc_opt_n_threads.restype = ctypes.c_int
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_F)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_I)
+
+
+def opt_n_threads(n):
+    return int(lib().orc_opt_n_threads(int(n)))
+
+
+def fps(xyz, npoint, temp=None, return_temp=False):
+    """xyz (B,N,3) f32 -> idx (B,npoint) i32 [sampling_gpu.cu:93-208]."""
+    xyz, px = _f(xyz)
+    B, N, _ = xyz.shape
+    temp = np.full((B, N), 1e10, np.float32) if temp is None else np.array(temp, np.float32)
+    idx = np.zeros((B, npoint), np.int32)
+    lib().orc_fps(B, N, npoint, px, temp.ctypes.data_as(_F), idx.ctypes.data_as(_I))
+    return (idx, temp) if return_temp else idx
+
+
+def fps_with_dist(dist, npoint):
+    """dist (B,N,N) f32 -> idx (B,npoint) i32 [sampling_gpu.cu:256-371]."""
+    dist, pd = _f(dist)
+    B, N, _ = dist.shape
+    temp = np.full((B, N), 1e10, np.float32)
+    idx = np.zeros((B, npoint), np.int32)
+    lib().orc_fps_with_dist(B, N, npoint, pd, temp.ctypes.data_as(_F), idx.ctypes.data_as(_I))
+    return idx
+
+
+def gather_points(points, idx):
+    """points (B,C,N), idx (B,M) -> (B,C,M) [sampling_gpu.cu:8-24]."""
+    points, pp = _f(points)
+    idx, pi = _i(idx)
+    B, C, N = points.shape
+    M = idx.shape[1]
+    out = np.empty((B, C, M), np.float32)
+    lib().orc_gather_points(B, C, N, M, pp, pi, out.ctypes.data_as(_F))
+    return out
+
+
+def gather_points_grad(grad_out, idx, N):
+    grad_out, pg = _f(grad_out)
+    idx, pi = _i(idx)
+    B, C, M = grad_out.shape
+    gp = np.zeros((B, C, N), np.float32)
+    lib().orc_gather_points_grad(B, C, N, M, pg, pi, gp.ctypes.data_as(_F))
+    return gp
+
+
+def ball_query(radius, nsample, xyz, new_xyz):
+    """-> idx (B,M,nsample) i32 [ball_query_gpu.cu:9-45]; argument order of BallQuery.forward."""
+    xyz, px = _f(xyz)
+    new_xyz, pn = _f(new_xyz)
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    idx = np.zeros((B, M, nsample), np.int32)
+    lib().orc_ball_query(B, N, M, ctypes.c_float(radius), nsample, pn, px, idx.ctypes.data_as(_I))
+    return idx
+
+
+def ball_query_dilated(max_radius, min_radius, nsample, xyz, new_xyz):
+    xyz, px = _f(xyz)
+    new_xyz, pn = _f(new_xyz)
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    idx = np.zeros((B, M, nsample), np.int32)
+    lib().orc_ball_query_dilated(B, N, M, ctypes.c_float(max_radius), ctypes.c_float(min_radius),
+                                 nsample, pn, px, idx.ctypes.data_as(_I))
+    return idx
+
+
+def group_points(points, idx):
+    """points (B,C,N), idx (B,M,ns) -> (B,C,M,ns) [group_points_gpu.cu:53-71]."""
+    points, pp = _f(points)
+    idx, pi = _i(idx)
+    B, C, N = points.shape
+    _, M, ns = idx.shape
+    out = np.empty((B, C, M, ns), np.float32)
+    lib().orc_group_points(B, C, N, M, ns, pp, pi, out.ctypes.data_as(_F))
+    return out
+
+
+def group_points_grad(grad_out, idx, N):
+    grad_out, pg = _f(grad_out)
+    idx, pi = _i(idx)
+    B, C, M, ns = grad_out.shape
+    gp = np.zeros((B, C, N), np.float32)
+    lib().orc_group_points_grad(B, C, N, M, ns, pg, pi, gp.ctypes.data_as(_F))
+    return gp
+
+
+def three_nn(unknown, known):
+    """-> (dist2 (B,n,3) f32, idx (B,n,3) i32) [interpolate_gpu.cu:16-58] (dist2, not sqrt)."""
+    unknown, pu = _f(unknown)
+    known, pk = _f(known)
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    d2 = np.empty((B, n, 3), np.float32)
+    idx = np.empty((B, n, 3), np.int32)
+    lib().orc_three_nn(B, n, m, pu, pk, d2.ctypes.data_as(_F), idx.ctypes.data_as(_I))
+    return d2, idx
+
+
+def three_interpolate(points, idx, weight):
+    points, pp = _f(points)
+    idx, pi = _i(idx)
+    weight, pw = _f(weight)
+    B, C, m = points.shape
+    n = idx.shape[1]
+    out = np.empty((B, C, n), np.float32)
+    lib().orc_three_interpolate(B, C, m, n, pp, pi, pw, out.ctypes.data_as(_F))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    grad_out, pg = _f(grad_out)
+    idx, pi = _i(idx)
+    weight, pw = _f(weight)
+    B, C, n = grad_out.shape
+    gp = np.zeros((B, C, m), np.float32)
+    lib().orc_three_interpolate_grad(B, C, n, m, pg, pi, pw, gp.ctypes.data_as(_F))
+    return gp
+
+
+def score_ctr(cls):
+    """cls (B,N,C) -> sigmoid(max_c) (B,N) [pointnet2_modules.py:288-289]."""
+    cls, pc = _f(cls)
+    B, N, C = cls.shape
+    s = np.empty((B, N), np.float32)
+    lib().orc_score_ctr(B, N, C, pc, s.ctypes.data_as(_F))
+    return s
+
+
+def score_stability(cls, stds):
+    """-> sigmoid(max_c cls) * (1 - sigmoid(stds/8-3)) (B,N) [pointnet2_modules.py:296-301]."""
+    cls, pc = _f(cls)
+    stds, ps = _f(stds)
+    B, N, C = cls.shape
+    s = np.empty((B, N), np.float32)
+    lib().orc_score_stability(B, N, C, pc, ps, s.ctypes.data_as(_F))
+    return s
+
+
+def topk_desc(score, k):
+    """(B,N) -> (B,k) i32: score descending, index ascending on ties."""
+    score, ps = _f(score)
+    B, N = score.shape
+    idx = np.empty((B, k), np.int32)
+    lib().orc_topk_desc(B, N, k, ps, idx.ctypes.data_as(_I))
+    return idx

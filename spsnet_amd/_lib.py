@@ -1,0 +1,71 @@
+"""ctypes binding of libspsnet_sa.so (the C ABI declared in include/spsnet_sa.h).
+
+Fails loudly when the library is missing: there is no fallback path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspsnet_sa.so")
+
+SPS_OK = 0
+ABI_VERSION = 1
+
+_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+
+# name -> argument types (every entry point returns int status unless noted)
+_PROTOS = {
+    "sps_farthest_point_sampling_kernel_launcher": [_i, _i, _i, _vp, _vp, _vp, _vp],
+    "sps_furthest_point_sampling_with_dist_kernel_launcher": [_i, _i, _i, _vp, _vp, _vp, _vp],
+    "sps_gather_points_kernel_launcher_fast": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sps_gather_points_grad_kernel_launcher_fast": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sps_ball_query_kernel_launcher_fast": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
+    "sps_ball_query_dilated_kernel_launcher_fast": [_i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp],
+    "sps_group_points_kernel_launcher_fast": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sps_group_points_grad_kernel_launcher_fast": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sps_three_nn_kernel_launcher_fast": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sps_three_interpolate_kernel_launcher_fast": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sps_three_interpolate_grad_kernel_launcher_fast": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sps_score_topk": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sps_query_and_group": [_i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+}
+EXPORTS = ["sps_abi_version", "sps_last_error", "sps_opt_n_threads"] + list(_PROTOS)
+
+_lib = None
+
+
+class SpsError(RuntimeError):
+    """A libspsnet_sa call returned a non-zero status (the reference would exit(-1))."""
+
+
+def load():
+    """Load libspsnet_sa.so and declare the prototypes.  Raises ImportError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C spsnet_amd/csrc` "
+            "(or __graft_entry__.build()).  spsnet_amd has no CPU/PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.sps_abi_version.restype = _i
+    lib.sps_abi_version.argtypes = []
+    lib.sps_last_error.restype = ctypes.c_char_p
+    lib.sps_last_error.argtypes = []
+    lib.sps_opt_n_threads.restype = _i
+    lib.sps_opt_n_threads.argtypes = [_i]
+    for name, args in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = _i
+        fn.argtypes = args
+    got = lib.sps_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"libspsnet_sa ABI {got} != expected {ABI_VERSION}; rebuild spsnet_amd/csrc")
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != SPS_OK:
+        msg = load().sps_last_error().decode("utf-8", "replace")
+        raise SpsError(f"{what} failed (status {status}): {msg}")

@@ -1,0 +1,211 @@
+"""Drop-in for the reference's pybind extension `pointnet2_batch_cuda`.
+
+Same 11 function names, positional signatures and return values as
+pcdet/ops/pointnet2/pointnet2_batch/src/pointnet2_api.cpp:10-26 (wrappers in
+src/{sampling,ball_query,group_points,interpolate}.cpp), so the reference's
+`from . import pointnet2_batch_cuda as pointnet2` (pointnet2_utils.py:7) can bind this
+module unchanged.  Each function hands raw device pointers and torch's
+current HIP stream to libspsnet_sa.so through its C ABI (include/spsnet_sa.h).
+
+Differences from the reference, both deliberate:
+  * a failed check or launch raises (TypeError / ValueError / SpsError) instead of exit(-1);
+  * kernels run on torch's *current* stream rather than the legacy default stream.
+"""
+import torch
+
+from . import _lib
+
+_L = _lib.load()
+
+
+def _ptr(t, dtype, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a CUDA/HIP tensor")  # ball_query.cpp:17-22 CHECK_CUDA
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")  # ball_query.cpp:24-29 CHECK_CONTIGUOUS
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")  # .data<float>() / .data<int>()
+    return t.data_ptr()
+
+
+def _need(t, numel, name):
+    if t.numel() < numel:
+        raise ValueError(f"{name} has {t.numel()} elements, the given sizes need {numel}")
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _on:
+    """Make the tensor's device current for the launch (no-op in the one-process-per-GPU case)."""
+
+    def __init__(self, t):
+        self.dev = t.device.index
+        self.prev = None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if self.dev is not None and self.dev != cur:
+            self.prev = cur
+            torch.cuda.set_device(self.dev)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+
+
+F32, I32 = torch.float32, torch.int32
+
+
+def farthest_point_sampling_wrapper(b, n, m, points_tensor, temp_tensor, idx_tensor):
+    """sampling.cpp:34-43.  points (B,N,3), temp (B,N) pre-filled 1e10, idx (B,M) -> 1."""
+    p, t, i = _ptr(points_tensor, F32, "points"), _ptr(temp_tensor, F32, "temp"), _ptr(idx_tensor, I32, "idx")
+    _need(points_tensor, b * n * 3, "points"); _need(temp_tensor, b * n, "temp"); _need(idx_tensor, b * m, "idx")
+    with _on(points_tensor):
+        _lib.check(_L.sps_farthest_point_sampling_kernel_launcher(b, n, m, p, t, i, _stream(points_tensor)),
+                   "farthest_point_sampling")
+    return 1
+
+
+def furthest_point_sampling_with_dist_wrapper(b, n, m, points_tensor, temp_tensor, idx_tensor):
+    """sampling.cpp:46-56.  points (B,N,N) distance matrix -> 2 (sic)."""
+    p, t, i = _ptr(points_tensor, F32, "points"), _ptr(temp_tensor, F32, "temp"), _ptr(idx_tensor, I32, "idx")
+    _need(points_tensor, b * n * n, "points"); _need(temp_tensor, b * n, "temp"); _need(idx_tensor, b * m, "idx")
+    with _on(points_tensor):
+        _lib.check(_L.sps_furthest_point_sampling_with_dist_kernel_launcher(b, n, m, p, t, i, _stream(points_tensor)),
+                   "furthest_point_sampling_with_dist")
+    return 2
+
+
+def gather_points_wrapper(b, c, n, npoints, points_tensor, idx_tensor, out_tensor):
+    """sampling.cpp:11-20.  points (B,C,N), idx (B,npoints) -> out (B,C,npoints); returns 1."""
+    p, i, o = _ptr(points_tensor, F32, "points"), _ptr(idx_tensor, I32, "idx"), _ptr(out_tensor, F32, "out")
+    _need(points_tensor, b * c * n, "points"); _need(idx_tensor, b * npoints, "idx"); _need(out_tensor, b * c * npoints, "out")
+    with _on(points_tensor):
+        _lib.check(_L.sps_gather_points_kernel_launcher_fast(b, c, n, npoints, p, i, o, _stream(points_tensor)),
+                   "gather_points")
+    return 1
+
+
+def gather_points_grad_wrapper(b, c, n, npoints, grad_out_tensor, idx_tensor, grad_points_tensor):
+    """sampling.cpp:22-31.  grad_out (B,C,npoints) scattered (+=) into zeroed grad_points (B,C,N)."""
+    g, i, o = _ptr(grad_out_tensor, F32, "grad_out"), _ptr(idx_tensor, I32, "idx"), _ptr(grad_points_tensor, F32, "grad_points")
+    _need(grad_out_tensor, b * c * npoints, "grad_out"); _need(idx_tensor, b * npoints, "idx"); _need(grad_points_tensor, b * c * n, "grad_points")
+    with _on(grad_out_tensor):
+        _lib.check(_L.sps_gather_points_grad_kernel_launcher_fast(b, c, n, npoints, g, i, o, _stream(grad_out_tensor)),
+                   "gather_points_grad")
+    return 1
+
+
+def ball_query_wrapper(b, n, m, radius, nsample, new_xyz_tensor, xyz_tensor, idx_tensor):
+    """ball_query.cpp:32-43.  new_xyz (B,M,3), xyz (B,N,3), idx (B,M,nsample) pre-zeroed -> 1."""
+    q, p, i = _ptr(new_xyz_tensor, F32, "new_xyz"), _ptr(xyz_tensor, F32, "xyz"), _ptr(idx_tensor, I32, "idx")
+    _need(new_xyz_tensor, b * m * 3, "new_xyz"); _need(xyz_tensor, b * n * 3, "xyz"); _need(idx_tensor, b * m * nsample, "idx")
+    with _on(xyz_tensor):
+        _lib.check(_L.sps_ball_query_kernel_launcher_fast(b, n, m, radius, nsample, q, p, i, _stream(xyz_tensor)),
+                   "ball_query")
+    return 1
+
+
+def ball_query_dilated_wrapper(b, n, m, max_radius, min_radius, nsample, new_xyz_tensor, xyz_tensor, idx_tensor):
+    """ball_query.cpp:45-57."""
+    q, p, i = _ptr(new_xyz_tensor, F32, "new_xyz"), _ptr(xyz_tensor, F32, "xyz"), _ptr(idx_tensor, I32, "idx")
+    _need(new_xyz_tensor, b * m * 3, "new_xyz"); _need(xyz_tensor, b * n * 3, "xyz"); _need(idx_tensor, b * m * nsample, "idx")
+    with _on(xyz_tensor):
+        _lib.check(_L.sps_ball_query_dilated_kernel_launcher_fast(b, n, m, max_radius, min_radius, nsample, q, p, i,
+                                                                  _stream(xyz_tensor)), "ball_query_dilated")
+    return 1
+
+
+def group_points_wrapper(b, c, n, npoints, nsample, points_tensor, idx_tensor, out_tensor):
+    """group_points.cpp:30-39.  points (B,C,N), idx (B,npoints,nsample) -> out (B,C,npoints,nsample)."""
+    p, i, o = _ptr(points_tensor, F32, "points"), _ptr(idx_tensor, I32, "idx"), _ptr(out_tensor, F32, "out")
+    _need(points_tensor, b * c * n, "points"); _need(idx_tensor, b * npoints * nsample, "idx"); _need(out_tensor, b * c * npoints * nsample, "out")
+    with _on(points_tensor):
+        _lib.check(_L.sps_group_points_kernel_launcher_fast(b, c, n, npoints, nsample, p, i, o, _stream(points_tensor)),
+                   "group_points")
+    return 1
+
+
+def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out_tensor, idx_tensor, grad_points_tensor):
+    """group_points.cpp:18-28."""
+    g, i, o = _ptr(grad_out_tensor, F32, "grad_out"), _ptr(idx_tensor, I32, "idx"), _ptr(grad_points_tensor, F32, "grad_points")
+    _need(grad_out_tensor, b * c * npoints * nsample, "grad_out"); _need(idx_tensor, b * npoints * nsample, "idx"); _need(grad_points_tensor, b * c * n, "grad_points")
+    with _on(grad_out_tensor):
+        _lib.check(_L.sps_group_points_grad_kernel_launcher_fast(b, c, n, npoints, nsample, g, i, o,
+                                                                 _stream(grad_out_tensor)), "group_points_grad")
+    return 1
+
+
+def three_nn_wrapper(b, n, m, unknown_tensor, known_tensor, dist2_tensor, idx_tensor):
+    """interpolate.cpp:21-30.  unknown (B,n,3), known (B,m,3) -> dist2, idx (B,n,3); returns None."""
+    u, k = _ptr(unknown_tensor, F32, "unknown"), _ptr(known_tensor, F32, "known")
+    d, i = _ptr(dist2_tensor, F32, "dist2"), _ptr(idx_tensor, I32, "idx")
+    _need(unknown_tensor, b * n * 3, "unknown"); _need(known_tensor, b * m * 3, "known")
+    _need(dist2_tensor, b * n * 3, "dist2"); _need(idx_tensor, b * n * 3, "idx")
+    with _on(unknown_tensor):
+        _lib.check(_L.sps_three_nn_kernel_launcher_fast(b, n, m, u, k, d, i, _stream(unknown_tensor)), "three_nn")
+
+
+def three_interpolate_wrapper(b, c, m, n, points_tensor, idx_tensor, weight_tensor, out_tensor):
+    """interpolate.cpp:32-44.  points (B,C,m), idx/weight (B,n,3) -> out (B,C,n); returns None."""
+    p, i = _ptr(points_tensor, F32, "points"), _ptr(idx_tensor, I32, "idx")
+    w, o = _ptr(weight_tensor, F32, "weight"), _ptr(out_tensor, F32, "out")
+    _need(points_tensor, b * c * m, "points"); _need(idx_tensor, b * n * 3, "idx")
+    _need(weight_tensor, b * n * 3, "weight"); _need(out_tensor, b * c * n, "out")
+    with _on(points_tensor):
+        _lib.check(_L.sps_three_interpolate_kernel_launcher_fast(b, c, m, n, p, i, w, o, _stream(points_tensor)),
+                   "three_interpolate")
+
+
+def three_interpolate_grad_wrapper(b, c, n, m, grad_out_tensor, idx_tensor, weight_tensor, grad_points_tensor):
+    """interpolate.cpp:46-58."""
+    g, i = _ptr(grad_out_tensor, F32, "grad_out"), _ptr(idx_tensor, I32, "idx")
+    w, o = _ptr(weight_tensor, F32, "weight"), _ptr(grad_points_tensor, F32, "grad_points")
+    _need(grad_out_tensor, b * c * n, "grad_out"); _need(idx_tensor, b * n * 3, "idx")
+    _need(weight_tensor, b * n * 3, "weight"); _need(grad_points_tensor, b * c * m, "grad_points")
+    with _on(grad_out_tensor):
+        _lib.check(_L.sps_three_interpolate_grad_kernel_launcher_fast(b, c, n, m, g, i, w, o, _stream(grad_out_tensor)),
+                   "three_interpolate_grad")
+
+
+# ---- fused entry points (not part of the reference extension) -----------------------------
+
+def score_topk(cls_features, npoint, stds=None, return_scores=False):
+    """Fused sampler of pointnet2_modules.py:287-303: cls (B,N,C) [, stds (B,N)] -> idx (B,npoint) i32."""
+    c = _ptr(cls_features, F32, "cls_features")
+    B, N, C = cls_features.shape
+    s = 0
+    if stds is not None:
+        s = _ptr(stds, F32, "stds")
+        _need(stds, B * N, "stds")
+    idx = torch.empty((B, npoint), dtype=I32, device=cls_features.device)
+    scores = torch.empty((B, N), dtype=F32, device=cls_features.device) if return_scores else None
+    with _on(cls_features):
+        _lib.check(_L.sps_score_topk(B, N, C, npoint, c, s, idx.data_ptr(),
+                                     scores.data_ptr() if scores is not None else 0, _stream(cls_features)),
+                   "score_topk")
+    return (idx, scores) if return_scores else idx
+
+
+def query_and_group(radius, nsample, xyz, new_xyz, features=None, use_xyz=True):
+    """Fused QueryAndGroup.forward (pointnet2_utils.py:299-322) -> (new_features, idx)."""
+    p, q = _ptr(xyz, F32, "xyz"), _ptr(new_xyz, F32, "new_xyz")
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    C = 0
+    f = 0
+    if features is not None:
+        f = _ptr(features, F32, "features")
+        C = features.shape[1]
+        _need(features, B * C * N, "features")
+    cout = C + (3 if use_xyz else 0)
+    idx = torch.empty((B, M, nsample), dtype=I32, device=xyz.device)
+    out = torch.empty((B, cout, M, nsample), dtype=F32, device=xyz.device)
+    with _on(xyz):
+        _lib.check(_L.sps_query_and_group(B, N, M, C, radius, nsample, 1 if use_xyz else 0, p, q, f,
+                                          idx.data_ptr(), out.data_ptr(), _stream(xyz)), "query_and_group")
+    return out, idx

@@ -1,0 +1,450 @@
+"""Set-abstraction (SA) modules of IA-SSD / SPSNet on top of the gfx950 ops.
+
+Class names, constructor keywords, forward signatures, return tuples and state_dict keys
+(`mlps.{i}.{0,1,3,4,6,7}`, `aggregation_layer.*`, `confidence_layers.*`, `mlp_modules.*`,
+`ctr_reg.*`, `mlp.*`) follow the reference's
+pcdet/ops/pointnet2/pointnet2_batch/pointnet2_modules.py so that IASSD_backbone.py:57-79,
+PAGNet_backbone.py and stability_generate/model.py:84-95 can build and load checkpoints
+unchanged.  The implementation is organised differently: layer stacks come from two small
+builders, the sampling strategies live in a dispatch table (`_SAMPLERS`, same precedence as the
+reference's if/elif chain at :284-419), score-based sampling is one fused kernel
+(`sps_score_topk`) and grouping uses the fused query+group kernel when no gradient is needed.
+"""
+from typing import Callable, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import pointnet2_batch_cuda as _ext
+from . import pointnet2_utils
+
+
+# ------------------------------------------------------------------------------------------
+# builders
+# ------------------------------------------------------------------------------------------
+def _conv_bn_relu_stack(widths: List[int], conv, norm) -> nn.Sequential:
+    """[conv1x1(bias=False), norm, ReLU] per consecutive width pair -> Sequential indices 0,1,2,3,4,5,..."""
+    layers = []
+    for cin, cout in zip(widths[:-1], widths[1:]):
+        layers += [conv(cin, cout, kernel_size=1, bias=False), norm(cout), nn.ReLU()]
+    return nn.Sequential(*layers)
+
+
+def _pool_over_samples(grouped: torch.Tensor, method: str) -> torch.Tensor:
+    """(B,C,M,ns) -> (B,C,M) (reference :66-75, :434-443)."""
+    window = [1, grouped.size(3)]
+    if method == 'max_pool':
+        pooled = F.max_pool2d(grouped, kernel_size=window)
+    elif method == 'avg_pool':
+        pooled = F.avg_pool2d(grouped, kernel_size=window)
+    else:
+        raise NotImplementedError
+    return pooled.squeeze(-1)
+
+
+class _PointnetSAModuleBase(nn.Module):
+    """Shared plumbing: FPS + multi-scale group/MLP/pool (reference :10-81)."""
+
+    def __init__(self):
+        super().__init__()
+        self.npoint = None
+        self.groupers = None
+        self.mlps = None
+        self.pool_method = 'max_pool'
+
+    def calc_square_dist(self, a, b, norm=True):
+        """Pairwise ||a_i - b_j||^2 as |a|^2 + |b|^2 - 2ab; a (B,n,c), b (B,m,c) -> (B,n,m).
+        Reference :19-43 (`norm` only switches 2.0 vs 2, numerically identical)."""
+        a_sq = (a * a).sum(dim=-1, keepdim=True)                   # (B,n,1)
+        b_sq = (b * b).sum(dim=-1, keepdim=True).transpose(1, 2)   # (B,1,m)
+        cross = torch.matmul(a, b.transpose(1, 2))
+        return a_sq.expand(-1, -1, b.shape[1]) + b_sq.expand(-1, a.shape[1], -1) - 2.0 * cross
+
+    def _group_mlp_pool(self, xyz, new_xyz, features):
+        scales = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            grouped = grouper(xyz, new_xyz, features)      # (B, C, M, ns)
+            scales.append(_pool_over_samples(mlp(grouped), self.pool_method))
+        return torch.cat(scales, dim=1)
+
+    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, new_xyz=None):
+        """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3), new_features (B,sum C_out,npoint)."""
+        if new_xyz is None and self.npoint is not None:
+            picked = pointnet2_utils.farthest_point_sample(xyz, self.npoint)
+            new_xyz = pointnet2_utils.gather_operation(
+                xyz.transpose(1, 2).contiguous(), picked).transpose(1, 2).contiguous()
+        return new_xyz, self._group_mlp_pool(xyz, new_xyz, features)
+
+
+class PointnetSAModuleMSG(_PointnetSAModuleBase):
+    """Multi-scale-grouping SA layer with plain D-FPS (reference :84-125)."""
+
+    def __init__(self, *, npoint: int, radii: List[float], nsamples: List[int], mlps: List[List[int]],
+                 bn: bool = True, use_xyz: bool = True, pool_method='max_pool', **kwargs):
+        super().__init__()
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.npoint = npoint
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        for radius, nsample, spec in zip(radii, nsamples, mlps):
+            self.groupers.append(pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz)
+                                 if npoint is not None else pointnet2_utils.GroupAll(use_xyz))
+            if use_xyz:
+                spec[0] += 3  # in place on the caller's list, like the reference (:108-109)
+            self.mlps.append(_conv_bn_relu_stack(spec, nn.Conv2d, nn.BatchNorm2d))
+        self.pool_method = pool_method
+
+
+# ------------------------------------------------------------------------------------------
+# sampling strategies.  Each takes the module and a _SampleInput and returns (B, npoint) int32;
+# strategies that thin `stds` update ctx.stds.
+# ------------------------------------------------------------------------------------------
+class _SampleInput:
+    __slots__ = ("xyz", "xyz_full", "xyz_flipped", "features_t", "cls", "npoint", "stds")
+
+    def __init__(self, xyz, xyz_full, xyz_flipped, features_t, cls, npoint, stds):
+        self.xyz, self.xyz_full, self.xyz_flipped = xyz, xyz_full, xyz_flipped
+        self.features_t, self.cls, self.npoint, self.stds = features_t, cls, npoint, stds
+
+
+def _thin_stds(ctx: _SampleInput, idx):
+    batch = ctx.xyz_flipped.shape[0]
+    ctx.stds = pointnet2_utils.gather_operation(ctx.stds.view(batch, 1, -1).contiguous(), idx).squeeze()
+
+
+def _sample_score(mod, ctx):
+    """'cls'/'ctr' aware: top-k of sigmoid(max_c logits) (reference :287-291), fused."""
+    return _ext.score_topk(ctx.cls.contiguous(), ctx.npoint)
+
+
+def _sample_stability(mod, ctx):
+    """SPSNet 'ss'/'sss': top-k of sigmoid(max_c logits) * (1 - sigmoid(stds/8 - 3)), then thin stds
+    (reference :293-305), fused."""
+    if ctx.stds is None:
+        raise NotImplementedError
+    batch, n = ctx.cls.shape[0], ctx.cls.shape[1]
+    idx = _ext.score_topk(ctx.cls.contiguous(), ctx.npoint, stds=ctx.stds.reshape(batch, n).contiguous())
+    _thin_stds(ctx, idx)
+    return idx
+
+
+def _sample_dfps(mod, ctx):
+    """Distance FPS (reference :307-310)."""
+    idx = pointnet2_utils.furthest_point_sample(ctx.xyz.contiguous(), ctx.npoint)
+    if ctx.stds is not None:
+        _thin_stds(ctx, idx)
+    return idx
+
+
+def _sample_sfps(mod, ctx):
+    """Stability FPS: FPS seeds, then inside each seed's (ss_radii, ss_nsamples) ball pick the point
+    with the smallest std; falls back to plain FPS when scene 0 keeps < 3500 distinct points
+    (reference :314-353, threshold hard-coded there)."""
+    if ctx.stds is None:
+        raise NotImplementedError
+    batch = ctx.xyz_flipped.shape[0]
+    stds = ctx.stds.view(batch, 1, -1).contiguous()
+    seeds = pointnet2_utils.furthest_point_sample(ctx.xyz.contiguous(), ctx.npoint)
+    seed_xyz = pointnet2_utils.gather_operation(ctx.xyz_flipped, seeds).transpose(1, 2).contiguous()
+    ball = pointnet2_utils.ball_query(mod.ss_radii, mod.ss_nsamples, ctx.xyz_full, seed_xyz)
+    ball_stds = pointnet2_utils.grouping_operation(stds, ball).squeeze()
+    steadiest = torch.argmin(ball_stds, dim=-1).view(ball.shape[0], -1, 1)
+    idx = torch.gather(ball, 2, steadiest).view(seed_xyz.shape[0], -1)
+    ctx.stds = pointnet2_utils.gather_operation(stds, idx).squeeze()
+    if idx[0].unique().shape[0] < 3500:
+        idx = pointnet2_utils.furthest_point_sample(ctx.xyz.contiguous(), ctx.npoint)
+    return idx
+
+
+def _feature_distance(mod, ctx):
+    joint = torch.cat([ctx.xyz, ctx.features_t], dim=-1)
+    return mod.calc_square_dist(joint, joint).contiguous()
+
+
+def _sample_ffps(mod, ctx):
+    """Feature FPS over xyz (+) features (reference :357-361)."""
+    return pointnet2_utils.furthest_point_sample_with_dist(_feature_distance(mod, ctx), ctx.npoint)
+
+
+def _sample_fs(mod, ctx):
+    """Fusion sampling = F-FPS ++ D-FPS -> (B, 2*npoint) (reference :363-369)."""
+    by_feature = pointnet2_utils.furthest_point_sample_with_dist(_feature_distance(mod, ctx), ctx.npoint)
+    by_distance = pointnet2_utils.furthest_point_sample(ctx.xyz, ctx.npoint)
+    return torch.cat([by_feature, by_distance], dim=-1)
+
+
+def _sample_rand(mod, ctx):
+    """One random permutation shared by the batch (reference :370-371)."""
+    perm = torch.randperm(ctx.xyz.shape[1], device=ctx.xyz.device)[None, :ctx.npoint].int()
+    return perm.repeat(ctx.xyz.shape[0], 1)
+
+
+def _sample_partitioned(key_fn: Callable[[torch.Tensor], torch.Tensor]):
+    """ds-FPS / ry-FPS: sort each scene by a scalar key, cut into 4 equal parts, FPS npoint/4 in each
+    part and map back to scene indices (reference :372-419)."""
+    parts = 4
+
+    def run(mod, ctx):
+        part_xyz, part_idx = [], []
+        for scene in ctx.xyz:
+            order = key_fn(scene).sort(dim=0, descending=False)[1]
+            part_xyz.append(scene[order].view(parts, -1, 3))
+            part_idx.append(order.view(parts, -1))
+        part_xyz = torch.cat(part_xyz, dim=0)
+        part_idx = torch.cat(part_idx, dim=0)
+        local = pointnet2_utils.furthest_point_sample(part_xyz, ctx.npoint // parts)
+        picked = [order[sel.long()] for sel, order in zip(local, part_idx)]
+        return torch.cat(picked, dim=-1).reshape(ctx.xyz_full.shape[0], ctx.npoint).int()
+
+    return run
+
+
+# (predicate on the sample-type string, strategy); first match wins -- reference order :287-419
+_SAMPLERS = [
+    (lambda t: 'cls' in t or 'ctr' in t, _sample_score),
+    (lambda t: 'ss' in t or 'sss' in t, _sample_stability),
+    (lambda t: 'D-FPS' in t or 'DFS' in t, _sample_dfps),
+    (lambda t: 'S-FPS' in t or 'SFS' in t, _sample_sfps),
+    (lambda t: 'F-FPS' in t or 'FFS' in t, _sample_ffps),
+    (lambda t: t == 'FS', _sample_fs),
+    (lambda t: 'Rand' in t, _sample_rand),
+    (lambda t: t in ('ds_FPS', 'ds-FPS'), _sample_partitioned(lambda p: p.norm(dim=-1) - 5)),
+    (lambda t: t in ('ry_FPS', 'ry-FPS'), _sample_partitioned(lambda p: torch.atan(p[:, 0] / p[:, 1]))),
+]
+
+
+def _identity_index(batch: int, n: int, device) -> torch.Tensor:
+    return torch.arange(n, device=device, dtype=torch.int32).unsqueeze(0).repeat(batch, 1)
+
+
+class _SamplingSAModule(_PointnetSAModuleBase):
+    """Common body of PointnetSAModuleMSG_WithSampling and PointnetSampling."""
+
+    _allowed_samplers = None  # None = all strategies
+
+    def _build_scales(self, npoint_list, radii, nsamples, mlps, use_xyz, dilated_group):
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.npoint_list = npoint_list
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        width = 0
+        for i, (radius, nsample, spec) in enumerate(zip(radii, nsamples, mlps)):
+            if npoint_list is None:
+                grouper = pointnet2_utils.GroupAll(use_xyz)
+            elif dilated_group:
+                inner = 0. if i == 0 else radii[i - 1]
+                grouper = pointnet2_utils.QueryDilatedAndGroup(radius, inner, nsample, use_xyz=use_xyz)
+            else:
+                grouper = pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz)
+            self.groupers.append(grouper)
+            if use_xyz:
+                spec[0] += 3  # in place on the caller's list, like the reference (:199-201)
+            self.mlps.append(_conv_bn_relu_stack(spec, nn.Conv2d, nn.BatchNorm2d))
+            width += spec[-1]
+        return width
+
+    def _build_aggregation(self, width, aggregation_mlp):
+        if aggregation_mlp and len(self.mlps) > 0:
+            self.aggregation_layer = _conv_bn_relu_stack([width] + list(aggregation_mlp), nn.Conv1d, nn.BatchNorm1d)
+            return aggregation_mlp[-1]
+        self.aggregation_layer = None
+        return width
+
+    def _sample(self, xyz, features, cls_features, stds):
+        """-> (sampled_idx (B, sum npoint) int32, stds).  Reference :270-424 / :709-726."""
+        xyz_flipped = xyz.transpose(1, 2).contiguous()
+        chunks = []
+        begin = 0
+        for sample_type, sample_range, npoint in zip(self.sample_type_list, self.sample_range_list,
+                                                     self.npoint_list):
+            if npoint <= 0:
+                continue
+            if sample_range == -1:
+                window = slice(begin, None)
+            else:
+                window = slice(begin, sample_range)
+                begin += sample_range  # sic: the reference adds the range end, not its length (:282)
+            xyz_w = xyz[:, window, :]
+            xyz_w = xyz_w if sample_range == -1 else xyz_w.contiguous()
+            feat_w = None
+            if features is not None:
+                feat_w = features.transpose(1, 2)[:, window, :]
+                feat_w = feat_w.contiguous() if sample_range == -1 else feat_w
+            cls_w = cls_features[:, window, :] if cls_features is not None else None
+
+            if xyz_w.shape[1] <= npoint:
+                chunks.append(_identity_index(xyz_w.shape[0], xyz_w.shape[1], xyz_w.device))
+                continue
+            for accepts, strategy in _SAMPLERS:
+                if accepts(sample_type) and (self._allowed_samplers is None or strategy in self._allowed_samplers):
+                    ctx = _SampleInput(xyz_w, xyz, xyz_flipped, feat_w, cls_w, npoint, stds)
+                    chunks.append(strategy(self, ctx))
+                    stds = ctx.stds
+                    break
+            else:
+                raise NotImplementedError(f"sampling method {sample_type!r}")
+        sampled_idx = torch.cat(chunks, dim=-1)
+        new_xyz = pointnet2_utils.gather_operation(xyz_flipped, sampled_idx).transpose(1, 2).contiguous()
+        return sampled_idx, new_xyz, stds
+
+    def _abstract(self, xyz, new_xyz, features, sampled_idx):
+        if len(self.groupers) > 0:
+            new_features = self._group_mlp_pool(xyz, new_xyz, features)
+            if self.aggregation_layer is not None:
+                new_features = self.aggregation_layer(new_features)
+            return new_features
+        return pointnet2_utils.gather_operation(features, sampled_idx).contiguous()
+
+
+class PointnetSAModuleMSG_WithSampling(_SamplingSAModule):
+    """SA layer with a configurable down-sampler, multi-scale grouping, an aggregation MLP and an
+    optional per-point confidence head (reference :128-460).
+
+    forward(xyz (B,N,3), features (B,C,N), cls_features (B,N,K)|None, new_xyz=None, ctr_xyz=None,
+            stds=...) -> (new_xyz (B,M,3), new_features (B,C',M), cls_features (B,M,K)|None,
+                          sampled_idx_list (B,M) int32 | [] when ctr_xyz is given, stds)
+    """
+
+    def __init__(self, *, npoint_list: List[int], sample_range_list: List[int], sample_type_list: List[str],
+                 radii: List[float], nsamples: List[int], mlps: List[List[int]], use_xyz: bool = True,
+                 dilated_group=False, pool_method='max_pool', aggregation_mlp: List[int],
+                 confidence_mlp: List[int], num_class, **kwargs):
+        super().__init__()
+        self.sample_type_list = sample_type_list
+        self.sample_range_list = sample_range_list
+        self.dilated_group = dilated_group
+        ss_radii = kwargs.get('ss_radii', None)
+        if ss_radii is not None and len(ss_radii) > 0:  # stable sampling ball (reference :166-173)
+            self.ss_radii = ss_radii[0]
+            self.ss_nsamples = kwargs['ss_nsamples'][0]
+
+        width = self._build_scales(npoint_list, radii, nsamples, mlps, use_xyz, dilated_group)
+        self.pool_method = pool_method
+        width = self._build_aggregation(width, aggregation_mlp)
+
+        if confidence_mlp:
+            head = list(_conv_bn_relu_stack([width] + list(confidence_mlp), nn.Conv1d, nn.BatchNorm1d))
+            head.append(nn.Conv1d(confidence_mlp[-1], num_class, kernel_size=1, bias=True))
+            self.confidence_layers = nn.Sequential(*head)
+        else:
+            self.confidence_layers = None
+
+    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, cls_features: torch.Tensor = None,
+                new_xyz=None, ctr_xyz=None, **kwargs):
+        stds = kwargs.get('stds', None)
+        if stds is not None:
+            stds = stds.view(xyz.shape[0], 1, -1).contiguous()
+        sampled_idx_list = []
+        if ctr_xyz is None:
+            sampled_idx_list, new_xyz, stds = self._sample(xyz, features, cls_features, stds)
+        else:
+            new_xyz = ctr_xyz
+        new_features = self._abstract(xyz, new_xyz, features, sampled_idx_list)
+        if self.confidence_layers is not None:
+            cls_features = self.confidence_layers(new_features).transpose(1, 2)
+        else:
+            cls_features = None
+        return new_xyz, new_features, cls_features, sampled_idx_list, stds
+
+
+class Vote_layer(nn.Module):
+    """Light voting module with a clamped centre offset (reference :462-516).
+
+    forward(xyz (B,M,3), features (B,C,M)) -> (vote_xyz, new_features (B,M,0), xyz, ctr_offsets)
+    """
+
+    def __init__(self, mlp_list, pre_channel, max_translate_range):
+        super().__init__()
+        self.mlp_list = mlp_list
+        if len(mlp_list) > 0:
+            # NOTE: the reference rebuilds its layer list inside the loop, so with more than one entry
+            # only the last block would survive; every shipped config has exactly one entry.
+            self.mlp_modules = _conv_bn_relu_stack([pre_channel] + list(mlp_list), nn.Conv1d, nn.BatchNorm1d)
+            pre_channel = mlp_list[-1]
+        else:
+            self.mlp_modules = None
+        self.ctr_reg = nn.Conv1d(pre_channel, 3, kernel_size=1)
+        self.max_offset_limit = (torch.tensor(max_translate_range).float()
+                                 if max_translate_range is not None else None)
+
+    def forward(self, xyz, features, **kwargs):
+        if kwargs.get('center_surface_futures', None) is not None:
+            self.center_surface_futures = kwargs['center_surface_futures']
+        hidden = features
+        if self.mlp_modules is not None:
+            if hasattr(self, 'center_surface_futures'):
+                hidden = torch.cat([self.center_surface_futures, hidden], dim=1)
+            hidden = self.mlp_modules(hidden)
+        offsets = self.ctr_reg(hidden).transpose(1, 2)      # (B, M, 3)
+        new_features = offsets[..., 3:]                      # empty: ctr_reg has exactly 3 outputs
+        ctr_offsets = offsets[..., :3]
+        if self.max_offset_limit is not None:
+            limit = self.max_offset_limit.to(xyz.device).view(1, 1, 3).expand_as(ctr_offsets)
+            clamped = torch.where(ctr_offsets > limit, limit, ctr_offsets)
+            clamped = torch.where(clamped < -limit, -limit, clamped)
+            vote_xyz = xyz + clamped
+        else:
+            vote_xyz = xyz + ctr_offsets
+        return vote_xyz, new_features, xyz, ctr_offsets
+
+
+class PointnetSAModule(PointnetSAModuleMSG):
+    """Single-scale SA layer (reference :519-536)."""
+
+    def __init__(self, *, mlp: List[int], npoint: int = None, radius: float = None, nsample: int = None,
+                 bn: bool = True, use_xyz: bool = True, pool_method='max_pool'):
+        super().__init__(mlps=[mlp], npoint=npoint, radii=[radius], nsamples=[nsample], bn=bn,
+                         use_xyz=use_xyz, pool_method=pool_method)
+
+
+class PointnetFPModule(nn.Module):
+    """Feature propagation by inverse-distance 3-NN interpolation (reference :539-587)."""
+
+    def __init__(self, *, mlp: List[int], bn: bool = True):
+        super().__init__()
+        self.mlp = _conv_bn_relu_stack(list(mlp), nn.Conv2d, nn.BatchNorm2d)
+
+    def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
+                known_feats: torch.Tensor) -> torch.Tensor:
+        """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n), known_feats (B,C2,m) -> (B,mlp[-1],n)."""
+        if known is not None:
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            inv = 1.0 / (dist + 1e-8)
+            weight = inv / torch.sum(inv, dim=2, keepdim=True)
+            spread = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+        else:
+            spread = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
+        stacked = torch.cat([spread, unknow_feats], dim=1) if unknow_feats is not None else spread
+        return self.mlp(stacked.unsqueeze(-1)).squeeze(-1)
+
+
+class PointnetSampling(_SamplingSAModule):
+    """D-FPS-only SA layer used by the stability generator (reference :590-763).
+
+    forward(...) -> (new_xyz (B,M,3), new_features (B,C',M), sampled_idx_list (B,M) int32)
+    """
+
+    _allowed_samplers = (_sample_dfps,)
+
+    def __init__(self, *, npoint_list: List[int], sample_range_list: List[int], sample_type_list: List[str],
+                 radii: List[float], nsamples: List[int], mlps: List[List[int]], use_xyz: bool = True,
+                 dilated_group=False, pool_method='max_pool', aggregation_mlp: List[int]):
+        super().__init__()
+        self.sample_type_list = sample_type_list
+        self.sample_range_list = sample_range_list
+        self.dilated_group = dilated_group
+        width = self._build_scales(npoint_list, radii, nsamples, mlps, use_xyz, dilated_group)
+        self.pool_method = pool_method
+        self._build_aggregation(width, aggregation_mlp)
+        self.confidence_layers = None
+
+    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, cls_features: torch.Tensor = None,
+                new_xyz=None, ctr_xyz=None, **kwargs):
+        sampled_idx_list = []
+        if ctr_xyz is None:
+            sampled_idx_list, new_xyz, _ = self._sample(xyz, features, cls_features, None)
+        else:
+            new_xyz = ctr_xyz
+        new_features = self._abstract(xyz, new_xyz, features, sampled_idx_list)
+        return new_xyz, new_features, sampled_idx_list

@@ -1,0 +1,80 @@
+"""IA-SSD / SPSNet set-abstraction stack driver (what bench.py times and the parity tests check).
+
+Builds the SA layers exactly as the reference's backbone does from its YAML
+(pcdet/models/backbones_3d/IASSD_backbone.py:30-84, config
+tools/cfgs/kitti_models/IA-SSD.yaml:35-55 / SPSNet.yaml:39-69) and drives them like
+IASSD_backbone.py:128-134: layer k consumes layer k-1's (xyz, features, cls prediction).
+Only the SA layers are built -- heads, losses and the voting branch stay out of scope.
+"""
+import copy
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+# the three down-sampling SA layers of BASELINE.json's metric (16 384 -> 4 096 -> 1 024 -> 512)
+IASSD_KITTI = dict(
+    npoint_list=[[4096], [1024], [512]],
+    sample_range_list=[[-1], [-1], [-1]],
+    sample_method_list=[['D-FPS'], ['D-FPS'], ['ctr_aware']],
+    radius_list=[[0.2, 0.8], [0.8, 1.6], [1.6, 4.8]],
+    nsample_list=[[16, 32], [16, 32], [16, 32]],
+    mlps=[[[16, 16, 32], [32, 32, 64]], [[64, 64, 128], [64, 96, 128]], [[128, 128, 256], [128, 256, 256]]],
+    aggregation_mlps=[[64], [128], [256]],
+    confidence_mlps=[[], [128], [256]],
+    dilated_group=[False, False, False],
+)
+
+
+def scaled_config(base=IASSD_KITTI, npoints=None, nsamples=None, sample_methods=None):
+    cfg = copy.deepcopy(base)
+    if npoints is not None:
+        cfg['npoint_list'] = [[p] for p in npoints]
+    if nsamples is not None:
+        cfg['nsample_list'] = [list(ns) for ns in nsamples]
+    if sample_methods is not None:
+        cfg['sample_method_list'] = [[m] for m in sample_methods]
+    return cfg
+
+
+def build_sa_layers(modules_pkg, cfg=IASSD_KITTI, input_channels=4, num_class=3, seed=0) -> nn.ModuleList:
+    """Instantiate the SA layers with `modules_pkg.PointnetSAModuleMSG_WithSampling` (the build's
+    pointnet2_modules or, for golden generation, the reference's) under a fixed seed, eval mode,
+    with non-trivial deterministic BatchNorm running statistics."""
+    torch.manual_seed(seed)
+    layers = nn.ModuleList()
+    channel_in = input_channels - 3
+    for k in range(len(cfg['npoint_list'])):
+        mlps = [[channel_in] + list(m) for m in cfg['mlps'][k]]
+        channel_out = sum(m[-1] for m in mlps)
+        agg = list(cfg['aggregation_mlps'][k]) or None
+        if agg:
+            channel_out = agg[-1]
+        conf = list(cfg['confidence_mlps'][k]) or None
+        layers.append(modules_pkg.PointnetSAModuleMSG_WithSampling(
+            npoint_list=cfg['npoint_list'][k], sample_range_list=cfg['sample_range_list'][k],
+            sample_type_list=cfg['sample_method_list'][k], radii=cfg['radius_list'][k],
+            nsamples=cfg['nsample_list'][k], mlps=mlps, use_xyz=True,
+            dilated_group=cfg['dilated_group'][k], aggregation_mlp=agg, confidence_mlp=conf,
+            num_class=num_class))
+        channel_in = channel_out
+    gen = torch.Generator().manual_seed(seed + 1)
+    for mod in layers.modules():
+        if isinstance(mod, (nn.BatchNorm1d, nn.BatchNorm2d)):
+            with torch.no_grad():
+                mod.running_mean.copy_(torch.randn(mod.num_features, generator=gen) * 0.1)
+                mod.running_var.copy_(torch.rand(mod.num_features, generator=gen) + 0.5)
+                mod.weight.copy_(torch.rand(mod.num_features, generator=gen) + 0.5)
+                mod.bias.copy_(torch.randn(mod.num_features, generator=gen) * 0.1)
+    return layers.eval()
+
+
+def run_sa_layers(layers, xyz, features, stds=None):
+    """IASSD_backbone.py:128-134 for SA layers: -> list of (new_xyz, new_features, cls, sampled_idx)."""
+    outs = []
+    cls_pred = None
+    for layer in layers:
+        kw = {} if stds is None else {'stds': stds}
+        xyz, features, cls_pred, idx, stds = layer(xyz, features, cls_pred, **kw)
+        outs.append((xyz, features, cls_pred, idx))
+    return outs

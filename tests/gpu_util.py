@@ -1,0 +1,59 @@
+"""numpy <-> HIP helpers for the GPU parity tests: every call goes through the C ABI
+(spsnet_amd.pointnet2_batch_cuda -> libspsnet_sa.so), mirroring how pointnet2_utils.py allocates."""
+import numpy as np
+import torch
+
+DEV = "cuda:0"
+
+
+def t(a, dtype=None):
+    x = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return x if dtype is None else x.to(dtype)
+
+
+def n(x):
+    return x.detach().cpu().numpy()
+
+
+def fps(ext, xyz, m, temp=None):
+    B, N, _ = xyz.shape
+    tx = t(xyz)
+    tt = torch.full((B, N), 1e10, dtype=torch.float32, device=DEV) if temp is None else t(temp)
+    idx = torch.zeros((B, m), dtype=torch.int32, device=DEV)
+    assert ext.farthest_point_sampling_wrapper(B, N, m, tx, tt, idx) == 1
+    return n(idx), n(tt)
+
+
+def fps_with_dist(ext, dist, m):
+    B, N, _ = dist.shape
+    tt = torch.full((B, N), 1e10, dtype=torch.float32, device=DEV)
+    idx = torch.zeros((B, m), dtype=torch.int32, device=DEV)
+    assert ext.furthest_point_sampling_with_dist_wrapper(B, N, m, t(dist), tt, idx) == 2
+    return n(idx)
+
+
+def ball_query(ext, radius, nsample, xyz, new_xyz, dilated_min=None):
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    idx = torch.zeros((B, M, nsample), dtype=torch.int32, device=DEV)
+    if dilated_min is None:
+        assert ext.ball_query_wrapper(B, N, M, radius, nsample, t(new_xyz), t(xyz), idx) == 1
+    else:
+        assert ext.ball_query_dilated_wrapper(B, N, M, radius, dilated_min, nsample, t(new_xyz), t(xyz), idx) == 1
+    return n(idx)
+
+
+def group(ext, pts, idx):
+    B, C, N = pts.shape
+    _, M, ns = idx.shape
+    out = torch.empty((B, C, M, ns), dtype=torch.float32, device=DEV)
+    assert ext.group_points_wrapper(B, C, N, M, ns, t(pts), t(idx), out) == 1
+    return n(out)
+
+
+def gather(ext, pts, idx):
+    B, C, N = pts.shape
+    M = idx.shape[1]
+    out = torch.empty((B, C, M), dtype=torch.float32, device=DEV)
+    assert ext.gather_points_wrapper(B, C, N, M, t(pts), t(idx), out) == 1
+    return n(out)

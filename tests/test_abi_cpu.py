@@ -1,0 +1,83 @@
+"""The C-ABI library loads on a GPU-less host and exports exactly what include/spsnet_sa.h declares.
+No kernel is launched here; argument validation is exercised because it runs before any HIP call."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "spsnet_sa.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sps_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_reference_surface():
+    names = declared_functions()
+    # the 11 launchers behind pointnet2_api.cpp:10-26
+    for stem in ("farthest_point_sampling_kernel_launcher", "furthest_point_sampling_with_dist_kernel_launcher",
+                 "gather_points_kernel_launcher_fast", "gather_points_grad_kernel_launcher_fast",
+                 "ball_query_kernel_launcher_fast", "ball_query_dilated_kernel_launcher_fast",
+                 "group_points_kernel_launcher_fast", "group_points_grad_kernel_launcher_fast",
+                 "three_nn_kernel_launcher_fast", "three_interpolate_kernel_launcher_fast",
+                 "three_interpolate_grad_kernel_launcher_fast"):
+        assert "sps_" + stem in names
+
+
+def test_library_exports_every_declared_symbol():
+    from spsnet_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} declared in include/spsnet_sa.h but not exported"
+    assert set(_lib.EXPORTS) == set(declared_functions())
+    assert _lib.load().sps_abi_version() == _lib.ABI_VERSION
+
+
+def test_opt_n_threads_matches_reference_rule():
+    from spsnet_amd import _lib
+    L = _lib.load()
+    assert [L.sps_opt_n_threads(n) for n in (1, 3, 64, 1000, 1024, 16384)] == [1, 2, 64, 512, 1024, 1024]
+
+
+def test_invalid_arguments_are_reported_not_fatal():
+    from spsnet_amd import _lib
+    L = _lib.load()
+    assert L.sps_farthest_point_sampling_kernel_launcher(-1, 16, 4, None, None, None, None) == 1
+    assert b"bad shape" in L.sps_last_error()
+    assert L.sps_farthest_point_sampling_kernel_launcher(1, 16, 4, None, None, None, None) == 1
+    assert b"null" in L.sps_last_error()
+    assert L.sps_score_topk(1, 100000, 3, 10, None, None, None, None, None) == 1
+    with pytest.raises(_lib.SpsError):
+        _lib.check(1, "demo")
+    # empty work is a successful no-op, like the reference's `if (m <= 0) return`
+    assert L.sps_farthest_point_sampling_kernel_launcher(0, 16, 4, None, None, None, None) == 0
+    assert L.sps_ball_query_kernel_launcher_fast(2, 16, 0, 1.0, 4, None, None, None, None) == 0
+
+
+def test_extension_module_surface():
+    import spsnet_amd.pointnet2_batch_cuda as ext
+    for fn in ("ball_query_wrapper", "ball_query_dilated_wrapper", "group_points_wrapper", "group_points_grad_wrapper",
+               "gather_points_wrapper", "gather_points_grad_wrapper", "farthest_point_sampling_wrapper",
+               "furthest_point_sampling_with_dist_wrapper", "three_nn_wrapper", "three_interpolate_wrapper",
+               "three_interpolate_grad_wrapper"):
+        assert callable(getattr(ext, fn))
+    import torch
+    with pytest.raises(ValueError):  # CPU tensors are rejected, never silently computed on the host
+        ext.farthest_point_sampling_wrapper(1, 8, 2, torch.zeros(1, 8, 3), torch.zeros(1, 8), torch.zeros(1, 2, dtype=torch.int32))
+
+
+def test_module_mirror_builds_with_reference_state_dict_keys():
+    import numpy as np
+    from spsnet_amd import pointnet2_modules as M
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sampler_ctr.npz"))
+    ref_keys = sorted(k[3:] for k in g.files if k.startswith("sd."))
+    mod = M.PointnetSAModuleMSG_WithSampling(
+        npoint_list=[256], sample_range_list=[-1], sample_type_list=['ctr_aware'], radii=[1.6, 4.8], nsamples=[8, 16],
+        mlps=[[6, 8, 16], [6, 8, 24]], use_xyz=True, dilated_group=False, aggregation_mlp=[32], confidence_mlp=[16],
+        num_class=3)
+    assert sorted(mod.state_dict().keys()) == ref_keys
+    for k, v in mod.state_dict().items():
+        assert tuple(v.shape) == tuple(g["sd." + k].shape), k
