@@ -5,6 +5,11 @@ Fails loudly when the library is missing: there is no fallback path.
 import ctypes
 import os
 
+# torch bundles its own libamdhip64.so.7; importing it FIRST makes the loader bind libspsnet_sa's
+# libamdhip64 dependency to that same runtime instance (one HIP runtime per process -- otherwise
+# device pointers and streams handed over from torch belong to a different runtime).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libspsnet_sa.so")
 

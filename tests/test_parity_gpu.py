@@ -204,7 +204,8 @@ def test_three_nn_and_interpolate(ext, G, oracle, dev, n, m):
 def test_score_topk_bit_exact(ext, G, oracle, N, K, C):
     rng = np.random.default_rng(N + K)
     cls = rng.normal(size=(2, N, C)).astype(np.float32) * 3
-    cls[:, ::7] = cls[:, 3:4]  # exact score ties -> index-ascending rule
+    if N > 8:
+        cls[:, ::7] = cls[:, 3:4]  # exact score ties -> index-ascending rule
     stds = rng.uniform(0, 40, (2, N)).astype(np.float32)
     idx, sc = ext.score_topk(G.t(cls), K, return_scores=True)
     want_s = oracle.score_ctr(cls)
