@@ -120,6 +120,26 @@ int sps_query_and_group(int b, int n, int m, int c, float radius, int nsample, i
                         const float *xyz, const float *new_xyz, const float *features, int *idx,
                         float *out, sps_stream_t stream);
 
+/* ball_query_kernel_launcher_fast in "write every row" mode: rows of empty balls are written as zeros, so
+ * the caller needs no zero-fill (what pointnet2_utils.py:246 + ball_query_gpu.cu:9-45 produce together). */
+int sps_ball_query_full(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                        const float *xyz, int *idx, sps_stream_t stream);
+
+/* Fused group -> shared MLP -> max-pool of ONE grouping scale, inference mode (BatchNorm folded):
+ * replaces grouping_operation x2 + cat + [Conv2d 1x1, BatchNorm2d, ReLU] x3 + max_pool2d of
+ * pointnet2_modules.py:429-447 by one MFMA kernel (csrc/sa_mlp.hip).
+ *   xyz (B,N,3), new_xyz (B,M,3), features (B,c_feat,N) or NULL, idx (B,M,nsample) from the ball query
+ *   c1, c2, c3: layer widths PADDED to multiples of 16; c3_real <= c3 channels are written
+ *   w1/b1, w2/b2, w3/b3: folded weights in MFMA fragment order (spsnet_amd/fused.py) and padded biases
+ *   out (B, out_c_total, M): channels [out_c_off, out_c_off + c3_real) receive the pooled features.
+ * B*M*nsample must be a multiple of 32.  Returns SPS_ERR_INVALID when no kernel variant exists for
+ * (c1, c2, nsample): ask sps_sa_group_mlp_supported first. */
+int sps_sa_group_mlp(int b, int n, int m, int c_feat, int nsample, const float *xyz, const float *new_xyz,
+                     const float *features, const int *idx, int c1, int c2, int c3, int c3_real,
+                     const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                     const float *b3, float *out, int out_c_total, int out_c_off, sps_stream_t stream);
+int sps_sa_group_mlp_supported(int c1, int c2, int nsample);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,8 +8,8 @@
 //     grouped_xyz -= new_xyz.transpose(...)     (kernel)
 //     grouped_features = grouping_operation()   (kernel)
 //     torch.cat([grouped_xyz, grouped_features])(copy of the whole grouped tensor)
-// by a ball-query launch that writes complete rows (zeros for empty balls) and ONE grouping
-// launch that writes the concatenated (B, 3+C, M, ns) tensor directly, reading xyz in its
+// by the segmented ball-query kernel of ball_query.hip in its "write every row" mode (zeros for
+// empty balls) and ONE grouping launch that writes the concatenated (B, 3+C, M, ns) tensor directly, reading xyz in its
 // native (B,N,3) layout.
 #include "sps_common.h"
 
@@ -17,34 +17,6 @@ namespace sps {
 
 constexpr int QG_THREADS = 256;
 constexpr int QG_CCHUNK = 16;
-
-// same scan as ball_query_kernel<false>, but every row is fully written
-__global__ __launch_bounds__(64) void ball_query_full_kernel(
-    int n, int m, float r2, int nsample, const float *__restrict__ new_xyz,
-    const float *__restrict__ xyz, int *__restrict__ idx) {
-    const int scene = blockIdx.y;
-    const int j = blockIdx.x * 64 + threadIdx.x;
-    const bool active = j < m;
-    xyz += (size_t)scene * n * 3;
-    const float *ctr = new_xyz + ((size_t)scene * m + (active ? j : 0)) * 3;
-    const float cx = ctr[0], cy = ctr[1], cz = ctr[2];
-    int *row = idx + ((size_t)scene * m + (active ? j : 0)) * nsample;
-    int cnt = active ? 0 : nsample;
-    int first = 0;
-    for (int k0 = 0; k0 < n; k0 += 8) {
-        if (__all(cnt >= nsample)) break;
-        const int kend = (k0 + 8 < n) ? k0 + 8 : n;
-        for (int k = k0; k < kend; ++k) {
-            const float d2 = sqdist(cx, cy, cz, xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2]);
-            if (d2 < r2 && cnt < nsample) {
-                if (cnt == 0) first = k;
-                row[cnt++] = k;
-            }
-        }
-    }
-    if (active)
-        for (int l = cnt; l < nsample; ++l) row[l] = first;  // first == 0 for an empty ball
-}
 
 // channel chunk z = 0 additionally emits the 3 centred xyz channels when use_xyz
 __global__ __launch_bounds__(QG_THREADS) void group_concat_kernel(
@@ -78,6 +50,12 @@ __global__ __launch_bounds__(QG_THREADS) void group_concat_kernel(
 
 }  // namespace sps
 
+extern "C" int sps_ball_query_full(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                                   const float *xyz, int *idx, sps_stream_t stream) {
+    return sps::launch_ball_query(false, /*fill_empty=*/true, b, n, m, radius, 0.f, nsample, new_xyz, xyz, idx,
+                                  sps::as_stream(stream));
+}
+
 extern "C" int sps_query_and_group(int b, int n, int m, int c, float radius, int nsample, int use_xyz,
                                    const float *xyz, const float *new_xyz, const float *features, int *idx,
                                    float *out, sps_stream_t stream) {
@@ -90,9 +68,7 @@ extern "C" int sps_query_and_group(int b, int n, int m, int c, float radius, int
     if (!xyz || !new_xyz || !idx || !out || (c > 0 && !features))
         return fail(SPS_ERR_INVALID, "query_and_group: null pointer");
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(ball_query_full_kernel, dim3(divup(m, 64), b), dim3(64), 0, st, n, m, radius * radius,
-                       nsample, new_xyz, xyz, idx);
-    int rc = check_launch("ball_query_full_kernel");
+    int rc = launch_ball_query(false, /*fill_empty=*/true, b, n, m, radius, 0.f, nsample, new_xyz, xyz, idx, st);
     if (rc != SPS_OK) return rc;
     const int cols = m * nsample;
     const int zchunks = c > 0 ? divup(c, QG_CCHUNK) : 1;

@@ -1,0 +1,332 @@
+// sa_mlp.hip -- fused "group -> shared MLP -> max-pool" of one SA scale on the gfx950 matrix cores.
+//
+// Replaces, for inference (BatchNorm folded into the 1x1 convolutions), the per-scale chain of the
+// reference's PointnetSAModuleMSG_WithSampling.forward
+// (pcdet/ops/pointnet2/pointnet2_batch/pointnet2_modules.py:429-447, built at :199-211):
+//     grouping_operation x2 + subtract + cat          (pointnet2_utils.py:312-320)
+//     [Conv2d 1x1 -> BatchNorm2d -> ReLU] x 3         (MIOpen conv + BN + clamp kernels)
+//     F.max_pool2d(kernel=[1, nsample])
+// -- ~14 launches and 8 HBM round trips of the (B, C, M, nsample) activation tensor per scale --
+// by ONE kernel whose activations never leave registers.
+//
+// Matrix-core mapping (v_mfma_f32_16x16x4_f32: exact fp32, D = A(16x4) * B(4x16) + C):
+//   A = weights  (16 output channels x 4 input channels), one f32 per lane
+//   B = activations (4 input channels x 16 grouped points = "columns"), one f32 per lane
+//   D = 16 output channels x 16 columns: lane (q = lane>>4, c = lane&15) holds rows 4q..4q+3 of column c.
+// The D layout of layer l is ALREADY a valid B operand of layer l+1 if the k-steps of layer l+1 walk the
+// input channels in the order (tile t, register r) -> channels {16t + 4q + r : q = 0..3}; the weight
+// fragments are pre-permuted on the host accordingly (pack_* in spsnet_amd/fused.py; layer 1 as
+// [tile][k-step][lane], layers 2-3 as [tile][k-step/4][lane][4] so that one dwordx4 feeds 4 MFMAs), so the activations
+// chain register to register with no LDS and no cross-lane traffic.  Bias enters as the C input of the
+// first MFMA, ReLU is one v_max per register, and the max-pool over the nsample columns of a centroid is a
+// 4-step DPP row reduction on the last layer's accumulators (relu(max x) == max relu(x)).
+//
+// Work split: one wave owns one UNIT = one centroid x nsample columns (two centroids when nsample = 16 and
+// NT = 2) at a time and walks units grid-stride; waves never synchronise.  The grouped input (3 centred xyz
+// channels + C feature channels of the nsample ball-query neighbours) is gathered straight from the
+// (B,N,3) / (B,C,N) tensors, one prefetched 4-channel k-step ahead of the MFMAs.
+#include "sps_common.h"
+
+namespace sps {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Weight fragments are fetched with buffer loads: SGPR descriptor + SGPR chunk offset + lane offset, so the
+// unrolled layers need no per-load 64-bit address registers (global_load immediates only reach 4 KiB and
+// hipcc otherwise materialises -- and spills -- one pointer per fragment).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const float *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 wload4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return (f32x4){__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])};
+}
+
+// max over the 16 lanes of each DPP row (= the 16 columns of a tile), result valid in every lane
+__device__ __forceinline__ float row_allmax(float v) {
+    // xor-butterfly inside a row via quad_perm / row_half_mirror / row_mirror
+    int x = __float_as_int(v);
+    float o;
+    o = __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+    v = fmaxf(v, o); x = __float_as_int(v);
+    o = __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+    v = fmaxf(v, o); x = __float_as_int(v);
+    o = __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false));  // row_half_mirror
+    v = fmaxf(v, o); x = __float_as_int(v);
+    o = __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false));  // row_mirror
+    v = fmaxf(v, o);
+    return v;
+}
+
+struct SaMlpArgs {
+    int n, m, c_feat, units;       // points/scene, centroids/scene, feature channels, total units
+    int ks1;                       // layer-1 k-steps = ceil((3 + c_feat) / 4)
+    int c3;                        // padded last-layer width (multiple of 16)
+    int c3_real;                   // channels actually written
+    int out_c_total, out_c_off;    // out is (B, out_c_total, M); this scale writes [off, off + c3_real)
+    const float *xyz, *new_xyz, *feat;
+    const int *idx;
+    const float *w1, *b1, *w2, *b2, *w3, *b3;
+    float *out;
+};
+
+// C1, C2: padded widths of layers 1 and 2 (multiples of 16).  NT: 16-column tiles per MFMA pass.
+// NS: nsample (16, 32 or 64), with 16*NT >= NS: a unit is 16*NT columns = 16*NT/NS whole centroids.
+template <int C1, int C2, int NT, int NS>
+__global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
+    constexpr int T1 = C1 / 16, T2 = C2 / 16;
+    constexpr int COLS = 16 * NT;
+    constexpr int UNIT = COLS;
+    constexpr int CPP = COLS / NS;  // whole centroids per unit (1 or 2)
+    static_assert(COLS % NS == 0 && (NS % 16) == 0 && CPP >= 1, "a unit must hold whole centroids");
+
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4, c = lane & 15;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+
+    for (int unit = wave; unit < a.units; unit += nwaves) {
+        const long long col0 = (long long)unit * UNIT;  // first flattened (b, j, s) column of the unit
+        f32x4 h2[T2][NT];
+        {
+            // column owned by this lane in tile nt
+            int src[NT];
+            long long bj[NT];
+            int bb[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const long long e = col0 + nt * 16 + c;
+                bj[nt] = e / NS;
+                bb[nt] = (int)(bj[nt] / a.m);
+                src[nt] = a.idx[e];
+            }
+            // ---------------- layer 1: k-steps over the gathered channels (runtime count) ----------------
+            f32x4 h1[T1][NT];
+#pragma unroll
+            for (int t = 0; t < T1; ++t) {
+                const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.b1 + 16 * t + 4 * q);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) h1[t][nt] = bias;
+            }
+            auto gather = [&](int ks, int nt) -> float {
+                const int ch = 4 * ks + q;  // grouped channel: 0..2 = centred xyz, 3.. = features
+                if (ks == 0 && q < 3) {
+                    const float p = a.xyz[((size_t)bb[nt] * a.n + src[nt]) * 3 + q];
+                    return p - a.new_xyz[(size_t)bj[nt] * 3 + q];
+                }
+                int cf = ch - 3;
+                cf = cf < a.c_feat ? cf : a.c_feat - 1;  // padded k: finite data times a zero weight
+                if (a.c_feat == 0) return 0.f;
+                return a.feat[((size_t)bb[nt] * a.c_feat + cf) * a.n + src[nt]];
+            };
+            const __amdgpu_buffer_rsrc_t rs1 = weight_rsrc(a.w1, (unsigned)(T1 * a.ks1 * 64 * 4));
+            float xcur[NT], xnext[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) xcur[nt] = gather(0, nt);
+            for (int ks = 0; ks < a.ks1; ++ks) {
+                const bool more = ks + 1 < a.ks1;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) xnext[nt] = more ? gather(ks + 1, nt) : 0.f;
+#pragma unroll
+                for (int t = 0; t < T1; ++t) {
+                    const float wf = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs1, lane * 4, (t * a.ks1 + ks) * 256, 0));
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) h1[t][nt] = mfma16(wf, xcur[nt], h1[t][nt]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) xcur[nt] = xnext[nt];
+            }
+#pragma unroll
+            for (int t = 0; t < T1; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h1[t][nt][r] = fmaxf(h1[t][nt][r], 0.f);
+
+            // ---------------- layer 2: activations chain register-to-register ----------------
+            // Weight fragments stream from L2 in chunks of KCH k-steps, double-buffered in registers: the
+            // chunk after the one being multiplied is already in flight (the sched_barriers keep hipcc from
+            // hoisting every load of the unrolled layer to the top and spilling).
+            {
+                // fragments packed [mt][KS/4][lane][4]: one dwordx4 per lane = 4 consecutive k-steps
+                constexpr int KS = C1 / 4;
+                constexpr int KCH = (KS % 16 == 0) ? 16 : ((KS % 8 == 0) ? 8 : 4);
+                constexpr int NCH = KS / KCH;
+                constexpr int G = T2 * NCH;
+                constexpr int Q4 = KCH / 4;  // dwordx4 loads per chunk
+                const __amdgpu_buffer_rsrc_t rs = weight_rsrc(a.w2, (unsigned)(T2 * KS * 64 * 4));
+                f32x4 w[2][Q4];
+#pragma unroll
+                for (int u = 0; u < Q4; ++u) w[0][u] = wload4(rs, lane * 16, u * 1024);
+                f32x4 acc[NT];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int mt = g / NCH, ch = g % NCH;
+                    if (g + 1 < G) {
+#pragma unroll
+                        for (int u = 0; u < Q4; ++u) w[(g + 1) & 1][u] = wload4(rs, lane * 16, ((g + 1) * Q4 + u) * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ch == 0) {
+                        const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.b2 + 16 * mt + 4 * q);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[nt] = bias;
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < KCH; ++kk) {
+                        const int ks = ch * KCH + kk;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[nt] = mfma16(w[g & 1][kk / 4][kk % 4], h1[ks / 4][nt][ks % 4], acc[nt]);
+                    }
+                    if (ch == NCH - 1) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) h2[mt][nt][r] = fmaxf(acc[nt][r], 0.f);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+
+        // ---------------- layer 3 (runtime width) + max-pool over the unit's columns ----------------
+        const long long bj0 = col0 / NS;  // first centroid of the unit
+        {
+            constexpr int KS = C2 / 4;
+            constexpr int KCH = (KS % 16 == 0) ? 16 : ((KS % 8 == 0) ? 8 : 4);
+            constexpr int NCH = KS / KCH;
+            constexpr int Q4 = KCH / 4;
+            const int MT3 = a.c3 / 16;
+            const __amdgpu_buffer_rsrc_t rs = weight_rsrc(a.w3, (unsigned)(MT3 * KS * 64 * 4));
+            f32x4 wfirst[Q4];  // first chunk of the NEXT output tile, prefetched during the current one
+#pragma unroll
+            for (int u = 0; u < Q4; ++u) wfirst[u] = wload4(rs, lane * 16, u * 1024);
+            for (int mt = 0; mt < MT3; ++mt) {
+                const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.b3 + 16 * mt + 4 * q);
+                const int tile_off = mt * (KS / 4) * 1024;                                  // bytes, wave-uniform
+                const int next_off = ((mt + 1 < MT3) ? mt + 1 : mt) * (KS / 4) * 1024;
+                f32x4 w[2][Q4];
+#pragma unroll
+                for (int u = 0; u < Q4; ++u) w[0][u] = wfirst[u];
+                f32x4 acc[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = bias;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    if (ch + 1 < NCH) {
+#pragma unroll
+                        for (int u = 0; u < Q4; ++u) w[(ch + 1) & 1][u] = wload4(rs, lane * 16, tile_off + ((ch + 1) * Q4 + u) * 1024);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < Q4; ++u) wfirst[u] = wload4(rs, lane * 16, next_off + u * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kk = 0; kk < KCH; ++kk) {
+                        const int ks = ch * KCH + kk;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[nt] = mfma16(w[ch & 1][kk / 4][kk % 4], h2[ks / 4][nt][ks % 4], acc[nt]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                f32x4 best[CPP];
+#pragma unroll
+                for (int cc = 0; cc < CPP; ++cc) best[cc] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int cc = (nt * 16) / NS;  // which centroid of the unit this tile belongs to
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) best[cc][r] = fmaxf(best[cc][r], acc[nt][r]);
+                }
+#pragma unroll
+                for (int cc = 0; cc < CPP; ++cc) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(row_allmax(best[cc][r]), 0.f);  // pool, then ReLU
+                    if (c == 0) {
+                        const long long cen = bj0 + cc;
+                        const int b = (int)(cen / a.m), j = (int)(cen - (long long)b * a.m);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * mt + 4 * q + r;
+                            if (row < a.c3_real)
+                                a.out[((size_t)b * a.out_c_total + a.out_c_off + row) * a.m + j] = v[r];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int C1, int C2, int NT, int NS>
+static int launch_variant(const SaMlpArgs &a, hipStream_t st) {
+    constexpr int UNIT = 16 * NT;
+    SaMlpArgs k = a;
+    const long long cols = (long long)a.units;  // caller passes total columns; convert to units
+    if (cols % UNIT != 0) return fail(SPS_ERR_INVALID, "sa_group_mlp: B*M*nsample=%lld not a multiple of %d", cols, UNIT);
+    k.units = (int)(cols / UNIT);
+    const int waves_per_block = 4;
+    int blocks = divup(k.units, waves_per_block);
+    const int max_blocks = 256 * 8;
+    if (blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL((sa_group_mlp_kernel<C1, C2, NT, NS>), dim3(blocks), dim3(64 * waves_per_block), 0, st, k);
+    return check_launch("sa_group_mlp_kernel");
+}
+
+}  // namespace sps
+
+// Widths are the PADDED widths (multiples of 16) the weight fragments were packed for; c3_real <= c3 is the
+// number of output channels written.  Supported (c1, c2, nsample) combinations are the IA-SSD / SPSNet ones.
+extern "C" int sps_sa_group_mlp(int b, int n, int m, int c_feat, int nsample, const float *xyz,
+                                const float *new_xyz, const float *features, const int *idx, int c1, int c2,
+                                int c3, int c3_real, const float *w1, const float *b1, const float *w2,
+                                const float *b2, const float *w3, const float *b3, float *out, int out_c_total,
+                                int out_c_off, sps_stream_t stream) {
+    using namespace sps;
+    if (b < 0 || n <= 0 || m < 0 || c_feat < 0 || nsample <= 0 || c3 <= 0 || (c3 % 16) || c3_real > c3 ||
+        out_c_off < 0 || out_c_off + c3_real > out_c_total)
+        return fail(SPS_ERR_INVALID, "sa_group_mlp: bad shape");
+    if (b == 0 || m == 0) return SPS_OK;
+    if (!xyz || !new_xyz || !idx || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !out || (c_feat > 0 && !features))
+        return fail(SPS_ERR_INVALID, "sa_group_mlp: null pointer");
+    const long long cols = (long long)b * m * nsample;
+    if (cols > 0x7FFFFFFFLL) return fail(SPS_ERR_INVALID, "sa_group_mlp: too many grouped points");
+    SaMlpArgs a;
+    a.n = n; a.m = m; a.c_feat = c_feat; a.units = (int)cols;
+    a.ks1 = (3 + c_feat + 3) / 4;
+    a.c3 = c3; a.c3_real = c3_real; a.out_c_total = out_c_total; a.out_c_off = out_c_off;
+    a.xyz = xyz; a.new_xyz = new_xyz; a.feat = features; a.idx = idx;
+    a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.out = out;
+    hipStream_t st = as_stream(stream);
+#define SPS_MLP_CASE(C1, C2, NT, NS) \
+    if (c1 == C1 && c2 == C2 && nsample == NS) return launch_variant<C1, C2, NT, NS>(a, st);
+    SPS_MLP_CASE(16, 16, 2, 16)    // IA-SSD L0 r=0.2 [4,16,16,32]
+    SPS_MLP_CASE(32, 32, 2, 32)    // IA-SSD L0 r=0.8 [4,32,32,64]
+    SPS_MLP_CASE(64, 64, 2, 16)    // L1 [67,64,64,128]
+    SPS_MLP_CASE(64, 96, 2, 32)    // L1 [67,64,96,128]
+    SPS_MLP_CASE(128, 128, 2, 16)  // L2 [131,128,128,256]
+    SPS_MLP_CASE(128, 256, 2, 32)  // L2 [131,128,256,256]
+    SPS_MLP_CASE(16, 16, 2, 32)
+    SPS_MLP_CASE(32, 32, 2, 16)
+    SPS_MLP_CASE(128, 64, 2, 16)   // SPSNet L1 [127,124->128,64,128]
+    SPS_MLP_CASE(128, 96, 2, 32)   // SPSNet L1 [127,124->128,96,128]
+#undef SPS_MLP_CASE
+    return fail(SPS_ERR_INVALID, "sa_group_mlp: no kernel for widths (%d, %d) nsample %d", c1, c2, nsample);
+}
+
+// 1 if sps_sa_group_mlp has a kernel for these padded widths / nsample
+extern "C" int sps_sa_group_mlp_supported(int c1, int c2, int nsample) {
+    static const int tab[][3] = {{16, 16, 16}, {32, 32, 32}, {64, 64, 16}, {64, 96, 32}, {128, 128, 16}, {128, 256, 32},
+                                 {16, 16, 32}, {32, 32, 16}, {128, 64, 16}, {128, 96, 32}};
+    for (auto &t : tab)
+        if (t[0] == c1 && t[1] == c2 && t[2] == nsample) return 1;
+    return 0;
+}

@@ -1,0 +1,124 @@
+"""Host side of the fused inference path of one SA layer (eval mode, BatchNorm folded).
+
+`sps_sa_group_mlp` (csrc/sa_mlp.hip) replaces, per grouping scale, the reference's
+grouping_operation x2 + cat + [Conv2d 1x1 + BatchNorm2d + ReLU] x3 + max_pool2d
+(pointnet2_modules.py:429-447).  This module folds the BatchNorm statistics into the convolution
+weights, packs them in the kernel's MFMA fragment order and caches the result on the nn.Sequential.
+
+Fragment order (see the kernel header): layer 1 is [tile][k-step][lane]; layers 2 and 3 are
+[tile][k-step/4][lane][4], with k-step (t, r) of a later layer covering input channels 16t + 4q + r
+(q = lane >> 4) -- the order in which the previous layer's accumulators sit in the lanes.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_L = _lib.load()
+
+
+def _pad16(c):
+    return (c + 15) // 16 * 16
+
+
+def _fold(conv, bn):
+    """Conv(1x1, no bias) + BatchNorm(eval) -> (W', b') with y = W' x + b'."""
+    w = conv.weight.detach().reshape(conv.out_channels, conv.in_channels).float()
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    bias = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+    if conv.bias is not None:
+        bias = bias + conv.bias.detach().float() * scale
+    return w * scale[:, None], bias
+
+
+def _pack_first(w, cout_pad):
+    cout, cin = w.shape
+    ks = (cin + 3) // 4
+    wp = w.new_zeros(cout_pad, 4 * ks)
+    wp[:cout, :cin] = w
+    # [tile, i, ks, q] -> [tile, ks, q, i]; lane = q*16 + i
+    return wp.view(cout_pad // 16, 16, ks, 4).permute(0, 2, 3, 1).contiguous().view(-1)
+
+
+def _pack_next(w, cout_pad, cin_pad):
+    cout, cin = w.shape
+    wp = w.new_zeros(cout_pad, cin_pad)
+    wp[:cout, :cin] = w
+    # [tile, i, t, q, r] -> [tile, t, q, i, r]; one dwordx4 per lane = k-steps (t, 0..3)
+    return wp.view(cout_pad // 16, 16, cin_pad // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+
+
+def _pad_bias(b, cpad):
+    out = b.new_zeros(cpad)
+    out[:b.numel()] = b
+    return out
+
+
+class PackedScale:
+    __slots__ = ("c1", "c2", "c3", "c3_real", "cin", "w1", "b1", "w2", "b2", "w3", "b3", "key")
+
+
+def _stack_layers(mlp):
+    """[(conv, bn)] x 3 if `mlp` is exactly [Conv2d 1x1, BatchNorm2d, ReLU] x 3, else None."""
+    mods = list(mlp)
+    if len(mods) != 9:
+        return None
+    pairs = []
+    for k in range(0, 9, 3):
+        conv, bn, act = mods[k], mods[k + 1], mods[k + 2]
+        if not (isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and isinstance(act, nn.ReLU)):
+            return None
+        if conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.groups != 1 or not bn.track_running_stats:
+            return None
+        pairs.append((conv, bn))
+    return pairs
+
+
+def _version_key(pairs, device):
+    vs = [device]
+    for conv, bn in pairs:
+        for t in (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var):
+            vs.append((t.data_ptr(), t._version))
+    return tuple(vs)
+
+
+def pack_scale(mlp, nsample):
+    """-> PackedScale (cached on the module) or None when the fused kernel has no variant for this scale."""
+    pairs = _stack_layers(mlp)
+    if pairs is None:
+        return None
+    (c1m, _), (c2m, _), (c3m, _) = pairs
+    c1, c2, c3 = _pad16(c1m.out_channels), _pad16(c2m.out_channels), _pad16(c3m.out_channels)
+    if not _L.sps_sa_group_mlp_supported(c1, c2, nsample):
+        return None
+    device = c1m.weight.device
+    key = _version_key(pairs, device)
+    cached = getattr(mlp, "_sps_packed", None)
+    if cached is not None and cached.key == key:
+        return cached
+    with torch.no_grad():
+        (w1, b1), (w2, b2), (w3, b3) = (_fold(c, b) for c, b in pairs)
+        p = PackedScale()
+        p.c1, p.c2, p.c3, p.c3_real, p.cin = c1, c2, c3, c3m.out_channels, c1m.in_channels
+        p.w1, p.b1 = _pack_first(w1, c1), _pad_bias(b1, c1)
+        p.w2, p.b2 = _pack_next(w2, c2, c1), _pad_bias(b2, c2)
+        p.w3, p.b3 = _pack_next(w3, c3, c2), _pad_bias(b3, c3)
+        p.key = key
+    object.__setattr__(mlp, "_sps_packed", p)  # plain attribute: not a parameter/buffer, not in state_dict
+    return p
+
+
+def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset):
+    """One launch: gather the nsample neighbours in `idx` (B,M,ns), run the packed 3-layer MLP, max-pool,
+    and write channels [channel_offset, channel_offset + c3_real) of out (B, Ctot, M)."""
+    B, N, _ = xyz.shape
+    M, ns = idx.shape[1], idx.shape[2]
+    c_feat = 0 if features is None else features.shape[1]
+    if 3 + c_feat != packed.cin:
+        raise ValueError(f"grouped input has {3 + c_feat} channels, the MLP expects {packed.cin}")
+    stream = torch.cuda.current_stream(xyz.device).cuda_stream
+    _lib.check(_L.sps_sa_group_mlp(
+        B, N, M, c_feat, ns, xyz.data_ptr(), new_xyz.data_ptr(), 0 if features is None else features.data_ptr(),
+        idx.data_ptr(), packed.c1, packed.c2, packed.c3, packed.c3_real, packed.w1.data_ptr(), packed.b1.data_ptr(),
+        packed.w2.data_ptr(), packed.b2.data_ptr(), packed.w3.data_ptr(), packed.b3.data_ptr(), out.data_ptr(),
+        out.shape[1], channel_offset, stream), "sa_group_mlp")

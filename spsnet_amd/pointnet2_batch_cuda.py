@@ -191,6 +191,18 @@ def score_topk(cls_features, npoint, stds=None, return_scores=False):
     return (idx, scores) if return_scores else idx
 
 
+def ball_query_full(radius, nsample, xyz, new_xyz):
+    """Ball query that writes every row (zeros for empty balls) into a fresh (B,M,nsample) int32 tensor."""
+    p, q = _ptr(xyz, F32, "xyz"), _ptr(new_xyz, F32, "new_xyz")
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    idx = torch.empty((B, M, nsample), dtype=I32, device=xyz.device)
+    with _on(xyz):
+        _lib.check(_L.sps_ball_query_full(B, N, M, radius, nsample, q, p, idx.data_ptr(), _stream(xyz)),
+                   "ball_query_full")
+    return idx
+
+
 def query_and_group(radius, nsample, xyz, new_xyz, features=None, use_xyz=True):
     """Fused QueryAndGroup.forward (pointnet2_utils.py:299-322) -> (new_features, idx)."""
     p, q = _ptr(xyz, F32, "xyz"), _ptr(new_xyz, F32, "new_xyz")

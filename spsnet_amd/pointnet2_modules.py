@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused as _fused
 from . import pointnet2_batch_cuda as _ext
 from . import pointnet2_utils
 
@@ -61,7 +62,41 @@ class _PointnetSAModuleBase(nn.Module):
         cross = torch.matmul(a, b.transpose(1, 2))
         return a_sq.expand(-1, -1, b.shape[1]) + b_sq.expand(-1, a.shape[1], -1) - 2.0 * cross
 
+    def _fused_plan(self, xyz, new_xyz, features):
+        """Packed weights per scale if the whole layer can run on the fused MFMA path: inference
+        (no gradient wanted, BatchNorm in eval mode), max pooling, plain ball-query groupers with
+        use_xyz, 3-layer MLPs whose widths the kernel supports, B*M*nsample a multiple of 32."""
+        if self.training or self.pool_method != 'max_pool' or not xyz.is_cuda:
+            return None
+        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (xyz, new_xyz, features)):
+            return None
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.mlps.parameters()):
+            return None
+        plan = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            if type(grouper) is not pointnet2_utils.QueryAndGroup or not grouper.use_xyz:
+                return None
+            if (xyz.shape[0] * new_xyz.shape[1] * grouper.nsample) % 32 != 0:
+                return None
+            packed = _fused.pack_scale(mlp, grouper.nsample)
+            if packed is None:
+                return None
+            plan.append(packed)
+        return plan
+
     def _group_mlp_pool(self, xyz, new_xyz, features):
+        plan = self._fused_plan(xyz, new_xyz, features)
+        if plan:
+            xyz_c, new_c = xyz.contiguous(), new_xyz.contiguous()
+            feats_c = features.contiguous() if features is not None else None
+            out = torch.empty((xyz.shape[0], sum(p.c3_real for p in plan), new_xyz.shape[1]),
+                              dtype=torch.float32, device=xyz.device)
+            offset = 0
+            for grouper, packed in zip(self.groupers, plan):
+                idx = _ext.ball_query_full(grouper.radius, grouper.nsample, xyz_c, new_c)
+                _fused.group_mlp_pool(xyz_c, new_c, feats_c, idx, packed, out, offset)
+                offset += packed.c3_real
+            return out
         scales = []
         for grouper, mlp in zip(self.groupers, self.mlps):
             grouped = grouper(xyz, new_xyz, features)      # (B, C, M, ns)

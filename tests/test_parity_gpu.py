@@ -393,3 +393,68 @@ def test_training_step_backward_runs(ext, G, dev):
     (nf.square().mean() + cls.square().mean()).backward()
     assert feats.grad is not None and torch.isfinite(feats.grad).all() and feats.grad.abs().sum() > 0
     assert all(p.grad is not None for p in mod.parameters())
+
+
+# ------------------------------------------------------------------ fused MFMA grouped MLP
+FUSED_CASES = [  # (c_feat, mlp widths, nsample, radius)
+    (1, [16, 16, 32], 16, 0.4), (1, [32, 32, 64], 32, 0.9), (64, [64, 64, 128], 16, 0.8), (64, [64, 96, 128], 32, 1.6),
+    (128, [128, 128, 256], 16, 1.6), (128, [128, 256, 256], 32, 3.0), (124, [124, 64, 128], 16, 0.8),
+    (5, [16, 16, 20], 32, 1.0), (0, [32, 32, 64], 16, 0.7),
+]
+
+
+@pytest.mark.parametrize("c_feat,widths,ns,radius", FUSED_CASES)
+def test_fused_group_mlp_matches_unfused(ext, G, dev, c_feat, widths, ns, radius):
+    """sps_sa_group_mlp (gather + 3 MFMA layers with folded BN + max-pool) against the unfused
+    Conv2d/BatchNorm2d/ReLU/max_pool2d path on the same weights (tolerance of BASELINE.json: 1e-4)."""
+    from spsnet_amd import pointnet2_modules as M
+    torch.manual_seed(c_feat * 100 + ns)
+    mod = M.PointnetSAModuleMSG_WithSampling(
+        npoint_list=[256], sample_range_list=[-1], sample_type_list=['D-FPS'], radii=[radius], nsamples=[ns],
+        mlps=[[c_feat] + list(widths)], use_xyz=True, dilated_group=False, aggregation_mlp=None, confidence_mlp=None,
+        num_class=3).to(dev).eval()
+    gen = torch.Generator().manual_seed(1)
+    for m_ in mod.modules():
+        if isinstance(m_, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m_.running_mean.copy_(torch.randn(m_.num_features, generator=gen) * 0.2)
+                m_.running_var.copy_(torch.rand(m_.num_features, generator=gen) + 0.5)
+                m_.weight.copy_(torch.rand(m_.num_features, generator=gen) + 0.5)
+                m_.bias.copy_(torch.randn(m_.num_features, generator=gen) * 0.2)
+    rng = np.random.default_rng(ns + c_feat)
+    xyz = G.t(cloud(rng, 2, 3000, dup=0.02))
+    feats = G.t(rng.normal(size=(2, c_feat, 3000)).astype(np.float32)) if c_feat else None
+    if feats is None:  # the module slices features when sampling: give it a dummy and drop it for grouping
+        pytest.skip("feature-less SA layers are not built by any config")
+    with torch.no_grad():
+        assert mod._fused_plan(xyz, xyz[:, :256].contiguous(), feats) is not None, "fused path not taken"
+        new_xyz, fused, _, idx, _ = mod(xyz, feats)
+        plan = mod._fused_plan
+        mod._fused_plan = lambda *a, **k: None  # force the unfused path
+        try:
+            _, unfused, _, idx2, _ = mod(xyz, feats)
+        finally:
+            mod._fused_plan = plan
+    assert torch.equal(idx, idx2)
+    scale = max(1.0, float(unfused.abs().max()))
+    assert float((fused - unfused).abs().max()) <= 1e-4 * scale
+    assert fused.shape == unfused.shape
+
+
+def test_fused_full_width_stack_against_cpu_oracle(ext, G, dev):
+    """IA-SSD L0-L2 at full channel widths (fused MFMA path) against the CPU oracle stack."""
+    from oracle import cpu_stack
+    from spsnet_amd import pointnet2_modules as M, sa_stack, scenes
+    cfg = sa_stack.scaled_config(npoints=[1024, 256, 128])
+    layers = sa_stack.build_sa_layers(M, cfg, seed=5)
+    xyz, feats = scenes.make_batch("kitti-lidar-v1", 2, 4096, seed0=77, dup_fraction=0.01)
+    want = cpu_stack.sa_stack_cpu(cpu_stack.cpu_copy(layers), xyz, feats)
+    layers = layers.to(dev)
+    with torch.no_grad():
+        got = sa_stack.run_sa_layers(layers, G.t(xyz), G.t(feats))
+    for k in (0, 1):
+        np.testing.assert_array_equal(G.n(got[k][3]), want[k][3])
+        np.testing.assert_array_equal(G.n(got[k][0]), want[k][0])
+        ref = want[k][1]
+        assert float(np.abs(G.n(got[k][1]) - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(G.n(got[1][2]), want[1][2], rtol=1e-4, atol=1e-4)
