@@ -39,6 +39,14 @@ int sps_abi_version(void);
 const char *sps_last_error(void);
 /* block size the reference would use for an n-point FPS (cuda_utils.h:10-14) */
 int sps_opt_n_threads(int work_size);
+/* FPS kernel selection: 0 = automatic (spatially pruned kernel where it applies), 1 = brute-force
+ * register-resident / streaming kernels only.  Both give bit-identical results; returns the old mode. */
+int sps_set_fps_mode(int mode);
+
+/* DIAGNOSTIC ONLY: s_memtime-instrumented build of the pruned FPS kernel (never on the product path).
+ * dbg (B, 8 waves, 8) u64 receives per-wave cycle sums of the loop segments. */
+int sps_debug_fps_profile(int b, int n, int m, const float *dataset, float *temp, int *idxs,
+                          unsigned long long *dbg, sps_stream_t stream);
 
 /* ---- the 11 functions of pointnet2_batch_cuda (src/pointnet2_api.cpp:10-26) ---------- */
 

@@ -203,6 +203,8 @@ __global__ __launch_bounds__(FPS_MAX_THREADS) void fps_stream_kernel(
     }
 }
 
+static int g_fps_mode = 0;  // 0 = auto (pruned where it applies), 1 = brute-force kernels only
+
 static int ilog2(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
 
 template <bool DIST>
@@ -210,6 +212,10 @@ static int launch_fps(int b, int n, int m, const float *dataset, float *temp, in
     if (b < 0 || n <= 0 || m < 0) return fail(SPS_ERR_INVALID, "fps: bad shape b=%d n=%d m=%d", b, n, m);
     if (b == 0 || m == 0) return SPS_OK;
     if (!dataset || !temp || !idxs) return fail(SPS_ERR_INVALID, "fps: null pointer");
+    if (!DIST && g_fps_mode == 0) {  // spatially pruned variant (fps_pruned.hip) where it applies
+        const int rc = launch_fps_pruned(b, n, m, dataset, temp, idxs, st);
+        if (rc >= 0) return rc;
+    }
     const int bs = sps_opt_n_threads(n);
     const int l2 = ilog2(bs);
     const int threads = bs < 64 ? 64 : bs;
@@ -234,6 +240,19 @@ static int launch_fps(int b, int n, int m, const float *dataset, float *temp, in
 }
 
 }  // namespace sps
+
+extern "C" int sps_set_fps_mode(int mode) {
+    const int old = sps::g_fps_mode;
+    sps::g_fps_mode = mode;
+    return old;
+}
+
+// Diagnostic only (tools/fps_profile.py): runs the s_memtime-instrumented build of the pruned kernel and
+// fills dbg[b][8 waves][8] = {test, update, wave-reduce, publish, barrier, pick, touched, tie-path} sums.
+extern "C" int sps_debug_fps_profile(int b, int n, int m, const float *dataset, float *temp, int *idxs,
+                                     unsigned long long *dbg, sps_stream_t stream) {
+    return sps::launch_fps_pruned_profile(b, n, m, dataset, temp, idxs, dbg, sps::as_stream(stream));
+}
 
 extern "C" int sps_opt_n_threads(int work_size) {
     // cuda_utils.h:10-14 (double log, truncation, clamp to [1, 1024])

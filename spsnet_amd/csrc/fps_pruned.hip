@@ -1,0 +1,458 @@
+// fps_pruned.hip -- exact farthest point sampling with spatial pruning (gfx950).
+//
+// Same contract and bit-identical results as fps.hip / the reference kernel
+// (pcdet/ops/pointnet2/pointnet2_batch/src/sampling_gpu.cu:93-208), including the
+// block-size-dependent tie rule (winner = largest running min-distance; ties -> smallest
+// bit-reversed reference thread (k mod BS), then smallest k), but it does NOT touch every point in
+// every iteration.
+//
+// Observation: once j samples exist, a new centre only lowers the running distance of the few points
+// that are closer to it than to every earlier sample (about N/j of them).  The kernel therefore
+//   1. sorts the scene's points by a 12-bit Morton-like cell key (in-kernel LDS counting sort), so
+//      that every run of 64 consecutive sorted points -- a BUCKET -- is spatially compact;
+//   2. keeps each bucket's points and running distances in the VGPRs of one wave (bucket g lives in
+//      slot g / W of wave g % W: neighbouring buckets sit in different waves) together with the bucket's
+//      bounding box, its current maximum distance and that maximum's tie-break rank and coordinates;
+//   3. per iteration tests every bucket against the new centre with ONE lane per bucket:
+//           lb = sqdist(clamp(centre, box), centre)     (same fp32 operation sequence as the real distance)
+//      Rounding is monotone, so lb <= the computed distance of every point in the box; if lb >= the
+//      bucket's maximum running distance, min(d, temp) == temp for all its points and the bucket is
+//      skipped WITHOUT changing any result.  On KITTI-shaped clouds ~6 of 256 buckets survive the test;
+//   4. re-evaluates only the surviving buckets (64 points, one per lane), refreshes their cached
+//      maximum, and reduces the per-bucket maxima: DPP inside the wave, one 64-bit LDS atomic max
+//      {distance | inverted rank | wave} across waves, ONE s_barrier per iteration.
+// The arithmetic on every point that IS evaluated is exactly the reference's, and skipped points are
+// provably unchanged, so indices and the final `temp` array are bit-identical to the brute-force sweep.
+#include "sps_common.h"
+
+#include <math.h>
+
+#include <type_traits>
+
+namespace sps {
+
+constexpr int PF_WAVES = 8;
+constexpr int PF_THREADS = PF_WAVES * 64;
+constexpr int PF_KEY_BITS = 12;
+constexpr int PF_BINS = 1 << PF_KEY_BITS;
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_or(int v, int identity) {
+    // lanes without a DPP source read `identity`
+    return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ int wave_max_i32_id(int v) {
+    constexpr int ID = (int)0x80000000;
+    v = imax(v, dpp_or<DPP_ROW_SHR1>(v, ID));
+    v = imax(v, dpp_or<DPP_ROW_SHR2>(v, ID));
+    v = imax(v, dpp_or<DPP_ROW_SHR4>(v, ID));
+    v = imax(v, dpp_or<DPP_ROW_SHR8>(v, ID));
+    v = imax(v, dpp_or<DPP_ROW_BCAST15, 0xA>(v, ID));
+    v = imax(v, dpp_or<DPP_ROW_BCAST31, 0xC>(v, ID));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// v_min_f32 without the canonicalising v_max hipcc puts in front of fminf(): IEEE mode already returns the
+// non-NaN operand, which is all the reference's min() needs
+__device__ __forceinline__ float fmin_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int wave_min_i32_id(int v) { return ~wave_max_i32_id(~v); }
+
+__device__ __forceinline__ float wave_allmin_f32(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_allmax_f32(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+struct PfGrid {       // wave-uniform description of the cell grid used for the spatial sort
+    float lo[3], scale[3];
+    int lim[3];              // cells per axis - 1
+    int axis[PF_KEY_BITS];   // key bit i (MSB first) is bit shift[i] of the cell coordinate on axis[i]
+    int shift[PF_KEY_BITS];
+};
+
+__device__ __forceinline__ int pf_cell_key(const PfGrid &g, float x, float y, float z) {
+    const float p[3] = {x, y, z};
+    int qv[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float u = (p[a] - g.lo[a]) * g.scale[a];
+        const int c = (u > 0.f) ? (int)fminf(u, (float)g.lim[a]) : 0;  // NaN / negative -> cell 0
+        qv[a] = c > g.lim[a] ? g.lim[a] : c;
+    }
+    int key = 0;
+#pragma unroll
+    for (int i = 0; i < PF_KEY_BITS; ++i) {
+        const int qa = g.axis[i] == 0 ? qv[0] : (g.axis[i] == 1 ? qv[1] : qv[2]);
+        key = (key << 1) | ((qa >> g.shift[i]) & 1);
+    }
+    return key;
+}
+
+struct PfShared {
+    int hist[PF_BINS];
+    float4 rec[2][PF_WAVES];
+    unsigned long long slot[3];
+    float red[6][PF_WAVES];
+    int wsum[PF_WAVES];
+};
+
+// tie-break rank of point k under the reference's block size bs = 2^l2: bit-reversed (k mod bs), then k / bs
+__device__ __forceinline__ unsigned pf_rank(unsigned k, int bs, int l2, int rb) {
+    const unsigned lowrev = (l2 == 0) ? 0u : (__brev(k & (unsigned)(bs - 1)) >> (32 - l2));
+    return (lowrev << rb) | (k >> l2);
+}
+__device__ __forceinline__ unsigned pf_unrank(unsigned rank, int l2, int rb) {
+    const unsigned hi = rank >> rb, lo = rank & ((1u << rb) - 1u);
+    const unsigned low = (l2 == 0) ? 0u : (__brev(hi) >> (32 - l2));
+    return (lo << l2) | low;
+}
+
+// P = bucket slots per wave: the wave holds P buckets x 64 points; N <= P * PF_THREADS.
+// PROF = diagnostic build: per-wave s_memtime sums of the loop segments go to `dbg` (never shipped on the
+// product path; the timed kernel is the PROF = false instantiation).
+template <int P, bool PROF = false>
+__global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
+    int n, int m, int bs, int l2, int rb, const float *__restrict__ dataset, float *__restrict__ temp,
+    int *__restrict__ idxs, unsigned long long *__restrict__ dbg = nullptr) {
+    if (m <= 0) return;
+    __shared__ PfShared sh;
+    __shared__ unsigned short sorted[P * PF_THREADS];
+
+    const int scene = blockIdx.x;
+    const float *xyz = dataset + (size_t)scene * n * 3;
+    temp += (size_t)scene * n;
+    idxs += (size_t)scene * m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ------------------------------------------------------------------ spatial sort (once)
+    float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = tid; k < n; k += PF_THREADS) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = xyz[k * 3 + a];
+            lo3[a] = fminf(lo3[a], v);
+            hi3[a] = fmaxf(hi3[a], v);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo3[a] = wave_allmin_f32(lo3[a]);
+        hi3[a] = wave_allmax_f32(hi3[a]);
+        if (lane == 0) { sh.red[a][wave] = lo3[a]; sh.red[3 + a][wave] = hi3[a]; }
+    }
+    for (int i = tid; i < PF_BINS; i += PF_THREADS) sh.hist[i] = 0;
+    __syncthreads();
+    PfGrid grid;
+    {
+        float ext[3];
+        int nb0 = 0, nb1 = 0, nb2 = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float l = sh.red[a][0], h = sh.red[3 + a][0];
+#pragma unroll
+            for (int w = 1; w < PF_WAVES; ++w) { l = fminf(l, sh.red[a][w]); h = fmaxf(h, sh.red[3 + a][w]); }
+            float e = h - l;
+            if (!(e > 0.f) || !(e < 3.0e38f)) e = 0.f;  // degenerate / infinite extent: one cell on this axis
+            grid.lo[a] = (l > -3.0e38f && l < 3.0e38f) ? l : 0.f;
+            ext[a] = e;
+        }
+        // hand out the key bits one at a time to the axis whose cells are currently the longest
+        float c0 = ext[0], c1 = ext[1], c2 = ext[2];
+#pragma unroll
+        for (int i = 0; i < PF_KEY_BITS; ++i) {
+            int a = 0;
+            float cm = c0;
+            if (c1 > cm) { a = 1; cm = c1; }
+            if (c2 > cm) { a = 2; }
+            grid.axis[i] = a;
+            if (a == 0) { nb0 += 1; c0 *= 0.5f; } else if (a == 1) { nb1 += 1; c1 *= 0.5f; } else { nb2 += 1; c2 *= 0.5f; }
+        }
+        int u0 = 0, u1 = 0, u2 = 0;
+#pragma unroll
+        for (int i = 0; i < PF_KEY_BITS; ++i) {  // the j-th bit given to an axis is its j-th most significant cell bit
+            const int a = grid.axis[i];
+            if (a == 0) { u0 += 1; grid.shift[i] = nb0 - u0; } else if (a == 1) { u1 += 1; grid.shift[i] = nb1 - u1; } else { u2 += 1; grid.shift[i] = nb2 - u2; }
+        }
+        const int nbs[3] = {nb0, nb1, nb2};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            grid.lim[a] = (1 << nbs[a]) - 1;
+            grid.scale[a] = (ext[a] > 0.f) ? (float)(1 << nbs[a]) / ext[a] : 0.f;
+        }
+    }
+    // cell keys of this thread's points stay in registers between the histogram and the scatter pass
+    int ckey[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int k = tid + i * PF_THREADS;
+        ckey[i] = 0;
+        if (k < n) {
+            ckey[i] = pf_cell_key(grid, xyz[k * 3], xyz[k * 3 + 1], xyz[k * 3 + 2]);
+            atomicAdd(&sh.hist[ckey[i]], 1);
+        }
+    }
+    __syncthreads();
+    {   // exclusive prefix sum of the histogram: 8 bins per thread, wave scan, cross-wave offsets
+        constexpr int PER = PF_BINS / PF_THREADS;
+        int loc[PER], sum = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { loc[i] = sh.hist[tid * PER + i]; sum += loc[i]; }
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) sh.wsum[wave] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += sh.wsum[w];
+        int run = base + incl - sum;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { sh.hist[tid * PER + i] = run; run += loc[i]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int k = tid + i * PF_THREADS;
+        if (k < n) sorted[atomicAdd(&sh.hist[ckey[i]], 1)] = (unsigned short)k;
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ load the wave's buckets
+    // bucket g = s * PF_WAVES + wave lives in slot s; lane l holds sorted position g*64 + l
+    float x[P], y[P], z[P], t[P];
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+        const int pos = (s * PF_WAVES + wave) * 64 + lane;
+        const bool ok = pos < n;
+        const int k = ok ? (int)sorted[pos] : 0;
+        x[s] = ok ? xyz[k * 3 + 0] : NAN;  // NaN coordinates: never inside a box, distance stays -1
+        y[s] = ok ? xyz[k * 3 + 1] : NAN;
+        z[s] = ok ? xyz[k * 3 + 2] : NAN;
+        t[s] = ok ? temp[k] : -1.f;
+    }
+
+    // per-bucket metadata, bucket s of this wave in lane s
+    float blo_x = INFINITY, blo_y = INFINITY, blo_z = INFINITY, bhi_x = -INFINITY, bhi_y = -INFINITY, bhi_z = -INFINITY;
+    int bmax = __float_as_int(-1.f);          // bits of the bucket's largest running distance
+    unsigned bkeylo = 0;                       // (0x0FFFFFFF - rank of that point) << 4
+    float bpx = 0.f, bpy = 0.f, bpz = 0.f;    // its coordinates
+
+    // recompute bucket S's cached maximum (after its distances changed)
+    unsigned long long nslow = 0;  // (PROF) refreshes that needed the tie-break path
+    auto refresh = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+        const int tb = __float_as_int(t[S]);
+        const int vmax = wave_max_i32_id(tb);
+        unsigned long long eq = __ballot(tb == vmax);
+        int wl = __builtin_ctzll(eq);
+        unsigned rank;
+        if (__builtin_popcountll(eq) > 1) {  // equal distances: the reference's tie rule decides
+            if constexpr (PROF) nslow += 1;
+            const int pos = (S * PF_WAVES + wave) * 64 + lane;
+            const unsigned myrank = (tb == vmax && pos < n) ? pf_rank(sorted[pos < n ? pos : 0], bs, l2, rb) : 0x7FFFFFFFu;
+            rank = (unsigned)wave_min_i32_id((int)myrank);
+            eq = __ballot(myrank == rank);
+            wl = __builtin_ctzll(eq);
+        } else {
+            const int pos = (S * PF_WAVES + wave) * 64 + wl;
+            rank = pf_rank(sorted[pos < n ? pos : 0], bs, l2, rb);
+        }
+        const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[S]), wl));
+        const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y[S]), wl));
+        const float pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z[S]), wl));
+        if (lane == S) {
+            bmax = vmax;
+            bkeylo = (0x0FFFFFFFu - rank) << 4;
+            bpx = px; bpy = py; bpz = pz;
+        }
+    };
+    // static dispatch: call f(integral_constant<s>) for the wave-uniform runtime slot s (register arrays
+    // need compile-time indices; the switch lowers to a branch tree / jump table)
+#define SPS_PF_SLOT(c) case c: if constexpr (c < P) f(std::integral_constant<int, (c < P ? c : 0)>{}); break;
+    auto for_slot = [&](int s, auto &&f) {
+        switch (s) {
+            SPS_PF_SLOT(0) SPS_PF_SLOT(1) SPS_PF_SLOT(2) SPS_PF_SLOT(3) SPS_PF_SLOT(4) SPS_PF_SLOT(5) SPS_PF_SLOT(6) SPS_PF_SLOT(7)
+            SPS_PF_SLOT(8) SPS_PF_SLOT(9) SPS_PF_SLOT(10) SPS_PF_SLOT(11) SPS_PF_SLOT(12) SPS_PF_SLOT(13) SPS_PF_SLOT(14) SPS_PF_SLOT(15)
+            SPS_PF_SLOT(16) SPS_PF_SLOT(17) SPS_PF_SLOT(18) SPS_PF_SLOT(19) SPS_PF_SLOT(20) SPS_PF_SLOT(21) SPS_PF_SLOT(22) SPS_PF_SLOT(23)
+            SPS_PF_SLOT(24) SPS_PF_SLOT(25) SPS_PF_SLOT(26) SPS_PF_SLOT(27) SPS_PF_SLOT(28) SPS_PF_SLOT(29) SPS_PF_SLOT(30) SPS_PF_SLOT(31)
+            SPS_PF_SLOT(32) SPS_PF_SLOT(33) SPS_PF_SLOT(34) SPS_PF_SLOT(35) SPS_PF_SLOT(36) SPS_PF_SLOT(37) SPS_PF_SLOT(38) SPS_PF_SLOT(39)
+            default: break;
+        }
+    };
+#undef SPS_PF_SLOT
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+        const float lx = wave_allmin_f32(x[s]), ly = wave_allmin_f32(y[s]), lz = wave_allmin_f32(z[s]);
+        const float hx = wave_allmax_f32(x[s]), hy = wave_allmax_f32(y[s]), hz = wave_allmax_f32(z[s]);
+        if (lane == s) { blo_x = lx; blo_y = ly; blo_z = lz; bhi_x = hx; bhi_y = hy; bhi_z = hz; }
+    }
+    for (int s = 0; s < P; ++s) for_slot(s, refresh);
+
+    if (tid == 0) {
+        idxs[0] = 0;
+        sh.slot[0] = 0ull; sh.slot[1] = 0ull; sh.slot[2] = 0ull;
+    }
+    float cx = xyz[0], cy = xyz[1], cz = xyz[2];
+    __syncthreads();
+
+    // this wave's current candidate (refreshed only when one of its buckets changed)
+    unsigned long long cand_key = 0ull;
+    float cand_x = 0.f, cand_y = 0.f, cand_z = 0.f;
+    bool cand_stale = true;
+    int slot_cur = 1;  // == j % 3
+
+    // ------------------------------------------------------------------ sampling loop
+    unsigned long long tseg[6] = {0, 0, 0, 0, 0, 0}, ntouch = 0;
+    nslow = 0;
+    auto stamp = [&]() -> unsigned long long {
+        if constexpr (PROF) {
+            unsigned long long tt;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            return tt;
+        } else {
+            return 0ull;
+        }
+    };
+    for (int j = 1; j < m; ++j) {
+        const unsigned long long s0 = stamp();
+        // 1. one lane per bucket: can the new centre lower any distance in the box?
+        const float qx = __builtin_amdgcn_fmed3f(cx, blo_x, bhi_x);
+        const float qy = __builtin_amdgcn_fmed3f(cy, blo_y, bhi_y);
+        const float qz = __builtin_amdgcn_fmed3f(cz, blo_z, bhi_z);
+        const float lb = sqdist(qx, qy, qz, cx, cy, cz);
+        const bool skip = lb >= __int_as_float(bmax);  // NaN -> not skipped
+        unsigned long long todo = __ballot(!skip && lane < P);
+        // 2. re-evaluate the surviving buckets (exactly the reference arithmetic, one point per lane)
+        if (todo) cand_stale = true;
+        const unsigned long long s1 = stamp();
+        if constexpr (PROF) ntouch += __builtin_popcountll(todo);
+        while (todo) {
+            const int s = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            for_slot(s, [&](auto S_) {
+                constexpr int S = decltype(S_)::value;
+                // opaque copy of the centre: keeps hipcc from hoisting the distance evaluation of EVERY slot
+                // out of the switch (it is loop-invariant inside this while loop)
+                float ox = cx, oy = cy, oz = cz;
+                asm volatile("" : "+s"(ox), "+s"(oy), "+s"(oz));
+                const float d = sqdist(x[S], y[S], z[S], ox, oy, oz);
+                t[S] = fmin_raw(d, t[S]);
+                refresh(S_);
+            });
+        }
+        const unsigned long long s2 = stamp();
+        // 3. the wave's best bucket: largest distance, then largest inverted rank
+        if (cand_stale) {
+            const int vmax = wave_max_i32_id(lane < P ? bmax : (int)0x80000000);
+            unsigned long long eq = __ballot(lane < P && bmax == vmax);
+            int wl = __builtin_ctzll(eq);
+            if (__builtin_popcountll(eq) > 1) {
+                const int kl = (lane < P && bmax == vmax) ? (int)(bkeylo >> 4) : -1;
+                const int kbest = wave_max_i32_id(kl);
+                wl = __builtin_ctzll(__ballot(kl == kbest));
+            }
+            const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)bkeylo, wl) | (unsigned)wave;
+            const unsigned khi = (unsigned)vmax ^ 0x80000000u;  // -1.0f (empty) sorts below +0
+            cand_key = ((unsigned long long)khi << 32) | klo;
+            cand_x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bpx), wl));
+            cand_y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bpy), wl));
+            cand_z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bpz), wl));
+            cand_stale = false;
+        }
+        const unsigned long long s3 = stamp();
+        // 4. across waves: one 64-bit LDS atomic max, one barrier
+        const int buf = j & 1, sl = slot_cur;
+        if (lane == 0) {
+            sh.rec[buf][wave] = make_float4(cand_x, cand_y, cand_z, 0.f);
+            atomicMax(&sh.slot[sl], cand_key);
+        }
+        slot_cur = (slot_cur == 2) ? 0 : slot_cur + 1;
+        if (tid == 0) sh.slot[slot_cur] = 0ull;  // next iteration's slot: its readers all passed the previous barrier
+        const unsigned long long s4 = stamp();
+        __syncthreads();
+        const unsigned long long s5 = stamp();
+        const unsigned long long win = sh.slot[sl];
+        const float4 mine = sh.rec[buf][lane & (PF_WAVES - 1)];
+        const int ww = (int)(win & 0xFull);
+        cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), ww));
+        cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), ww));
+        cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), ww));
+        if (tid == 0) {
+            const unsigned rank = 0x0FFFFFFFu - (unsigned)((win >> 4) & 0x0FFFFFFFull);
+            idxs[j] = (int)pf_unrank(rank, l2, rb);
+        }
+        if constexpr (PROF) {
+            const unsigned long long s6 = stamp();
+            tseg[0] += s1 - s0; tseg[1] += s2 - s1; tseg[2] += s3 - s2; tseg[3] += s4 - s3; tseg[4] += s5 - s4; tseg[5] += s6 - s5;
+        }
+    }
+    if constexpr (PROF) {
+        if (lane == 0 && dbg) {
+            unsigned long long *o = dbg + ((size_t)scene * PF_WAVES + wave) * 8;
+            for (int i = 0; i < 6; ++i) o[i] = tseg[i];
+            o[6] = ntouch; o[7] = nslow;
+        }
+    }
+
+    // the reference leaves the final running min-distances in `temp`
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+        const int pos = (s * PF_WAVES + wave) * 64 + lane;
+        if (pos < n) temp[sorted[pos]] = t[s];
+    }
+}
+
+// diagnostic: P = 32 profile build on one configuration (tools/fps_profile.py)
+int launch_fps_pruned_profile(int b, int n, int m, const float *dataset, float *temp, int *idxs,
+                              unsigned long long *dbg, hipStream_t st) {
+    if (divup(n, PF_THREADS) > 32 || n < 2048) return fail(SPS_ERR_INVALID, "fps profile build: 2048 <= n <= 16384");
+    const int bs = sps_opt_n_threads(n);
+    int l2 = 0;
+    while ((1 << (l2 + 1)) <= bs) ++l2;
+    int rb = 0;
+    while ((1 << rb) < divup(n, bs)) ++rb;
+    hipLaunchKernelGGL((fps_pruned_kernel<32, true>), dim3(b), dim3(PF_THREADS), 0, st, n, m, bs, l2, rb, dataset, temp,
+                       idxs, dbg);
+    return check_launch("fps_pruned_kernel<profile>");
+}
+
+// returns SPS_OK after launching, or -1 if this variant does not apply (caller falls back to fps.hip)
+int launch_fps_pruned(int b, int n, int m, const float *dataset, float *temp, int *idxs, hipStream_t st) {
+    if (n < 2048 || n > 40 * PF_THREADS || n > 65535) return -1;
+    const int bs = sps_opt_n_threads(n);
+    int l2 = 0;
+    while ((1 << (l2 + 1)) <= bs) ++l2;
+    int rb = 0;
+    while ((1 << rb) < divup(n, bs)) ++rb;
+    const int P = divup(n, PF_THREADS);
+    dim3 grid(b), block(PF_THREADS);
+#define SPS_PF_CASE(PP)                                                                                        \
+    if (P <= PP) {                                                                                             \
+        hipLaunchKernelGGL((fps_pruned_kernel<PP, false>), grid, block, 0, st, n, m, bs, l2, rb, dataset, temp, idxs, \
+                           (unsigned long long *)nullptr);                                                     \
+        return check_launch("fps_pruned_kernel");                                                             \
+    }
+    SPS_PF_CASE(4)
+    SPS_PF_CASE(8)
+    SPS_PF_CASE(16)
+    SPS_PF_CASE(24)
+    SPS_PF_CASE(32)
+    SPS_PF_CASE(40)
+#undef SPS_PF_CASE
+    return -1;
+}
+
+}  // namespace sps

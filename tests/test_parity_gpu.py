@@ -458,3 +458,48 @@ def test_fused_full_width_stack_against_cpu_oracle(ext, G, dev):
         ref = want[k][1]
         assert float(np.abs(G.n(got[k][1]) - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
     np.testing.assert_allclose(G.n(got[1][2]), want[1][2], rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------ pruned vs brute-force FPS kernels
+@pytest.mark.parametrize("N,m,kind", [(2048, 512, "lattice"), (4096, 1024, "dup"), (5000, 700, "dup"), (16384, 4096, "kitti"),
+                                      (16384, 600, "lattice"), (20480, 300, "dup"), (12345, 999, "uniform")])
+def test_fps_pruned_equals_bruteforce_and_oracle(ext, G, oracle, N, m, kind):
+    """Both FPS kernel families (spatially pruned / brute-force register-resident) against the oracle,
+    indices AND final running distances bit-exact."""
+    from spsnet_amd import _lib, scenes
+    rng = np.random.default_rng(N + m)
+    if kind == "lattice":
+        xyz = cloud(rng, 2, N, lattice=True)
+    elif kind == "kitti":
+        xyz, _ = scenes.make_batch("kitti-lidar-v1", 2, N, seed0=11, dup_fraction=0.02)
+    elif kind == "uniform":
+        xyz, _ = scenes.make_batch("uniform-v1", 2, N, seed0=12)
+    else:
+        xyz = cloud(rng, 2, N, dup=0.2)
+    want, want_t = oracle.fps(xyz, m, return_temp=True)
+    L = _lib.load()
+    for mode in (0, 1):
+        old = L.sps_set_fps_mode(mode)
+        try:
+            got, got_t = G.fps(ext, xyz, m)
+        finally:
+            L.sps_set_fps_mode(old)
+        np.testing.assert_array_equal(got, want, err_msg=f"fps mode {mode}")
+        np.testing.assert_array_equal(got_t, want_t, err_msg=f"fps mode {mode}")
+
+
+def test_fps_pruned_degenerate_clouds(ext, G, oracle):
+    """All points identical / collinear / containing NaN and Inf: the cell grid degenerates, results must not."""
+    N, m = 4096, 300
+    same = np.ones((1, N, 3), np.float32) * 2.5
+    line = np.zeros((1, N, 3), np.float32)
+    line[0, :, 0] = np.random.default_rng(0).permutation(N).astype(np.float32) * 0.01
+    bad = cloud(np.random.default_rng(1), 1, N)
+    bad[0, 17] = np.nan
+    bad[0, 900, 2] = np.inf
+    bad[0, 901, 0] = -np.inf
+    for xyz in (same, line, bad):
+        want, want_t = oracle.fps(xyz, m, return_temp=True)
+        got, got_t = G.fps(ext, xyz, m)
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(got_t, want_t)

@@ -1,0 +1,21 @@
+"""Where does an iteration of the pruned FPS kernel spend its cycles?  (diagnostic build, s_memtime stamps)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from spsnet_amd import _lib, scenes
+L = _lib.load()
+B, N, M = 8, int(sys.argv[1]) if len(sys.argv) > 1 else 16384, int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+xyz, _ = scenes.make_batch("kitti-lidar-v1", B, N, seed0=0)
+x = torch.from_numpy(xyz).cuda()
+temp = torch.full((B, N), 1e10, device="cuda")
+idx = torch.zeros((B, M), dtype=torch.int32, device="cuda")
+dbg = torch.zeros((B, 8, 8), dtype=torch.int64, device="cuda")
+_lib.check(L.sps_debug_fps_profile(B, N, M, x.data_ptr(), temp.data_ptr(), idx.data_ptr(), dbg.data_ptr(), 0), "profile")
+torch.cuda.synchronize()
+d = dbg.cpu().numpy().astype(np.float64)
+names = ["test", "update", "wave-reduce", "publish", "barrier", "pick"]
+it = M - 1
+print(f"N={N} m={M}: per-iteration cycles per wave (mean over scenes), stamp cost ~40 included in each segment")
+for w in range(8):
+    row = d[:, w].mean(0)
+    print(f"wave {w}: " + "  ".join(f"{n}={row[i]/it:7.1f}" for i, n in enumerate(names)) + f"  total={row[:6].sum()/it:7.1f}  touched/iter={row[6]/it:.2f} tie-path/iter={row[7]/it:.3f}")
