@@ -230,12 +230,19 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
 
     // ------------------------------------------------------------------ load the wave's buckets
     // bucket g = s * PF_WAVES + wave lives in slot s; lane l holds sorted position g*64 + l
-    float x[P], y[P], z[P], t[P];
+    // Register-resident buckets as VECTORS: a wave-uniform runtime slot index then lowers to VGPR-index mode
+    // (s_set_gpr_idx_on + v_mov) instead of a branch tree over P cases -- taken branches are what a lone wave
+    // pays most for (instruction-buffer refill), and there is one dispatch per touched bucket.
+    typedef float vfP __attribute__((ext_vector_type(P)));
+    typedef int viP __attribute__((ext_vector_type(P)));
+    vfP x, y, z, t;
+    viP rk;  // tie-break rank of the point (0x0FFFFFFF for padding lanes)
 #pragma unroll
     for (int s = 0; s < P; ++s) {
         const int pos = (s * PF_WAVES + wave) * 64 + lane;
         const bool ok = pos < n;
         const int k = ok ? (int)sorted[pos] : 0;
+        rk[s] = ok ? (int)pf_rank((unsigned)k, bs, l2, rb) : 0x0FFFFFFF;
         x[s] = ok ? xyz[k * 3 + 0] : NAN;  // NaN coordinates: never inside a box, distance stays -1
         y[s] = ok ? xyz[k * 3 + 1] : NAN;
         z[s] = ok ? xyz[k * 3 + 2] : NAN;
@@ -250,54 +257,63 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
 
     // recompute bucket S's cached maximum (after its distances changed)
     unsigned long long nslow = 0;  // (PROF) refreshes that needed the tie-break path
-    auto refresh = [&](auto S_) {
-        constexpr int S = decltype(S_)::value;
-        const int tb = __float_as_int(t[S]);
+    int bhold = 0;                              // lane holding the bucket's maximum
+    // scalar results of the last refresh; committed to lane `slot` of the metadata registers by commit()
+    int r_vmax = 0, r_keylo = 0, r_px = 0, r_py = 0, r_pz = 0, r_wl = 0;
+    // recompute a bucket's maximum from its 64 running distances `tv` (ranks / coordinates of its points in
+    // rv, xv, yv, zv) -> r_*
+    auto refresh = [&](float tv, int rv, float xv, float yv, float zv) {
+        const int tb = __float_as_int(tv);
         const int vmax = wave_max_i32_id(tb);
         unsigned long long eq = __ballot(tb == vmax);
         int wl = __builtin_ctzll(eq);
-        unsigned rank;
         if (__builtin_popcountll(eq) > 1) {  // equal distances: the reference's tie rule decides
             if constexpr (PROF) nslow += 1;
-            const int pos = (S * PF_WAVES + wave) * 64 + lane;
-            const unsigned myrank = (tb == vmax && pos < n) ? pf_rank(sorted[pos < n ? pos : 0], bs, l2, rb) : 0x7FFFFFFFu;
-            rank = (unsigned)wave_min_i32_id((int)myrank);
-            eq = __ballot(myrank == rank);
-            wl = __builtin_ctzll(eq);
-        } else {
-            const int pos = (S * PF_WAVES + wave) * 64 + wl;
-            rank = pf_rank(sorted[pos < n ? pos : 0], bs, l2, rb);
+            const int inv = (tb == vmax) ? (0x0FFFFFFF - rv) : -1;
+            const int best = wave_max_i32_id(inv);
+            wl = __builtin_ctzll(__ballot(inv == best));
         }
-        const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[S]), wl));
-        const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y[S]), wl));
-        const float pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z[S]), wl));
-        if (lane == S) {
-            bmax = vmax;
-            bkeylo = (0x0FFFFFFFu - rank) << 4;
-            bpx = px; bpy = py; bpz = pz;
-        }
+        const int rank = __builtin_amdgcn_readlane(rv, wl);
+        r_px = __builtin_amdgcn_readlane(__float_as_int(xv), wl);
+        r_py = __builtin_amdgcn_readlane(__float_as_int(yv), wl);
+        r_pz = __builtin_amdgcn_readlane(__float_as_int(zv), wl);
+        r_vmax = vmax;
+        r_keylo = (int)((0x0FFFFFFFu - (unsigned)rank) << 4);
+        r_wl = wl;
     };
-    // static dispatch: call f(integral_constant<s>) for the wave-uniform runtime slot s (register arrays
-    // need compile-time indices; the switch lowers to a branch tree / jump table)
-#define SPS_PF_SLOT(c) case c: if constexpr (c < P) f(std::integral_constant<int, (c < P ? c : 0)>{}); break;
-    auto for_slot = [&](int s, auto &&f) {
-        switch (s) {
-            SPS_PF_SLOT(0) SPS_PF_SLOT(1) SPS_PF_SLOT(2) SPS_PF_SLOT(3) SPS_PF_SLOT(4) SPS_PF_SLOT(5) SPS_PF_SLOT(6) SPS_PF_SLOT(7)
-            SPS_PF_SLOT(8) SPS_PF_SLOT(9) SPS_PF_SLOT(10) SPS_PF_SLOT(11) SPS_PF_SLOT(12) SPS_PF_SLOT(13) SPS_PF_SLOT(14) SPS_PF_SLOT(15)
-            SPS_PF_SLOT(16) SPS_PF_SLOT(17) SPS_PF_SLOT(18) SPS_PF_SLOT(19) SPS_PF_SLOT(20) SPS_PF_SLOT(21) SPS_PF_SLOT(22) SPS_PF_SLOT(23)
-            SPS_PF_SLOT(24) SPS_PF_SLOT(25) SPS_PF_SLOT(26) SPS_PF_SLOT(27) SPS_PF_SLOT(28) SPS_PF_SLOT(29) SPS_PF_SLOT(30) SPS_PF_SLOT(31)
-            SPS_PF_SLOT(32) SPS_PF_SLOT(33) SPS_PF_SLOT(34) SPS_PF_SLOT(35) SPS_PF_SLOT(36) SPS_PF_SLOT(37) SPS_PF_SLOT(38) SPS_PF_SLOT(39)
-            default: break;
-        }
+    // bucket metadata lives in lane `slot`: six v_writelane with an SGPR lane select (no builtin exists).  The
+    // SGPR sources were produced by v_readlane / SALU; s_nop 3 covers the VALU-writes-SGPR wait states hipcc
+    // cannot see inside asm.
+    auto commit = [&](int slot) {
+        int m0 = bmax, m1 = (int)bkeylo, m2 = __float_as_int(bpx), m3 = __float_as_int(bpy), m4 = __float_as_int(bpz), m5 = bhold;
+        // two different SGPRs (data + lane select) exceed gfx9's one-scalar-operand limit, so the lane select goes
+        // through M0 (saved and restored: M0 belongs to the compiler)
+        unsigned keep;
+        asm volatile("s_mov_b32 %6, m0\n\t"
+                     "s_mov_b32 m0, %13\n\t"
+                     "s_nop 3\n\t"
+                     "v_writelane_b32 %0, %7, m0\n\t"
+                     "v_writelane_b32 %1, %8, m0\n\t"
+                     "v_writelane_b32 %2, %9, m0\n\t"
+                     "v_writelane_b32 %3, %10, m0\n\t"
+                     "v_writelane_b32 %4, %11, m0\n\t"
+                     "v_writelane_b32 %5, %12, m0\n\t"
+                     "s_mov_b32 m0, %6"
+                     : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "+v"(m4), "+v"(m5), "=&s"(keep)
+                     : "s"(r_vmax), "s"(r_keylo), "s"(r_px), "s"(r_py), "s"(r_pz), "s"(r_wl), "s"(slot));
+        bmax = m0; bkeylo = (unsigned)m1; bpx = __int_as_float(m2); bpy = __int_as_float(m3); bpz = __int_as_float(m4); bhold = m5;
     };
-#undef SPS_PF_SLOT
 #pragma unroll
     for (int s = 0; s < P; ++s) {
         const float lx = wave_allmin_f32(x[s]), ly = wave_allmin_f32(y[s]), lz = wave_allmin_f32(z[s]);
         const float hx = wave_allmax_f32(x[s]), hy = wave_allmax_f32(y[s]), hz = wave_allmax_f32(z[s]);
         if (lane == s) { blo_x = lx; blo_y = ly; blo_z = lz; bhi_x = hx; bhi_y = hy; bhi_z = hz; }
     }
-    for (int s = 0; s < P; ++s) for_slot(s, refresh);
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+        refresh(t[s], rk[s], x[s], y[s], z[s]);
+        commit(s);
+    }
 
     if (tid == 0) {
         idxs[0] = 0;
@@ -310,7 +326,8 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
     unsigned long long cand_key = 0ull;
     float cand_x = 0.f, cand_y = 0.f, cand_z = 0.f;
     bool cand_stale = true;
-    int slot_cur = 1;  // == j % 3
+    int cand_slot = -1;  // bucket slot the candidate came from: only its refresh can change the candidate
+    int slot_cur = 1;    // == j % 3
 
     // ------------------------------------------------------------------ sampling loop
     unsigned long long tseg[6] = {0, 0, 0, 0, 0, 0}, ntouch = 0;
@@ -336,22 +353,24 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
         const bool skip = lb >= __int_as_float(bmax);  // NaN -> not skipped
         unsigned long long todo = __ballot(!skip && lane < P);
         // 2. re-evaluate the surviving buckets (exactly the reference arithmetic, one point per lane)
-        if (todo) cand_stale = true;
         const unsigned long long s1 = stamp();
         if constexpr (PROF) ntouch += __builtin_popcountll(todo);
         while (todo) {
             const int s = __builtin_ctzll(todo);
             todo &= todo - 1;
-            for_slot(s, [&](auto S_) {
-                constexpr int S = decltype(S_)::value;
-                // opaque copy of the centre: keeps hipcc from hoisting the distance evaluation of EVERY slot
-                // out of the switch (it is loop-invariant inside this while loop)
-                float ox = cx, oy = cy, oz = cz;
-                asm volatile("" : "+s"(ox), "+s"(oy), "+s"(oz));
-                const float d = sqdist(x[S], y[S], z[S], ox, oy, oz);
-                t[S] = fmin_raw(d, t[S]);
-                refresh(S_);
-            });
+            // the cached maximum only changes if the point holding it moved closer to a sample
+            const int hl = __builtin_amdgcn_readlane(bhold, s);
+            const int oldmax = __builtin_amdgcn_readlane(bmax, s);
+            const float xs = x[s], ys = y[s], zs = z[s];  // wave-uniform dynamic index -> VGPR-index mode
+            const float d = sqdist(xs, ys, zs, cx, cy, cz);
+            const float tn = fmin_raw(d, t[s]);
+            t[s] = tn;
+            const bool changed = __builtin_amdgcn_readlane(__float_as_int(tn), hl) != oldmax;
+            if (changed) refresh(tn, rk[s], xs, ys, zs);
+            if (changed) {
+                commit(s);
+                if (s == cand_slot) cand_stale = true;
+            }
         }
         const unsigned long long s2 = stamp();
         // 3. the wave's best bucket: largest distance, then largest inverted rank
@@ -370,6 +389,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
             cand_x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bpx), wl));
             cand_y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bpy), wl));
             cand_z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bpz), wl));
+            cand_slot = wl;
             cand_stale = false;
         }
         const unsigned long long s3 = stamp();
@@ -431,7 +451,7 @@ int launch_fps_pruned_profile(int b, int n, int m, const float *dataset, float *
 
 // returns SPS_OK after launching, or -1 if this variant does not apply (caller falls back to fps.hip)
 int launch_fps_pruned(int b, int n, int m, const float *dataset, float *temp, int *idxs, hipStream_t st) {
-    if (n < 2048 || n > 40 * PF_THREADS || n > 65535) return -1;
+    if (n < 2048 || n > 32 * PF_THREADS) return -1;  // 32 bucket slots per wave = 16 384 points
     const int bs = sps_opt_n_threads(n);
     int l2 = 0;
     while ((1 << (l2 + 1)) <= bs) ++l2;
@@ -448,9 +468,7 @@ int launch_fps_pruned(int b, int n, int m, const float *dataset, float *temp, in
     SPS_PF_CASE(4)
     SPS_PF_CASE(8)
     SPS_PF_CASE(16)
-    SPS_PF_CASE(24)
     SPS_PF_CASE(32)
-    SPS_PF_CASE(40)
 #undef SPS_PF_CASE
     return -1;
 }
