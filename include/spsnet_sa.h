@@ -128,6 +128,10 @@ int sps_query_and_group(int b, int n, int m, int c, float radius, int nsample, i
                         const float *xyz, const float *new_xyz, const float *features, int *idx,
                         float *out, sps_stream_t stream);
 
+/* new_xyz (B,M,3) = rows idx (B,M) of xyz (B,N,3): the transpose + gather_points + transpose of
+ * pointnet2_modules.py:261,423-424 without the two layout copies (same values, it is a pure copy). */
+int sps_gather_xyz(int b, int n, int m, const float *xyz, const int *idx, float *out, sps_stream_t stream);
+
 /* ball_query_kernel_launcher_fast in "write every row" mode: rows of empty balls are written as zeros, so
  * the caller needs no zero-fill (what pointnet2_utils.py:246 + ball_query_gpu.cu:9-45 produce together). */
 int sps_ball_query_full(int b, int n, int m, float radius, int nsample, const float *new_xyz,

@@ -191,6 +191,17 @@ def score_topk(cls_features, npoint, stds=None, return_scores=False):
     return (idx, scores) if return_scores else idx
 
 
+def gather_xyz(xyz, idx):
+    """xyz (B,N,3), idx (B,M) int32 -> (B,M,3): rows of xyz, without the (B,3,N) detour."""
+    p, i = _ptr(xyz, F32, "xyz"), _ptr(idx, I32, "idx")
+    B, N, _ = xyz.shape
+    M = idx.shape[1]
+    out = torch.empty((B, M, 3), dtype=F32, device=xyz.device)
+    with _on(xyz):
+        _lib.check(_L.sps_gather_xyz(B, N, M, p, i, out.data_ptr(), _stream(xyz)), "gather_xyz")
+    return out
+
+
 def ball_query_full(radius, nsample, xyz, new_xyz):
     """Ball query that writes every row (zeros for empty balls) into a fresh (B,M,nsample) int32 tensor."""
     p, q = _ptr(xyz, F32, "xyz"), _ptr(new_xyz, F32, "new_xyz")

@@ -136,15 +136,28 @@ class PointnetSAModuleMSG(_PointnetSAModuleBase):
 # strategies that thin `stds` update ctx.stds.
 # ------------------------------------------------------------------------------------------
 class _SampleInput:
-    __slots__ = ("xyz", "xyz_full", "xyz_flipped", "features_t", "cls", "npoint", "stds")
+    __slots__ = ("xyz", "xyz_full", "_features", "_window", "_contig", "cls", "npoint", "stds")
 
-    def __init__(self, xyz, xyz_full, xyz_flipped, features_t, cls, npoint, stds):
-        self.xyz, self.xyz_full, self.xyz_flipped = xyz, xyz_full, xyz_flipped
-        self.features_t, self.cls, self.npoint, self.stds = features_t, cls, npoint, stds
+    def __init__(self, xyz, xyz_full, features, window, contig, cls, npoint, stds):
+        self.xyz, self.xyz_full = xyz, xyz_full
+        self._features, self._window, self._contig = features, window, contig
+        self.cls, self.npoint, self.stds = cls, npoint, stds
+
+    @property
+    def xyz_flipped(self):
+        return self.xyz_full.transpose(1, 2).contiguous()
+
+    @property
+    def features_t(self):
+        """(B, n_window, C) view of the features; only the feature-space samplers pay for it."""
+        if self._features is None:
+            return None
+        ft = self._features.transpose(1, 2)[:, self._window, :]
+        return ft.contiguous() if self._contig else ft
 
 
 def _thin_stds(ctx: _SampleInput, idx):
-    batch = ctx.xyz_flipped.shape[0]
+    batch = ctx.xyz_full.shape[0]
     ctx.stds = pointnet2_utils.gather_operation(ctx.stds.view(batch, 1, -1).contiguous(), idx).squeeze()
 
 
@@ -165,7 +178,19 @@ def _sample_stability(mod, ctx):
 
 
 def _sample_dfps(mod, ctx):
-    """Distance FPS (reference :307-310)."""
+    """Distance FPS (reference :307-310).  sa_stack.run_sa_layers may have started this FPS early on a side
+    stream (it depends only on the previous layer's new_xyz, not on its features): pick that result up."""
+    pre = getattr(mod, "_presampled", None)
+    if pre is not None:
+        mod._presampled = None
+        idx, done, src = pre
+        if src is ctx.xyz and idx.shape[1] == ctx.npoint:
+            main = torch.cuda.current_stream(idx.device)
+            main.wait_event(done)
+            idx.record_stream(main)
+            if ctx.stds is not None:
+                _thin_stds(ctx, idx)
+            return idx
     idx = pointnet2_utils.furthest_point_sample(ctx.xyz.contiguous(), ctx.npoint)
     if ctx.stds is not None:
         _thin_stds(ctx, idx)
@@ -178,7 +203,7 @@ def _sample_sfps(mod, ctx):
     (reference :314-353, threshold hard-coded there)."""
     if ctx.stds is None:
         raise NotImplementedError
-    batch = ctx.xyz_flipped.shape[0]
+    batch = ctx.xyz_full.shape[0]
     stds = ctx.stds.view(batch, 1, -1).contiguous()
     seeds = pointnet2_utils.furthest_point_sample(ctx.xyz.contiguous(), ctx.npoint)
     seed_xyz = pointnet2_utils.gather_operation(ctx.xyz_flipped, seeds).transpose(1, 2).contiguous()
@@ -288,7 +313,6 @@ class _SamplingSAModule(_PointnetSAModuleBase):
 
     def _sample(self, xyz, features, cls_features, stds):
         """-> (sampled_idx (B, sum npoint) int32, stds).  Reference :270-424 / :709-726."""
-        xyz_flipped = xyz.transpose(1, 2).contiguous()
         chunks = []
         begin = 0
         for sample_type, sample_range, npoint in zip(self.sample_type_list, self.sample_range_list,
@@ -300,12 +324,9 @@ class _SamplingSAModule(_PointnetSAModuleBase):
             else:
                 window = slice(begin, sample_range)
                 begin += sample_range  # sic: the reference adds the range end, not its length (:282)
-            xyz_w = xyz[:, window, :]
+            whole = window.start == 0 and window.stop is None
+            xyz_w = xyz if whole else xyz[:, window, :]
             xyz_w = xyz_w if sample_range == -1 else xyz_w.contiguous()
-            feat_w = None
-            if features is not None:
-                feat_w = features.transpose(1, 2)[:, window, :]
-                feat_w = feat_w.contiguous() if sample_range == -1 else feat_w
             cls_w = cls_features[:, window, :] if cls_features is not None else None
 
             if xyz_w.shape[1] <= npoint:
@@ -313,14 +334,21 @@ class _SamplingSAModule(_PointnetSAModuleBase):
                 continue
             for accepts, strategy in _SAMPLERS:
                 if accepts(sample_type) and (self._allowed_samplers is None or strategy in self._allowed_samplers):
-                    ctx = _SampleInput(xyz_w, xyz, xyz_flipped, feat_w, cls_w, npoint, stds)
+                    ctx = _SampleInput(xyz_w, xyz, features, window, sample_range == -1, cls_w, npoint, stds)
                     chunks.append(strategy(self, ctx))
                     stds = ctx.stds
                     break
             else:
                 raise NotImplementedError(f"sampling method {sample_type!r}")
-        sampled_idx = torch.cat(chunks, dim=-1)
-        new_xyz = pointnet2_utils.gather_operation(xyz_flipped, sampled_idx).transpose(1, 2).contiguous()
+        sampled_idx = chunks[0] if len(chunks) == 1 else torch.cat(chunks, dim=-1)
+        if xyz.is_cuda and not (torch.is_grad_enabled() and xyz.requires_grad):
+            new_xyz = _ext.gather_xyz(xyz.contiguous(), sampled_idx.contiguous())  # (B,N,3) rows, no transposes
+        else:
+            new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(),
+                                                       sampled_idx).transpose(1, 2).contiguous()
+        hook = getattr(self, "_on_new_xyz", None)
+        if hook is not None:
+            hook(new_xyz)
         return sampled_idx, new_xyz, stds
 
     def _abstract(self, xyz, new_xyz, features, sampled_idx):

@@ -69,12 +69,58 @@ def build_sa_layers(modules_pkg, cfg=IASSD_KITTI, input_channels=4, num_class=3,
     return layers.eval()
 
 
-def run_sa_layers(layers, xyz, features, stds=None):
-    """IASSD_backbone.py:128-134 for SA layers: -> list of (new_xyz, new_features, cls, sampled_idx)."""
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+def _prefetch_dfps(next_layer, new_xyz):
+    """Start the NEXT layer's D-FPS on a side stream as soon as this layer's centroids exist: it needs only
+    their coordinates, so it runs beside this layer's ball queries and grouped MLPs (FPS occupies one CU per
+    scene; the rest of the chip is free).  The next layer's sampler waits on the event."""
+    from . import pointnet2_utils
+    main = torch.cuda.current_stream(new_xyz.device)
+    side = _side_stream(new_xyz.device)
+    ready = torch.cuda.Event()
+    ready.record(main)
+    new_xyz.record_stream(side)
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        idx = pointnet2_utils.furthest_point_sample(new_xyz, next_layer.npoint_list[0])
+        done = torch.cuda.Event()
+        done.record(side)
+    next_layer._presampled = (idx, done, new_xyz)
+
+
+def _can_prefetch(layer, nxt):
+    types = getattr(nxt, "sample_type_list", None)
+    if not types or len(types) != 1 or nxt.sample_range_list[0] != -1:
+        return False
+    t = types[0]
+    is_dfps = ('D-FPS' in t or 'DFS' in t) and not ('cls' in t or 'ctr' in t or 'ss' in t)
+    return is_dfps and sum(p for p in layer.npoint_list if p > 0) > nxt.npoint_list[0] > 0
+
+
+def run_sa_layers(layers, xyz, features, stds=None, overlap=True):
+    """IASSD_backbone.py:128-134 for SA layers: -> list of (new_xyz, new_features, cls, sampled_idx).
+    With overlap (inference on a GPU), layer k+1's D-FPS is issued on a side stream the moment layer k's
+    new_xyz exists; results are identical, only the schedule changes."""
     outs = []
     cls_pred = None
-    for layer in layers:
+    use_overlap = overlap and xyz.is_cuda and not torch.is_grad_enabled() and stds is None
+    for k, layer in enumerate(layers):
+        nxt = layers[k + 1] if k + 1 < len(layers) else None
+        if use_overlap and nxt is not None and _can_prefetch(layer, nxt):
+            layer._on_new_xyz = lambda nx, _n=nxt: _prefetch_dfps(_n, nx)
         kw = {} if stds is None else {'stds': stds}
-        xyz, features, cls_pred, idx, stds = layer(xyz, features, cls_pred, **kw)
+        try:
+            xyz, features, cls_pred, idx, stds = layer(xyz, features, cls_pred, **kw)
+        finally:
+            layer._on_new_xyz = None
         outs.append((xyz, features, cls_pred, idx))
     return outs
