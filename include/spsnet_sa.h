@@ -108,6 +108,15 @@ int sps_three_interpolate_grad_kernel_launcher_fast(int b, int c, int n, int m, 
                                                     const int *idx, const float *weight, float *grad_points,
                                                     sps_stream_t stream);
 
+/* D-FPS of a cloud that is itself the output of a D-FPS, in pick order (layer k+1 of IA-SSD sampling layer k's
+ * centroids, IASSD_backbone.py:128-134): the answer is 0..m-1 unless exact distance ties interfere, so it is
+ * CHECKED in two parallel passes (csrc/fps_verify.hip) and only scenes that fail the check are recomputed by
+ * the ordinary kernel.  Always bit-identical to sps_farthest_point_sampling_kernel_launcher on the same
+ * input, for ANY input (an unordered cloud just fails the check and is recomputed).
+ * Device workspace from the caller: work_T (B*m f32), work_temp (B*n f32), flags (B i32). */
+int sps_fps_ordered_prefix(int b, int n, int m, const float *xyz, float *temp, int *idxs, float *work_T,
+                           float *work_temp, int *flags, sps_stream_t stream);
+
 /* ---- fused entry points for the SA module layer (pointnet2_modules.py) ----------------- */
 
 /* Score + top-k sampler: replaces the max/sigmoid/(mul)/topk/int chain of

@@ -199,6 +199,23 @@ def fp_module(M):
     np.savez_compressed(os.path.join(OUT, "fp_module.npz"), **d)
 
 
+def surface_features():
+    """surface_feature.py FeatureExtraction, static and dynamic graph (reference Python over the oracle)."""
+    import importlib
+    SF = importlib.import_module("pcdet.ops.pointnet2.pointnet2_batch.surface_feature")
+    xyz, _ = scenes.make_batch("kitti-lidar-v1", 2, 384, seed0=600)
+    xyz = (xyz - xyz.mean(1, keepdims=True)).astype(np.float32) * 0.2   # dense enough for r = 0.8 balls
+    d = dict(xyz=xyz)
+    for name, dyn in (("static", False), ("dynamic", True)):
+        torch.manual_seed(41)
+        net = SF.FeatureExtraction(dynamic_graph=dyn).eval()
+        with torch.no_grad():
+            out = net(torch.from_numpy(xyz))
+        d["out_" + name] = _np(out)
+        d.update(_state(net, prefix=f"sd_{name}."))
+    np.savez_compressed(os.path.join(OUT, "surface_feature.npz"), **d)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     U, M = ref_harness.load_reference()
@@ -209,6 +226,7 @@ def main():
     stack3(M)
     generator_layer(M)
     fp_module(M)
+    surface_features()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -52,11 +52,12 @@ __device__ __forceinline__ float4 fps_pick(const FpsShared &sh, int buf, int nwa
 template <int P, bool DIST>
 __global__ __launch_bounds__(FPS_MAX_THREADS) void fps_reg_kernel(
     int n, int m, int bs, int log2bs, const float *__restrict__ dataset, float *__restrict__ temp,
-    int *__restrict__ idxs) {
+    int *__restrict__ idxs, const int *__restrict__ redo = nullptr, const float *__restrict__ temp_done = nullptr) {
     if (m <= 0) return;  // sampling_gpu.cu:101
     __shared__ FpsShared sh;
 
     const int scene = blockIdx.x;
+    if (fps_already_done(redo, temp_done, temp, scene, n)) return;
     const float *xyz = dataset + (size_t)scene * n * (DIST ? (size_t)n : 3);
     temp += (size_t)scene * n;
     idxs += (size_t)scene * m;
@@ -149,12 +150,13 @@ __global__ __launch_bounds__(FPS_MAX_THREADS) void fps_reg_kernel(
 template <bool DIST>
 __global__ __launch_bounds__(FPS_MAX_THREADS) void fps_stream_kernel(
     int n, int m, int bs, int log2bs, const float *__restrict__ dataset, float *__restrict__ temp,
-    int *__restrict__ idxs) {
+    int *__restrict__ idxs, const int *__restrict__ redo = nullptr, const float *__restrict__ temp_done = nullptr) {
     if (m <= 0) return;
     __shared__ unsigned long long key[2][FPS_MAX_WAVES];
     __shared__ int cand[2][FPS_MAX_WAVES];
 
     const int scene = blockIdx.x;
+    if (fps_already_done(redo, temp_done, temp, scene, n)) return;
     const float *xyz = dataset + (size_t)scene * n * (DIST ? (size_t)n : 3);
     temp += (size_t)scene * n;
     idxs += (size_t)scene * m;
@@ -208,12 +210,13 @@ static int g_fps_mode = 0;  // 0 = auto (pruned where it applies), 1 = brute-for
 static int ilog2(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
 
 template <bool DIST>
-static int launch_fps(int b, int n, int m, const float *dataset, float *temp, int *idxs, hipStream_t st) {
+static int launch_fps(int b, int n, int m, const float *dataset, float *temp, int *idxs, hipStream_t st,
+                      const int *redo = nullptr, const float *temp_done = nullptr) {
     if (b < 0 || n <= 0 || m < 0) return fail(SPS_ERR_INVALID, "fps: bad shape b=%d n=%d m=%d", b, n, m);
     if (b == 0 || m == 0) return SPS_OK;
     if (!dataset || !temp || !idxs) return fail(SPS_ERR_INVALID, "fps: null pointer");
     if (!DIST && g_fps_mode == 0) {  // spatially pruned variant (fps_pruned.hip) where it applies
-        const int rc = launch_fps_pruned(b, n, m, dataset, temp, idxs, st);
+        const int rc = launch_fps_pruned(b, n, m, dataset, temp, idxs, st, redo, temp_done);
         if (rc >= 0) return rc;
     }
     const int bs = sps_opt_n_threads(n);
@@ -223,7 +226,7 @@ static int launch_fps(int b, int n, int m, const float *dataset, float *temp, in
     dim3 grid(b), block(threads);
 #define SPS_FPS_CASE(PP)                                                                              \
     if (P <= PP) {                                                                                    \
-        hipLaunchKernelGGL((fps_reg_kernel<PP, DIST>), grid, block, 0, st, n, m, bs, l2, dataset, temp, idxs); \
+        hipLaunchKernelGGL((fps_reg_kernel<PP, DIST>), grid, block, 0, st, n, m, bs, l2, dataset, temp, idxs, redo, temp_done); \
         return check_launch("fps_reg_kernel");                                                       \
     }
     SPS_FPS_CASE(1)
@@ -235,8 +238,15 @@ static int launch_fps(int b, int n, int m, const float *dataset, float *temp, in
     SPS_FPS_CASE(20)
     SPS_FPS_CASE(24)
 #undef SPS_FPS_CASE
-    hipLaunchKernelGGL((fps_stream_kernel<DIST>), grid, block, 0, st, n, m, bs, l2, dataset, temp, idxs);
+    hipLaunchKernelGGL((fps_stream_kernel<DIST>), grid, block, 0, st, n, m, bs, l2, dataset, temp, idxs, redo, temp_done);
     return check_launch("fps_stream_kernel");
+}
+
+// fps_verify.hip: finish a batch whose guess was checked -- confirmed scenes only copy their final temp,
+// flagged scenes (redo[scene] != 0) run the ordinary kernel
+int launch_fps_resolve(int b, int n, int m, const float *dataset, float *temp, int *idxs, const int *redo,
+                       const float *temp_done, hipStream_t st) {
+    return launch_fps<false>(b, n, m, dataset, temp, idxs, st, redo, temp_done);
 }
 
 }  // namespace sps

@@ -121,12 +121,14 @@ __device__ __forceinline__ unsigned pf_unrank(unsigned rank, int l2, int rb) {
 template <int P, bool PROF = false>
 __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
     int n, int m, int bs, int l2, int rb, const float *__restrict__ dataset, float *__restrict__ temp,
-    int *__restrict__ idxs, unsigned long long *__restrict__ dbg = nullptr) {
+    int *__restrict__ idxs, unsigned long long *__restrict__ dbg = nullptr, const int *__restrict__ redo = nullptr,
+    const float *__restrict__ temp_done = nullptr) {
     if (m <= 0) return;
     __shared__ PfShared sh;
     __shared__ unsigned short sorted[P * PF_THREADS];
 
     const int scene = blockIdx.x;
+    if (fps_already_done(redo, temp_done, temp, scene, n)) return;
     const float *xyz = dataset + (size_t)scene * n * 3;
     temp += (size_t)scene * n;
     idxs += (size_t)scene * m;
@@ -450,7 +452,8 @@ int launch_fps_pruned_profile(int b, int n, int m, const float *dataset, float *
 }
 
 // returns SPS_OK after launching, or -1 if this variant does not apply (caller falls back to fps.hip)
-int launch_fps_pruned(int b, int n, int m, const float *dataset, float *temp, int *idxs, hipStream_t st) {
+int launch_fps_pruned(int b, int n, int m, const float *dataset, float *temp, int *idxs, hipStream_t st,
+                      const int *redo, const float *temp_done) {
     if (n < 2048 || n > 32 * PF_THREADS) return -1;  // 32 bucket slots per wave = 16 384 points
     const int bs = sps_opt_n_threads(n);
     int l2 = 0;
@@ -462,7 +465,7 @@ int launch_fps_pruned(int b, int n, int m, const float *dataset, float *temp, in
 #define SPS_PF_CASE(PP)                                                                                        \
     if (P <= PP) {                                                                                             \
         hipLaunchKernelGGL((fps_pruned_kernel<PP, false>), grid, block, 0, st, n, m, bs, l2, rb, dataset, temp, idxs, \
-                           (unsigned long long *)nullptr);                                                     \
+                           (unsigned long long *)nullptr, redo, temp_done);                                    \
         return check_launch("fps_pruned_kernel");                                                             \
     }
     SPS_PF_CASE(4)

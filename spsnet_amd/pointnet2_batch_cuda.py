@@ -191,6 +191,23 @@ def score_topk(cls_features, npoint, stds=None, return_scores=False):
     return (idx, scores) if return_scores else idx
 
 
+def fps_ordered_prefix(xyz, npoint, return_flags=False):
+    """D-FPS of an FPS-ordered cloud (B,N,3) -> (B,npoint) int32: checks the identity-prefix guess in parallel and
+    recomputes only scenes where fp32 distance ties break it.  Bit-identical to farthest_point_sampling_wrapper."""
+    p = _ptr(xyz, F32, "xyz")
+    B, N, _ = xyz.shape
+    dev = xyz.device
+    temp = torch.full((B, N), 1e10, dtype=F32, device=dev)
+    idx = torch.empty((B, npoint), dtype=I32, device=dev)
+    work_t = torch.empty((B, max(npoint, 1)), dtype=F32, device=dev)
+    work_temp = torch.empty((B, N), dtype=F32, device=dev)
+    flags = torch.empty((B,), dtype=I32, device=dev)
+    with _on(xyz):
+        _lib.check(_L.sps_fps_ordered_prefix(B, N, npoint, p, temp.data_ptr(), idx.data_ptr(), work_t.data_ptr(),
+                                             work_temp.data_ptr(), flags.data_ptr(), _stream(xyz)), "fps_ordered_prefix")
+    return (idx, flags, temp) if return_flags else idx
+
+
 def gather_xyz(xyz, idx):
     """xyz (B,N,3), idx (B,M) int32 -> (B,M,3): rows of xyz, without the (B,3,N) detour."""
     p, i = _ptr(xyz, F32, "xyz"), _ptr(idx, I32, "idx")

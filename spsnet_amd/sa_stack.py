@@ -79,7 +79,7 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
-def _prefetch_dfps(next_layer, new_xyz):
+def _prefetch_dfps(next_layer, new_xyz, fps_ordered=False):
     """Start the NEXT layer's D-FPS on a side stream as soon as this layer's centroids exist: it needs only
     their coordinates, so it runs beside this layer's ball queries and grouped MLPs (FPS occupies one CU per
     scene; the rest of the chip is free).  The next layer's sampler waits on the event."""
@@ -91,7 +91,13 @@ def _prefetch_dfps(next_layer, new_xyz):
     new_xyz.record_stream(side)
     with torch.cuda.stream(side):
         side.wait_event(ready)
-        idx = pointnet2_utils.furthest_point_sample(new_xyz, next_layer.npoint_list[0])
+        if fps_ordered:
+            # new_xyz is a D-FPS pick sequence: its own D-FPS is the identity prefix up to distance ties, which
+            # sps_fps_ordered_prefix verifies in parallel (and recomputes where it fails) -- same result, ~20x faster
+            from . import pointnet2_batch_cuda as _ext
+            idx = _ext.fps_ordered_prefix(new_xyz, next_layer.npoint_list[0])
+        else:
+            idx = pointnet2_utils.furthest_point_sample(new_xyz, next_layer.npoint_list[0])
         done = torch.cuda.Event()
         done.record(side)
     next_layer._presampled = (idx, done, new_xyz)
@@ -106,6 +112,15 @@ def _can_prefetch(layer, nxt):
     return is_dfps and sum(p for p in layer.npoint_list if p > 0) > nxt.npoint_list[0] > 0
 
 
+def _is_plain_dfps(layer, n_in):
+    """True if the layer's centroids are ONE D-FPS pick sequence over its whole input."""
+    types = getattr(layer, "sample_type_list", None)
+    if not types or len(types) != 1 or layer.sample_range_list[0] != -1:
+        return False
+    t = types[0]
+    return ('D-FPS' in t or 'DFS' in t) and not ('cls' in t or 'ctr' in t or 'ss' in t) and n_in > layer.npoint_list[0] > 0
+
+
 def run_sa_layers(layers, xyz, features, stds=None, overlap=True):
     """IASSD_backbone.py:128-134 for SA layers: -> list of (new_xyz, new_features, cls, sampled_idx).
     With overlap (inference on a GPU), layer k+1's D-FPS is issued on a side stream the moment layer k's
@@ -116,7 +131,8 @@ def run_sa_layers(layers, xyz, features, stds=None, overlap=True):
     for k, layer in enumerate(layers):
         nxt = layers[k + 1] if k + 1 < len(layers) else None
         if use_overlap and nxt is not None and _can_prefetch(layer, nxt):
-            layer._on_new_xyz = lambda nx, _n=nxt: _prefetch_dfps(_n, nx)
+            ordered = _is_plain_dfps(layer, xyz.shape[1])
+            layer._on_new_xyz = lambda nx, _n=nxt, _o=ordered: _prefetch_dfps(_n, nx, _o)
         kw = {} if stds is None else {'stds': stds}
         try:
             xyz, features, cls_pred, idx, stds = layer(xyz, features, cls_pred, **kw)

@@ -81,3 +81,14 @@ def test_module_mirror_builds_with_reference_state_dict_keys():
     assert sorted(mod.state_dict().keys()) == ref_keys
     for k, v in mod.state_dict().items():
         assert tuple(v.shape) == tuple(g["sd." + k].shape), k
+
+
+def test_surface_feature_mirror_has_reference_state_dict_keys():
+    import numpy as np
+    from spsnet_amd import surface_feature as SF
+    g = np.load(os.path.join(ROOT, "tests", "golden", "surface_feature.npz"))
+    ref = {k[len("sd_static."):]: g[k].shape for k in g.files if k.startswith("sd_static.")}
+    net = SF.FeatureExtraction(dynamic_graph=False)
+    mine = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert mine == {k: tuple(v) for k, v in ref.items()}
+    assert net.out_channels == 60  # the "surface feature C=60" of SURVEY.md 8a-3

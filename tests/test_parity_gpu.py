@@ -503,3 +503,52 @@ def test_fps_pruned_degenerate_clouds(ext, G, oracle):
         got, got_t = G.fps(ext, xyz, m)
         np.testing.assert_array_equal(got, want)
         np.testing.assert_array_equal(got_t, want_t)
+
+
+@pytest.mark.parametrize("mode", ["static", "dynamic"])
+def test_golden_surface_feature(ext, G, dev, mode):
+    """FeatureExtraction / DenseEdgeConv (surface_feature.py:45-187) against the reference's output, including
+    the dynamic-graph quirk where a d-channel feature tensor is read as packed xyz triples."""
+    from spsnet_amd import surface_feature as SF
+    g = np.load(os.path.join(GOLD, "surface_feature.npz"))
+    net = SF.FeatureExtraction(dynamic_graph=(mode == "dynamic"))
+    pre = f"sd_{mode}."
+    net.load_state_dict({k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}, strict=True)
+    net = net.to(dev).eval()
+    with torch.no_grad():
+        out = net(G.t(g["xyz"]))
+    ref = g["out_" + mode]
+    assert out.shape == ref.shape
+    assert float(np.abs(G.n(out) - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+# ------------------------------------------------------------------ FPS of an FPS-ordered cloud (verified shortcut)
+def test_fps_ordered_prefix_shortcut(ext, G, oracle):
+    """D-FPS on the pick sequence of a previous D-FPS: confirmed scenes take the parallel check, everything is
+    bit-identical to the plain kernel and the oracle (indices and final running distances)."""
+    from spsnet_amd import scenes
+    xyz, _ = scenes.make_batch("kitti-lidar-v1", 4, 8192, seed0=21)
+    i0 = oracle.fps(xyz, 2048)
+    x1 = gather_xyz(xyz, i0)                      # FPS-ordered cloud (B, 2048, 3)
+    x1[3] = x1[3][np.random.default_rng(0).permutation(2048)]   # scene 3: order destroyed -> must be recomputed
+    want, want_t = oracle.fps(x1, 512, return_temp=True)
+    idx, flags, temp = ext.fps_ordered_prefix(G.t(x1), 512, return_flags=True)
+    np.testing.assert_array_equal(G.n(idx), want)
+    np.testing.assert_array_equal(G.n(temp), want_t)
+    f = G.n(flags)
+    assert f[:3].tolist() == [0, 0, 0] and f[3] == 1            # shortcut taken where it applies, refused where not
+    assert (want[:3] == np.arange(512, dtype=np.int32)[None]).all()
+    np.testing.assert_array_equal(G.fps(ext, x1, 512)[0], want)
+
+
+@pytest.mark.parametrize("N,m", [(600, 300), (4096, 1024), (4096, 4096), (5000, 100)])
+def test_fps_ordered_prefix_with_ties(ext, G, oracle, N, m):
+    """Lattice clouds: equal distances everywhere, the two runs' tie rules differ, so the guess often fails --
+    the result must still equal the reference algorithm on that input."""
+    rng = np.random.default_rng(N)
+    base = cloud(rng, 2, 4 * N, lattice=True)
+    x1 = gather_xyz(base, oracle.fps(base, N))
+    want, want_t = oracle.fps(x1, m, return_temp=True)
+    idx, flags, temp = ext.fps_ordered_prefix(G.t(x1), m, return_flags=True)
+    np.testing.assert_array_equal(G.n(idx), want)
+    np.testing.assert_array_equal(G.n(temp), want_t)
