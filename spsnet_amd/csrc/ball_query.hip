@@ -68,18 +68,42 @@ __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_seg_kernel(
     int cnt = active ? 0 : nsample;  // inactive lanes never record
     const int kbeg = seg * seg_len;
     const int kend = (kbeg + seg_len < n) ? kbeg + seg_len : n;
+    // Per batch of 8 points: 8 branch-free distance evaluations, ONE wave-uniform test "can any lane still
+    // take any of them?" (min of the 8 distances against the lane's remaining threshold), and only then the
+    // ordered per-point append path.  Hits are rare (a point lies in few of the 64 balls), and a lone wave pays
+    // ~40 cycles per taken branch, so testing per point cost 3x more than the arithmetic.
+    // Scalar loads return out of order (hipcc can only wait lgkmcnt(0)), so the next batch is requested right
+    // AFTER the wait for the current one and BEFORE its arithmetic, which then hides the scalar-cache latency.
     int k0 = kbeg;
+    float p[BQ_BATCH * 3], pn[BQ_BATCH * 3];
+    if (k0 + BQ_BATCH <= kend) {
+#pragma unroll
+        for (int u = 0; u < BQ_BATCH * 3; ++u) p[u] = xyz[(size_t)k0 * 3 + u];
+    }
+    float thr = (cnt < nsample) ? r2max : -1.f;  // full / inactive lanes can no longer be hit
     for (; k0 + BQ_BATCH <= kend; k0 += BQ_BATCH) {
-        if (__all(cnt >= nsample)) break;
-        float p[BQ_BATCH * 3];
-        const float *src = xyz + (size_t)k0 * 3;
+        if (__all(thr < 0.f)) break;
+        asm volatile("" ::"s"(p[0]), "s"(p[BQ_BATCH * 3 - 1]));  // the current batch has landed
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = k0 + 2 * BQ_BATCH <= kend;
+        const float *nsrc = xyz + (size_t)(more ? k0 + BQ_BATCH : k0) * 3;
 #pragma unroll
-        for (int u = 0; u < BQ_BATCH * 3; ++u) p[u] = src[u];  // wave-uniform -> scalar loads
+        for (int u = 0; u < BQ_BATCH * 3; ++u) pn[u] = nsrc[u];
+        __builtin_amdgcn_sched_barrier(0);
+        float d2[BQ_BATCH];
 #pragma unroll
-        for (int u = 0; u < BQ_BATCH; ++u) {
-            const float d2 = sqdist(cx, cy, cz, p[u * 3], p[u * 3 + 1], p[u * 3 + 2]);
-            bq_test<DILATED>(d2, r2max, r2min, hits, nsample, lane, k0 + u, cnt);
+        for (int u = 0; u < BQ_BATCH; ++u) d2[u] = sqdist(cx, cy, cz, p[u * 3], p[u * 3 + 1], p[u * 3 + 2]);
+        float dmin = d2[0];
+#pragma unroll
+        for (int u = 1; u < BQ_BATCH; ++u) dmin = fminf(dmin, d2[u]);
+        const bool maybe = DILATED ? (dmin < thr || (dmin == 0.f && thr >= 0.f)) : (dmin < thr);
+        if (__any(maybe)) {
+#pragma unroll
+            for (int u = 0; u < BQ_BATCH; ++u) bq_test<DILATED>(d2[u], r2max, r2min, hits, nsample, lane, k0 + u, cnt);
+            thr = (cnt < nsample) ? r2max : -1.f;
         }
+#pragma unroll
+        for (int u = 0; u < BQ_BATCH * 3; ++u) p[u] = pn[u];
     }
     if (!__all(cnt >= nsample)) {
         for (; k0 < kend; ++k0) {
@@ -118,6 +142,109 @@ __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_seg_kernel(
     }
 }
 
+// Two radii in ONE scan (the two grouping scales of an SA layer share centroids and points): the distance
+// is evaluated once per pair and tested against both radii; each radius keeps its own ordered hit list.
+// LDS (ints): hitsA[S][nsA][64] | hitsB[S][nsB][64] | cnt[2][S][64] | final[max(nsA,nsB)][65].  Rows are always
+// fully written (zeros for empty balls), like sps_ball_query_full.
+__global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_dual_kernel(
+    int n, int m, int seg_len, float r2a, float r2b, int nsa, int nsb, const float *__restrict__ new_xyz,
+    const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b) {
+    extern __shared__ __attribute__((aligned(16))) int bq_lds[];
+    const int S = blockDim.x / BQ_LANES;
+    const int lane = threadIdx.x & 63;
+    const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int *hits_a = bq_lds + seg * nsa * BQ_LANES;
+    int *hits_b = bq_lds + S * nsa * BQ_LANES + seg * nsb * BQ_LANES;
+    int *cnts = bq_lds + S * (nsa + nsb) * BQ_LANES;  // [2][S][64]
+    int *final_img = cnts + 2 * S * BQ_LANES;
+
+    const int scene = blockIdx.y;
+    const int j0 = blockIdx.x * BQ_LANES;
+    const int j = j0 + lane;
+    const bool active = j < m;
+    xyz += (size_t)scene * n * 3;
+    const float *ctr = new_xyz + ((size_t)scene * m + (active ? j : 0)) * 3;
+    const float cx = ctr[0], cy = ctr[1], cz = ctr[2];
+
+    int ca = active ? 0 : nsa, cb = active ? 0 : nsb;
+    const int kbeg = seg * seg_len;
+    const int kend = (kbeg + seg_len < n) ? kbeg + seg_len : n;
+    int k0 = kbeg;
+    float p[BQ_BATCH * 3], pn[BQ_BATCH * 3];  // current / next scalar-load batch (see ball_query_seg_kernel)
+    if (k0 + BQ_BATCH <= kend) {
+#pragma unroll
+        for (int u = 0; u < BQ_BATCH * 3; ++u) p[u] = xyz[(size_t)k0 * 3 + u];
+    }
+    // largest squared radius this lane can still use (-1 when both lists are full / the lane is inactive)
+    auto lane_thr = [&]() { return fmaxf(ca < nsa ? r2a : -1.f, cb < nsb ? r2b : -1.f); };
+    float thr = lane_thr();
+    for (; k0 + BQ_BATCH <= kend; k0 += BQ_BATCH) {
+        if (__all(thr < 0.f)) break;
+        asm volatile("" ::"s"(p[0]), "s"(p[BQ_BATCH * 3 - 1]));
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = k0 + 2 * BQ_BATCH <= kend;
+        const float *nsrc = xyz + (size_t)(more ? k0 + BQ_BATCH : k0) * 3;
+#pragma unroll
+        for (int u = 0; u < BQ_BATCH * 3; ++u) pn[u] = nsrc[u];
+        __builtin_amdgcn_sched_barrier(0);
+        float d2[BQ_BATCH];
+#pragma unroll
+        for (int u = 0; u < BQ_BATCH; ++u) d2[u] = sqdist(cx, cy, cz, p[u * 3], p[u * 3 + 1], p[u * 3 + 2]);
+        float dmin = d2[0];
+#pragma unroll
+        for (int u = 1; u < BQ_BATCH; ++u) dmin = fminf(dmin, d2[u]);
+        if (__any(dmin < thr)) {
+#pragma unroll
+            for (int u = 0; u < BQ_BATCH; ++u) {
+                if (d2[u] < r2a) bq_append(hits_a, nsa, lane, k0 + u, ca);
+                if (d2[u] < r2b) bq_append(hits_b, nsb, lane, k0 + u, cb);
+            }
+            thr = lane_thr();
+        }
+#pragma unroll
+        for (int u = 0; u < BQ_BATCH * 3; ++u) p[u] = pn[u];
+    }
+    if (!__all(ca >= nsa && cb >= nsb)) {
+        for (; k0 < kend; ++k0) {
+            const float d2 = sqdist(cx, cy, cz, xyz[(size_t)k0 * 3], xyz[(size_t)k0 * 3 + 1], xyz[(size_t)k0 * 3 + 2]);
+            if (d2 < r2a) bq_append(hits_a, nsa, lane, k0, ca);
+            if (d2 < r2b) bq_append(hits_b, nsb, lane, k0, cb);
+        }
+    }
+    cnts[seg * BQ_LANES + lane] = active ? ca : 0;
+    cnts[(S + seg) * BQ_LANES + lane] = active ? cb : 0;
+    __syncthreads();
+    const int rows = (m - j0 < BQ_LANES) ? m - j0 : BQ_LANES;
+    // merge + write-out, one radius after the other through the shared `final` image
+    for (int which = 0; which < 2; ++which) {
+        const int ns = which ? nsb : nsa;
+        const int *hits = which ? hits_b : hits_a;
+        const int *cn = cnts + which * S * BQ_LANES;
+        int before = 0, total = 0;
+        for (int s = 0; s < S; ++s) {
+            const int c = cn[s * BQ_LANES + lane];
+            before += (s < seg) ? c : 0;
+            total += c;
+        }
+        const int mine = cn[seg * BQ_LANES + lane];
+        for (int i = 0; i < mine && before + i < ns; ++i)
+            final_img[(before + i) * (BQ_LANES + 1) + lane] = hits[i * BQ_LANES + lane];
+        __syncthreads();
+        if (seg == 0) {
+            const int kept = total < ns ? total : ns;
+            const int pad = kept > 0 ? final_img[lane] : 0;
+            for (int i = kept; i < ns; ++i) final_img[i * (BQ_LANES + 1) + lane] = pad;
+        }
+        __syncthreads();
+        int *dst = (which ? idx_b : idx_a) + ((size_t)scene * m + j0) * ns;
+        for (int e = threadIdx.x; e < rows * ns; e += blockDim.x) {
+            const int c = e / ns, i = e - c * ns;
+            dst[e] = final_img[i * (BQ_LANES + 1) + c];
+        }
+        __syncthreads();
+    }
+}
+
 int launch_ball_query(bool dilated, bool fill_empty, int b, int n, int m, float rmax, float rmin, int nsample,
                       const float *new_xyz, const float *xyz, int *idx, hipStream_t st) {
     if (b < 0 || n < 0 || m < 0 || nsample < 0)
@@ -149,6 +276,31 @@ int launch_ball_query(bool dilated, bool fill_empty, int b, int n, int m, float 
 }
 
 }  // namespace sps
+
+extern "C" int sps_ball_query_full2(int b, int n, int m, float radius_a, int nsample_a, float radius_b, int nsample_b,
+                                    const float *new_xyz, const float *xyz, int *idx_a, int *idx_b, sps_stream_t stream) {
+    using namespace sps;
+    if (b < 0 || n < 0 || m < 0 || nsample_a <= 0 || nsample_b <= 0)
+        return fail(SPS_ERR_INVALID, "ball_query_full2: bad shape b=%d n=%d m=%d ns=(%d,%d)", b, n, m, nsample_a, nsample_b);
+    if (b == 0 || m == 0) return SPS_OK;
+    if (!new_xyz || (!xyz && n > 0) || !idx_a || !idx_b) return fail(SPS_ERR_INVALID, "ball_query_full2: null pointer");
+    if (b > 65535) return fail(SPS_ERR_INVALID, "ball_query_full2: batch %d exceeds the grid limit", b);
+    const int groups = divup(m, BQ_LANES);
+    int S = divup(4096, b * groups);
+    S = S < 1 ? 1 : (S > BQ_MAX_SEG ? BQ_MAX_SEG : S);
+    while (S > 1 && n / S < 256) --S;
+    const int nsmax = nsample_a > nsample_b ? nsample_a : nsample_b;
+    auto lds_bytes = [&](int s) {
+        return (size_t)4 * ((size_t)s * (nsample_a + nsample_b) * BQ_LANES + 2 * s * BQ_LANES + (size_t)nsmax * (BQ_LANES + 1));
+    };
+    while (S > 1 && lds_bytes(S) > 64 * 1024) --S;
+    if (lds_bytes(S) > 64 * 1024) return fail(SPS_ERR_INVALID, "ball_query_full2: nsample too large for LDS");
+    int seg_len = divup(n > 0 ? n : 1, S);
+    seg_len = divup(seg_len, BQ_BATCH) * BQ_BATCH;
+    hipLaunchKernelGGL(ball_query_dual_kernel, dim3(groups, b), dim3(BQ_LANES * S), lds_bytes(S), as_stream(stream), n, m,
+                       seg_len, radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b);
+    return check_launch("ball_query_dual_kernel");
+}
 
 extern "C" int sps_ball_query_kernel_launcher_fast(int b, int n, int m, float radius, int nsample,
                                                    const float *new_xyz, const float *xyz, int *idx,

@@ -118,7 +118,9 @@ __device__ __forceinline__ unsigned pf_unrank(unsigned rank, int l2, int rb) {
 // P = bucket slots per wave: the wave holds P buckets x 64 points; N <= P * PF_THREADS.
 // PROF = diagnostic build: per-wave s_memtime sums of the loop segments go to `dbg` (never shipped on the
 // product path; the timed kernel is the PROF = false instantiation).
-template <int P, bool PROF = false>
+// RESOLVE = this launch follows a checked guess (fps_verify.hip): scenes whose guess was confirmed only install
+// their final running distances.  A separate instantiation so that the plain kernel is untouched by it.
+template <int P, bool PROF = false, bool RESOLVE = false>
 __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
     int n, int m, int bs, int l2, int rb, const float *__restrict__ dataset, float *__restrict__ temp,
     int *__restrict__ idxs, unsigned long long *__restrict__ dbg = nullptr, const int *__restrict__ redo = nullptr,
@@ -128,7 +130,9 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
     __shared__ unsigned short sorted[P * PF_THREADS];
 
     const int scene = blockIdx.x;
-    if (fps_already_done(redo, temp_done, temp, scene, n)) return;
+    if constexpr (RESOLVE) {
+        if (fps_already_done(redo, temp_done, temp, scene, n)) return;
+    }
     const float *xyz = dataset + (size_t)scene * n * 3;
     temp += (size_t)scene * n;
     idxs += (size_t)scene * m;
@@ -464,8 +468,13 @@ int launch_fps_pruned(int b, int n, int m, const float *dataset, float *temp, in
     dim3 grid(b), block(PF_THREADS);
 #define SPS_PF_CASE(PP)                                                                                        \
     if (P <= PP) {                                                                                             \
-        hipLaunchKernelGGL((fps_pruned_kernel<PP, false>), grid, block, 0, st, n, m, bs, l2, rb, dataset, temp, idxs, \
-                           (unsigned long long *)nullptr, redo, temp_done);                                    \
+        if (redo)                                                                                              \
+            hipLaunchKernelGGL((fps_pruned_kernel<PP, false, true>), grid, block, 0, st, n, m, bs, l2, rb, dataset,   \
+                               temp, idxs, (unsigned long long *)nullptr, redo, temp_done);                    \
+        else                                                                                                   \
+            hipLaunchKernelGGL((fps_pruned_kernel<PP, false, false>), grid, block, 0, st, n, m, bs, l2, rb, dataset,  \
+                               temp, idxs, (unsigned long long *)nullptr, (const int *)nullptr,                \
+                               (const float *)nullptr);                                                        \
         return check_launch("fps_pruned_kernel");                                                             \
     }
     SPS_PF_CASE(4)

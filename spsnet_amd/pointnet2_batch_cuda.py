@@ -231,6 +231,19 @@ def ball_query_full(radius, nsample, xyz, new_xyz):
     return idx
 
 
+def ball_query_full2(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz):
+    """Two radii in one scan -> (idx_a (B,M,nsample_a), idx_b (B,M,nsample_b)), every row written."""
+    p, q = _ptr(xyz, F32, "xyz"), _ptr(new_xyz, F32, "new_xyz")
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    ia = torch.empty((B, M, nsample_a), dtype=I32, device=xyz.device)
+    ib = torch.empty((B, M, nsample_b), dtype=I32, device=xyz.device)
+    with _on(xyz):
+        _lib.check(_L.sps_ball_query_full2(B, N, M, radius_a, nsample_a, radius_b, nsample_b, q, p, ia.data_ptr(),
+                                           ib.data_ptr(), _stream(xyz)), "ball_query_full2")
+    return ia, ib
+
+
 def query_and_group(radius, nsample, xyz, new_xyz, features=None, use_xyz=True):
     """Fused QueryAndGroup.forward (pointnet2_utils.py:299-322) -> (new_features, idx)."""
     p, q = _ptr(xyz, F32, "xyz"), _ptr(new_xyz, F32, "new_xyz")

@@ -92,8 +92,12 @@ class _PointnetSAModuleBase(nn.Module):
             out = torch.empty((xyz.shape[0], sum(p.c3_real for p in plan), new_xyz.shape[1]),
                               dtype=torch.float32, device=xyz.device)
             offset = 0
-            for grouper, packed in zip(self.groupers, plan):
-                idx = _ext.ball_query_full(grouper.radius, grouper.nsample, xyz_c, new_c)
+            if len(plan) == 2:  # the usual two-scale layer: both ball queries share one scan
+                ga, gb = self.groupers
+                idxs = _ext.ball_query_full2(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz_c, new_c)
+            else:
+                idxs = [_ext.ball_query_full(g.radius, g.nsample, xyz_c, new_c) for g in self.groupers]
+            for idx, packed in zip(idxs, plan):
                 _fused.group_mlp_pool(xyz_c, new_c, feats_c, idx, packed, out, offset)
                 offset += packed.c3_real
             return out

@@ -552,3 +552,16 @@ def test_fps_ordered_prefix_with_ties(ext, G, oracle, N, m):
     idx, flags, temp = ext.fps_ordered_prefix(G.t(x1), m, return_flags=True)
     np.testing.assert_array_equal(G.n(idx), want)
     np.testing.assert_array_equal(G.n(temp), want_t)
+
+
+@pytest.mark.parametrize("N,M,ra,nsa,rb,nsb", [(16384, 4096, 0.2, 16, 0.8, 32), (4096, 1000, 0.8, 16, 1.6, 32),
+                                                (1024, 512, 1.6, 16, 4.8, 32), (333, 70, 0.5, 4, 0.3, 64)])
+def test_ball_query_dual_radius(ext, G, oracle, N, M, ra, nsa, rb, nsb):
+    from spsnet_amd import scenes
+    xyz, _ = scenes.make_batch("kitti-lidar-v1", 2, N, seed0=N)
+    rng = np.random.default_rng(M)
+    new_xyz = xyz[:, rng.integers(0, N, M)].copy()
+    new_xyz[:, -1] = 500.0
+    ia, ib = ext.ball_query_full2(ra, nsa, rb, nsb, G.t(xyz), G.t(new_xyz))
+    np.testing.assert_array_equal(G.n(ia), oracle.ball_query(ra, nsa, xyz, new_xyz))
+    np.testing.assert_array_equal(G.n(ib), oracle.ball_query(rb, nsb, xyz, new_xyz))
