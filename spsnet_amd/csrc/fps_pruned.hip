@@ -458,7 +458,9 @@ int launch_fps_pruned_profile(int b, int n, int m, const float *dataset, float *
 // returns SPS_OK after launching, or -1 if this variant does not apply (caller falls back to fps.hip)
 int launch_fps_pruned(int b, int n, int m, const float *dataset, float *temp, int *idxs, hipStream_t st,
                       const int *redo, const float *temp_done) {
-    if (n < 2048 || n > 32 * PF_THREADS) return -1;  // 32 bucket slots per wave = 16 384 points
+    // measured cross-over (tools/fps_time.py): below ~6k points the brute-force register kernel's iteration
+    // (N/1024 points per lane) is shorter than the pruned kernel's fixed test/reduce chain
+    if (n < 6144 || n > 32 * PF_THREADS) return -1;  // 32 bucket slots per wave = 16 384 points
     const int bs = sps_opt_n_threads(n);
     int l2 = 0;
     while ((1 << (l2 + 1)) <= bs) ++l2;

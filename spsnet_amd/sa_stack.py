@@ -73,7 +73,8 @@ _SIDE_STREAMS = {}
 
 
 def _side_stream(device):
-    key = (device.type, device.index)
+    """One helper stream per (device, current stream): concurrent passes on different streams do not share it."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]

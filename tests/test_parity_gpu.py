@@ -461,7 +461,7 @@ def test_fused_full_width_stack_against_cpu_oracle(ext, G, dev):
 
 
 # ------------------------------------------------------------------ pruned vs brute-force FPS kernels
-@pytest.mark.parametrize("N,m,kind", [(2048, 512, "lattice"), (4096, 1024, "dup"), (5000, 700, "dup"), (16384, 4096, "kitti"),
+@pytest.mark.parametrize("N,m,kind", [(6144, 512, "lattice"), (8192, 1024, "dup"), (7000, 700, "dup"), (16384, 4096, "kitti"),
                                       (16384, 600, "lattice"), (20480, 300, "dup"), (12345, 999, "uniform")])
 def test_fps_pruned_equals_bruteforce_and_oracle(ext, G, oracle, N, m, kind):
     """Both FPS kernel families (spatially pruned / brute-force register-resident) against the oracle,
@@ -490,7 +490,7 @@ def test_fps_pruned_equals_bruteforce_and_oracle(ext, G, oracle, N, m, kind):
 
 def test_fps_pruned_degenerate_clouds(ext, G, oracle):
     """All points identical / collinear / containing NaN and Inf: the cell grid degenerates, results must not."""
-    N, m = 4096, 300
+    N, m = 8192, 300
     same = np.ones((1, N, 3), np.float32) * 2.5
     line = np.zeros((1, N, 3), np.float32)
     line[0, :, 0] = np.random.default_rng(0).permutation(N).astype(np.float32) * 0.01
