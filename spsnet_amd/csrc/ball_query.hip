@@ -19,6 +19,7 @@
 //   * the finished 64 x nsample block of idx is contiguous in HBM and is written coalesced from a
 //     padded LDS image instead of one 4-byte store per hit per lane.
 #include "sps_common.h"
+#include "spatial_grid.h"
 
 namespace sps {
 
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_seg_kernel(
 // fully written (zeros for empty balls), like sps_ball_query_full.
 __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_dual_kernel(
     int n, int m, int seg_len, float r2a, float r2b, int nsa, int nsb, const float *__restrict__ new_xyz,
-    const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b) {
+    const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b, const int *__restrict__ perm) {
     extern __shared__ __attribute__((aligned(16))) int bq_lds[];
     const int S = blockDim.x / BQ_LANES;
     const int lane = threadIdx.x & 63;
@@ -160,10 +161,12 @@ __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_dual_kernel(
 
     const int scene = blockIdx.y;
     const int j0 = blockIdx.x * BQ_LANES;
-    const int j = j0 + lane;
-    const bool active = j < m;
+    const bool active = j0 + lane < m;
+    // With `perm` (centroid_order_kernel) the 64 lanes take 64 spatially neighbouring centroids instead of 64
+    // consecutive ones: far fewer 8-point batches contain a hit for ANY lane, and neighbours fill up together.
+    const int j = active ? (perm ? perm[(size_t)scene * m + j0 + lane] : j0 + lane) : 0;
     xyz += (size_t)scene * n * 3;
-    const float *ctr = new_xyz + ((size_t)scene * m + (active ? j : 0)) * 3;
+    const float *ctr = new_xyz + ((size_t)scene * m + j) * 3;
     const float cx = ctr[0], cy = ctr[1], cz = ctr[2];
 
     int ca = active ? 0 : nsa, cb = active ? 0 : nsb;
@@ -236,12 +239,69 @@ __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_dual_kernel(
             for (int i = kept; i < ns; ++i) final_img[i * (BQ_LANES + 1) + lane] = pad;
         }
         __syncthreads();
-        int *dst = (which ? idx_b : idx_a) + ((size_t)scene * m + j0) * ns;
+        int *out = (which ? idx_b : idx_a) + (size_t)scene * m * ns;
         for (int e = threadIdx.x; e < rows * ns; e += blockDim.x) {
             const int c = e / ns, i = e - c * ns;
-            dst[e] = final_img[i * (BQ_LANES + 1) + c];
+            const int row = perm ? perm[(size_t)scene * m + j0 + c] : j0 + c;  // rows stay ns*4-byte contiguous
+            out[(size_t)row * ns + i] = final_img[i * (BQ_LANES + 1) + c];
         }
         __syncthreads();
+    }
+}
+
+// perm[b, :] = the scene's centroids sorted by 12-bit cell key (counting sort in LDS, one workgroup per scene;
+// order inside a cell is arbitrary -- it only affects speed, never results).
+constexpr int CO_THREADS = 512;
+__global__ __launch_bounds__(CO_THREADS) void centroid_order_kernel(int m, const float *__restrict__ new_xyz,
+                                                                    int *__restrict__ perm) {
+    __shared__ int hist[PF_BINS];
+    __shared__ float red[6][CO_THREADS / 64];
+    __shared__ int wsum[CO_THREADS / 64];
+    const int scene = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *c = new_xyz + (size_t)scene * m * 3;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = tid; k < m; k += CO_THREADS)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], c[k * 3 + a]); hi[a] = fmaxf(hi[a], c[k * 3 + a]); }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o)); }
+        if (lane == 0) { red[a][wave] = lo[a]; red[3 + a][wave] = hi[a]; }
+    }
+    for (int i = tid; i < PF_BINS; i += CO_THREADS) hist[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = red[a][0]; hi[a] = red[3 + a][0];
+        for (int w = 1; w < CO_THREADS / 64; ++w) { lo[a] = fminf(lo[a], red[a][w]); hi[a] = fmaxf(hi[a], red[3 + a][w]); }
+    }
+    const PfGrid grid = pf_make_grid(lo, hi);
+    for (int k = tid; k < m; k += CO_THREADS) atomicAdd(&hist[pf_cell_key(grid, c[k * 3], c[k * 3 + 1], c[k * 3 + 2])], 1);
+    __syncthreads();
+    {
+        constexpr int PER = PF_BINS / CO_THREADS;
+        int loc[PER], sum = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { loc[i] = hist[tid * PER + i]; sum += loc[i]; }
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        int run = base + incl - sum;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { hist[tid * PER + i] = run; run += loc[i]; }
+    }
+    __syncthreads();
+    for (int k = tid; k < m; k += CO_THREADS) {
+        const int pos = atomicAdd(&hist[pf_cell_key(grid, c[k * 3], c[k * 3 + 1], c[k * 3 + 2])], 1);
+        perm[(size_t)scene * m + pos] = k;
     }
 }
 
@@ -278,7 +338,8 @@ int launch_ball_query(bool dilated, bool fill_empty, int b, int n, int m, float 
 }  // namespace sps
 
 extern "C" int sps_ball_query_full2(int b, int n, int m, float radius_a, int nsample_a, float radius_b, int nsample_b,
-                                    const float *new_xyz, const float *xyz, int *idx_a, int *idx_b, sps_stream_t stream) {
+                                    const float *new_xyz, const float *xyz, int *idx_a, int *idx_b, int *perm_work,
+                                    sps_stream_t stream) {
     using namespace sps;
     if (b < 0 || n < 0 || m < 0 || nsample_a <= 0 || nsample_b <= 0)
         return fail(SPS_ERR_INVALID, "ball_query_full2: bad shape b=%d n=%d m=%d ns=(%d,%d)", b, n, m, nsample_a, nsample_b);
@@ -297,8 +358,16 @@ extern "C" int sps_ball_query_full2(int b, int n, int m, float radius_a, int nsa
     if (lds_bytes(S) > 64 * 1024) return fail(SPS_ERR_INVALID, "ball_query_full2: nsample too large for LDS");
     int seg_len = divup(n > 0 ? n : 1, S);
     seg_len = divup(seg_len, BQ_BATCH) * BQ_BATCH;
+    const int *perm = nullptr;
+    if (perm_work && m >= 4 * BQ_LANES) {  // worth a sort only when a scene has several groups of centroids
+        hipLaunchKernelGGL(centroid_order_kernel, dim3(b), dim3(CO_THREADS), 0, as_stream(stream), m, new_xyz, perm_work);
+        const int rc = check_launch("centroid_order_kernel");
+        if (rc != SPS_OK) return rc;
+        perm = perm_work;
+    }
     hipLaunchKernelGGL(ball_query_dual_kernel, dim3(groups, b), dim3(BQ_LANES * S), lds_bytes(S), as_stream(stream), n, m,
-                       seg_len, radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b);
+                       seg_len, radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b,
+                       perm);
     return check_launch("ball_query_dual_kernel");
 }
 

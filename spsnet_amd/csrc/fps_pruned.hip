@@ -24,6 +24,7 @@
 // The arithmetic on every point that IS evaluated is exactly the reference's, and skipped points are
 // provably unchanged, so indices and the final `temp` array are bit-identical to the brute-force sweep.
 #include "sps_common.h"
+#include "spatial_grid.h"
 
 #include <math.h>
 
@@ -33,8 +34,6 @@ namespace sps {
 
 constexpr int PF_WAVES = 8;
 constexpr int PF_THREADS = PF_WAVES * 64;
-constexpr int PF_KEY_BITS = 12;
-constexpr int PF_BINS = 1 << PF_KEY_BITS;
 
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ int dpp_or(int v, int identity) {
@@ -69,31 +68,6 @@ __device__ __forceinline__ float wave_allmax_f32(float v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
-}
-
-struct PfGrid {       // wave-uniform description of the cell grid used for the spatial sort
-    float lo[3], scale[3];
-    int lim[3];              // cells per axis - 1
-    int axis[PF_KEY_BITS];   // key bit i (MSB first) is bit shift[i] of the cell coordinate on axis[i]
-    int shift[PF_KEY_BITS];
-};
-
-__device__ __forceinline__ int pf_cell_key(const PfGrid &g, float x, float y, float z) {
-    const float p[3] = {x, y, z};
-    int qv[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float u = (p[a] - g.lo[a]) * g.scale[a];
-        const int c = (u > 0.f) ? (int)fminf(u, (float)g.lim[a]) : 0;  // NaN / negative -> cell 0
-        qv[a] = c > g.lim[a] ? g.lim[a] : c;
-    }
-    int key = 0;
-#pragma unroll
-    for (int i = 0; i < PF_KEY_BITS; ++i) {
-        const int qa = g.axis[i] == 0 ? qv[0] : (g.axis[i] == 1 ? qv[1] : qv[2]);
-        key = (key << 1) | ((qa >> g.shift[i]) & 1);
-    }
-    return key;
 }
 
 struct PfShared {
@@ -157,44 +131,15 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
     }
     for (int i = tid; i < PF_BINS; i += PF_THREADS) sh.hist[i] = 0;
     __syncthreads();
-    PfGrid grid;
-    {
-        float ext[3];
-        int nb0 = 0, nb1 = 0, nb2 = 0;
+    float glo[3], ghi[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            float l = sh.red[a][0], h = sh.red[3 + a][0];
+    for (int a = 0; a < 3; ++a) {
+        float l = sh.red[a][0], h = sh.red[3 + a][0];
 #pragma unroll
-            for (int w = 1; w < PF_WAVES; ++w) { l = fminf(l, sh.red[a][w]); h = fmaxf(h, sh.red[3 + a][w]); }
-            float e = h - l;
-            if (!(e > 0.f) || !(e < 3.0e38f)) e = 0.f;  // degenerate / infinite extent: one cell on this axis
-            grid.lo[a] = (l > -3.0e38f && l < 3.0e38f) ? l : 0.f;
-            ext[a] = e;
-        }
-        // hand out the key bits one at a time to the axis whose cells are currently the longest
-        float c0 = ext[0], c1 = ext[1], c2 = ext[2];
-#pragma unroll
-        for (int i = 0; i < PF_KEY_BITS; ++i) {
-            int a = 0;
-            float cm = c0;
-            if (c1 > cm) { a = 1; cm = c1; }
-            if (c2 > cm) { a = 2; }
-            grid.axis[i] = a;
-            if (a == 0) { nb0 += 1; c0 *= 0.5f; } else if (a == 1) { nb1 += 1; c1 *= 0.5f; } else { nb2 += 1; c2 *= 0.5f; }
-        }
-        int u0 = 0, u1 = 0, u2 = 0;
-#pragma unroll
-        for (int i = 0; i < PF_KEY_BITS; ++i) {  // the j-th bit given to an axis is its j-th most significant cell bit
-            const int a = grid.axis[i];
-            if (a == 0) { u0 += 1; grid.shift[i] = nb0 - u0; } else if (a == 1) { u1 += 1; grid.shift[i] = nb1 - u1; } else { u2 += 1; grid.shift[i] = nb2 - u2; }
-        }
-        const int nbs[3] = {nb0, nb1, nb2};
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            grid.lim[a] = (1 << nbs[a]) - 1;
-            grid.scale[a] = (ext[a] > 0.f) ? (float)(1 << nbs[a]) / ext[a] : 0.f;
-        }
+        for (int w = 1; w < PF_WAVES; ++w) { l = fminf(l, sh.red[a][w]); h = fmaxf(h, sh.red[3 + a][w]); }
+        glo[a] = l; ghi[a] = h;
     }
+    const PfGrid grid = pf_make_grid(glo, ghi);
     // cell keys of this thread's points stay in registers between the histogram and the scatter pass
     int ckey[P];
 #pragma unroll

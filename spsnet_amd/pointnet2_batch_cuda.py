@@ -231,16 +231,21 @@ def ball_query_full(radius, nsample, xyz, new_xyz):
     return idx
 
 
-def ball_query_full2(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz):
-    """Two radii in one scan -> (idx_a (B,M,nsample_a), idx_b (B,M,nsample_b)), every row written."""
+def ball_query_full2(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz, spatial_groups=False):
+    """Two radii in one scan -> (idx_a (B,M,nsample_a), idx_b (B,M,nsample_b)), every row written.
+    spatial_groups: process centroids in spatially sorted groups of 64 (same result).  Measured on MI355X
+    (tools/bq_time.py, 8 x 4096 centroids over 16384 points): no gain at the IA-SSD radii (0.2/0.8: 353 us either
+    way), 1.5x faster at radius 3.0, slower for tiny balls -- hence off by default."""
     p, q = _ptr(xyz, F32, "xyz"), _ptr(new_xyz, F32, "new_xyz")
     B, N, _ = xyz.shape
     M = new_xyz.shape[1]
     ia = torch.empty((B, M, nsample_a), dtype=I32, device=xyz.device)
     ib = torch.empty((B, M, nsample_b), dtype=I32, device=xyz.device)
+    work = torch.empty((B, M), dtype=I32, device=xyz.device) if spatial_groups else None
     with _on(xyz):
         _lib.check(_L.sps_ball_query_full2(B, N, M, radius_a, nsample_a, radius_b, nsample_b, q, p, ia.data_ptr(),
-                                           ib.data_ptr(), _stream(xyz)), "ball_query_full2")
+                                           ib.data_ptr(), work.data_ptr() if work is not None else 0, _stream(xyz)),
+                   "ball_query_full2")
     return ia, ib
 
 

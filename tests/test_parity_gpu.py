@@ -562,6 +562,7 @@ def test_ball_query_dual_radius(ext, G, oracle, N, M, ra, nsa, rb, nsb):
     rng = np.random.default_rng(M)
     new_xyz = xyz[:, rng.integers(0, N, M)].copy()
     new_xyz[:, -1] = 500.0
-    ia, ib = ext.ball_query_full2(ra, nsa, rb, nsb, G.t(xyz), G.t(new_xyz))
-    np.testing.assert_array_equal(G.n(ia), oracle.ball_query(ra, nsa, xyz, new_xyz))
-    np.testing.assert_array_equal(G.n(ib), oracle.ball_query(rb, nsb, xyz, new_xyz))
+    for grouped in (True, False):
+        ia, ib = ext.ball_query_full2(ra, nsa, rb, nsb, G.t(xyz), G.t(new_xyz), spatial_groups=grouped)
+        np.testing.assert_array_equal(G.n(ia), oracle.ball_query(ra, nsa, xyz, new_xyz))
+        np.testing.assert_array_equal(G.n(ib), oracle.ball_query(rb, nsb, xyz, new_xyz))
