@@ -148,10 +148,13 @@ int sps_ball_query_full(int b, int n, int m, float radius, int nsample, const fl
 
 /* The two ball queries of a two-scale SA layer (same centroids, same points, two radii / nsample) in ONE scan:
  * identical to two sps_ball_query_full calls, the pair distance is evaluated once.  perm_work: optional device
- * scratch of B*M int32; when given, centroids are processed in spatially sorted groups (faster, same result). */
+ * scratch of B*M int32; when given, centroids are processed in spatially sorted groups of 64 (same result).
+ * sps_ball_query_full2_wave is the one-wave-per-centroid variant (per-centroid early exit; same result). */
 int sps_ball_query_full2(int b, int n, int m, float radius_a, int nsample_a, float radius_b, int nsample_b,
                          const float *new_xyz, const float *xyz, int *idx_a, int *idx_b, int *perm_work,
                          sps_stream_t stream);
+int sps_ball_query_full2_wave(int b, int n, int m, float radius_a, int nsample_a, float radius_b, int nsample_b,
+                              const float *new_xyz, const float *xyz, int *idx_a, int *idx_b, sps_stream_t stream);
 
 /* Fused group -> shared MLP -> max-pool of ONE grouping scale, inference mode (BatchNorm folded):
  * replaces grouping_operation x2 + cat + [Conv2d 1x1, BatchNorm2d, ReLU] x3 + max_pool2d of

@@ -39,6 +39,7 @@ _PROTOS = {
     "sps_gather_xyz": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "sps_ball_query_full": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
     "sps_ball_query_full2": [_i, _i, _i, _f, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_ball_query_full2_wave": [_i, _i, _i, _f, _i, _f, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_sa_group_mlp": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                          _i, _i, _vp],
     "sps_sa_group_mlp_supported": [_i, _i, _i],

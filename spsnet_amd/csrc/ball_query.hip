@@ -197,10 +197,25 @@ __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_dual_kernel(
 #pragma unroll
         for (int u = 1; u < BQ_BATCH; ++u) dmin = fminf(dmin, d2[u]);
         if (__any(dmin < thr)) {
+            // branch-free per-lane hit bitmasks of the 8 points, then each lane walks only its own set bits
+            // (ascending point index, so the ordered-fill rule holds); most lanes have none, the rest one or two
+            unsigned bits_a = 0u, bits_b = 0u;
 #pragma unroll
             for (int u = 0; u < BQ_BATCH; ++u) {
-                if (d2[u] < r2a) bq_append(hits_a, nsa, lane, k0 + u, ca);
-                if (d2[u] < r2b) bq_append(hits_b, nsb, lane, k0 + u, cb);
+                bits_a |= (d2[u] < r2a ? 1u : 0u) << u;
+                bits_b |= (d2[u] < r2b ? 1u : 0u) << u;
+            }
+            while (bits_a != 0u && ca < nsa) {
+                const int u = __builtin_ctz(bits_a);
+                bits_a &= bits_a - 1u;
+                hits_a[ca * BQ_LANES + lane] = k0 + u;
+                ++ca;
+            }
+            while (bits_b != 0u && cb < nsb) {
+                const int u = __builtin_ctz(bits_b);
+                bits_b &= bits_b - 1u;
+                hits_b[cb * BQ_LANES + lane] = k0 + u;
+                ++cb;
             }
             thr = lane_thr();
         }
@@ -247,6 +262,66 @@ __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_dual_kernel(
         }
         __syncthreads();
     }
+}
+
+// ---- wave-per-centroid variant ---------------------------------------------------------------------------
+// One WAVE per centroid, one LANE per scanned point (64 points per step, coalesced 12-byte reads served by
+// L1/L2): hits are ordered with ballot + prefix popcount, and the scan of a centroid stops as soon as ITS lists
+// are full.  In lidar clouds most balls fill after a fraction of the cloud, which the lane-per-centroid kernel
+// cannot exploit (it stops only when all 64 centroids of a wave are full) and whose per-hit divergent appends
+// cost more than its distance arithmetic (tools/bq_time.py: 353 us vs 150 us without hits at the layer-0 shape).
+constexpr int BQW_WAVES = 4;   // centroids per workgroup
+constexpr int BQW_UNROLL = 4;  // 64-point steps in flight per loop trip
+
+__global__ __launch_bounds__(64 * BQW_WAVES) void ball_query_wave_dual_kernel(
+    int n, int m, float r2a, float r2b, int nsa, int nsb, const float *__restrict__ new_xyz,
+    const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b) {
+    const int scene = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * BQW_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (j >= m) return;
+    xyz += (size_t)scene * n * 3;
+    const float *ctr = new_xyz + ((size_t)scene * m + j) * 3;
+    const float cx = ctr[0], cy = ctr[1], cz = ctr[2];
+    int *row_a = idx_a + ((size_t)scene * m + j) * nsa;
+    int *row_b = idx_b + ((size_t)scene * m + j) * nsb;
+    const unsigned long long below = (1ull << lane) - 1ull;  // lanes (= points) before mine in this step
+
+    int ca = 0, cb = 0, first_a = 0, first_b = 0;  // wave-uniform
+    for (int base = 0; base < n; base += 64 * BQW_UNROLL) {
+        float px[BQW_UNROLL], py[BQW_UNROLL], pz[BQW_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BQW_UNROLL; ++u) {
+            const int k = base + u * 64 + lane;
+            const int kk = k < n ? k : n - 1;
+            px[u] = xyz[kk * 3 + 0]; py[u] = xyz[kk * 3 + 1]; pz[u] = xyz[kk * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < BQW_UNROLL; ++u) {
+            const int k = base + u * 64 + lane;
+            const float d2 = sqdist(cx, cy, cz, px[u], py[u], pz[u]);
+            const bool in = k < n;
+            const bool ha = in && d2 < r2a, hb = in && d2 < r2b;
+            const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
+            if (ma != 0ull && ca < nsa) {
+                if (ca == 0) first_a = base + u * 64 + __builtin_ctzll(ma);
+                const int pos = ca + __builtin_popcountll(ma & below);
+                if (ha && pos < nsa) row_a[pos] = k;
+                ca += __builtin_popcountll(ma);
+            }
+            if (mb != 0ull && cb < nsb) {
+                if (cb == 0) first_b = base + u * 64 + __builtin_ctzll(mb);
+                const int pos = cb + __builtin_popcountll(mb & below);
+                if (hb && pos < nsb) row_b[pos] = k;
+                cb += __builtin_popcountll(mb);
+            }
+        }
+        if (ca >= nsa && cb >= nsb) break;
+    }
+    // pad with the first hit (zeros for an empty ball: first_* is still 0)
+    const int ka = ca < nsa ? ca : nsa, kb = cb < nsb ? cb : nsb;
+    for (int l = ka + lane; l < nsa; l += 64) row_a[l] = first_a;
+    for (int l = kb + lane; l < nsb; l += 64) row_b[l] = first_b;
 }
 
 // perm[b, :] = the scene's centroids sorted by 12-bit cell key (counting sort in LDS, one workgroup per scene;
@@ -346,6 +421,7 @@ extern "C" int sps_ball_query_full2(int b, int n, int m, float radius_a, int nsa
     if (b == 0 || m == 0) return SPS_OK;
     if (!new_xyz || (!xyz && n > 0) || !idx_a || !idx_b) return fail(SPS_ERR_INVALID, "ball_query_full2: null pointer");
     if (b > 65535) return fail(SPS_ERR_INVALID, "ball_query_full2: batch %d exceeds the grid limit", b);
+    if (n == 0) return fail(SPS_ERR_INVALID, "ball_query_full2: n == 0");
     const int groups = divup(m, BQ_LANES);
     int S = divup(4096, b * groups);
     S = S < 1 ? 1 : (S > BQ_MAX_SEG ? BQ_MAX_SEG : S);
@@ -369,6 +445,21 @@ extern "C" int sps_ball_query_full2(int b, int n, int m, float radius_a, int nsa
                        seg_len, radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b,
                        perm);
     return check_launch("ball_query_dual_kernel");
+}
+
+// wave-per-centroid variant of sps_ball_query_full2 (same result; faster when balls fill early, i.e. large radii)
+extern "C" int sps_ball_query_full2_wave(int b, int n, int m, float radius_a, int nsample_a, float radius_b,
+                                         int nsample_b, const float *new_xyz, const float *xyz, int *idx_a, int *idx_b,
+                                         sps_stream_t stream) {
+    using namespace sps;
+    if (b < 0 || n <= 0 || m < 0 || nsample_a <= 0 || nsample_b <= 0)
+        return fail(SPS_ERR_INVALID, "ball_query_full2_wave: bad shape b=%d n=%d m=%d ns=(%d,%d)", b, n, m, nsample_a, nsample_b);
+    if (b == 0 || m == 0) return SPS_OK;
+    if (!new_xyz || !xyz || !idx_a || !idx_b) return fail(SPS_ERR_INVALID, "ball_query_full2_wave: null pointer");
+    if (b > 65535) return fail(SPS_ERR_INVALID, "ball_query_full2_wave: batch %d exceeds the grid limit", b);
+    hipLaunchKernelGGL(ball_query_wave_dual_kernel, dim3(divup(m, BQW_WAVES), b), dim3(64 * BQW_WAVES), 0, as_stream(stream),
+                       n, m, radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b);
+    return check_launch("ball_query_wave_dual_kernel");
 }
 
 extern "C" int sps_ball_query_kernel_launcher_fast(int b, int n, int m, float radius, int nsample,

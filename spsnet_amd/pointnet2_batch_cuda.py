@@ -231,7 +231,7 @@ def ball_query_full(radius, nsample, xyz, new_xyz):
     return idx
 
 
-def ball_query_full2(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz, spatial_groups=False):
+def ball_query_full2(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz, spatial_groups=False, wave_per_centroid=False):
     """Two radii in one scan -> (idx_a (B,M,nsample_a), idx_b (B,M,nsample_b)), every row written.
     spatial_groups: process centroids in spatially sorted groups of 64 (same result).  Measured on MI355X
     (tools/bq_time.py, 8 x 4096 centroids over 16384 points): no gain at the IA-SSD radii (0.2/0.8: 353 us either
@@ -241,6 +241,11 @@ def ball_query_full2(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz, spa
     M = new_xyz.shape[1]
     ia = torch.empty((B, M, nsample_a), dtype=I32, device=xyz.device)
     ib = torch.empty((B, M, nsample_b), dtype=I32, device=xyz.device)
+    if wave_per_centroid:
+        with _on(xyz):
+            _lib.check(_L.sps_ball_query_full2_wave(B, N, M, radius_a, nsample_a, radius_b, nsample_b, q, p, ia.data_ptr(),
+                                                    ib.data_ptr(), _stream(xyz)), "ball_query_full2_wave")
+        return ia, ib
     work = torch.empty((B, M), dtype=I32, device=xyz.device) if spatial_groups else None
     with _on(xyz):
         _lib.check(_L.sps_ball_query_full2(B, N, M, radius_a, nsample_a, radius_b, nsample_b, q, p, ia.data_ptr(),

@@ -562,7 +562,8 @@ def test_ball_query_dual_radius(ext, G, oracle, N, M, ra, nsa, rb, nsb):
     rng = np.random.default_rng(M)
     new_xyz = xyz[:, rng.integers(0, N, M)].copy()
     new_xyz[:, -1] = 500.0
-    for grouped in (True, False):
-        ia, ib = ext.ball_query_full2(ra, nsa, rb, nsb, G.t(xyz), G.t(new_xyz), spatial_groups=grouped)
+    for grouped, wave in ((True, False), (False, False), (False, True)):
+        ia, ib = ext.ball_query_full2(ra, nsa, rb, nsb, G.t(xyz), G.t(new_xyz), spatial_groups=grouped,
+                                      wave_per_centroid=wave)
         np.testing.assert_array_equal(G.n(ia), oracle.ball_query(ra, nsa, xyz, new_xyz))
         np.testing.assert_array_equal(G.n(ib), oracle.ball_query(rb, nsb, xyz, new_xyz))

@@ -17,5 +17,6 @@ def t(fn, n=5):
 for ra, rb in ((0.2, 0.8), (1e-4, 2e-4), (0.2, 0.2), (0.8, 0.8), (3.0, 3.0)):
     print(f"radii ({ra},{rb}) dual grouped  : {t(lambda: ext.ball_query_full2(ra, 16, rb, 32, xyz, new_xyz, True)):8.1f} us")
     print(f"radii ({ra},{rb}) dual ungrouped: {t(lambda: ext.ball_query_full2(ra, 16, rb, 32, xyz, new_xyz, False)):8.1f} us")
+    print(f"radii ({ra},{rb}) dual wave/ctr : {t(lambda: ext.ball_query_full2(ra, 16, rb, 32, xyz, new_xyz, False, True)):8.1f} us")
 for r, ns in ((0.2, 16), (0.8, 32)):
     print(f"single r={r} ns={ns}: {t(lambda: ext.ball_query_full(r, ns, xyz, new_xyz)):8.1f} us")
