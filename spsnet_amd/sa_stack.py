@@ -128,7 +128,7 @@ def run_sa_layers(layers, xyz, features, stds=None, overlap=True):
     new_xyz exists; results are identical, only the schedule changes."""
     outs = []
     cls_pred = None
-    use_overlap = overlap and xyz.is_cuda and not torch.is_grad_enabled() and stds is None
+    use_overlap = overlap and xyz.is_cuda and not torch.is_grad_enabled()
     for k, layer in enumerate(layers):
         nxt = layers[k + 1] if k + 1 < len(layers) else None
         if use_overlap and nxt is not None and _can_prefetch(layer, nxt):
