@@ -58,9 +58,11 @@ class FpsProbe:
     def __init__(self, ext, n_points):
         self.ext, self.n = ext, n_points
         self.orig = ext.farthest_point_sampling_wrapper
+        self.orig_publish = ext.fps_publish
         self.pairs = []
         self.on = False
         ext.farthest_point_sampling_wrapper = self
+        ext.fps_publish = self.publish
 
     def __call__(self, b, n, m, points, temp, idx):
         if not (self.on and n == self.n):
@@ -71,6 +73,16 @@ class FpsProbe:
         e.record()
         self.pairs.append((s, e, b, n, m))
         return r
+
+    def publish(self, xyz, temp, idx, progress):
+        """Same probe around the publishing launch used by the streamed first layer (same kernel, same stream)."""
+        if not (self.on and xyz.shape[1] == self.n):
+            return self.orig_publish(xyz, temp, idx, progress)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        self.orig_publish(xyz, temp, idx, progress)
+        e.record()
+        self.pairs.append((s, e, xyz.shape[0], xyz.shape[1], idx.shape[1]))
 
     def summary(self):
         if not self.pairs:

@@ -171,6 +171,27 @@ int sps_sa_group_mlp(int b, int n, int m, int c_feat, int nsample, const float *
                      const float *b3, float *out, int out_c_total, int out_c_off, sps_stream_t stream);
 int sps_sa_group_mlp_supported(int c1, int c2, int nsample);
 
+/* ---- chunked layer 0: consume FPS output while FPS is still running (spsnet_amd/sa_stack.py) ------------
+ * sps_fps_publish: the pruned FPS kernel (6144 <= n <= 16384) storing its samples write-through and publishing
+ * progress[scene] = samples written so far every 64 samples (device i32 per scene; the CALLER zeroes it before
+ * releasing any consumer stream).
+ * sps_wait_progress: enqueue a bounded spin on `stream` until every scene has published `need` samples.
+ * The *_range variants restrict the centroid loop of every scene to [j0, j0+jcount) (jcount a multiple of 64
+ * for the ball query / MLP); buffers keep their full (B, M, ...) shapes. */
+int sps_fps_publish(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress,
+                    sps_stream_t stream);
+int sps_wait_progress(const int *progress, int b, int need, int *timed_out, sps_stream_t stream);
+int sps_gather_xyz_range(int b, int n, int m, int j0, int jcount, const float *xyz, const int *idx, float *out,
+                         sps_stream_t stream);
+int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcount, float radius_a, int nsample_a,
+                               float radius_b, int nsample_b, const float *new_xyz, const float *xyz, int *idx_a,
+                               int *idx_b, int *perm_work, sps_stream_t stream);
+int sps_sa_group_mlp_range(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,
+                           const float *new_xyz, const float *features, const int *idx, int c1, int c2, int c3,
+                           int c3_real, const float *w1, const float *b1, const float *w2, const float *b2,
+                           const float *w3, const float *b3, float *out, int out_c_total, int out_c_off,
+                           sps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

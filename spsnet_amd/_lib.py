@@ -43,6 +43,12 @@ _PROTOS = {
     "sps_sa_group_mlp": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                          _i, _i, _vp],
     "sps_sa_group_mlp_supported": [_i, _i, _i],
+    "sps_fps_publish": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sps_wait_progress": [_vp, _i, _i, _vp, _vp],
+    "sps_gather_xyz_range": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sps_ball_query_full2_range": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_sa_group_mlp_range": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
+                               _vp, _vp, _i, _i, _vp],
 }
 EXPORTS = ["sps_abi_version", "sps_last_error", "sps_opt_n_threads"] + list(_PROTOS)
 

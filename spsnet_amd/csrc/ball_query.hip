@@ -149,7 +149,8 @@ __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_seg_kernel(
 // fully written (zeros for empty balls), like sps_ball_query_full.
 __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_dual_kernel(
     int n, int m, int seg_len, float r2a, float r2b, int nsa, int nsb, const float *__restrict__ new_xyz,
-    const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b, const int *__restrict__ perm) {
+    const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b, const int *__restrict__ perm,
+    int jbeg, int jend) {
     extern __shared__ __attribute__((aligned(16))) int bq_lds[];
     const int S = blockDim.x / BQ_LANES;
     const int lane = threadIdx.x & 63;
@@ -160,8 +161,8 @@ __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_dual_kernel(
     int *final_img = cnts + 2 * S * BQ_LANES;
 
     const int scene = blockIdx.y;
-    const int j0 = blockIdx.x * BQ_LANES;
-    const bool active = j0 + lane < m;
+    const int j0 = jbeg + blockIdx.x * BQ_LANES;  // centroid range [jbeg, jend) of every scene
+    const bool active = j0 + lane < jend;
     // With `perm` (centroid_order_kernel) the 64 lanes take 64 spatially neighbouring centroids instead of 64
     // consecutive ones: far fewer 8-point batches contain a hit for ANY lane, and neighbours fill up together.
     const int j = active ? (perm ? perm[(size_t)scene * m + j0 + lane] : j0 + lane) : 0;
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_dual_kernel(
     cnts[seg * BQ_LANES + lane] = active ? ca : 0;
     cnts[(S + seg) * BQ_LANES + lane] = active ? cb : 0;
     __syncthreads();
-    const int rows = (m - j0 < BQ_LANES) ? m - j0 : BQ_LANES;
+    const int rows = (jend - j0 < BQ_LANES) ? jend - j0 : BQ_LANES;
     // merge + write-out, one radius after the other through the shared `final` image
     for (int which = 0; which < 2; ++which) {
         const int ns = which ? nsb : nsa;
@@ -415,14 +416,23 @@ int launch_ball_query(bool dilated, bool fill_empty, int b, int n, int m, float 
 extern "C" int sps_ball_query_full2(int b, int n, int m, float radius_a, int nsample_a, float radius_b, int nsample_b,
                                     const float *new_xyz, const float *xyz, int *idx_a, int *idx_b, int *perm_work,
                                     sps_stream_t stream) {
+    return sps_ball_query_full2_range(b, n, m, 0, m, radius_a, nsample_a, radius_b, nsample_b, new_xyz, xyz, idx_a, idx_b,
+                                      perm_work, stream);
+}
+
+extern "C" int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcount, float radius_a, int nsample_a,
+                                          float radius_b, int nsample_b, const float *new_xyz, const float *xyz,
+                                          int *idx_a, int *idx_b, int *perm_work, sps_stream_t stream) {
     using namespace sps;
-    if (b < 0 || n < 0 || m < 0 || nsample_a <= 0 || nsample_b <= 0)
-        return fail(SPS_ERR_INVALID, "ball_query_full2: bad shape b=%d n=%d m=%d ns=(%d,%d)", b, n, m, nsample_a, nsample_b);
-    if (b == 0 || m == 0) return SPS_OK;
+    if (b < 0 || n < 0 || m < 0 || nsample_a <= 0 || nsample_b <= 0 || j0 < 0 || jcount < 0 || j0 + jcount > m)
+        return fail(SPS_ERR_INVALID, "ball_query_full2: bad shape b=%d n=%d m=%d ns=(%d,%d) range [%d,+%d)", b, n, m,
+                    nsample_a, nsample_b, j0, jcount);
+    if (perm_work && !(j0 == 0 && jcount == m)) return fail(SPS_ERR_INVALID, "ball_query_full2: perm_work needs the full range");
+    if (b == 0 || jcount == 0) return SPS_OK;
     if (!new_xyz || (!xyz && n > 0) || !idx_a || !idx_b) return fail(SPS_ERR_INVALID, "ball_query_full2: null pointer");
     if (b > 65535) return fail(SPS_ERR_INVALID, "ball_query_full2: batch %d exceeds the grid limit", b);
     if (n == 0) return fail(SPS_ERR_INVALID, "ball_query_full2: n == 0");
-    const int groups = divup(m, BQ_LANES);
+    const int groups = divup(jcount, BQ_LANES);
     int S = divup(4096, b * groups);
     S = S < 1 ? 1 : (S > BQ_MAX_SEG ? BQ_MAX_SEG : S);
     while (S > 1 && n / S < 256) --S;
@@ -443,7 +453,7 @@ extern "C" int sps_ball_query_full2(int b, int n, int m, float radius_a, int nsa
     }
     hipLaunchKernelGGL(ball_query_dual_kernel, dim3(groups, b), dim3(BQ_LANES * S), lds_bytes(S), as_stream(stream), n, m,
                        seg_len, radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b,
-                       perm);
+                       perm, j0, j0 + jcount);
     return check_launch("ball_query_dual_kernel");
 }
 

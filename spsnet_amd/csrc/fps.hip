@@ -264,6 +264,47 @@ extern "C" int sps_debug_fps_profile(int b, int n, int m, const float *dataset, 
     return sps::launch_fps_pruned_profile(b, n, m, dataset, temp, idxs, dbg, sps::as_stream(stream));
 }
 
+// One workgroup, one wave: spin (bounded, with s_sleep) until every scene has published `need` samples.
+__global__ __launch_bounds__(64) void wait_progress_kernel(const int *progress, int b, int need, int *timed_out) {
+    const int lane = threadIdx.x;
+    for (int base = 0; base < b; base += 64) {
+        const int sc = base + lane;
+        bool done = sc >= b;
+        for (unsigned spins = 0;; ++spins) {
+            if (!done) done = __hip_atomic_load(&progress[sc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+            if (__all(done)) break;
+            if (spins > (1u << 22)) {  // seconds: the producer is gone
+                if (lane == 0) *timed_out = 1;
+                return;
+            }
+            __builtin_amdgcn_s_sleep(64);
+        }
+    }
+}
+
+// FPS whose output can be consumed while it runs (pruned kernel sizes only: 6144 <= n <= 16384).
+// progress (B i32, device) counts the samples each scene has published.  The CALLER zeroes it -- before it lets
+// any consumer stream go (a memset enqueued here would race with a wait already running on another stream).
+extern "C" int sps_fps_publish(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress,
+                               sps_stream_t stream) {
+    using namespace sps;
+    if (b <= 0 || n <= 0 || m <= 0 || !dataset || !temp || !idxs || !progress)
+        return fail(SPS_ERR_INVALID, "fps_publish: bad arguments");
+    hipStream_t st = as_stream(stream);
+    const int rc = launch_fps_pruned_publish(b, n, m, dataset, temp, idxs, progress, st);
+    if (rc < 0) return fail(SPS_ERR_INVALID, "fps_publish: no publishing kernel for n=%d", n);
+    return rc;
+}
+
+// Block `stream` until every scene's progress counter reaches `need` (a tiny spinning kernel, bounded).
+// timed_out (device i32, caller-zeroed) is set to 1 if the bound was hit.
+extern "C" int sps_wait_progress(const int *progress, int b, int need, int *timed_out, sps_stream_t stream) {
+    using namespace sps;
+    if (b <= 0 || !progress || !timed_out) return fail(SPS_ERR_INVALID, "wait_progress: bad arguments");
+    hipLaunchKernelGGL(wait_progress_kernel, dim3(1), dim3(64), 0, as_stream(stream), progress, b, need, timed_out);
+    return check_launch("wait_progress_kernel");
+}
+
 extern "C" int sps_opt_n_threads(int work_size) {
     // cuda_utils.h:10-14 (double log, truncation, clamp to [1, 1024])
     const int pow_2 = (int)(log((double)work_size) / log(2.0));

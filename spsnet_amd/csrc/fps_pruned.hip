@@ -94,11 +94,15 @@ __device__ __forceinline__ unsigned pf_unrank(unsigned rank, int l2, int rb) {
 // product path; the timed kernel is the PROF = false instantiation).
 // RESOLVE = this launch follows a checked guess (fps_verify.hip): scenes whose guess was confirmed only install
 // their final running distances.  A separate instantiation so that the plain kernel is untouched by it.
-template <int P, bool PROF = false, bool RESOLVE = false>
+// PUBLISH = consumers on other CUs read idxs while this kernel is still running (sa_stack's chunked layer 0):
+// the samples are stored write-through (sc1) by ONE lane, and after every 64th that lane drains its stores
+// (s_waitcnt vmcnt(0)) and stores progress[scene] = number of samples written, also sc1 -- the R1 hand-off of
+// cdna_hip_programming.md Guideline 16 (one lane signals for all its own stores; consumers poll relaxed).
+template <int P, bool PROF = false, bool RESOLVE = false, bool PUBLISH = false>
 __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
     int n, int m, int bs, int l2, int rb, const float *__restrict__ dataset, float *__restrict__ temp,
     int *__restrict__ idxs, unsigned long long *__restrict__ dbg = nullptr, const int *__restrict__ redo = nullptr,
-    const float *__restrict__ temp_done = nullptr) {
+    const float *__restrict__ temp_done = nullptr, int *__restrict__ progress = nullptr) {
     if (m <= 0) return;
     __shared__ PfShared sh;
     __shared__ unsigned short sorted[P * PF_THREADS];
@@ -267,7 +271,8 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
     }
 
     if (tid == 0) {
-        idxs[0] = 0;
+        if constexpr (PUBLISH) __hip_atomic_store(&idxs[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else idxs[0] = 0;
         sh.slot[0] = 0ull; sh.slot[1] = 0ull; sh.slot[2] = 0ull;
     }
     float cx = xyz[0], cy = xyz[1], cz = xyz[2];
@@ -363,7 +368,16 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
         cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), ww));
         if (tid == 0) {
             const unsigned rank = 0x0FFFFFFFu - (unsigned)((win >> 4) & 0x0FFFFFFFull);
-            idxs[j] = (int)pf_unrank(rank, l2, rb);
+            const int picked = (int)pf_unrank(rank, l2, rb);
+            if constexpr (PUBLISH) {
+                __hip_atomic_store(&idxs[j], picked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((j & 63) == 63 || j == m - 1) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&progress[blockIdx.x], j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                idxs[j] = picked;
+            }
         }
         if constexpr (PROF) {
             const unsigned long long s6 = stamp();
@@ -398,6 +412,30 @@ int launch_fps_pruned_profile(int b, int n, int m, const float *dataset, float *
     hipLaunchKernelGGL((fps_pruned_kernel<32, true>), dim3(b), dim3(PF_THREADS), 0, st, n, m, bs, l2, rb, dataset, temp,
                        idxs, dbg);
     return check_launch("fps_pruned_kernel<profile>");
+}
+
+// publishing variant for chunked consumers; -1 if the pruned kernel does not apply to this size
+int launch_fps_pruned_publish(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress,
+                              hipStream_t st) {
+    if (n < 6144 || n > 32 * PF_THREADS || m < 2) return -1;
+    const int bs = sps_opt_n_threads(n);
+    int l2 = 0;
+    while ((1 << (l2 + 1)) <= bs) ++l2;
+    int rb = 0;
+    while ((1 << rb) < divup(n, bs)) ++rb;
+    const int P = divup(n, PF_THREADS);
+    dim3 grid(b), block(PF_THREADS);
+#define SPS_PFP_CASE(PP)                                                                                         \
+    if (P <= PP) {                                                                                               \
+        hipLaunchKernelGGL((fps_pruned_kernel<PP, false, false, true>), grid, block, 0, st, n, m, bs, l2, rb, dataset, \
+                           temp, idxs, (unsigned long long *)nullptr, (const int *)nullptr, (const float *)nullptr, \
+                           progress);                                                                            \
+        return check_launch("fps_pruned_kernel<publish>");                                                      \
+    }
+    SPS_PFP_CASE(16)
+    SPS_PFP_CASE(32)
+#undef SPS_PFP_CASE
+    return -1;
 }
 
 // returns SPS_OK after launching, or -1 if this variant does not apply (caller falls back to fps.hip)

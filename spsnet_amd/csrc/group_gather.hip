@@ -46,11 +46,12 @@ __global__ __launch_bounds__(GG_THREADS) void group_grad_kernel(
 
 // new_xyz[b,j,:] = xyz[b,idx[b,j],:] on the native (B,N,3) layout: what the reference obtains with
 // transpose + gather_operation + transpose (pointnet2_modules.py:261,423-424), without the two copies
-__global__ __launch_bounds__(GG_THREADS) void gather_xyz_kernel(int n, int m, const float *__restrict__ xyz,
+__global__ __launch_bounds__(GG_THREADS) void gather_xyz_kernel(int n, int m, int j0, int jcount,
+                                                                 const float *__restrict__ xyz,
                                                                  const int *__restrict__ idx, float *__restrict__ out) {
     const int scene = blockIdx.y;
-    const int j = blockIdx.x * GG_THREADS + threadIdx.x;
-    if (j >= m) return;
+    const int j = j0 + blockIdx.x * GG_THREADS + threadIdx.x;
+    if (j >= j0 + jcount) return;
     const float *p = xyz + ((size_t)scene * n + idx[(size_t)scene * m + j]) * 3;
     float *o = out + ((size_t)scene * m + j) * 3;
     o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
@@ -76,13 +77,20 @@ static int launch_group(bool grad, const char *what, int b, int c, int n, int np
 }  // namespace sps
 
 extern "C" int sps_gather_xyz(int b, int n, int m, const float *xyz, const int *idx, float *out, sps_stream_t stream) {
+    return sps_gather_xyz_range(b, n, m, 0, m, xyz, idx, out, stream);
+}
+
+extern "C" int sps_gather_xyz_range(int b, int n, int m, int j0, int jcount, const float *xyz, const int *idx, float *out,
+                                    sps_stream_t stream) {
     using namespace sps;
-    if (b < 0 || n < 0 || m < 0) return fail(SPS_ERR_INVALID, "gather_xyz: bad shape b=%d n=%d m=%d", b, n, m);
-    if (b == 0 || m == 0) return SPS_OK;
+    if (b < 0 || n < 0 || m < 0 || j0 < 0 || jcount < 0 || j0 + jcount > m)
+        return fail(SPS_ERR_INVALID, "gather_xyz: bad shape b=%d n=%d m=%d range [%d,+%d)", b, n, m, j0, jcount);
+    if (b == 0 || jcount == 0) return SPS_OK;
     if (n == 0) return fail(SPS_ERR_INVALID, "gather_xyz: n == 0 with a non-empty index");
     if (!xyz || !idx || !out) return fail(SPS_ERR_INVALID, "gather_xyz: null pointer");
     if (b > 65535) return fail(SPS_ERR_INVALID, "gather_xyz: grid too large");
-    hipLaunchKernelGGL(gather_xyz_kernel, dim3(divup(m, GG_THREADS), b), dim3(GG_THREADS), 0, as_stream(stream), n, m, xyz, idx, out);
+    hipLaunchKernelGGL(gather_xyz_kernel, dim3(divup(jcount, GG_THREADS), b), dim3(GG_THREADS), 0, as_stream(stream), n, m, j0,
+                       jcount, xyz, idx, out);
     return check_launch("gather_xyz_kernel");
 }
 

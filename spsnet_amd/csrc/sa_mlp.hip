@@ -65,6 +65,7 @@ __device__ __forceinline__ float row_allmax(float v) {
 
 struct SaMlpArgs {
     int n, m, c_feat, units;       // points/scene, centroids/scene, feature channels, total units
+    int j0, ups;                   // centroid range start within every scene; units per scene
     int ks1;                       // layer-1 k-steps = ceil((3 + c_feat) / 4)
     int c3;                        // padded last-layer width (multiple of 16)
     int c3_real;                   // channels actually written
@@ -91,7 +92,9 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
     const int nwaves = gridDim.x * (blockDim.x >> 6);
 
     for (int unit = wave; unit < a.units; unit += nwaves) {
-        const long long col0 = (long long)unit * UNIT;  // first flattened (b, j, s) column of the unit
+        // first flattened (b, j, s) column of the unit: scene = unit / ups, centroids from j0 on
+        const int ub = unit / a.ups;
+        const long long col0 = ((long long)ub * a.m + a.j0) * NS + (long long)(unit - ub * a.ups) * UNIT;
         f32x4 h2[T2][NT];
         {
             // column owned by this lane in tile nt
@@ -270,9 +273,11 @@ template <int C1, int C2, int NT, int NS>
 static int launch_variant(const SaMlpArgs &a, hipStream_t st) {
     constexpr int UNIT = 16 * NT;
     SaMlpArgs k = a;
-    const long long cols = (long long)a.units;  // caller passes total columns; convert to units
-    if (cols % UNIT != 0) return fail(SPS_ERR_INVALID, "sa_group_mlp: B*M*nsample=%lld not a multiple of %d", cols, UNIT);
-    k.units = (int)(cols / UNIT);
+    const long long cols_scene = (long long)a.ups * NS;  // caller passes centroids per scene in `ups`, scenes in `units`
+    if (cols_scene % UNIT != 0)
+        return fail(SPS_ERR_INVALID, "sa_group_mlp: centroids*nsample per scene (%lld) not a multiple of %d", cols_scene, UNIT);
+    k.ups = (int)(cols_scene / UNIT);
+    k.units = a.units * k.ups;
     const int waves_per_block = 4;
     int blocks = divup(k.units, waves_per_block);
     const int max_blocks = 256 * 8;
@@ -290,17 +295,29 @@ extern "C" int sps_sa_group_mlp(int b, int n, int m, int c_feat, int nsample, co
                                 int c3, int c3_real, const float *w1, const float *b1, const float *w2,
                                 const float *b2, const float *w3, const float *b3, float *out, int out_c_total,
                                 int out_c_off, sps_stream_t stream) {
+    return sps_sa_group_mlp_range(b, n, m, 0, m, c_feat, nsample, xyz, new_xyz, features, idx, c1, c2, c3, c3_real, w1, b1,
+                                  w2, b2, w3, b3, out, out_c_total, out_c_off, stream);
+}
+
+extern "C" int sps_sa_group_mlp_range(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,
+                                      const float *new_xyz, const float *features, const int *idx, int c1, int c2,
+                                      int c3, int c3_real, const float *w1, const float *b1, const float *w2,
+                                      const float *b2, const float *w3, const float *b3, float *out, int out_c_total,
+                                      int out_c_off, sps_stream_t stream) {
     using namespace sps;
     if (b < 0 || n <= 0 || m < 0 || c_feat < 0 || nsample <= 0 || c3 <= 0 || (c3 % 16) || c3_real > c3 ||
-        out_c_off < 0 || out_c_off + c3_real > out_c_total)
+        out_c_off < 0 || out_c_off + c3_real > out_c_total || j0 < 0 || jcount < 0 || j0 + jcount > m)
         return fail(SPS_ERR_INVALID, "sa_group_mlp: bad shape");
-    if (b == 0 || m == 0) return SPS_OK;
+    if (b == 0 || jcount == 0) return SPS_OK;
     if (!xyz || !new_xyz || !idx || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !out || (c_feat > 0 && !features))
         return fail(SPS_ERR_INVALID, "sa_group_mlp: null pointer");
     const long long cols = (long long)b * m * nsample;
     if (cols > 0x7FFFFFFFLL) return fail(SPS_ERR_INVALID, "sa_group_mlp: too many grouped points");
     SaMlpArgs a;
-    a.n = n; a.m = m; a.c_feat = c_feat; a.units = (int)cols;
+    a.n = n; a.m = m; a.c_feat = c_feat;
+    a.units = b;       // scenes (launch_variant turns this into the total unit count)
+    a.ups = jcount;    // centroids per scene in the range (launch_variant turns this into units per scene)
+    a.j0 = j0;
     a.ks1 = (3 + c_feat + 3) / 4;
     a.c3 = c3; a.c3_real = c3_real; a.out_c_total = out_c_total; a.out_c_off = out_c_off;
     a.xyz = xyz; a.new_xyz = new_xyz; a.feat = features; a.idx = idx;

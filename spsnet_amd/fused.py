@@ -108,17 +108,19 @@ def pack_scale(mlp, nsample):
     return p
 
 
-def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset):
+def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=0, jcount=None):
     """One launch: gather the nsample neighbours in `idx` (B,M,ns), run the packed 3-layer MLP, max-pool,
-    and write channels [channel_offset, channel_offset + c3_real) of out (B, Ctot, M)."""
+    and write channels [channel_offset, channel_offset + c3_real) of out (B, Ctot, M); optionally only for the
+    centroids [j0, j0+jcount) of every scene."""
     B, N, _ = xyz.shape
     M, ns = idx.shape[1], idx.shape[2]
+    jcount = M if jcount is None else jcount
     c_feat = 0 if features is None else features.shape[1]
     if 3 + c_feat != packed.cin:
         raise ValueError(f"grouped input has {3 + c_feat} channels, the MLP expects {packed.cin}")
     stream = torch.cuda.current_stream(xyz.device).cuda_stream
-    _lib.check(_L.sps_sa_group_mlp(
-        B, N, M, c_feat, ns, xyz.data_ptr(), new_xyz.data_ptr(), 0 if features is None else features.data_ptr(),
+    _lib.check(_L.sps_sa_group_mlp_range(
+        B, N, M, j0, jcount, c_feat, ns, xyz.data_ptr(), new_xyz.data_ptr(), 0 if features is None else features.data_ptr(),
         idx.data_ptr(), packed.c1, packed.c2, packed.c3, packed.c3_real, packed.w1.data_ptr(), packed.b1.data_ptr(),
         packed.w2.data_ptr(), packed.b2.data_ptr(), packed.w3.data_ptr(), packed.b3.data_ptr(), out.data_ptr(),
         out.shape[1], channel_offset, stream), "sa_group_mlp")

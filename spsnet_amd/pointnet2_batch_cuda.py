@@ -208,6 +208,41 @@ def fps_ordered_prefix(xyz, npoint, return_flags=False):
     return (idx, flags, temp) if return_flags else idx
 
 
+def current_stream_handle(t):
+    return _stream(t)
+
+
+def fps_publish(xyz, temp, idx, progress):
+    """Launch the publishing FPS (sps_fps_publish) on the current stream; all tensors are caller-allocated."""
+    B, N, _ = xyz.shape
+    with _on(xyz):
+        _lib.check(_L.sps_fps_publish(B, N, idx.shape[1], _ptr(xyz, F32, "xyz"), _ptr(temp, F32, "temp"),
+                                      _ptr(idx, I32, "idx"), _ptr(progress, I32, "progress"), _stream(xyz)), "fps_publish")
+
+
+def wait_progress(progress, need, timed_out):
+    """Enqueue a bounded device-side wait on the current stream until all scenes published `need` samples."""
+    with _on(progress):
+        _lib.check(_L.sps_wait_progress(_ptr(progress, I32, "progress"), progress.numel(), need,
+                                        _ptr(timed_out, I32, "timed_out"), _stream(progress)), "wait_progress")
+
+
+def gather_xyz_range(xyz, idx, out, j0, jcount):
+    B, N, _ = xyz.shape
+    with _on(xyz):
+        _lib.check(_L.sps_gather_xyz_range(B, N, idx.shape[1], j0, jcount, _ptr(xyz, F32, "xyz"), _ptr(idx, I32, "idx"),
+                                           _ptr(out, F32, "out"), _stream(xyz)), "gather_xyz_range")
+
+
+def ball_query_full2_range(radius_a, radius_b, xyz, new_xyz, idx_a, idx_b, j0, jcount):
+    B, N, _ = xyz.shape
+    with _on(xyz):
+        _lib.check(_L.sps_ball_query_full2_range(B, N, new_xyz.shape[1], j0, jcount, radius_a, idx_a.shape[2], radius_b,
+                                                 idx_b.shape[2], _ptr(new_xyz, F32, "new_xyz"), _ptr(xyz, F32, "xyz"),
+                                                 _ptr(idx_a, I32, "idx_a"), _ptr(idx_b, I32, "idx_b"), 0, _stream(xyz)),
+                   "ball_query_full2_range")
+
+
 def gather_xyz(xyz, idx):
     """xyz (B,N,3), idx (B,M) int32 -> (B,M,3): rows of xyz, without the (B,3,N) detour."""
     p, i = _ptr(xyz, F32, "xyz"), _ptr(idx, I32, "idx")

@@ -113,6 +113,90 @@ def _can_prefetch(layer, nxt):
     return is_dfps and sum(p for p in layer.npoint_list if p > 0) > nxt.npoint_list[0] > 0
 
 
+_CHUNKS = 4           # centroid chunks of the streamed first layer
+_TIMEOUT_FLAGS = []   # device flags of the bounded waits issued so far (see check_timeouts)
+
+
+def check_timeouts():
+    """True if any device-side progress wait gave up (synchronises; for tests / debugging)."""
+    bad = any(int(f.item()) != 0 for f in _TIMEOUT_FLAGS)
+    _TIMEOUT_FLAGS.clear()
+    return bad
+
+
+def _streamed_first_layer(layer, nxt, xyz, features):
+    """Layer 0 with its grouping/MLP consuming the D-FPS output WHILE the FPS kernel is still running.
+
+    FPS is a serial chain on one CU per scene (~2.9 ms for 8 x 16384 -> 4096); the ball queries and grouped MLPs of
+    the centroids it has already produced need nothing else, so they run chunk by chunk on a second stream, each
+    chunk gated by a bounded device-side wait on the kernel's published progress counter (csrc: sps_fps_publish /
+    sps_wait_progress, the write-through hand-off of the CDNA guide).  Same kernels, same results; only the
+    schedule differs.  Returns None when the layer does not qualify (caller falls back to layer.forward)."""
+    from . import fused as _fused
+    from . import pointnet2_batch_cuda as _ext
+    from . import pointnet2_utils
+    B, N, _ = xyz.shape
+    M = layer.npoint_list[0]
+    if not (_is_plain_dfps(layer, N) and 6144 <= N <= 16384 and M % (64 * _CHUNKS) == 0 and len(layer.groupers) == 2):
+        return None
+    if layer.training or features is None or not xyz.is_contiguous() or not features.is_contiguous():
+        return None
+    dev = xyz.device
+    new_xyz = torch.empty((B, M, 3), dtype=torch.float32, device=dev)
+    plan = layer._fused_plan(xyz, new_xyz, features)
+    if not plan:
+        return None
+    ga, gb = layer.groupers
+    main = torch.cuda.current_stream(dev)
+    key = (dev.type, dev.index, main.cuda_stream, "chunks")
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    side = _SIDE_STREAMS[key]
+
+    idx = torch.empty((B, M), dtype=torch.int32, device=dev)
+    temp = torch.full((B, N), 1e10, dtype=torch.float32, device=dev)
+    progress = torch.zeros((B,), dtype=torch.int32, device=dev)  # zeroed on `main` BEFORE the consumer is released
+    timed_out = torch.zeros((1,), dtype=torch.int32, device=dev)
+    idx_a = torch.empty((B, M, ga.nsample), dtype=torch.int32, device=dev)
+    idx_b = torch.empty((B, M, gb.nsample), dtype=torch.int32, device=dev)
+    out = torch.empty((B, sum(p.c3_real for p in plan), M), dtype=torch.float32, device=dev)
+    _TIMEOUT_FLAGS.append(timed_out)
+    if len(_TIMEOUT_FLAGS) > 64:
+        del _TIMEOUT_FLAGS[:32]
+
+    start = torch.cuda.Event()
+    start.record(main)
+    _ext.fps_publish(xyz, temp, idx, progress)          # producer, on the main stream
+    for t in (xyz, features, idx, progress, timed_out, new_xyz, idx_a, idx_b, out):
+        t.record_stream(side)
+    chunk = M // _CHUNKS
+    with torch.cuda.stream(side):                        # consumer
+        side.wait_event(start)
+        for c in range(_CHUNKS):
+            j0 = c * chunk
+            _ext.wait_progress(progress, j0 + chunk, timed_out)
+            _ext.gather_xyz_range(xyz, idx, new_xyz, j0, chunk)
+            if c == _CHUNKS - 1:
+                xyz_ready = torch.cuda.Event()
+                xyz_ready.record(side)
+            _ext.ball_query_full2_range(ga.radius, gb.radius, xyz, new_xyz, idx_a, idx_b, j0, chunk)
+            off = 0
+            for ix, packed in zip((idx_a, idx_b), plan):
+                _fused.group_mlp_pool(xyz, new_xyz, features, ix, packed, out, off, j0, chunk)
+                off += packed.c3_real
+        done = torch.cuda.Event()
+        done.record(side)
+    main.wait_event(xyz_ready)                           # all centroids exist: the next layer's FPS check can start
+    if nxt is not None and _can_prefetch(layer, nxt):
+        _prefetch_dfps(nxt, new_xyz, True)
+    main.wait_event(done)
+    new_features = out
+    if layer.aggregation_layer is not None:
+        new_features = layer.aggregation_layer(new_features)
+    cls = layer.confidence_layers(new_features).transpose(1, 2) if layer.confidence_layers is not None else None
+    return new_xyz, new_features, cls, idx, None
+
+
 def _is_plain_dfps(layer, n_in):
     """True if the layer's centroids are ONE D-FPS pick sequence over its whole input."""
     types = getattr(layer, "sample_type_list", None)
@@ -122,15 +206,25 @@ def _is_plain_dfps(layer, n_in):
     return ('D-FPS' in t or 'DFS' in t) and not ('cls' in t or 'ctr' in t or 'ss' in t) and n_in > layer.npoint_list[0] > 0
 
 
-def run_sa_layers(layers, xyz, features, stds=None, overlap=True):
+def run_sa_layers(layers, xyz, features, stds=None, overlap=True, stream_first_layer=False):
     """IASSD_backbone.py:128-134 for SA layers: -> list of (new_xyz, new_features, cls, sampled_idx).
     With overlap (inference on a GPU), layer k+1's D-FPS is issued on a side stream the moment layer k's
-    new_xyz exists; results are identical, only the schedule changes."""
+    new_xyz exists; results are identical, only the schedule changes.
+    stream_first_layer: additionally let layer 0's grouping/MLP consume the FPS output while FPS runs
+    (_streamed_first_layer).  Exact and tested, but measured on MI355X it gains only ~1 % (each chunk's ball query
+    still scans the whole cloud, and its waves slow the FPS workgroups they share CUs with), so it is off by
+    default."""
     outs = []
     cls_pred = None
     use_overlap = overlap and xyz.is_cuda and not torch.is_grad_enabled()
     for k, layer in enumerate(layers):
         nxt = layers[k + 1] if k + 1 < len(layers) else None
+        if use_overlap and k == 0 and stds is None and cls_pred is None and stream_first_layer:
+            res = _streamed_first_layer(layer, nxt, xyz, features)
+            if res is not None:
+                xyz, features, cls_pred, idx, _ = res
+                outs.append((xyz, features, cls_pred, idx))
+                continue
         if use_overlap and nxt is not None and _can_prefetch(layer, nxt):
             ordered = _is_plain_dfps(layer, xyz.shape[1])
             layer._on_new_xyz = lambda nx, _n=nxt, _o=ordered: _prefetch_dfps(_n, nx, _o)

@@ -567,3 +567,34 @@ def test_ball_query_dual_radius(ext, G, oracle, N, M, ra, nsa, rb, nsb):
                                       wave_per_centroid=wave)
         np.testing.assert_array_equal(G.n(ia), oracle.ball_query(ra, nsa, xyz, new_xyz))
         np.testing.assert_array_equal(G.n(ib), oracle.ball_query(rb, nsb, xyz, new_xyz))
+
+
+def test_streamed_first_layer_equals_sequential(ext, G, dev):
+    """Layer 0 with its grouping/MLP consuming the FPS output while FPS runs (progress hand-off) against the plain
+    sequential schedule: every output of every layer bit-identical, no wait timed out."""
+    from spsnet_amd import pointnet2_modules as M, sa_stack, scenes
+    layers = sa_stack.build_sa_layers(M, sa_stack.IASSD_KITTI, seed=2).to(dev)
+    xyz, feats = scenes.make_batch("kitti-lidar-v1", 4, 16384, seed0=31, dup_fraction=0.01)
+    x, f = G.t(xyz), G.t(feats)
+    with torch.no_grad():
+        b = sa_stack.run_sa_layers(layers, x, f, overlap=False)
+        for rep in range(3):
+            # poison the caching allocator's free blocks with in-bounds but wrong values: a consumer that ran ahead
+            # of the producer (or read a stale cache line) would then compute visibly wrong results, not fault
+            junk_i = torch.full((32 << 20,), 1 + rep, dtype=torch.int32, device=dev)
+            junk_f = torch.full((32 << 20,), 0.5 + rep, dtype=torch.float32, device=dev)
+            del junk_i, junk_f
+            a = sa_stack.run_sa_layers(layers, x, f, stream_first_layer=True)
+            torch.cuda.synchronize()
+            assert not sa_stack.check_timeouts()
+            for la, lb in zip(a, b):
+                for ta, tb in zip(la, lb):
+                    assert (ta is None and tb is None) or torch.equal(ta, tb), f"repetition {rep}"
+    torch.cuda.synchronize()
+    assert not sa_stack.check_timeouts()
+    for la, lb in zip(a, b):
+        for ta, tb in zip(la, lb):
+            if ta is None:
+                assert tb is None
+            else:
+                assert torch.equal(ta, tb)
