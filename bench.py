@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--dataset", default="kitti-lidar-v1", choices=["kitti-lidar-v1", "uniform-v1"])
     ap.add_argument("--sampler", default="ctr_aware", choices=["ctr_aware", "sss_aware"],
                     help="layer-2 sampler (BASELINE configs[1] / configs[3])")
+    ap.add_argument("--mlp-precision", default="fp16x2", choices=["fp32", "fp16x2"],
+                    help="grouped-MLP arithmetic: exact fp32 MFMA, or split-fp16 (hi+lo halves, 3 MFMAs, ~1e-6 rel.)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-batches-in-flight measurement")
     ap.add_argument("--cpu-scenes", type=int, default=8, help="scenes in the bounded CPU-baseline sample")
@@ -147,6 +149,8 @@ def main():
     from spsnet_amd import pointnet2_modules as M, sa_stack, scenes
     from spsnet_amd.dist import all_gather_sampled_idx
 
+    from spsnet_amd import fused
+    fused.set_precision(args.mlp_precision)
     cfg = sa_stack.scaled_config(sample_methods=['D-FPS', 'D-FPS', args.sampler])
     layers = sa_stack.build_sa_layers(M, cfg, seed=0).to(dev)
 
@@ -218,7 +222,7 @@ def main():
         line = {
             "metric": METRIC, "value": total_points / elapsed, "unit": "points/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.mlp_precision == "fp32" else "f32 (wide grouped-MLP scales as split-fp16 hi+lo pairs on MFMA, fp32 accumulate, <=2e-5 rel. vs fp32)",
             "data": "synthetic",
             "config": {"workload": f"batch={args.batch}/GPU x {args.points} pts ({args.dataset}), IA-SSD SA L0-L2 "
                                    f"(4096/1024/512 centroids, nsample 16&32, layer-2 sampler {args.sampler}), fp32",

@@ -170,6 +170,10 @@ int sps_sa_group_mlp(int b, int n, int m, int c_feat, int nsample, const float *
                      const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                      const float *b3, float *out, int out_c_total, int out_c_off, sps_stream_t stream);
 int sps_sa_group_mlp_supported(int c1, int c2, int nsample);
+/* Arithmetic of sps_sa_group_mlp: 0 = exact fp32 MFMA (default), 1 = split-fp16: every operand as hi+lo halves,
+ * three v_mfma_f32_16x16x16_f16 per product block, fp32 accumulate (~1e-6 relative, csrc/sa_mlp_f16.hip).  The
+ * weight buffers passed afterwards must be packed for the selected mode (spsnet_amd/fused.py).  Returns the old mode. */
+int sps_set_mlp_precision(int mode);
 
 /* ---- chunked layer 0: consume FPS output while FPS is still running (spsnet_amd/sa_stack.py) ------------
  * sps_fps_publish: the pruned FPS kernel (6144 <= n <= 16384) storing its samples write-through and publishing
@@ -191,6 +195,15 @@ int sps_sa_group_mlp_range(int b, int n, int m, int j0, int jcount, int c_feat, 
                            int c3_real, const float *w1, const float *b1, const float *w2, const float *b2,
                            const float *w3, const float *b3, float *out, int out_c_total, int out_c_off,
                            sps_stream_t stream);
+
+/* sps_sa_group_mlp_range with the arithmetic chosen per call (split_fp16 = 0 / 1, weights packed accordingly) and,
+ * for the split-fp16 kernel, a device flag that is set to 1 if an operand left the exactly splittable range
+ * (|x| > 131 000: the value was clamped).  overflow_flag may be NULL. */
+int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,
+                        const float *new_xyz, const float *features, const int *idx, int c1, int c2, int c3,
+                        int c3_real, const float *w1, const float *b1, const float *w2, const float *b2,
+                        const float *w3, const float *b3, float *out, int out_c_total, int out_c_off,
+                        int split_fp16, int *overflow_flag, sps_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -43,6 +43,9 @@ _PROTOS = {
     "sps_sa_group_mlp": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                          _i, _i, _vp],
     "sps_sa_group_mlp_supported": [_i, _i, _i],
+    "sps_set_mlp_precision": [_i],
+    "sps_sa_group_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
+                            _vp, _vp, _i, _i, _i, _vp, _vp],
     "sps_fps_publish": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_wait_progress": [_vp, _i, _i, _vp, _vp],
     "sps_gather_xyz_range": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],

@@ -26,6 +26,7 @@
 // channels + C feature channels of the nsample ball-query neighbours) is gathered straight from the
 // (B,N,3) / (B,C,N) tensors, one prefetched 4-channel k-step ahead of the MFMAs.
 #include "sps_common.h"
+#include "sa_mlp_args.h"
 
 namespace sps {
 
@@ -62,19 +63,6 @@ __device__ __forceinline__ float row_allmax(float v) {
     v = fmaxf(v, o);
     return v;
 }
-
-struct SaMlpArgs {
-    int n, m, c_feat, units;       // points/scene, centroids/scene, feature channels, total units
-    int j0, ups;                   // centroid range start within every scene; units per scene
-    int ks1;                       // layer-1 k-steps = ceil((3 + c_feat) / 4)
-    int c3;                        // padded last-layer width (multiple of 16)
-    int c3_real;                   // channels actually written
-    int out_c_total, out_c_off;    // out is (B, out_c_total, M); this scale writes [off, off + c3_real)
-    const float *xyz, *new_xyz, *feat;
-    const int *idx;
-    const float *w1, *b1, *w2, *b2, *w3, *b3;
-    float *out;
-};
 
 // C1, C2: padded widths of layers 1 and 2 (multiples of 16).  NT: 16-column tiles per MFMA pass.
 // NS: nsample (16, 32 or 64), with 16*NT >= NS: a unit is 16*NT columns = 16*NT/NS whole centroids.
@@ -288,6 +276,16 @@ static int launch_variant(const SaMlpArgs &a, hipStream_t st) {
 
 }  // namespace sps
 
+namespace sps { int g_mlp_f16 = 0; }
+
+// 0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32), 1 = split-fp16 (hi+lo) on v_mfma_f32_16x16x16_f16 (sa_mlp_f16.hip).
+// The weight buffers handed to sps_sa_group_mlp must be packed for the mode in force.  Returns the old mode.
+extern "C" int sps_set_mlp_precision(int mode) {
+    const int old = sps::g_mlp_f16;
+    sps::g_mlp_f16 = mode ? 1 : 0;
+    return old;
+}
+
 // Widths are the PADDED widths (multiples of 16) the weight fragments were packed for; c3_real <= c3 is the
 // number of output channels written.  Supported (c1, c2, nsample) combinations are the IA-SSD / SPSNet ones.
 extern "C" int sps_sa_group_mlp(int b, int n, int m, int c_feat, int nsample, const float *xyz,
@@ -304,6 +302,15 @@ extern "C" int sps_sa_group_mlp_range(int b, int n, int m, int j0, int jcount, i
                                       int c3, int c3_real, const float *w1, const float *b1, const float *w2,
                                       const float *b2, const float *w3, const float *b3, float *out, int out_c_total,
                                       int out_c_off, sps_stream_t stream) {
+    return sps_sa_group_mlp_ex(b, n, m, j0, jcount, c_feat, nsample, xyz, new_xyz, features, idx, c1, c2, c3, c3_real, w1, b1,
+                               w2, b2, w3, b3, out, out_c_total, out_c_off, sps::g_mlp_f16, nullptr, stream);
+}
+
+extern "C" int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,
+                                   const float *new_xyz, const float *features, const int *idx, int c1, int c2,
+                                   int c3, int c3_real, const float *w1, const float *b1, const float *w2,
+                                   const float *b2, const float *w3, const float *b3, float *out, int out_c_total,
+                                   int out_c_off, int split_fp16, int *overflow_flag, sps_stream_t stream) {
     using namespace sps;
     if (b < 0 || n <= 0 || m < 0 || c_feat < 0 || nsample <= 0 || c3 <= 0 || (c3 % 16) || c3_real > c3 ||
         out_c_off < 0 || out_c_off + c3_real > out_c_total || j0 < 0 || jcount < 0 || j0 + jcount > m)
@@ -322,7 +329,9 @@ extern "C" int sps_sa_group_mlp_range(int b, int n, int m, int j0, int jcount, i
     a.c3 = c3; a.c3_real = c3_real; a.out_c_total = out_c_total; a.out_c_off = out_c_off;
     a.xyz = xyz; a.new_xyz = new_xyz; a.feat = features; a.idx = idx;
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.out = out;
+    a.overflow = overflow_flag;
     hipStream_t st = as_stream(stream);
+    if (split_fp16) return launch_sa_mlp_f16(a, c1, c2, nsample, st);
 #define SPS_MLP_CASE(C1, C2, NT, NS) \
     if (c1 == C1 && c2 == C2 && nsample == NS) return launch_variant<C1, C2, NT, NS>(a, st);
     SPS_MLP_CASE(16, 16, 2, 16)    // IA-SSD L0 r=0.2 [4,16,16,32]

@@ -48,6 +48,23 @@ def _pack_next(w, cout_pad, cin_pad):
     return wp.view(cout_pad // 16, 16, cin_pad // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous().view(-1)
 
 
+def _split_halves(frag_f32, lanes_inner=4):
+    """fp32 fragment tensor [..., lane, 4] -> int16-bit tensor [..., lane, hi x4 | lo x4] (the split-fp16 kernel's
+    16-byte-per-lane weight fragment)."""
+    hi = frag_f32.half()
+    lo = (frag_f32 - hi.float()).half()
+    return torch.cat([hi, lo], dim=-1).contiguous().view(torch.int16).view(-1)
+
+
+def _pack_f16(w, cout_pad, cin_pad):
+    """[tile][k16][lane = q*16+i][jj]: W[16*tile + i][16*k16 + 4*q + jj], split into fp16 hi/lo."""
+    cout, cin = w.shape
+    wp = w.new_zeros(cout_pad, cin_pad)
+    wp[:cout, :cin] = w
+    frag = wp.view(cout_pad // 16, 16, cin_pad // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()  # [tile,t,q,i,jj]
+    return _split_halves(frag)
+
+
 def _pad_bias(b, cpad):
     out = b.new_zeros(cpad)
     out[:b.numel()] = b
@@ -55,7 +72,7 @@ def _pad_bias(b, cpad):
 
 
 class PackedScale:
-    __slots__ = ("c1", "c2", "c3", "c3_real", "cin", "w1", "b1", "w2", "b2", "w3", "b3", "key")
+    __slots__ = ("c1", "c2", "c3", "c3_real", "cin", "w1", "b1", "w2", "b2", "w3", "b3", "key", "split")
 
 
 def _stack_layers(mlp):
@@ -82,6 +99,40 @@ def _version_key(pairs, device):
     return tuple(vs)
 
 
+# "fp16x2" (default): scales whose first hidden width is >= 32 run on the fp16 matrix cores with every fp32 operand
+#           carried as a hi+lo pair of halves (3 MFMAs per block, fp32 accumulate; ~1e-6 relative, csrc/sa_mlp_f16.hip);
+#           narrower scales stay on the fp32 MFMA kernel (their 4-channel input would be padded to 16).
+# "fp32":   every scale on the exact fp32 MFMA kernel.
+PRECISION = "fp16x2"
+_OVERFLOW = {}
+
+
+def set_precision(mode):
+    """Select the grouped-MLP arithmetic ("fp16x2" or "fp32"); returns the previous mode."""
+    global PRECISION
+    if mode not in ("fp32", "fp16x2"):
+        raise ValueError(mode)
+    old, PRECISION = PRECISION, mode
+    return old
+
+
+def _overflow_flag(device):
+    key = (device.type, device.index)
+    if key not in _OVERFLOW:
+        _OVERFLOW[key] = torch.zeros((1,), dtype=torch.int32, device=device)
+    return _OVERFLOW[key]
+
+
+def check_overflow():
+    """True if a split-fp16 launch met an operand beyond the exactly splittable range (|x| > 131 000) since the last
+    call; such values were clamped.  Synchronises the device.  Use set_precision("fp32") for unbounded inputs."""
+    bad = False
+    for f in _OVERFLOW.values():
+        bad |= bool(int(f.item()))
+        f.zero_()
+    return bad
+
+
 def pack_scale(mlp, nsample):
     """-> PackedScale (cached on the module) or None when the fused kernel has no variant for this scale."""
     pairs = _stack_layers(mlp)
@@ -92,7 +143,7 @@ def pack_scale(mlp, nsample):
     if not _L.sps_sa_group_mlp_supported(c1, c2, nsample):
         return None
     device = c1m.weight.device
-    key = _version_key(pairs, device)
+    key = _version_key(pairs, device) + (PRECISION,)
     cached = getattr(mlp, "_sps_packed", None)
     if cached is not None and cached.key == key:
         return cached
@@ -100,9 +151,13 @@ def pack_scale(mlp, nsample):
         (w1, b1), (w2, b2), (w3, b3) = (_fold(c, b) for c, b in pairs)
         p = PackedScale()
         p.c1, p.c2, p.c3, p.c3_real, p.cin = c1, c2, c3, c3m.out_channels, c1m.in_channels
-        p.w1, p.b1 = _pack_first(w1, c1), _pad_bias(b1, c1)
-        p.w2, p.b2 = _pack_next(w2, c2, c1), _pad_bias(b2, c2)
-        p.w3, p.b3 = _pack_next(w3, c3, c2), _pad_bias(b3, c3)
+        p.split = PRECISION == "fp16x2" and c1 >= 32
+        if p.split:
+            cin_pad = (c1m.in_channels + 15) // 16 * 16
+            p.w1, p.w2, p.w3 = _pack_f16(w1, c1, cin_pad), _pack_f16(w2, c2, c1), _pack_f16(w3, c3, c2)
+        else:
+            p.w1, p.w2, p.w3 = _pack_first(w1, c1), _pack_next(w2, c2, c1), _pack_next(w3, c3, c2)
+        p.b1, p.b2, p.b3 = _pad_bias(b1, c1), _pad_bias(b2, c2), _pad_bias(b3, c3)
         p.key = key
     object.__setattr__(mlp, "_sps_packed", p)  # plain attribute: not a parameter/buffer, not in state_dict
     return p
@@ -119,8 +174,9 @@ def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=
     if 3 + c_feat != packed.cin:
         raise ValueError(f"grouped input has {3 + c_feat} channels, the MLP expects {packed.cin}")
     stream = torch.cuda.current_stream(xyz.device).cuda_stream
-    _lib.check(_L.sps_sa_group_mlp_range(
+    _lib.check(_L.sps_sa_group_mlp_ex(
         B, N, M, j0, jcount, c_feat, ns, xyz.data_ptr(), new_xyz.data_ptr(), 0 if features is None else features.data_ptr(),
         idx.data_ptr(), packed.c1, packed.c2, packed.c3, packed.c3_real, packed.w1.data_ptr(), packed.b1.data_ptr(),
         packed.w2.data_ptr(), packed.b2.data_ptr(), packed.w3.data_ptr(), packed.b3.data_ptr(), out.data_ptr(),
-        out.shape[1], channel_offset, stream), "sa_group_mlp")
+        out.shape[1], channel_offset, 1 if packed.split else 0,
+        _overflow_flag(xyz.device).data_ptr() if packed.split else 0, stream), "sa_group_mlp")

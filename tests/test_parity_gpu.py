@@ -598,3 +598,69 @@ def test_streamed_first_layer_equals_sequential(ext, G, dev):
                 assert tb is None
             else:
                 assert torch.equal(ta, tb)
+
+
+@pytest.mark.parametrize("c_feat,widths,ns,radius", FUSED_CASES[:7])
+def test_fused_group_mlp_split_fp16(ext, G, dev, c_feat, widths, ns, radius):
+    """The split-fp16 (hi+lo, 3 MFMAs) variant of the fused kernel against the unfused fp32 torch path: the 1e-4
+    bar of BASELINE.json with a wide margin, and close to the fp32 MFMA kernel."""
+    from spsnet_amd import fused, pointnet2_modules as M
+    torch.manual_seed(c_feat * 100 + ns)
+    mod = M.PointnetSAModuleMSG_WithSampling(
+        npoint_list=[256], sample_range_list=[-1], sample_type_list=['D-FPS'], radii=[radius], nsamples=[ns],
+        mlps=[[c_feat] + list(widths)], use_xyz=True, dilated_group=False, aggregation_mlp=None, confidence_mlp=None,
+        num_class=3).to(dev).eval()
+    gen = torch.Generator().manual_seed(1)
+    for m_ in mod.modules():
+        if isinstance(m_, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m_.running_mean.copy_(torch.randn(m_.num_features, generator=gen) * 0.2)
+                m_.running_var.copy_(torch.rand(m_.num_features, generator=gen) + 0.5)
+                m_.weight.copy_(torch.rand(m_.num_features, generator=gen) + 0.5)
+                m_.bias.copy_(torch.randn(m_.num_features, generator=gen) * 0.2)
+    rng = np.random.default_rng(ns + c_feat)
+    xyz = G.t(cloud(rng, 2, 3000, dup=0.02))
+    feats = G.t((rng.normal(size=(2, c_feat, 3000)) * 3).astype(np.float32))
+    with torch.no_grad():
+        old32 = fused.set_precision("fp32")
+        try:
+            _, f32_out, _, _, _ = mod(xyz, feats)
+        finally:
+            fused.set_precision(old32)
+        old = fused.set_precision("fp16x2")
+        try:
+            _, h_out, _, _, _ = mod(xyz, feats)
+        finally:
+            fused.set_precision(old)
+        plan = mod._fused_plan
+        mod._fused_plan = lambda *a, **k: None
+        try:
+            _, ref, _, _, _ = mod(xyz, feats)
+        finally:
+            mod._fused_plan = plan
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((h_out - ref).abs().max()) <= 2e-5 * scale
+    assert float((h_out - f32_out).abs().max()) <= 2e-5 * scale
+    assert not fused.check_overflow()
+
+
+def test_split_fp16_flags_out_of_range_operands(ext, G, dev):
+    """Operands beyond the exactly splittable range are clamped (finite output) and reported, never silent."""
+    from spsnet_amd import fused, pointnet2_modules as M
+    torch.manual_seed(0)
+    mod = M.PointnetSAModuleMSG_WithSampling(
+        npoint_list=[256], sample_range_list=[-1], sample_type_list=['D-FPS'], radii=[1.0], nsamples=[32],
+        mlps=[[5, 32, 32, 64]], use_xyz=True, dilated_group=False, aggregation_mlp=None, confidence_mlp=None,
+        num_class=3).to(dev).eval()
+    xyz = G.t(cloud(np.random.default_rng(0), 2, 2000))
+    feats = torch.full((2, 5, 2000), 3.0e5, device=dev)
+    old = fused.set_precision("fp16x2")
+    try:
+        with torch.no_grad():
+            fused.check_overflow()
+            _, out, _, _, _ = mod(xyz, feats)
+        assert torch.isfinite(out).all()
+        assert fused.check_overflow()
+        assert not fused.check_overflow()  # the flag resets
+    finally:
+        fused.set_precision(old)
