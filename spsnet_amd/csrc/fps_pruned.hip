@@ -72,8 +72,7 @@ __device__ __forceinline__ float wave_allmax_f32(float v) {
 
 struct PfShared {
     int hist[PF_BINS];
-    float4 rec[2][PF_WAVES];
-    unsigned long long slot[3];
+    int4 rec[2][PF_WAVES][2];  // per round parity: each wave's record {dist, keylo, x, y | z, bound, -, -}
     float red[6][PF_WAVES];
     int wsum[PF_WAVES];
 };
@@ -273,19 +272,30 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
     if (tid == 0) {
         if constexpr (PUBLISH) __hip_atomic_store(&idxs[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else idxs[0] = 0;
-        sh.slot[0] = 0ull; sh.slot[1] = 0ull; sh.slot[2] = 0ull;
     }
-    float cx = xyz[0], cy = xyz[1], cz = xyz[2];
     __syncthreads();
 
-    // this wave's current candidate (refreshed only when one of its buckets changed)
-    unsigned long long cand_key = 0ull;
-    float cand_x = 0.f, cand_y = 0.f, cand_z = 0.f;
+    // ------------------------------------------------------------------ sampling loop, several picks per round
+    // Every round each wave publishes its best point e_w (largest key = {running distance, inverted rank}) plus a
+    // BOUND_w >= the running distance of every other point it holds.  With the records sorted by key,
+    // e_(1) > e_(2) > ..., sequential FPS is known to pick e_(1), ..., e_(L) in that order as long as for every k <= L
+    //   (a) no earlier e_(i) lowers e_(k)'s running distance:  !(sqdist(e_(k), e_(i)) < t_(k)),     and
+    //   (b) t_(k) > BOUND of every earlier e_(i)'s wave (which includes e_(i)'s own distance after it was picked)
+    // because running distances only ever decrease: after the earlier picks e_(k) is unchanged while every other
+    // point is still <= its old value, which was below e_(k)'s key -- (b) covers the points that were not
+    // published.  The round accepts the longest such prefix (L >= 1: e_(1) is the plain FPS pick), then applies the L
+    // updates (min is order-independent).  Rejecting is always safe, so every comparison that involves a NaN
+    // rejects.  One barrier and one LDS exchange per ROUND instead of per sample.
+    constexpr int IMIN = (int)0x80000000;
+    int4 crec = make_int4(0, 0, 0, 0);  // the wave's record as lanes 0/1 publish it: {dist, keylo, x, y} / {z, bound, -, -}
     bool cand_stale = true;
-    int cand_slot = -1;  // bucket slot the candidate came from: only its refresh can change the candidate
-    int slot_cur = 1;    // == j % 3
+    int cand_slot = -1;   // bucket slot the candidate came from: only its refresh can change the candidate
+    // centres accepted by the previous round and still to be applied: record r in lane r of (ax, ay, az)
+    float ax = xyz[0], ay = xyz[1], az = xyz[2];
+    unsigned pend = m > 1 ? 1u : 0u;
+    int j = 1;  // picks made so far
+    int round = 0;
 
-    // ------------------------------------------------------------------ sampling loop
     unsigned long long tseg[6] = {0, 0, 0, 0, 0, 0}, ntouch = 0;
     nslow = 0;
     auto stamp = [&]() -> unsigned long long {
@@ -299,89 +309,127 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
             return 0ull;
         }
     };
-    for (int j = 1; j < m; ++j) {
+    for (;;) {
         const unsigned long long s0 = stamp();
-        // 1. one lane per bucket: can the new centre lower any distance in the box?
-        const float qx = __builtin_amdgcn_fmed3f(cx, blo_x, bhi_x);
-        const float qy = __builtin_amdgcn_fmed3f(cy, blo_y, bhi_y);
-        const float qz = __builtin_amdgcn_fmed3f(cz, blo_z, bhi_z);
-        const float lb = sqdist(qx, qy, qz, cx, cy, cz);
-        const bool skip = lb >= __int_as_float(bmax);  // NaN -> not skipped
-        unsigned long long todo = __ballot(!skip && lane < P);
-        // 2. re-evaluate the surviving buckets (exactly the reference arithmetic, one point per lane)
-        const unsigned long long s1 = stamp();
-        if constexpr (PROF) ntouch += __builtin_popcountll(todo);
-        while (todo) {
-            const int s = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            // the cached maximum only changes if the point holding it moved closer to a sample
-            const int hl = __builtin_amdgcn_readlane(bhold, s);
-            const int oldmax = __builtin_amdgcn_readlane(bmax, s);
-            const float xs = x[s], ys = y[s], zs = z[s];  // wave-uniform dynamic index -> VGPR-index mode
-            const float d = sqdist(xs, ys, zs, cx, cy, cz);
-            const float tn = fmin_raw(d, t[s]);
-            t[s] = tn;
-            const bool changed = __builtin_amdgcn_readlane(__float_as_int(tn), hl) != oldmax;
-            if (changed) refresh(tn, rk[s], xs, ys, zs);
-            if (changed) {
-                commit(s);
-                if (s == cand_slot) cand_stale = true;
+        while (pend) {
+            const int r = __builtin_ctz(pend);
+            pend &= pend - 1;
+            const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax), r));
+            const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay), r));
+            const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(az), r));
+            // 1. one lane per bucket: can the new centre lower any distance in the box?
+            const float qx = __builtin_amdgcn_fmed3f(cx, blo_x, bhi_x);
+            const float qy = __builtin_amdgcn_fmed3f(cy, blo_y, bhi_y);
+            const float qz = __builtin_amdgcn_fmed3f(cz, blo_z, bhi_z);
+            const float lb = sqdist(qx, qy, qz, cx, cy, cz);
+            const bool skip = lb >= __int_as_float(bmax);  // NaN -> not skipped
+            unsigned long long todo = __ballot(!skip && lane < P);
+            if constexpr (PROF) ntouch += __builtin_popcountll(todo);
+            // 2. re-evaluate the surviving buckets (exactly the reference arithmetic, one point per lane)
+            while (todo) {
+                const int s = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                // the cached maximum only changes if the point holding it moved closer to a sample
+                const int hl = __builtin_amdgcn_readlane(bhold, s);
+                const int oldmax = __builtin_amdgcn_readlane(bmax, s);
+                const float xs = x[s], ys = y[s], zs = z[s];  // wave-uniform dynamic index -> VGPR-index mode
+                const float d = sqdist(xs, ys, zs, cx, cy, cz);
+                const float tn = fmin_raw(d, t[s]);
+                t[s] = tn;
+                const bool changed = __builtin_amdgcn_readlane(__float_as_int(tn), hl) != oldmax;
+                if (changed) refresh(tn, rk[s], xs, ys, zs);
+                if (changed) {
+                    commit(s);
+                    if (s == cand_slot) cand_stale = true;
+                }
             }
         }
-        const unsigned long long s2 = stamp();
-        // 3. the wave's best bucket: largest distance, then largest inverted rank
+        if (j >= m) break;
+        const unsigned long long s1 = stamp();
+        // 3. the wave's record: best bucket (largest distance, then largest inverted rank) and the bound
         if (cand_stale) {
-            const int vmax = wave_max_i32_id(lane < P ? bmax : (int)0x80000000);
-            unsigned long long eq = __ballot(lane < P && bmax == vmax);
+            const bool mine = lane < P;
+            const int vmax = wave_max_i32_id(mine ? bmax : IMIN);
+            unsigned long long eq = __ballot(mine && bmax == vmax);
             int wl = __builtin_ctzll(eq);
             if (__builtin_popcountll(eq) > 1) {
-                const int kl = (lane < P && bmax == vmax) ? (int)(bkeylo >> 4) : -1;
+                const int kl = (mine && bmax == vmax) ? (int)(bkeylo >> 4) : -1;
                 const int kbest = wave_max_i32_id(kl);
                 wl = __builtin_ctzll(__ballot(kl == kbest));
             }
-            const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)bkeylo, wl) | (unsigned)wave;
-            const unsigned khi = (unsigned)vmax ^ 0x80000000u;  // -1.0f (empty) sorts below +0
-            cand_key = ((unsigned long long)khi << 32) | klo;
-            cand_x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bpx), wl));
-            cand_y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bpy), wl));
-            cand_z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bpz), wl));
+            // bound: every other bucket's maximum, and the runner-up inside the best bucket
+            const int hl = __builtin_amdgcn_readlane(bhold, wl);
+            const int v2b = wave_max_i32_id((mine && lane != wl) ? bmax : IMIN);
+            const float tw = t[wl];
+            const int t2 = wave_max_i32_id(lane != hl ? __float_as_int(tw) : IMIN);
+            const int klo = __builtin_amdgcn_readlane((int)bkeylo, wl);
+            const int px = __builtin_amdgcn_readlane(__float_as_int(bpx), wl);
+            const int py = __builtin_amdgcn_readlane(__float_as_int(bpy), wl);
+            const int pz = __builtin_amdgcn_readlane(__float_as_int(bpz), wl);
+            // ... and the candidate's own running distance once it has been picked (0 unless its coordinates are
+            // Inf/NaN, in which case the update leaves it where it is and the reference picks it again)
+            const float fx = __int_as_float(px), fy = __int_as_float(py), fz = __int_as_float(pz);
+            const float own = fmin_raw(sqdist(fx, fy, fz, fx, fy, fz), __int_as_float(vmax));
+            const int bound = imax(imax(v2b, t2), __float_as_int(own));
+            crec.x = lane == 0 ? vmax : pz;
+            crec.y = lane == 0 ? klo : bound;
+            crec.z = px;
+            crec.w = py;
             cand_slot = wl;
             cand_stale = false;
         }
+        const unsigned long long s2 = stamp();
+        // 4. exchange: lanes 0/1 store the record, ONE barrier, every wave evaluates all 8x8 ordered pairs
+        const int buf = round & 1;
+        if (lane < 2) sh.rec[buf][wave][lane] = crec;
         const unsigned long long s3 = stamp();
-        // 4. across waves: one 64-bit LDS atomic max, one barrier
-        const int buf = j & 1, sl = slot_cur;
-        if (lane == 0) {
-            sh.rec[buf][wave] = make_float4(cand_x, cand_y, cand_z, 0.f);
-            atomicMax(&sh.slot[sl], cand_key);
-        }
-        slot_cur = (slot_cur == 2) ? 0 : slot_cur + 1;
-        if (tid == 0) sh.slot[slot_cur] = 0ull;  // next iteration's slot: its readers all passed the previous barrier
-        const unsigned long long s4 = stamp();
         __syncthreads();
-        const unsigned long long s5 = stamp();
-        const unsigned long long win = sh.slot[sl];
-        const float4 mine = sh.rec[buf][lane & (PF_WAVES - 1)];
-        const int ww = (int)(win & 0xFull);
-        cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), ww));
-        cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), ww));
-        cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), ww));
-        if (tid == 0) {
-            const unsigned rank = 0x0FFFFFFFu - (unsigned)((win >> 4) & 0x0FFFFFFFull);
+        const unsigned long long s4 = stamp();
+        const int ri = lane & (PF_WAVES - 1), rj = lane >> 3;  // pair (i, j): does picking i first allow j later?
+        const int4 i0 = sh.rec[buf][ri][0], i1 = sh.rec[buf][ri][1];
+        const int4 j0 = sh.rec[buf][rj][0], j1 = sh.rec[buf][rj][1];
+        const float ix = __int_as_float(i0.z), iy = __int_as_float(i0.w), iz = __int_as_float(i1.x);
+        const float jx = __int_as_float(j0.z), jy = __int_as_float(j0.w), jz = __int_as_float(j1.x);
+        const float jt = __int_as_float(j0.x);
+        const bool before = i0.x > j0.x || (i0.x == j0.x && (unsigned)i0.y > (unsigned)j0.y);
+        const float dij = sqdist(jx, jy, jz, ix, iy, iz);            // as the update would compute it: point j, centre i
+        const bool lowered = !(dij >= jt);
+        const bool hidden = !(jt > __int_as_float(i1.y));
+        const unsigned long long bef = __ballot(before);
+        const unsigned long long bad = __ballot(before && (lowered || hidden));
+        // lane r < 8 looks at column r (bits 8r..8r+7): position of record r in the order, and whether it may follow
+        const unsigned sh8 = (unsigned)ri * 8u;
+        const int pos = __builtin_popcount((unsigned)(bef >> sh8) & 0xFFu);
+        const bool okc = ((unsigned)(bad >> sh8) & 0xFFu) == 0u;
+        int firstbad = (lane < PF_WAVES && !okc) ? pos : PF_WAVES;
+        firstbad = -imax(-firstbad, dpp_or<DPP_ROW_SHR1>(-firstbad, IMIN));
+        firstbad = -imax(-firstbad, dpp_or<DPP_ROW_SHR2>(-firstbad, IMIN));
+        firstbad = -imax(-firstbad, dpp_or<DPP_ROW_SHR4>(-firstbad, IMIN));
+        int L = __builtin_amdgcn_readlane(firstbad, PF_WAVES - 1);
+        L = L < m - j ? L : m - j;
+        const bool taken = lane < PF_WAVES && pos < L;
+        if (tid < PF_WAVES && taken) {
+            const unsigned rank = 0x0FFFFFFFu - ((unsigned)i0.y >> 4);
             const int picked = (int)pf_unrank(rank, l2, rb);
-            if constexpr (PUBLISH) {
-                __hip_atomic_store(&idxs[j], picked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((j & 63) == 63 || j == m - 1) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(&progress[blockIdx.x], j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            } else {
-                idxs[j] = picked;
+            if constexpr (PUBLISH) __hip_atomic_store(&idxs[j + pos], picked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else idxs[j + pos] = picked;
+        }
+        if constexpr (PUBLISH) {
+            if (tid == 0 && (((j + L) >> 6) != (j >> 6) || j + L == m)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores (lanes 0..7) have left
+                __hip_atomic_store(&progress[blockIdx.x], j + L, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        // the reference never applies its last pick to `temp`
+        pend = (unsigned)__ballot(taken && (j + pos) != m - 1);
+        ax = ix; ay = iy; az = iz;
+        j += L;
+        round += 1;
         if constexpr (PROF) {
-            const unsigned long long s6 = stamp();
-            tseg[0] += s1 - s0; tseg[1] += s2 - s1; tseg[2] += s3 - s2; tseg[3] += s4 - s3; tseg[4] += s5 - s4; tseg[5] += s6 - s5;
+            const unsigned long long s5 = stamp();
+            tseg[0] += s1 - s0; tseg[1] += s2 - s1; tseg[2] += s3 - s2; tseg[3] += s4 - s3; tseg[4] += s5 - s4;
+            tseg[5] += 1;
         }
     }
     if constexpr (PROF) {

@@ -13,9 +13,10 @@ dbg = torch.zeros((B, 8, 8), dtype=torch.int64, device="cuda")
 _lib.check(L.sps_debug_fps_profile(B, N, M, x.data_ptr(), temp.data_ptr(), idx.data_ptr(), dbg.data_ptr(), 0), "profile")
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().astype(np.float64)
-names = ["test", "update", "wave-reduce", "publish", "barrier", "pick"]
+names = ["apply", "candidate", "publish", "barrier", "accept"]
 it = M - 1
-print(f"N={N} m={M}: per-iteration cycles per wave (mean over scenes), stamp cost ~40 included in each segment")
+print(f"N={N} m={M}: per-ROUND cycles per wave (mean over scenes), stamp cost ~40 included in each segment")
 for w in range(8):
     row = d[:, w].mean(0)
-    print(f"wave {w}: " + "  ".join(f"{n}={row[i]/it:7.1f}" for i, n in enumerate(names)) + f"  total={row[:6].sum()/it:7.1f}  touched/iter={row[6]/it:.2f} tie-path/iter={row[7]/it:.3f}")
+    rounds = row[5]
+    print(f"wave {w}: " + "  ".join(f"{n}={row[i]/rounds:7.1f}" for i, n in enumerate(names)) + f"  total/round={row[:5].sum()/rounds:7.1f}  picks/round={it/rounds:.2f}  cycles/pick={row[:5].sum()/it:7.1f}  touched/pick={row[6]/it:.2f} tie-path/pick={row[7]/it:.3f}")
