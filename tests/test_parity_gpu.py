@@ -488,6 +488,40 @@ def test_fps_pruned_equals_bruteforce_and_oracle(ext, G, oracle, N, m, kind):
         np.testing.assert_array_equal(got_t, want_t, err_msg=f"fps mode {mode}")
 
 
+def _adversarial_cloud(kind, N, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "mirror4":      # 4-fold mirror symmetry about the first point: exact distance ties in different buckets
+        q = rng.uniform(0.05, 30.0, size=(N // 4, 3)).astype(np.float32)
+        q[:, 2] = rng.uniform(-1, 1, size=N // 4).astype(np.float32)
+        xyz = np.concatenate([q * np.array(sg, np.float32) for sg in ((1, 1, 1), (-1, 1, 1), (1, -1, 1), (-1, -1, 1))])
+        xyz = xyz[rng.permutation(len(xyz))]
+        xyz[0] = 0.0
+    elif kind == "clusters":   # tight far-apart clumps: the hidden points of a wave are nearly as far as its best one
+        c = rng.uniform(-40, 40, size=(24, 3)).astype(np.float32)
+        xyz = (c[rng.integers(0, 24, N)] + rng.normal(0, 0.05, size=(N, 3))).astype(np.float32)
+    elif kind == "stacked":    # 200 distinct locations, every point a duplicate: running distances tie exactly, many zeros
+        c = rng.uniform(-20, 20, size=(200, 3)).astype(np.float32)
+        xyz = c[rng.integers(0, 200, N)]
+    elif kind == "sheet":      # integer grid on a plane: everything ties
+        g = rng.integers(0, 96, size=(N, 2)).astype(np.float32)
+        xyz = np.concatenate([g, np.zeros((N, 1), np.float32)], 1)
+    else:
+        raise ValueError(kind)
+    return np.ascontiguousarray(xyz[None].astype(np.float32))
+
+
+@pytest.mark.parametrize("kind,N,m", [("mirror4", 16384, 4096), ("clusters", 16384, 2048), ("stacked", 8192, 1024),
+                                      ("sheet", 12288, 3000), ("mirror4", 6144, 6144), ("clusters", 9000, 4500)])
+def test_fps_multi_pick_rounds_adversarial(ext, G, oracle, kind, N, m):
+    """The pruned kernel accepts several picks per round when it can prove sequential FPS would make them in that
+    order.  Clouds built to stress that proof: exact ties across buckets, near-equal hidden points, duplicates."""
+    xyz = np.concatenate([_adversarial_cloud(kind, N, s) for s in (1, 2)])
+    want, want_t = oracle.fps(xyz, m, return_temp=True)
+    got, got_t = G.fps(ext, xyz, m)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(got_t, want_t)
+
+
 def test_fps_pruned_degenerate_clouds(ext, G, oracle):
     """All points identical / collinear / containing NaN and Inf: the cell grid degenerates, results must not."""
     N, m = 8192, 300
