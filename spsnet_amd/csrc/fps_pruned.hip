@@ -70,9 +70,16 @@ __device__ __forceinline__ float wave_allmax_f32(float v) {
     return v;
 }
 
+// v[LANE] = value (wave-uniform), LANE a compile-time constant
+template <int LANE>
+__device__ __forceinline__ void put_lane(int &v, int value) {
+    asm volatile("s_nop 0\n\tv_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(value)), "n"(LANE));
+}
+
 struct PfShared {
     int hist[PF_BINS];
-    int4 rec[2][PF_WAVES][2];  // per round parity: each wave's record {dist, keylo, x, y | z, bound, -, -}
+    // per round parity: soa[field][record], fields {dist, keylo, x, y, z, bound}, records 2w and 2w+1 from wave w
+    __attribute__((aligned(16))) int soa[2][6][2 * PF_WAVES];
     float red[6][PF_WAVES];
     int wsum[PF_WAVES];
 };
@@ -287,12 +294,12 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
     // updates (min is order-independent).  Rejecting is always safe, so every comparison that involves a NaN
     // rejects.  One barrier and one LDS exchange per ROUND instead of per sample.
     constexpr int IMIN = (int)0x80000000;
-    int4 crec = make_int4(0, 0, 0, 0);  // the wave's record as lanes 0/1 publish it: {dist, keylo, x, y} / {z, bound, -, -}
+    int crec = 0;  // the wave's two records as lanes 0..11 publish them: lane 2f+r = field f {dist, keylo, x, y, z, bound} of record r
     bool cand_stale = true;
-    int cand_slot = -1;   // bucket slot the candidate came from: only its refresh can change the candidate
+    int cand_slot = -1, cand_slot2 = -1;  // bucket slots the two records came from: only their refresh changes the records
     // centres accepted by the previous round and still to be applied: record r in lane r of (ax, ay, az)
     float ax = xyz[0], ay = xyz[1], az = xyz[2];
-    unsigned pend = m > 1 ? 1u : 0u;
+    unsigned long long pend = m > 1 ? 1ull : 0ull;
     int j = 1;  // picks made so far
     int round = 0;
 
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
     for (;;) {
         const unsigned long long s0 = stamp();
         while (pend) {
-            const int r = __builtin_ctz(pend);
+            const int r = __builtin_ctzll(pend);
             pend &= pend - 1;
             const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax), r));
             const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay), r));
@@ -340,90 +347,116 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
                 if (changed) refresh(tn, rk[s], xs, ys, zs);
                 if (changed) {
                     commit(s);
-                    if (s == cand_slot) cand_stale = true;
+                    if (s == cand_slot || s == cand_slot2) cand_stale = true;
                 }
             }
         }
         if (j >= m) break;
         const unsigned long long s1 = stamp();
-        // 3. the wave's record: best bucket (largest distance, then largest inverted rank) and the bound
+        // 3. the wave's two records: the maxima of its two best buckets (largest distance, then largest inverted rank)
+        //    and, for each, the bound that takes over once it has been picked
         if (cand_stale) {
             const bool mine = lane < P;
-            const int vmax = wave_max_i32_id(mine ? bmax : IMIN);
-            unsigned long long eq = __ballot(mine && bmax == vmax);
-            int wl = __builtin_ctzll(eq);
-            if (__builtin_popcountll(eq) > 1) {
-                const int kl = (mine && bmax == vmax) ? (int)(bkeylo >> 4) : -1;
-                const int kbest = wave_max_i32_id(kl);
-                wl = __builtin_ctzll(__ballot(kl == kbest));
-            }
-            // bound: every other bucket's maximum, and the runner-up inside the best bucket
-            const int hl = __builtin_amdgcn_readlane(bhold, wl);
-            const int v2b = wave_max_i32_id((mine && lane != wl) ? bmax : IMIN);
-            const float tw = t[wl];
-            const int t2 = wave_max_i32_id(lane != hl ? __float_as_int(tw) : IMIN);
-            const int klo = __builtin_amdgcn_readlane((int)bkeylo, wl);
-            const int px = __builtin_amdgcn_readlane(__float_as_int(bpx), wl);
-            const int py = __builtin_amdgcn_readlane(__float_as_int(bpy), wl);
-            const int pz = __builtin_amdgcn_readlane(__float_as_int(bpz), wl);
-            // ... and the candidate's own running distance once it has been picked (0 unless its coordinates are
-            // Inf/NaN, in which case the update leaves it where it is and the reference picks it again)
-            const float fx = __int_as_float(px), fy = __int_as_float(py), fz = __int_as_float(pz);
-            const float own = fmin_raw(sqdist(fx, fy, fz, fx, fy, fz), __int_as_float(vmax));
-            const int bound = imax(imax(v2b, t2), __float_as_int(own));
-            crec.x = lane == 0 ? vmax : pz;
-            crec.y = lane == 0 ? klo : bound;
-            crec.z = px;
-            crec.w = py;
-            cand_slot = wl;
+            // best bucket among the lanes in `in`: its distance bits and lane
+            auto best_bucket = [&](bool in, int &vmax) -> int {
+                vmax = wave_max_i32_id(in ? bmax : IMIN);
+                const unsigned long long eq = __ballot(in && bmax == vmax);
+                int wl = __builtin_ctzll(eq);
+                if (__builtin_popcountll(eq) > 1) {
+                    const int kl = (in && bmax == vmax) ? (int)(bkeylo >> 4) : -1;
+                    const int kbest = wave_max_i32_id(kl);
+                    wl = __builtin_ctzll(__ballot(kl == kbest));
+                }
+                return wl;
+            };
+            int v1, v2;
+            const int wl1 = best_bucket(mine, v1);
+            const int wl2 = best_bucket(mine && lane != wl1, v2);
+            const int v3 = wave_max_i32_id((mine && lane != wl1 && lane != wl2) ? bmax : IMIN);
+            // runner-up inside each of the two buckets
+            const int hl1 = __builtin_amdgcn_readlane(bhold, wl1), hl2 = __builtin_amdgcn_readlane(bhold, wl2);
+            const float tw1 = t[wl1], tw2 = t[wl2];
+            const int t21 = wave_max_i32_id(lane != hl1 ? __float_as_int(tw1) : IMIN);
+            const int t22 = wave_max_i32_id(lane != hl2 ? __float_as_int(tw2) : IMIN);
+            auto record = [&](int wl, int vmax, int others, auto r) {
+                constexpr int R = decltype(r)::value;
+                const int klo = __builtin_amdgcn_readlane((int)bkeylo, wl);
+                const int px = __builtin_amdgcn_readlane(__float_as_int(bpx), wl);
+                const int py = __builtin_amdgcn_readlane(__float_as_int(bpy), wl);
+                const int pz = __builtin_amdgcn_readlane(__float_as_int(bpz), wl);
+                // the point's own running distance once it has been picked (0 unless its coordinates are Inf/NaN:
+                // then the update leaves it where it is and the reference picks it again)
+                const float fx = __int_as_float(px), fy = __int_as_float(py), fz = __int_as_float(pz);
+                const float own = fmin_raw(sqdist(fx, fy, fz, fx, fy, fz), __int_as_float(vmax));
+                const int bound = imax(others, __builtin_amdgcn_readfirstlane(__float_as_int(own)));
+                put_lane<0 + R>(crec, vmax);
+                put_lane<2 + R>(crec, klo);
+                put_lane<4 + R>(crec, px);
+                put_lane<6 + R>(crec, py);
+                put_lane<8 + R>(crec, pz);
+                put_lane<10 + R>(crec, bound);
+            };
+            // once record 1 is gone: the rest of its bucket (everything else is still below record 2);
+            // once record 2 is gone too: the rest of its bucket and all other buckets
+            record(wl1, v1, t21, std::integral_constant<int, 0>{});
+            record(wl2, v2, imax(t22, v3), std::integral_constant<int, 1>{});
+            cand_slot = wl1;
+            cand_slot2 = wl2;
             cand_stale = false;
         }
         const unsigned long long s2 = stamp();
-        // 4. exchange: lanes 0/1 store the record, ONE barrier, every wave evaluates all 8x8 ordered pairs
+        // 4. exchange: lanes 0..11 store the two records field by field (soa[field][record]), ONE barrier, then every
+        //    wave evaluates all 16x16 ordered pairs, four per lane: lane 4j+b holds record j against records 4b..4b+3
         const int buf = round & 1;
-        if (lane < 2) sh.rec[buf][wave][lane] = crec;
+        if (lane < 12) sh.soa[buf][lane >> 1][2 * wave + (lane & 1)] = crec;
         const unsigned long long s3 = stamp();
         __syncthreads();
         const unsigned long long s4 = stamp();
-        const int ri = lane & (PF_WAVES - 1), rj = lane >> 3;  // pair (i, j): does picking i first allow j later?
-        const int4 i0 = sh.rec[buf][ri][0], i1 = sh.rec[buf][ri][1];
-        const int4 j0 = sh.rec[buf][rj][0], j1 = sh.rec[buf][rj][1];
-        const float ix = __int_as_float(i0.z), iy = __int_as_float(i0.w), iz = __int_as_float(i1.x);
-        const float jx = __int_as_float(j0.z), jy = __int_as_float(j0.w), jz = __int_as_float(j1.x);
-        const float jt = __int_as_float(j0.x);
-        const bool before = i0.x > j0.x || (i0.x == j0.x && (unsigned)i0.y > (unsigned)j0.y);
-        const float dij = sqdist(jx, jy, jz, ix, iy, iz);            // as the update would compute it: point j, centre i
-        const bool lowered = !(dij >= jt);
-        const bool hidden = !(jt > __int_as_float(i1.y));
-        const unsigned long long bef = __ballot(before);
-        const unsigned long long bad = __ballot(before && (lowered || hidden));
-        // lane r < 8 looks at column r (bits 8r..8r+7): position of record r in the order, and whether it may follow
-        const unsigned sh8 = (unsigned)ri * 8u;
-        const int pos = __builtin_popcount((unsigned)(bef >> sh8) & 0xFFu);
-        const bool okc = ((unsigned)(bad >> sh8) & 0xFFu) == 0u;
-        int firstbad = (lane < PF_WAVES && !okc) ? pos : PF_WAVES;
-        firstbad = -imax(-firstbad, dpp_or<DPP_ROW_SHR1>(-firstbad, IMIN));
-        firstbad = -imax(-firstbad, dpp_or<DPP_ROW_SHR2>(-firstbad, IMIN));
-        firstbad = -imax(-firstbad, dpp_or<DPP_ROW_SHR4>(-firstbad, IMIN));
-        int L = __builtin_amdgcn_readlane(firstbad, PF_WAVES - 1);
-        L = L < m - j ? L : m - j;
-        const bool taken = lane < PF_WAVES && pos < L;
-        if (tid < PF_WAVES && taken) {
-            const unsigned rank = 0x0FFFFFFFu - ((unsigned)i0.y >> 4);
+        const int rj = lane >> 2, rb4 = lane & 3;
+        const int4 id = *(const int4 *)&sh.soa[buf][0][rb4 * 4], ik = *(const int4 *)&sh.soa[buf][1][rb4 * 4];
+        const int4 ixv = *(const int4 *)&sh.soa[buf][2][rb4 * 4], iyv = *(const int4 *)&sh.soa[buf][3][rb4 * 4];
+        const int4 izv = *(const int4 *)&sh.soa[buf][4][rb4 * 4], ibv = *(const int4 *)&sh.soa[buf][5][rb4 * 4];
+        const int jd = sh.soa[buf][0][rj], jk = sh.soa[buf][1][rj];
+        const float jx = __int_as_float(sh.soa[buf][2][rj]), jy = __int_as_float(sh.soa[buf][3][rj]);
+        const float jz = __int_as_float(sh.soa[buf][4][rj]);
+        const float jt = __int_as_float(jd);
+        int nbef = 0, nbad = 0;
+        auto pair = [&](int idist, int iklo, int ixb, int iyb, int izb, int ibound) {
+            const bool before = (idist > jd) | ((idist == jd) & ((unsigned)iklo > (unsigned)jk));  // no short circuit: no branches
+            // as the update would compute it: point j, centre i
+            const float dij = sqdist(jx, jy, jz, __int_as_float(ixb), __int_as_float(iyb), __int_as_float(izb));
+            const bool lowered = !(dij >= jt);
+            const bool hidden = !(jt > __int_as_float(ibound));
+            nbef += before ? 1 : 0;
+            nbad += (before & (lowered | hidden)) ? 1 : 0;
+        };
+        pair(id.x, ik.x, ixv.x, iyv.x, izv.x, ibv.x);
+        pair(id.y, ik.y, ixv.y, iyv.y, izv.y, ibv.y);
+        pair(id.z, ik.z, ixv.z, iyv.z, izv.z, ibv.z);
+        pair(id.w, ik.w, ixv.w, iyv.w, izv.w, ibv.w);
+        // sum over the four lanes of record j: its position in the order, and whether it may follow
+        int cnt = nbef | (nbad << 8);
+        cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+        cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+        const int pos = cnt & 0xFF;
+        const int firstbad = -wave_max_i32_id((cnt >> 8) ? -pos : -2 * PF_WAVES);
+        int L = firstbad < m - j ? firstbad : m - j;
+        const bool taken = rb4 == 0 && pos < L;
+        if (tid < 64 && taken) {
+            const unsigned rank = 0x0FFFFFFFu - ((unsigned)jk >> 4);
             const int picked = (int)pf_unrank(rank, l2, rb);
             if constexpr (PUBLISH) __hip_atomic_store(&idxs[j + pos], picked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else idxs[j + pos] = picked;
         }
         if constexpr (PUBLISH) {
             if (tid == 0 && (((j + L) >> 6) != (j >> 6) || j + L == m)) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores (lanes 0..7) have left
-                __hip_atomic_store(&progress[blockIdx.x], j + L, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left
+                __hip_atomic_store(&progress[blockIdx.x], j + L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         // the reference never applies its last pick to `temp`
-        pend = (unsigned)__ballot(taken && (j + pos) != m - 1);
-        ax = ix; ay = iy; az = iz;
+        pend = __ballot(taken && (j + pos) != m - 1);  // bit 4r: record r
+        ax = jx; ay = jy; az = jz;
         j += L;
         round += 1;
         if constexpr (PROF) {
