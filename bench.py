@@ -47,6 +47,8 @@ def parse():
                     help="layer-2 sampler (BASELINE configs[1] / configs[3])")
     ap.add_argument("--mlp-precision", default="fp16x2", choices=["fp32", "fp16x2"],
                     help="grouped-MLP arithmetic: exact fp32 MFMA, or split-fp16 (hi+lo halves, 3 MFMAs, ~1e-6 rel.)")
+    ap.add_argument("--no-stream-first-layer", dest="stream_first_layer", action="store_false",
+                    help="do not let layer 0's ball query / MLP consume the D-FPS picks while FPS is still running")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-batches-in-flight measurement")
     ap.add_argument("--cpu-scenes", type=int, default=8, help="scenes in the bounded CPU-baseline sample")
@@ -167,7 +169,7 @@ def main():
 
     def step():
         with torch.no_grad():
-            return sa_stack.run_sa_layers(layers, xyz, feats, stds)
+            return sa_stack.run_sa_layers(layers, xyz, feats, stds, stream_first_layer=args.stream_first_layer)
 
     for _ in range(args.warmup):
         outs = step()

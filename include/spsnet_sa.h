@@ -116,6 +116,13 @@ int sps_three_interpolate_grad_kernel_launcher_fast(int b, int c, int n, int m, 
  * Device workspace from the caller: work_T (B*m f32), work_temp (B*n f32), flags (B i32). */
 int sps_fps_ordered_prefix(int b, int n, int m, const float *xyz, float *temp, int *idxs, float *work_T,
                            float *work_temp, int *flags, sps_stream_t stream);
+/* The two passes of sps_fps_ordered_prefix as separate calls (m <= 2048).  _begin (flags <- 0, pass 1) reads only the
+ * first m points of every scene, so a caller that receives the cloud piecewise can issue it as soon as those exist;
+ * _finish (pass 2 + recomputation of flagged scenes) needs the whole cloud. */
+int sps_fps_ordered_prefix_begin(int b, int n, int m, const float *xyz, const float *temp, float *work_T, int *flags,
+                                 sps_stream_t stream);
+int sps_fps_ordered_prefix_finish(int b, int n, int m, const float *xyz, float *temp, int *idxs, const float *work_T,
+                                  float *work_temp, int *flags, sps_stream_t stream);
 
 /* ---- fused entry points for the SA module layer (pointnet2_modules.py) ----------------- */
 

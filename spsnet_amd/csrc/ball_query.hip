@@ -19,17 +19,21 @@
 //   * the finished 64 x nsample block of idx is contiguous in HBM and is written coalesced from a
 //     padded LDS image instead of one 4-byte store per hit per lane.
 #include "sps_common.h"
+
+#include <stdlib.h>
 #include "spatial_grid.h"
 
 namespace sps {
 
 constexpr int BQ_LANES = 64;
-constexpr int BQ_MAX_SEG = 8;
+constexpr int BQ_MAX_SEG = 8;        // segments (waves) per workgroup, general launches
+constexpr int BQ_MAX_SEG_DUAL = 16;  // dual kernel: small launches (streamed chunks) use up to 16, LDS permitting
 constexpr int BQ_BATCH = 8;  // points per scalar-load batch
 
-__device__ __forceinline__ void bq_append(int *hits, int nsample, int lane, int k, int &cnt) {
+template <typename HitT>
+__device__ __forceinline__ void bq_append(HitT *hits, int nsample, int lane, int k, int &cnt) {
     if (cnt < nsample) {
-        hits[cnt * BQ_LANES + lane] = k;
+        hits[cnt * BQ_LANES + lane] = (HitT)k;
         ++cnt;
     }
 }
@@ -145,9 +149,12 @@ __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_seg_kernel(
 
 // Two radii in ONE scan (the two grouping scales of an SA layer share centroids and points): the distance
 // is evaluated once per pair and tested against both radii; each radius keeps its own ordered hit list.
-// LDS (ints): hitsA[S][nsA][64] | hitsB[S][nsB][64] | cnt[2][S][64] | final[max(nsA,nsB)][65].  Rows are always
-// fully written (zeros for empty balls), like sps_ball_query_full.
-__global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_dual_kernel(
+// LDS: cnt[2][S][64] | final[max(nsA,nsB)][65] (ints) | hitsA[S][nsA][64] | hitsB[S][nsB][64] (HitT).  The hit lists
+// hold point indices RELATIVE to the segment start, as 16-bit values whenever a segment is shorter than 65 536
+// points: half the LDS, so twice the segments (waves) per workgroup fit -- the kernel is latency-bound per wave.
+// Rows are always fully written (zeros for empty balls), like sps_ball_query_full.
+template <typename HitT>
+__global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG_DUAL) void ball_query_dual_kernel(
     int n, int m, int seg_len, float r2a, float r2b, int nsa, int nsb, const float *__restrict__ new_xyz,
     const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b, const int *__restrict__ perm,
     int jbeg, int jend) {
@@ -155,10 +162,11 @@ __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_dual_kernel(
     const int S = blockDim.x / BQ_LANES;
     const int lane = threadIdx.x & 63;
     const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int *hits_a = bq_lds + seg * nsa * BQ_LANES;
-    int *hits_b = bq_lds + S * nsa * BQ_LANES + seg * nsb * BQ_LANES;
-    int *cnts = bq_lds + S * (nsa + nsb) * BQ_LANES;  // [2][S][64]
+    int *cnts = bq_lds;  // [2][S][64]
     int *final_img = cnts + 2 * S * BQ_LANES;
+    HitT *hits_base = (HitT *)(final_img + (nsa > nsb ? nsa : nsb) * (BQ_LANES + 1) + 1);  // +1: keeps 8-byte alignment irrelevant, HitT <= 4 B
+    HitT *hits_a = hits_base + seg * nsa * BQ_LANES;
+    HitT *hits_b = hits_base + S * nsa * BQ_LANES + seg * nsb * BQ_LANES;
 
     const int scene = blockIdx.y;
     const int j0 = jbeg + blockIdx.x * BQ_LANES;  // centroid range [jbeg, jend) of every scene
@@ -174,26 +182,14 @@ __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_dual_kernel(
     const int kbeg = seg * seg_len;
     const int kend = (kbeg + seg_len < n) ? kbeg + seg_len : n;
     int k0 = kbeg;
-    float p[BQ_BATCH * 3], pn[BQ_BATCH * 3];  // current / next scalar-load batch (see ball_query_seg_kernel)
-    if (k0 + BQ_BATCH <= kend) {
-#pragma unroll
-        for (int u = 0; u < BQ_BATCH * 3; ++u) p[u] = xyz[(size_t)k0 * 3 + u];
-    }
     // largest squared radius this lane can still use (-1 when both lists are full / the lane is inactive)
     auto lane_thr = [&]() { return fmaxf(ca < nsa ? r2a : -1.f, cb < nsb ? r2b : -1.f); };
     float thr = lane_thr();
-    for (; k0 + BQ_BATCH <= kend; k0 += BQ_BATCH) {
-        if (__all(thr < 0.f)) break;
-        asm volatile("" ::"s"(p[0]), "s"(p[BQ_BATCH * 3 - 1]));
-        __builtin_amdgcn_sched_barrier(0);
-        const bool more = k0 + 2 * BQ_BATCH <= kend;
-        const float *nsrc = xyz + (size_t)(more ? k0 + BQ_BATCH : k0) * 3;
-#pragma unroll
-        for (int u = 0; u < BQ_BATCH * 3; ++u) pn[u] = nsrc[u];
-        __builtin_amdgcn_sched_barrier(0);
+    // one batch of BQ_BATCH points (wave-uniform coordinates q[]) starting at index kb
+    auto batch = [&](int kb, const float *q) {
         float d2[BQ_BATCH];
 #pragma unroll
-        for (int u = 0; u < BQ_BATCH; ++u) d2[u] = sqdist(cx, cy, cz, p[u * 3], p[u * 3 + 1], p[u * 3 + 2]);
+        for (int u = 0; u < BQ_BATCH; ++u) d2[u] = sqdist(cx, cy, cz, q[u * 3], q[u * 3 + 1], q[u * 3 + 2]);
         float dmin = d2[0];
 #pragma unroll
         for (int u = 1; u < BQ_BATCH; ++u) dmin = fminf(dmin, d2[u]);
@@ -209,25 +205,43 @@ __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_dual_kernel(
             while (bits_a != 0u && ca < nsa) {
                 const int u = __builtin_ctz(bits_a);
                 bits_a &= bits_a - 1u;
-                hits_a[ca * BQ_LANES + lane] = k0 + u;
+                hits_a[ca * BQ_LANES + lane] = (HitT)(kb - kbeg + u);
                 ++ca;
             }
             while (bits_b != 0u && cb < nsb) {
                 const int u = __builtin_ctz(bits_b);
                 bits_b &= bits_b - 1u;
-                hits_b[cb * BQ_LANES + lane] = k0 + u;
+                hits_b[cb * BQ_LANES + lane] = (HitT)(kb - kbeg + u);
                 ++cb;
             }
             thr = lane_thr();
         }
+    };
+    {
+        float p[BQ_BATCH * 3], pn[BQ_BATCH * 3];  // current / next scalar-load batch (see ball_query_seg_kernel)
+        if (k0 + BQ_BATCH <= kend) {
 #pragma unroll
-        for (int u = 0; u < BQ_BATCH * 3; ++u) p[u] = pn[u];
+            for (int u = 0; u < BQ_BATCH * 3; ++u) p[u] = xyz[(size_t)k0 * 3 + u];
+        }
+        for (; k0 + BQ_BATCH <= kend; k0 += BQ_BATCH) {
+            if (__all(thr < 0.f)) break;
+            asm volatile("" ::"s"(p[0]), "s"(p[BQ_BATCH * 3 - 1]));
+            __builtin_amdgcn_sched_barrier(0);
+            const bool more = k0 + 2 * BQ_BATCH <= kend;
+            const float *nsrc = xyz + (size_t)(more ? k0 + BQ_BATCH : k0) * 3;
+#pragma unroll
+            for (int u = 0; u < BQ_BATCH * 3; ++u) pn[u] = nsrc[u];
+            __builtin_amdgcn_sched_barrier(0);
+            batch(k0, p);
+#pragma unroll
+            for (int u = 0; u < BQ_BATCH * 3; ++u) p[u] = pn[u];
+        }
     }
     if (!__all(ca >= nsa && cb >= nsb)) {
         for (; k0 < kend; ++k0) {
             const float d2 = sqdist(cx, cy, cz, xyz[(size_t)k0 * 3], xyz[(size_t)k0 * 3 + 1], xyz[(size_t)k0 * 3 + 2]);
-            if (d2 < r2a) bq_append(hits_a, nsa, lane, k0, ca);
-            if (d2 < r2b) bq_append(hits_b, nsb, lane, k0, cb);
+            if (d2 < r2a) bq_append(hits_a, nsa, lane, k0 - kbeg, ca);
+            if (d2 < r2b) bq_append(hits_b, nsb, lane, k0 - kbeg, cb);
         }
     }
     cnts[seg * BQ_LANES + lane] = active ? ca : 0;
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_dual_kernel(
     // merge + write-out, one radius after the other through the shared `final` image
     for (int which = 0; which < 2; ++which) {
         const int ns = which ? nsb : nsa;
-        const int *hits = which ? hits_b : hits_a;
+        const HitT *hits = which ? hits_b : hits_a;
         const int *cn = cnts + which * S * BQ_LANES;
         int before = 0, total = 0;
         for (int s = 0; s < S; ++s) {
@@ -247,7 +261,7 @@ __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_dual_kernel(
         }
         const int mine = cn[seg * BQ_LANES + lane];
         for (int i = 0; i < mine && before + i < ns; ++i)
-            final_img[(before + i) * (BQ_LANES + 1) + lane] = hits[i * BQ_LANES + lane];
+            final_img[(before + i) * (BQ_LANES + 1) + lane] = kbeg + (int)hits[i * BQ_LANES + lane];
         __syncthreads();
         if (seg == 0) {
             const int kept = total < ns ? total : ns;
@@ -272,15 +286,16 @@ __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG) void ball_query_dual_kernel(
 // cannot exploit (it stops only when all 64 centroids of a wave are full) and whose per-hit divergent appends
 // cost more than its distance arithmetic (tools/bq_time.py: 353 us vs 150 us without hits at the layer-0 shape).
 constexpr int BQW_WAVES = 4;   // centroids per workgroup
+constexpr long long BQ_WAVE_MAX_CENTROIDS = 8192;  // b * centroids up to which sps_ball_query_full2_range prefers this kernel
 constexpr int BQW_UNROLL = 4;  // 64-point steps in flight per loop trip
 
 __global__ __launch_bounds__(64 * BQW_WAVES) void ball_query_wave_dual_kernel(
     int n, int m, float r2a, float r2b, int nsa, int nsb, const float *__restrict__ new_xyz,
-    const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b) {
+    const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b, int jbeg, int jend) {
     const int scene = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * BQW_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (j >= m) return;
+    const int j = jbeg + blockIdx.x * BQW_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (j >= jend) return;
     xyz += (size_t)scene * n * 3;
     const float *ctr = new_xyz + ((size_t)scene * m + j) * 3;
     const float cx = ctr[0], cy = ctr[1], cz = ctr[2];
@@ -432,18 +447,39 @@ extern "C" int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcoun
     if (!new_xyz || (!xyz && n > 0) || !idx_a || !idx_b) return fail(SPS_ERR_INVALID, "ball_query_full2: null pointer");
     if (b > 65535) return fail(SPS_ERR_INVALID, "ball_query_full2: batch %d exceeds the grid limit", b);
     if (n == 0) return fail(SPS_ERR_INVALID, "ball_query_full2: n == 0");
+    // Few centroids: the lane-per-centroid kernel below would put a 64-centroid group's whole scan on ONE CU (its
+    // segments are waves of one workgroup); one wave per centroid spreads the same work over the chip.
+    bool per_wave = !perm_work && (long long)b * jcount <= BQ_WAVE_MAX_CENTROIDS;
+    if (const char *force = getenv("SPS_BQ_WAVE")) per_wave = force[0] == '1';  // diagnostic override (tools/bq_time.py)
+    if (per_wave) {
+        hipLaunchKernelGGL(ball_query_wave_dual_kernel, dim3(divup(jcount, BQW_WAVES), b), dim3(64 * BQW_WAVES), 0,
+                           as_stream(stream), n, m, radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz,
+                           xyz, idx_a, idx_b, j0, j0 + jcount);
+        return check_launch("ball_query_wave_dual_kernel");
+    }
     const int groups = divup(jcount, BQ_LANES);
     int S = divup(4096, b * groups);
-    S = S < 1 ? 1 : (S > BQ_MAX_SEG ? BQ_MAX_SEG : S);
+    S = S < 1 ? 1 : (S > BQ_MAX_SEG_DUAL ? BQ_MAX_SEG_DUAL : S);
     while (S > 1 && n / S < 256) --S;
     const int nsmax = nsample_a > nsample_b ? nsample_a : nsample_b;
+    auto seg_of = [&](int s) { return divup(divup(n, s), BQ_BATCH) * BQ_BATCH; };
     auto lds_bytes = [&](int s) {
-        return (size_t)4 * ((size_t)s * (nsample_a + nsample_b) * BQ_LANES + 2 * s * BQ_LANES + (size_t)nsmax * (BQ_LANES + 1));
+        const size_t hit = seg_of(s) <= 65536 ? 2 : 4;
+        return hit * (size_t)s * (nsample_a + nsample_b) * BQ_LANES +
+               (size_t)4 * (2 * s * BQ_LANES + (size_t)nsmax * (BQ_LANES + 1) + 1);
     };
-    while (S > 1 && lds_bytes(S) > 64 * 1024) --S;
-    if (lds_bytes(S) > 64 * 1024) return fail(SPS_ERR_INVALID, "ball_query_full2: nsample too large for LDS");
-    int seg_len = divup(n > 0 ? n : 1, S);
-    seg_len = divup(seg_len, BQ_BATCH) * BQ_BATCH;
+    // 64 KiB keeps two workgroups on a CU; a launch with fewer workgroups than CUs may take up to 150 KiB each
+    static int num_cu = 0;
+    if (num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
+        if (num_cu <= 0) num_cu = 256;
+    }
+    const size_t lds_cap = (b * groups <= num_cu) ? 150 * 1024 : 64 * 1024;
+    while (S > 1 && lds_bytes(S) > lds_cap) --S;
+    if (lds_bytes(S) > lds_cap) return fail(SPS_ERR_INVALID, "ball_query_full2: nsample too large for LDS");
+    const int seg_len = seg_of(S);
     const int *perm = nullptr;
     if (perm_work && m >= 4 * BQ_LANES) {  // worth a sort only when a scene has several groups of centroids
         hipLaunchKernelGGL(centroid_order_kernel, dim3(b), dim3(CO_THREADS), 0, as_stream(stream), m, new_xyz, perm_work);
@@ -451,9 +487,22 @@ extern "C" int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcoun
         if (rc != SPS_OK) return rc;
         perm = perm_work;
     }
-    hipLaunchKernelGGL(ball_query_dual_kernel, dim3(groups, b), dim3(BQ_LANES * S), lds_bytes(S), as_stream(stream), n, m,
-                       seg_len, radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b,
-                       perm, j0, j0 + jcount);
+    typedef void (*dual_fn)(int, int, int, float, float, int, int, const float *, const float *, int *, int *, const int *, int, int);
+    const dual_fn fn = seg_len <= 65536 ? ball_query_dual_kernel<unsigned short> : ball_query_dual_kernel<int>;
+    if (lds_bytes(S) > 64 * 1024) {
+        static const void *raised[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool have = false;
+        for (const void *r : raised) have |= r == (const void *)fn;
+        if (!have) {
+            if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+                return fail(SPS_ERR_LAUNCH, "ball_query_full2: cannot raise the dynamic LDS limit");
+            for (const void *&r : raised)
+                if (!r) { r = (const void *)fn; break; }
+        }
+    }
+    hipLaunchKernelGGL(fn, dim3(groups, b), dim3(BQ_LANES * S), lds_bytes(S), as_stream(stream), n, m, seg_len,
+                       radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, perm, j0,
+                       j0 + jcount);
     return check_launch("ball_query_dual_kernel");
 }
 
@@ -468,7 +517,7 @@ extern "C" int sps_ball_query_full2_wave(int b, int n, int m, float radius_a, in
     if (!new_xyz || !xyz || !idx_a || !idx_b) return fail(SPS_ERR_INVALID, "ball_query_full2_wave: null pointer");
     if (b > 65535) return fail(SPS_ERR_INVALID, "ball_query_full2_wave: batch %d exceeds the grid limit", b);
     hipLaunchKernelGGL(ball_query_wave_dual_kernel, dim3(divup(m, BQW_WAVES), b), dim3(64 * BQW_WAVES), 0, as_stream(stream),
-                       n, m, radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b);
+                       n, m, radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, 0, m);
     return check_launch("ball_query_wave_dual_kernel");
 }
 

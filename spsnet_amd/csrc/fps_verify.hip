@@ -18,87 +18,98 @@
 
 namespace sps {
 
-constexpr int FV_THREADS = 256;
-constexpr int FV_BATCH = 8;  // centres per scalar-load batch
+constexpr int FV_SEG = 8;                    // waves per workgroup = segments of the centre range
+constexpr int FV_THREADS = 64 * FV_SEG;
+constexpr int FV_MAX_M = 2048;               // centres staged in LDS (32 KiB as float4)
 
 __device__ __forceinline__ unsigned fv_rank(unsigned k, int bs, int l2, int rb) {
     const unsigned lowrev = (l2 == 0) ? 0u : (__brev(k & (unsigned)(bs - 1)) >> (32 - l2));
     return (lowrev << rb) | (k >> l2);
 }
 
-// pass 1: thread j computes T[j] over the centres i < j (j < m)
+// Both passes use the same shape: a workgroup owns 64 points (one per lane) and its FV_SEG waves split the centre
+// range into equal segments.  The centres are staged once in LDS as {x, y, z, T} and read back with wave-uniform
+// (broadcast) ds_read_b128 -- the first version walked them with one scalar-load batch in flight per wave and was
+// bound by that load's latency (136 us for 8 x 4096 points x 1024 centres with 4 waves per CU).
+// min is order-independent, so splitting the running minimum over segments changes no value:
+//   phase 1: wave s reduces its own segment to segmin[s][lane];
+//   phase 2 (check only): wave s starts from min(temp, segmin[0..s-1]) and replays its segment step by step.
+
+// pass 1: T[j] = min(temp[j], min_{i<j} d(j, i)) for j < m
 __global__ __launch_bounds__(FV_THREADS) void fps_prefix_dist_kernel(int n, int m, const float *__restrict__ xyz,
                                                                      const float *__restrict__ temp, float *__restrict__ T) {
+    __shared__ float4 ctr[FV_MAX_M];
+    __shared__ float segmin[FV_SEG][64];
     const int scene = blockIdx.y;
-    const int j = blockIdx.x * FV_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63, seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j0 = blockIdx.x * 64, j = j0 + lane;
     xyz += (size_t)scene * n * 3;
+    const int need = (j0 + 63 < m ? j0 + 63 : m - 1);  // centres 0 .. need-1 matter to this workgroup
+    for (int i = threadIdx.x; i < need; i += FV_THREADS) ctr[i] = make_float4(xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2], 0.f);
+    __syncthreads();
     const bool live = j < m;
     const int jj = live ? j : 0;
     const float px = xyz[jj * 3], py = xyz[jj * 3 + 1], pz = xyz[jj * 3 + 2];
-    float t = temp[(size_t)scene * n + jj];
-    // all lanes of the wave walk the centres up to the wave's largest j (wave-uniform trip count -> scalar loads);
-    // a lane stops taking the min once i reaches its own j
-    const int jmax = __builtin_amdgcn_readfirstlane(blockIdx.x * FV_THREADS + (threadIdx.x | 63));
-    const int stop = jmax < m ? jmax : m - 1;
-    int i = 0;
-    for (; i + FV_BATCH <= stop; i += FV_BATCH) {  // wave-uniform -> one scalar-load batch of 8 centres
-        float c[FV_BATCH * 3];
-#pragma unroll
-        for (int u = 0; u < FV_BATCH * 3; ++u) c[u] = xyz[i * 3 + u];
-#pragma unroll
-        for (int u = 0; u < FV_BATCH; ++u) {
-            const float d = sqdist(px, py, pz, c[u * 3], c[u * 3 + 1], c[u * 3 + 2]);
-            t = (i + u < j) ? fminf(d, t) : t;
-        }
-    }
-    for (; i < stop; ++i) {
-        const float d = sqdist(px, py, pz, xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]);
+    const int len = (need + FV_SEG - 1) / FV_SEG;
+    const int ibeg = seg * len, iend = (ibeg + len < need) ? ibeg + len : need;
+    float t = INFINITY;
+    for (int i = ibeg; i < iend; ++i) {
+        const float4 c = ctr[i];
+        const float d = sqdist(px, py, pz, c.x, c.y, c.z);
         t = (i < j) ? fminf(d, t) : t;
     }
-    if (live) T[(size_t)scene * m + j] = t;
+    segmin[seg][lane] = t;
+    __syncthreads();
+    if (seg == 0 && live) {
+        float r = temp[(size_t)scene * n + j];
+#pragma unroll
+        for (int s = 0; s < FV_SEG; ++s) r = fminf(segmin[s][lane], r);
+        T[(size_t)scene * m + j] = r;
+    }
 }
 
-// pass 2: thread k replays its running distance and checks every step of the guess
+// pass 2: point k replays its running distance and checks every step of the guess
 __global__ __launch_bounds__(FV_THREADS) void fps_prefix_check_kernel(
     int n, int m, int bs, int l2, int rb, const float *__restrict__ xyz, const float *__restrict__ temp,
     const float *__restrict__ T, float *__restrict__ temp_done, int *__restrict__ idx, int *__restrict__ bad) {
+    __shared__ float4 step[FV_MAX_M];  // step j (1 <= j < m): {centre j-1, T[j]} at step[j-1]
+    __shared__ float segmin[FV_SEG][64];
     const int scene = blockIdx.y;
-    const int k = blockIdx.x * FV_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63, seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = blockIdx.x * 64 + lane;
     xyz += (size_t)scene * n * 3;
     T += (size_t)scene * m;
+    const int steps = m - 1;
+    for (int i = threadIdx.x; i < steps; i += FV_THREADS) step[i] = make_float4(xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2], T[i + 1]);
+    __syncthreads();
     const bool live = k < n;
     const int kk = live ? k : 0;
     const float px = xyz[kk * 3], py = xyz[kk * 3 + 1], pz = xyz[kk * 3 + 2];
+    const int len = (steps + FV_SEG - 1) / FV_SEG;
+    const int ibeg = seg * len, iend = (ibeg + len < steps) ? ibeg + len : steps;
+    float local = INFINITY;
+    for (int i = ibeg; i < iend; ++i) {
+        const float4 c = step[i];
+        local = fminf(sqdist(px, py, pz, c.x, c.y, c.z), local);
+    }
+    segmin[seg][lane] = local;
+    __syncthreads();
     float t = temp[(size_t)scene * n + kk];
+    for (int s = 0; s < seg; ++s) t = fminf(segmin[s][lane], t);
     const unsigned myrank = fv_rank((unsigned)kk, bs, l2, rb);
     bool violated = false;
-    // step j (1 <= j < m): centre j-1 has been applied, the guess says point j is picked now
-    int j = 1;
-    for (; j + FV_BATCH <= m; j += FV_BATCH) {  // centres j-1 .. j+6, one scalar-load batch
-        float c[FV_BATCH * 3], tj[FV_BATCH];
-#pragma unroll
-        for (int u = 0; u < FV_BATCH * 3; ++u) c[u] = xyz[(j - 1) * 3 + u];
-#pragma unroll
-        for (int u = 0; u < FV_BATCH; ++u) tj[u] = T[j + u];
-#pragma unroll
-        for (int u = 0; u < FV_BATCH; ++u) {
-            const float d = sqdist(px, py, pz, c[u * 3], c[u * 3 + 1], c[u * 3 + 2]);
-            t = fminf(d, t);
-            const unsigned rj = fv_rank((unsigned)(j + u), bs, l2, rb);
-            violated |= (k != j + u) && (t > tj[u] || (t == tj[u] && myrank < rj));
-        }
-    }
-    for (; j < m; ++j) {
-        const int c = j - 1;
-        const float d = sqdist(px, py, pz, xyz[c * 3], xyz[c * 3 + 1], xyz[c * 3 + 2]);
-        t = fminf(d, t);
-        const float tj = T[j];
-        const unsigned rj = fv_rank((unsigned)j, bs, l2, rb);
-        violated |= (k != j) && (t > tj || (t == tj && myrank < rj));
+    for (int i = ibeg; i < iend; ++i) {  // step j = i + 1: centre i has been applied, the guess says point j is picked now
+        const float4 c = step[i];
+        t = fminf(sqdist(px, py, pz, c.x, c.y, c.z), t);
+        const unsigned rj = fv_rank((unsigned)(i + 1), bs, l2, rb);
+        violated |= (k != i + 1) && (t > c.w || (t == c.w && myrank < rj));
     }
     if (live) {
-        temp_done[(size_t)scene * n + k] = t;  // the reference's final `temp` if the guess holds
-        if (k < m) idx[(size_t)scene * m + k] = k;
+        if (seg == FV_SEG - 1) {
+            float r = fminf(local, t);  // == t when the last segment is not empty
+            temp_done[(size_t)scene * n + k] = r;  // the reference's final `temp` if the guess holds
+            if (k < m) idx[(size_t)scene * m + k] = k;
+        }
         if (violated) bad[scene] = 1;
     }
 }
@@ -107,27 +118,59 @@ __global__ __launch_bounds__(FV_THREADS) void fps_prefix_check_kernel(
 
 // Workspace (device, caller-allocated): work_T (B*m f32), work_temp (B*n f32), flags (B i32).
 // `temp` is the usual caller-filled running-distance buffer (1e10); on return it holds the final values.
-extern "C" int sps_fps_ordered_prefix(int b, int n, int m, const float *xyz, float *temp, int *idxs, float *work_T,
-                                      float *work_temp, int *flags, sps_stream_t stream) {
+//
+// The two passes are also exported separately: pass 1 reads only the first m points, so a caller that receives the
+// cloud piecewise (sa_stack's streamed first layer) can run it as soon as those exist and pass 2 when the rest is in.
+static int fv_check_args(const char *who, int b, int n, int m, const void *xyz, const void *temp, const void *work_T,
+                         const void *flags) {
     using namespace sps;
-    if (b < 0 || n <= 0 || m < 0 || m > n) return fail(SPS_ERR_INVALID, "fps_ordered_prefix: bad shape b=%d n=%d m=%d", b, n, m);
-    if (b == 0 || m == 0) return SPS_OK;
-    if (!xyz || !temp || !idxs || !work_T || !work_temp || !flags) return fail(SPS_ERR_INVALID, "fps_ordered_prefix: null pointer");
-    if (b > 65535) return fail(SPS_ERR_INVALID, "fps_ordered_prefix: batch too large");
+    if (b < 0 || n <= 0 || m < 0 || m > n) return fail(SPS_ERR_INVALID, "%s: bad shape b=%d n=%d m=%d", who, b, n, m);
+    if (!xyz || !temp || !work_T || !flags) return fail(SPS_ERR_INVALID, "%s: null pointer", who);
+    if (b > 65535) return fail(SPS_ERR_INVALID, "%s: batch too large", who);
+    if (m > FV_MAX_M) return fail(SPS_ERR_INVALID, "%s: m=%d exceeds the %d centres the kernels stage in LDS", who, m, FV_MAX_M);
+    return SPS_OK;
+}
+
+extern "C" int sps_fps_ordered_prefix_begin(int b, int n, int m, const float *xyz, const float *temp, float *work_T,
+                                            int *flags, sps_stream_t stream) {
+    using namespace sps;
+    int rc = fv_check_args("fps_ordered_prefix_begin", b, n, m, xyz, temp, work_T, flags);
+    if (rc != SPS_OK || b == 0 || m == 0) return rc;
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(flags, 0, sizeof(int) * (size_t)b, st) != hipSuccess) return fail(SPS_ERR_LAUNCH, "fps_ordered_prefix: memset failed");
+    hipLaunchKernelGGL(fps_prefix_dist_kernel, dim3(divup(m, 64), b), dim3(FV_THREADS), 0, st, n, m, xyz, temp, work_T);
+    return check_launch("fps_prefix_dist_kernel");
+}
+
+extern "C" int sps_fps_ordered_prefix_finish(int b, int n, int m, const float *xyz, float *temp, int *idxs,
+                                             const float *work_T, float *work_temp, int *flags, sps_stream_t stream) {
+    using namespace sps;
+    int rc = fv_check_args("fps_ordered_prefix_finish", b, n, m, xyz, temp, work_T, flags);
+    if (rc != SPS_OK || b == 0 || m == 0) return rc;
+    if (!idxs || !work_temp) return fail(SPS_ERR_INVALID, "fps_ordered_prefix_finish: null pointer");
     hipStream_t st = as_stream(stream);
     const int bs = sps_opt_n_threads(n);
     int l2 = 0;
     while ((1 << (l2 + 1)) <= bs) ++l2;
     int rb = 0;
     while ((1 << rb) < divup(n, bs)) ++rb;
-    if (hipMemsetAsync(flags, 0, sizeof(int) * (size_t)b, st) != hipSuccess) return fail(SPS_ERR_LAUNCH, "fps_ordered_prefix: memset failed");
-    hipLaunchKernelGGL(fps_prefix_dist_kernel, dim3(divup(m, FV_THREADS), b), dim3(FV_THREADS), 0, st, n, m, xyz, temp, work_T);
-    int rc = check_launch("fps_prefix_dist_kernel");
-    if (rc != SPS_OK) return rc;
-    hipLaunchKernelGGL(fps_prefix_check_kernel, dim3(divup(n, FV_THREADS), b), dim3(FV_THREADS), 0, st, n, m, bs, l2, rb, xyz,
+    hipLaunchKernelGGL(fps_prefix_check_kernel, dim3(divup(n, 64), b), dim3(FV_THREADS), 0, st, n, m, bs, l2, rb, xyz,
                        temp, work_T, work_temp, idxs, flags);
     rc = check_launch("fps_prefix_check_kernel");
     if (rc != SPS_OK) return rc;
     // confirmed scenes: copy work_temp -> temp and stop; flagged scenes: the ordinary FPS kernel recomputes them
     return launch_fps_resolve(b, n, m, xyz, temp, idxs, flags, work_temp, st);
+}
+
+extern "C" int sps_fps_ordered_prefix(int b, int n, int m, const float *xyz, float *temp, int *idxs, float *work_T,
+                                      float *work_temp, int *flags, sps_stream_t stream) {
+    using namespace sps;
+    if (b < 0 || n <= 0 || m < 0 || m > n) return fail(SPS_ERR_INVALID, "fps_ordered_prefix: bad shape b=%d n=%d m=%d", b, n, m);
+    if (b == 0 || m == 0) return SPS_OK;
+    if (!xyz || !temp || !idxs || !work_T || !work_temp || !flags) return fail(SPS_ERR_INVALID, "fps_ordered_prefix: null pointer");
+    // more centres than the verification kernels stage in LDS: no shortcut, the ordinary kernel computes the result
+    if (m > FV_MAX_M) return sps_farthest_point_sampling_kernel_launcher(b, n, m, xyz, temp, idxs, stream);
+    const int rc = sps_fps_ordered_prefix_begin(b, n, m, xyz, temp, work_T, flags, stream);
+    if (rc != SPS_OK) return rc;
+    return sps_fps_ordered_prefix_finish(b, n, m, xyz, temp, idxs, work_T, work_temp, flags, stream);
 }

@@ -208,6 +208,41 @@ def fps_ordered_prefix(xyz, npoint, return_flags=False):
     return (idx, flags, temp) if return_flags else idx
 
 
+class OrderedPrefix:
+    """sps_fps_ordered_prefix in two steps for callers that receive the FPS-ordered cloud piecewise: begin() once the
+    first `npoint` points of every scene exist, finish() once all of them do (possibly on another stream, ordered
+    after begin by the caller)."""
+
+    def __init__(self, xyz, npoint):
+        B, N, _ = xyz.shape
+        dev = xyz.device
+        self.xyz, self.npoint = xyz, npoint
+        self.temp = torch.full((B, N), 1e10, dtype=F32, device=dev)
+        self.idx = torch.empty((B, npoint), dtype=I32, device=dev)
+        self.work_t = torch.empty((B, max(npoint, 1)), dtype=F32, device=dev)
+        self.work_temp = torch.empty((B, N), dtype=F32, device=dev)
+        self.flags = torch.empty((B,), dtype=I32, device=dev)
+
+    def tensors(self):
+        return (self.temp, self.idx, self.work_t, self.work_temp, self.flags)
+
+    def begin(self):
+        B, N, _ = self.xyz.shape
+        with _on(self.xyz):
+            _lib.check(_L.sps_fps_ordered_prefix_begin(B, N, self.npoint, _ptr(self.xyz, F32, "xyz"), self.temp.data_ptr(),
+                                                        self.work_t.data_ptr(), self.flags.data_ptr(), _stream(self.xyz)),
+                       "fps_ordered_prefix_begin")
+
+    def finish(self):
+        B, N, _ = self.xyz.shape
+        with _on(self.xyz):
+            _lib.check(_L.sps_fps_ordered_prefix_finish(B, N, self.npoint, _ptr(self.xyz, F32, "xyz"), self.temp.data_ptr(),
+                                                         self.idx.data_ptr(), self.work_t.data_ptr(),
+                                                         self.work_temp.data_ptr(), self.flags.data_ptr(),
+                                                         _stream(self.xyz)), "fps_ordered_prefix_finish")
+        return self.idx
+
+
 def current_stream_handle(t):
     return _stream(t)
 

