@@ -203,7 +203,9 @@ int sps_sa_group_mlp_range(int b, int n, int m, int j0, int jcount, int c_feat, 
                            const float *w3, const float *b3, float *out, int out_c_total, int out_c_off,
                            sps_stream_t stream);
 
-/* sps_sa_group_mlp_range with the arithmetic chosen per call (split_fp16 = 0 / 1, weights packed accordingly) and,
+/* sps_sa_group_mlp_range with the arithmetic chosen per call (split_fp16 = 0: fp32 MFMA; 1: split-fp16, per-layer
+ * fragment arrays; 2: split-fp16 with ONE concatenated fragment stream in w1 that a workgroup's waves share through
+ * LDS -- first hidden width a multiple of 64; w2 / w3 are ignored; weights packed accordingly by the caller) and,
  * for the split-fp16 kernel, a device flag that is set to 1 if an operand left the exactly splittable range
  * (|x| > 131 000: the value was clamped).  overflow_flag may be NULL. */
 int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,

@@ -331,6 +331,7 @@ extern "C" int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int 
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.out = out;
     a.overflow = overflow_flag;
     hipStream_t st = as_stream(stream);
+    if (split_fp16 == 2) return launch_sa_mlp_f16_lds(a, c1, c2, nsample, st);
     if (split_fp16) return launch_sa_mlp_f16(a, c1, c2, nsample, st);
 #define SPS_MLP_CASE(C1, C2, NT, NS) \
     if (c1 == C1 && c2 == C2 && nsample == NS) return launch_variant<C1, C2, NT, NS>(a, st);

@@ -65,6 +65,34 @@ def _pack_f16(w, cout_pad, cin_pad):
     return _split_halves(frag)
 
 
+def _pack_stream(w1, w2, w3, c1, c2, c3, cin):
+    """The three layers' split-fp16 fragments as ONE stream in the order csrc/sa_mlp_f16_lds.hip consumes them:
+    layer 1 as [k32][tile]; then, for every k32-step s of layer 3, the layer-2 tiles 2s and 2s+1 as [tile][k32]
+    followed by the layer-3 fragments (tile, s) of all tiles.  A fragment is 2 KiB: [lane][8 hi halves] then
+    [lane][8 lo halves]; k-slot (q, j) of step s is input channel 32 s + 16 (j // 4) + 4 q + j % 4 (lane = 16 q + i)."""
+    def frags(w, cout_pad, cin_pad):
+        cout, cin_ = w.shape
+        wp = w.new_zeros(cout_pad, cin_pad)
+        wp[:cout, :cin_] = w
+        # channel = 32 s + 16 h + 4 q + r  ->  [tile, i, s, h, q, r] -> [tile, s, q, i, h, r] -> [tile, s, lane, j]
+        f = wp.view(cout_pad // 16, 16, cin_pad // 32, 2, 4, 4).permute(0, 2, 4, 1, 3, 5)
+        f = f.reshape(cout_pad // 16, cin_pad // 32, 64, 8)
+        hi = f.half()
+        lo = (f - hi.float()).half()
+        return torch.stack([hi, lo], dim=2).contiguous().view(torch.int16)  # [tile, s, hi|lo, lane, 8] (as int16)
+    cin_pad = (cin + 31) // 32 * 32
+    f1, f2, f3 = frags(w1, c1, cin_pad), frags(w2, c2, c1), frags(w3, c3, c2)
+    parts = [f1.permute(1, 0, 2, 3, 4).reshape(-1)]
+    for s in range(c2 // 32):
+        parts.append(f2[2 * s:2 * s + 2].reshape(-1))
+        parts.append(f3[:, s].reshape(-1))
+    return torch.cat(parts).contiguous()
+
+
+def _lds_stream_ok(c1, c2, c3):
+    return (c1, c2, c3) in ((64, 64, 128), (64, 96, 128), (128, 128, 256), (128, 256, 256))
+
+
 def _pad_bias(b, cpad):
     out = b.new_zeros(cpad)
     out[:b.numel()] = b
@@ -104,6 +132,8 @@ def _version_key(pairs, device):
 #           narrower scales stay on the fp32 MFMA kernel (their 4-channel input would be padded to 16).
 # "fp32":   every scale on the exact fp32 MFMA kernel.
 PRECISION = "fp16x2"
+# wide split-fp16 scales: the four waves of a workgroup share one weight stream through LDS (csrc/sa_mlp_f16_lds.hip)
+SHARE_WEIGHTS = True
 _OVERFLOW = {}
 
 
@@ -143,7 +173,7 @@ def pack_scale(mlp, nsample):
     if not _L.sps_sa_group_mlp_supported(c1, c2, nsample):
         return None
     device = c1m.weight.device
-    key = _version_key(pairs, device) + (PRECISION,)
+    key = _version_key(pairs, device) + (PRECISION, SHARE_WEIGHTS)
     cached = getattr(mlp, "_sps_packed", None)
     if cached is not None and cached.key == key:
         return cached
@@ -151,9 +181,14 @@ def pack_scale(mlp, nsample):
         (w1, b1), (w2, b2), (w3, b3) = (_fold(c, b) for c, b in pairs)
         p = PackedScale()
         p.c1, p.c2, p.c3, p.c3_real, p.cin = c1, c2, c3, c3m.out_channels, c1m.in_channels
-        p.split = PRECISION == "fp16x2" and c1 >= 32
-        if p.split:
-            cin_pad = (c1m.in_channels + 15) // 16 * 16
+        p.split = 0
+        if PRECISION == "fp16x2" and c1 >= 32:
+            p.split = 2 if (SHARE_WEIGHTS and _lds_stream_ok(c1, c2, c3)) else 1
+        cin_pad = (c1m.in_channels + 15) // 16 * 16
+        if p.split == 2:
+            p.w1 = _pack_stream(w1, w2, w3, c1, c2, c3, c1m.in_channels)
+            p.w2 = p.w3 = p.w1
+        elif p.split:
             p.w1, p.w2, p.w3 = _pack_f16(w1, c1, cin_pad), _pack_f16(w2, c2, c1), _pack_f16(w3, c3, c2)
         else:
             p.w1, p.w2, p.w3 = _pack_first(w1, c1), _pack_next(w2, c2, c1), _pack_next(w3, c3, c2)
@@ -178,5 +213,5 @@ def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=
         B, N, M, j0, jcount, c_feat, ns, xyz.data_ptr(), new_xyz.data_ptr(), 0 if features is None else features.data_ptr(),
         idx.data_ptr(), packed.c1, packed.c2, packed.c3, packed.c3_real, packed.w1.data_ptr(), packed.b1.data_ptr(),
         packed.w2.data_ptr(), packed.b2.data_ptr(), packed.w3.data_ptr(), packed.b3.data_ptr(), out.data_ptr(),
-        out.shape[1], channel_offset, 1 if packed.split else 0,
+        out.shape[1], channel_offset, int(packed.split),
         _overflow_flag(xyz.device).data_ptr() if packed.split else 0, stream), "sa_group_mlp")
