@@ -50,7 +50,9 @@ def parse():
     ap.add_argument("--no-stream-first-layer", dest="stream_first_layer", action="store_false",
                     help="do not let layer 0's ball query / MLP consume the D-FPS picks while FPS is still running")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-batches-in-flight measurement")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="also time the same passes with two batches in flight on two streams (informational object)")
+    ap.add_argument("--no-pipelined", action="store_true", help=argparse.SUPPRESS)  # accepted for older command lines
     ap.add_argument("--cpu-scenes", type=int, default=8, help="scenes in the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -199,7 +201,7 @@ def main():
     # Extra, reported separately (never `value`): the same K complete passes with TWO batches in flight on two
     # streams -- layer-0 FPS keeps one CU per scene busy for most of a pass, so a second pass fits beside it.
     pipelined = None
-    if world == 1 and not args.no_pipelined:
+    if world == 1 and args.pipelined and not args.no_pipelined:
         streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         for s_ in streams:
             s_.wait_stream(torch.cuda.current_stream(dev))
