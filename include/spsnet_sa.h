@@ -214,6 +214,15 @@ int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int c_feat, int
                         const float *w3, const float *b3, float *out, int out_c_total, int out_c_off,
                         int split_fp16, int *overflow_flag, sps_stream_t stream);
 
+/* Aggregation stack (+ confidence head) of an SA layer as one kernel -- replaces, for inference with BatchNorm folded,
+ * Conv1d+BN+ReLU (pointnet2_modules.py:213-228, 449-450) and Conv1d+BN+ReLU, Conv1d(bias) (:230-245, 454-455).
+ * x (b, cin, m) -> y1 (b, c1, m) = relu(W1 x + b1); if w2 != NULL also y3 (b, m, classes) = W3 relu(W2 y1 + b2) + b3.
+ * m, cin, c1, c2 multiples of 16; classes <= 16 (w3 / b3 padded to 16 rows); weights in the fragment order of
+ * spsnet_amd/fused.py:_pack_pw.  Exact fp32 (MFMA f32). */
+int sps_pointwise_mlp(int b, int m, int cin, int c1, int c2, int classes, const float *x, const float *w1,
+                      const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, float *y1,
+                      float *y3, sps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

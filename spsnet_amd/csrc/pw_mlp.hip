@@ -1,0 +1,149 @@
+// pw_mlp.hip -- the per-point ("1x1") layer stacks that follow the grouped MLPs of an SA layer, as ONE kernel:
+//   aggregation  Conv1d(Ccat -> Cagg, no bias) + BatchNorm1d + ReLU          (pointnet2_modules.py:213-228, 449-450)
+//   confidence   Conv1d(Cagg -> Cagg) + BatchNorm1d + ReLU, Conv1d(Cagg -> num_class, bias)   (:230-245, 454-455)
+// The reference runs them as 3 + 4 separate cuDNN/elementwise launches per layer (here: hipBLASLt GEMM, MIOpen BN,
+// clamp, ...: ~12 launches, 60-90 us per SA layer); BatchNorm is folded on the host (eval mode).
+//
+// Exact fp32 on the matrix cores (v_mfma_f32_16x16x4_f32 = an fmaf chain per output).  A workgroup owns 16 consecutive
+// points (the 16 columns of an MFMA) of one scene; its 4..16 waves split the 16-row output tiles of each layer; the
+// input columns and the activations of each layer sit in LDS ([channel][16 + 1 pad]).  Layer 1 writes the aggregated
+// features (B, C1, M) and keeps them for layer 2;
+// layer 3 (num_class <= 16 rows) writes the class scores point-major (B, M, num_class), which is the layout the
+// samplers of the next SA layer read (the reference returns a transposed view and copies later).
+// Weight fragments are packed by the host as [tile][k16][lane = 16 q + i][r]: W[16 tile + i][16 k16 + 4 r + q], i.e. one
+// dwordx4 per lane feeds the four MFMAs of a 16-channel step.
+#include "sps_common.h"
+
+namespace sps {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PW_MAX_WAVES = 16;
+constexpr int PW_PAD = 17;  // LDS row pitch of the activation images (floats)
+
+struct PwArgs {
+    int m, cin, c1, c2, c3, c3_real;
+    const float *x, *w1, *b1, *w2, *b2, *w3, *b3;
+    float *y1, *y3;
+};
+
+__device__ __forceinline__ f32x4 pw_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// one 16-row output tile: acc += W[tile] * act (act = LDS image [k][17]), four 16-channel steps per trip so that four
+// weight fragments are in flight
+__device__ __forceinline__ f32x4 pw_tile(const f32x4 *__restrict__ wp, const float *__restrict__ act, int k16n, int q, int c,
+                                         f32x4 acc) {
+    const float *ap = act + q * PW_PAD + c;
+    int k = 0;
+    for (; k + 3 < k16n; k += 4) {
+        f32x4 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = wp[(size_t)(k + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = pw_mfma(w[u][r], ap[(16 * (k + u) + 4 * r) * PW_PAD], acc);
+    }
+    for (; k < k16n; ++k) {
+        const f32x4 w = wp[(size_t)k * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = pw_mfma(w[r], ap[(16 * k + 4 * r) * PW_PAD], acc);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(64 * PW_MAX_WAVES) void pw_mlp_kernel(PwArgs a) {
+    extern __shared__ float pw_lds[];
+    // [x tile | layer-2 output] share a region (the input tile is dead once layer 1 is done), then layer-1 output
+    const int r0 = (a.cin > a.c2 ? a.cin : a.c2) * PW_PAD;
+    float *xt = pw_lds, *act2 = pw_lds, *act1 = pw_lds + r0;
+    const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int scene = blockIdx.y, m0 = blockIdx.x * 16;
+
+    // ---- stage the 16 input columns: cin rows of 64 bytes, coalesced ----
+    {
+        const float *xs = a.x + (size_t)scene * a.cin * a.m + m0;
+        for (int e = threadIdx.x; e < a.cin * 16; e += blockDim.x) {
+            const int ch = e >> 4, col = e & 15;
+            xt[ch * PW_PAD + col] = xs[(size_t)ch * a.m + col];
+        }
+    }
+    __syncthreads();
+    // ---- layer 1 -> y1 (global) and act1 (LDS) ----
+    {
+        const int k16n = a.cin / 16;
+        for (int t = wv; t < a.c1 / 16; t += nw) {
+            f32x4 acc = *reinterpret_cast<const f32x4 *>(a.b1 + 16 * t + 4 * q);
+            acc = pw_tile(reinterpret_cast<const f32x4 *>(a.w1) + (size_t)t * k16n * 64 + lane, xt, k16n, q, c, acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = fmaxf(acc[r], 0.f);
+                const int row = 16 * t + 4 * q + r;
+                a.y1[((size_t)scene * a.c1 + row) * a.m + m0 + c] = v;
+                act1[row * PW_PAD + c] = v;
+            }
+        }
+    }
+    if (!a.w2) return;
+    __syncthreads();
+    // ---- layer 2: act1 -> act2 ----
+    {
+        const int k16n = a.c1 / 16;
+        for (int t = wv; t < a.c2 / 16; t += nw) {
+            f32x4 acc = *reinterpret_cast<const f32x4 *>(a.b2 + 16 * t + 4 * q);
+            acc = pw_tile(reinterpret_cast<const f32x4 *>(a.w2) + (size_t)t * k16n * 64 + lane, act1, k16n, q, c, acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) act2[(16 * t + 4 * q + r) * PW_PAD + c] = fmaxf(acc[r], 0.f);
+        }
+    }
+    __syncthreads();
+    // ---- layer 3: one 16-row tile (num_class <= 16), no ReLU, point-major output ----
+    if (wv == 0) {
+        f32x4 acc = *reinterpret_cast<const f32x4 *>(a.b3 + 4 * q);
+        acc = pw_tile(reinterpret_cast<const f32x4 *>(a.w3) + lane, act2, a.c2 / 16, q, c, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * q + r;
+            if (row < a.c3_real) a.y3[((size_t)scene * a.m + m0 + c) * a.c3_real + row] = acc[r];
+        }
+    }
+}
+
+}  // namespace sps
+
+extern "C" int sps_pointwise_mlp(int b, int m, int cin, int c1, int c2, int c3_real, const float *x, const float *w1,
+                                 const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
+                                 float *y1, float *y3, sps_stream_t stream) {
+    using namespace sps;
+    if (b < 0 || m < 0 || cin <= 0 || c1 <= 0) return fail(SPS_ERR_INVALID, "pointwise_mlp: bad shape b=%d m=%d cin=%d c1=%d", b, m, cin, c1);
+    if (b == 0 || m == 0) return SPS_OK;
+    if (m % 16 || cin % 16 || c1 % 16) return fail(SPS_ERR_INVALID, "pointwise_mlp: m, cin, c1 (%d, %d, %d) must be multiples of 16", m, cin, c1);
+    if (!x || !w1 || !b1 || !y1) return fail(SPS_ERR_INVALID, "pointwise_mlp: null pointer");
+    const bool deep = w2 != nullptr;
+    if (deep) {
+        if (c2 <= 0 || c2 % 16 || c3_real <= 0 || c3_real > 16 || !b2 || !w3 || !b3 || !y3)
+            return fail(SPS_ERR_INVALID, "pointwise_mlp: head needs c2 %% 16 == 0 (got %d), 1 <= classes <= 16 (got %d), all pointers", c2, c3_real);
+    }
+    if (b > 65535) return fail(SPS_ERR_INVALID, "pointwise_mlp: batch %d exceeds the grid limit", b);
+    PwArgs a;
+    a.m = m; a.cin = cin; a.c1 = c1; a.c2 = deep ? c2 : 0; a.c3 = 16; a.c3_real = deep ? c3_real : 0;
+    a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = deep ? w2 : nullptr; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.y1 = y1; a.y3 = y3;
+    const int wide = (deep && c2 > cin) ? c2 : cin;
+    const size_t lds = sizeof(float) * (size_t)PW_PAD * ((size_t)wide + c1);
+    if (lds > 150 * 1024) return fail(SPS_ERR_INVALID, "pointwise_mlp: widths (%d, %d, %d) need more LDS than a workgroup has", cin, c1, c2);
+    static bool raised = false;
+    if (lds > 64 * 1024 && !raised) {
+        if (hipFuncSetAttribute((const void *)pw_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return fail(SPS_ERR_LAUNCH, "pointwise_mlp: cannot raise the dynamic LDS limit");
+        raised = true;
+    }
+    // one wave per output tile of the widest layer (4..16): the tiles of a layer are independent, a tile is a serial
+    // chain of MFMAs fed by L2-latency weight loads, so waves are what hides that latency
+    int tiles = c1 / 16;
+    if (deep && c2 / 16 > tiles) tiles = c2 / 16;
+    const int waves = tiles < 4 ? 4 : (tiles > PW_MAX_WAVES ? PW_MAX_WAVES : tiles);
+    hipLaunchKernelGGL(pw_mlp_kernel, dim3(m / 16, b), dim3(64 * waves), lds, as_stream(stream), a);
+    return check_launch("pw_mlp_kernel");
+}

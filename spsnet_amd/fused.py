@@ -217,3 +217,93 @@ def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=
         packed.w2.data_ptr(), packed.b2.data_ptr(), packed.w3.data_ptr(), packed.b3.data_ptr(), out.data_ptr(),
         out.shape[1], channel_offset, int(packed.split),
         _overflow_flag(xyz.device).data_ptr() if packed.split else 0, stream), "sa_group_mlp")
+
+
+# ------------------------------------------------------------------ aggregation + confidence stacks (csrc/pw_mlp.hip)
+def _pack_pw(w, cout_pad):
+    """(cout, cin) -> [tile][k16][lane = 16 q + i][r] = W[16 tile + i][16 k16 + 4 r + q]"""
+    cout, cin = w.shape
+    wp = w.new_zeros(cout_pad, cin)
+    wp[:cout] = w
+    return wp.view(cout_pad // 16, 16, cin // 16, 4, 4).permute(0, 2, 4, 1, 3).contiguous().view(-1)
+
+
+class PackedTail:
+    __slots__ = ("key", "cin", "c1", "c2", "classes", "w1", "b1", "w2", "b2", "w3", "b3")
+
+
+def _tail_layers(agg, head):
+    """(conv, bn) of the aggregation stack and (conv, bn), conv of the head if they have the reference's shape."""
+    mods = list(agg)
+    if len(mods) != 3 or not (isinstance(mods[0], nn.Conv1d) and isinstance(mods[1], nn.BatchNorm1d) and isinstance(mods[2], nn.ReLU)):
+        return None
+    convs = [mods[0]]
+    out = [(mods[0], mods[1])]
+    if head is not None:
+        h = list(head)
+        if len(h) != 4 or not (isinstance(h[0], nn.Conv1d) and isinstance(h[1], nn.BatchNorm1d) and isinstance(h[2], nn.ReLU)
+                               and isinstance(h[3], nn.Conv1d)):
+            return None
+        convs += [h[0], h[3]]
+        out += [(h[0], h[1]), h[3]]
+    for cv in convs:
+        if cv.kernel_size != (1,) or cv.stride != (1,) or cv.groups != 1:
+            return None
+    for _, bn in out[:2] if head is not None else out[:1]:
+        if not bn.track_running_stats:
+            return None
+    return out
+
+
+def pointwise_tail(agg, head, pooled):
+    """Aggregation stack (+ confidence head) of an SA layer on `pooled` (B, C, M) as one kernel ->
+    (new_features (B, Cagg, M), cls (B, M, K) | None), or None when the fused path does not apply (training, gradients
+    wanted, widths that are not multiples of 16, more than 16 classes, ...)."""
+    if agg.training or (head is not None and head.training) or not pooled.is_cuda or pooled.dtype != torch.float32:
+        return None
+    if torch.is_grad_enabled() and (pooled.requires_grad or any(p.requires_grad for p in agg.parameters())):
+        return None
+    layers = _tail_layers(agg, head)
+    if layers is None:
+        return None
+    (c_agg, bn_agg) = layers[0]
+    B, cin, M = pooled.shape
+    c1 = c_agg.out_channels
+    if cin != c_agg.in_channels or cin % 16 or c1 % 16 or M % 16:
+        return None
+    c2 = classes = 0
+    if head is not None:
+        (c_h, bn_h), c_out = layers[1], layers[2]
+        c2, classes = c_h.out_channels, c_out.out_channels
+        if c2 % 16 or classes > 16 or c_h.in_channels != c1 or c_out.in_channels != c2:
+            return None
+    if 17 * 4 * (max(cin, c2) + c1) > 150 * 1024:
+        return None
+    pairs = [(c_agg, bn_agg)] + ([layers[1]] if head is not None else [])
+    key = _version_key(pairs, pooled.device)
+    if head is not None:
+        key = key + tuple((t.data_ptr(), t._version) for t in (layers[2].weight, layers[2].bias) if t is not None)
+    packed = getattr(agg, "_sps_tail", None)
+    if packed is None or packed.key != key:
+        with torch.no_grad():
+            packed = PackedTail()
+            packed.key, packed.cin, packed.c1, packed.c2, packed.classes = key, cin, c1, c2, classes
+            w, b = _fold(c_agg, bn_agg)
+            packed.w1, packed.b1 = _pack_pw(w, c1), b.contiguous()
+            packed.w2 = packed.b2 = packed.w3 = packed.b3 = None
+            if head is not None:
+                w, b = _fold(*layers[1])
+                packed.w2, packed.b2 = _pack_pw(w, c2), b.contiguous()
+                c_out = layers[2]
+                w3 = c_out.weight.detach().reshape(classes, c2).float()
+                b3 = c_out.bias.detach().float() if c_out.bias is not None else w3.new_zeros(classes)
+                packed.w3, packed.b3 = _pack_pw(w3, 16), _pad_bias(b3, 16)
+        object.__setattr__(agg, "_sps_tail", packed)
+    x = pooled.contiguous()
+    y1 = torch.empty((B, c1, M), dtype=torch.float32, device=pooled.device)
+    y3 = torch.empty((B, M, classes), dtype=torch.float32, device=pooled.device) if head is not None else None
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+    _lib.check(_L.sps_pointwise_mlp(B, M, cin, c1, c2, classes, x.data_ptr(), ptr(packed.w1), ptr(packed.b1), ptr(packed.w2),
+                                    ptr(packed.b2), ptr(packed.w3), ptr(packed.b3), y1.data_ptr(), ptr(y3),
+                                    torch.cuda.current_stream(pooled.device).cuda_stream), "pointwise_mlp")
+    return y1, y3

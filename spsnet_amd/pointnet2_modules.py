@@ -355,13 +355,25 @@ class _SamplingSAModule(_PointnetSAModuleBase):
             hook(new_xyz)
         return sampled_idx, new_xyz, stds
 
+    def _tail(self, pooled):
+        """Aggregation stack and confidence head (reference :449-455) -> (new_features, cls (B,M,K) | None).  In
+        inference both run as ONE kernel (csrc/pw_mlp.hip, BatchNorm folded, exact fp32) when their shapes allow."""
+        head = getattr(self, "confidence_layers", None)
+        if self.aggregation_layer is not None:
+            done = _fused.pointwise_tail(self.aggregation_layer, head, pooled)
+            if done is not None:
+                return done
+            pooled = self.aggregation_layer(pooled)
+        cls = head(pooled).transpose(1, 2) if head is not None else None
+        return pooled, cls
+
     def _abstract(self, xyz, new_xyz, features, sampled_idx):
+        """-> (new_features, cls | None)"""
         if len(self.groupers) > 0:
-            new_features = self._group_mlp_pool(xyz, new_xyz, features)
-            if self.aggregation_layer is not None:
-                new_features = self.aggregation_layer(new_features)
-            return new_features
-        return pointnet2_utils.gather_operation(features, sampled_idx).contiguous()
+            return self._tail(self._group_mlp_pool(xyz, new_xyz, features))
+        new_features = pointnet2_utils.gather_operation(features, sampled_idx).contiguous()
+        head = getattr(self, "confidence_layers", None)
+        return new_features, (head(new_features).transpose(1, 2) if head is not None else None)
 
 
 class PointnetSAModuleMSG_WithSampling(_SamplingSAModule):
@@ -407,11 +419,7 @@ class PointnetSAModuleMSG_WithSampling(_SamplingSAModule):
             sampled_idx_list, new_xyz, stds = self._sample(xyz, features, cls_features, stds)
         else:
             new_xyz = ctr_xyz
-        new_features = self._abstract(xyz, new_xyz, features, sampled_idx_list)
-        if self.confidence_layers is not None:
-            cls_features = self.confidence_layers(new_features).transpose(1, 2)
-        else:
-            cls_features = None
+        new_features, cls_features = self._abstract(xyz, new_xyz, features, sampled_idx_list)
         return new_xyz, new_features, cls_features, sampled_idx_list, stds
 
 
@@ -513,5 +521,5 @@ class PointnetSampling(_SamplingSAModule):
             sampled_idx_list, new_xyz, _ = self._sample(xyz, features, cls_features, None)
         else:
             new_xyz = ctr_xyz
-        new_features = self._abstract(xyz, new_xyz, features, sampled_idx_list)
+        new_features, _ = self._abstract(xyz, new_xyz, features, sampled_idx_list)
         return new_xyz, new_features, sampled_idx_list

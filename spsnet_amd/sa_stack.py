@@ -213,10 +213,7 @@ def _streamed_first_layer(layer, nxt, xyz, features):
     elif nxt is not None and _can_prefetch(layer, nxt):
         _prefetch_dfps(nxt, new_xyz, True)
     main.wait_event(done)
-    new_features = out
-    if layer.aggregation_layer is not None:
-        new_features = layer.aggregation_layer(new_features)
-    cls = layer.confidence_layers(new_features).transpose(1, 2) if layer.confidence_layers is not None else None
+    new_features, cls = layer._tail(out)
     return new_xyz, new_features, cls, idx, None
 
 

@@ -698,3 +698,41 @@ def test_split_fp16_flags_out_of_range_operands(ext, G, dev):
         assert not fused.check_overflow()  # the flag resets
     finally:
         fused.set_precision(old)
+
+
+# ------------------------------------------------------------------ aggregation + confidence stacks as one kernel
+@pytest.mark.parametrize("cin,cagg,conf,M", [(96, 64, None, 4096), (256, 128, 128, 1024), (512, 256, 256, 512),
+                                             (48, 32, 48, 64), (1536, 512, None, 256)])
+def test_pointwise_tail_matches_torch(ext, G, dev, cin, cagg, conf, M):
+    """csrc/pw_mlp.hip (BatchNorm folded, fp32 MFMA) against the unfused torch modules it replaces
+    (Conv1d+BN+ReLU; Conv1d+BN+ReLU+Conv1d) at the IA-SSD layer widths: 1e-4 of the output scale."""
+    from spsnet_amd import fused, pointnet2_modules as M_
+    torch.manual_seed(cin + cagg)
+    mod = M_.PointnetSAModuleMSG_WithSampling(
+        npoint_list=[M], sample_range_list=[-1], sample_type_list=['D-FPS'], radii=[0.5, 1.0], nsamples=[16, 16],
+        mlps=[[4, 16, 16, cin // 2], [4, 16, 16, cin // 2]], use_xyz=True, dilated_group=False, aggregation_mlp=[cagg],
+        confidence_mlp=[conf] if conf else None, num_class=3).to(dev).eval()
+    gen = torch.Generator().manual_seed(3)
+    for m_ in mod.modules():
+        if isinstance(m_, torch.nn.BatchNorm1d):
+            with torch.no_grad():
+                m_.running_mean.copy_(torch.randn(m_.num_features, generator=gen) * 0.1)
+                m_.running_var.copy_(torch.rand(m_.num_features, generator=gen) + 0.5)
+                m_.weight.copy_(torch.rand(m_.num_features, generator=gen) + 0.5)
+                m_.bias.copy_(torch.randn(m_.num_features, generator=gen) * 0.1)
+    pooled = torch.randn(3, cin, M, device=dev).relu()
+    with torch.no_grad():
+        got = fused.pointwise_tail(mod.aggregation_layer, mod.confidence_layers, pooled)
+        assert got is not None, "fused tail did not apply"
+        want_f = mod.aggregation_layer(pooled)
+        want_c = mod.confidence_layers(want_f).transpose(1, 2) if conf else None
+    assert got[0].shape == want_f.shape
+    assert float((got[0] - want_f).abs().max()) <= 1e-4 * max(1.0, float(want_f.abs().max()))
+    if conf:
+        assert got[1].shape == want_c.shape and got[1].is_contiguous()
+        assert float((got[1] - want_c).abs().max()) <= 1e-4 * max(1.0, float(want_c.abs().max()))
+    else:
+        assert got[1] is None
+    # module-level switch: training mode keeps the reference's op sequence
+    mod.train()
+    assert fused.pointwise_tail(mod.aggregation_layer, mod.confidence_layers, pooled) is None
