@@ -6,10 +6,11 @@
 // gfx950 is no faster than the VALU).  |x| is clamped to the fp16 range before the split, so an out-of-range
 // activation degrades gracefully (error grows beyond |x| ~ 1.3e5) instead of producing inf/NaN.
 //
-// Layout: with K = 16 per MFMA the D tile of layer l (lane (q,c): rows 4q..4q+3 of column c) IS the B fragment of
-// layer l+1's k-step over channels 16t..16t+15 (lane (q,c) supplies channels 16t+4q+{0..3}) -- activations chain
-// register to register exactly as in the fp32 kernel, with natural channel order.  Weight fragments are packed
-// [tile][k16][lane][hi x4 | lo x4] (16 B per lane: one buffer_load_dwordx4 per k-step).
+// Layout: v_mfma_f32_16x16x32_f16 wants 8 consecutive k per lane.  The D tiles of layer l (lane (q,c): rows 4q..4q+3 of
+// column c) of TWO consecutive 16-row tiles form the B operand of one k32-step of layer l+1 if k-slot (q, j) of step s
+// stands for channel 32 s + 16 (j / 4) + 4 q + j % 4 -- activations chain register to register exactly as in the fp32
+// kernel, the host packs the weights in that order: [tile][k32][hi | lo][lane][8 halves], 2 KiB per fragment
+// (fused._pack_f16).  (The K = 16 instruction this file first used issues at a quarter of the rate)
 #include "sps_common.h"
 #include "sa_mlp_args.h"
 
@@ -18,28 +19,42 @@ namespace sps {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ f32x4 mfma16h(h4 a, h4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+// K = 32: the K = 16 form issues at 32 cycles on gfx950, this one at 16 for twice the work
+__device__ __forceinline__ f32x4 mfma32h(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 // |x| <= 131008 splits exactly to 22 bits (hi saturates at 65504, lo carries the rest); beyond that the value is
 // clamped and `bad` is raised so that the host can tell (fused.check_overflow) -- never inf/NaN, never silent.
-__device__ __forceinline__ void split4(const f32x4 v, h4 &hi, h4 &lo, bool &bad) {
+template <int OFF>
+__device__ __forceinline__ void split4(const f32x4 v, h8 &hi, h8 &lo, bool &bad) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         bad |= fabsf(v[r]) > 131000.f;
         const float c = __builtin_amdgcn_fmed3f(v[r], -65504.f, 65504.f);
         const _Float16 h = (_Float16)c;
-        hi[r] = h;
-        lo[r] = (_Float16)__builtin_amdgcn_fmed3f(v[r] - (float)h, -65504.f, 65504.f);
+        hi[OFF + r] = h;
+        lo[OFF + r] = (_Float16)__builtin_amdgcn_fmed3f(v[r] - (float)h, -65504.f, 65504.f);
     }
 }
 
-struct WFrag { h4 hi, lo; };
+// a fragment = (16-row tile, 32-channel step): 2 KiB = [lane][hi x8] then [lane][lo x8]
+struct WFrag { h8 hi, lo; };
+constexpr int FRAG = 2048;
 __device__ __forceinline__ WFrag wload_h(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    union { int i[2]; h4 h; } a, b;
-    a.i[0] = v[0]; a.i[1] = v[1]; b.i[0] = v[2]; b.i[1] = v[3];
+    union { i32x4 i; h8 h; } a, b;
+    a.i = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    b.i = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff + 1024, 0);
     return WFrag{a.h, b.h};
+}
+template <int NT>
+__device__ __forceinline__ void mac3(const WFrag &w, const h8 (&xh)[NT], const h8 (&xl)[NT], f32x4 (&acc)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32h(w.hi, xh[nt], acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32h(w.hi, xl[nt], acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32h(w.lo, xh[nt], acc[nt]);
 }
 
 __device__ __forceinline__ float row_allmax_h(float v) {
@@ -55,13 +70,15 @@ __device__ __forceinline__ float row_allmax_h(float v) {
     return fmaxf(v, o);
 }
 
-// a.ks1 = layer-1 k-steps of 16 grouped channels = ceil((3 + c_feat) / 16)
+// a.ks1 = layer-1 k-steps of 32 grouped channels = ceil((3 + c_feat) / 32)
 template <int C1, int C2, int NT, int NS>
 __global__ __launch_bounds__(256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
     constexpr int T1 = C1 / 16, T2 = C2 / 16;
+    constexpr int S1 = T1 / 2, S2 = T2 / 2;  // k32-steps over the previous layer's channels
     constexpr int UNIT = 16 * NT;
     constexpr int CPP = UNIT / NS;
     static_assert(UNIT % NS == 0 && (NS % 16) == 0 && CPP >= 1, "a unit must hold whole centroids");
+    static_assert(T1 % 2 == 0 && T2 % 2 == 0, "two 16-row tiles chain into one K = 32 operand");
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, c = lane & 15;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -71,7 +88,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
     for (int unit = wave; unit < a.units; unit += nwaves) {
         const int ub = unit / a.ups;
         const long long col0 = ((long long)ub * a.m + a.j0) * NS + (long long)(unit - ub * a.ups) * UNIT;
-        h4 h2hi[T2][NT], h2lo[T2][NT];
+        h8 h2hi[S2][NT], h2lo[S2][NT];
         {
             int src[NT];
             long long bj[NT];
@@ -83,7 +100,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
                 bb[nt] = (int)(bj[nt] / a.m);
                 src[nt] = a.idx[e];
             }
-            // ---------------- layer 1: k-steps of 16 gathered channels ----------------
+            // ---------------- layer 1: k-steps of 32 gathered channels ----------------
             f32x4 acc1[T1][NT];
 #pragma unroll
             for (int t = 0; t < T1; ++t) {
@@ -91,11 +108,11 @@ __global__ __launch_bounds__(256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc1[t][nt] = bias;
             }
-            auto gather4 = [&](int ks, int nt) -> f32x4 {
+            auto gather4 = [&](int k16, int nt) -> f32x4 {
                 f32x4 v;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const int ch = 16 * ks + 4 * q + jj;  // grouped channel: 0..2 centred xyz, 3.. features
+                    const int ch = 16 * k16 + 4 * q + jj;  // grouped channel: 0..2 centred xyz, 3.. features
                     float x;
                     if (ch < 3) {
                         x = a.xyz[((size_t)bb[nt] * a.n + src[nt]) * 3 + ch] - a.new_xyz[(size_t)bj[nt] * 3 + ch];
@@ -110,31 +127,32 @@ __global__ __launch_bounds__(256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
                 }
                 return v;
             };
-            const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)a.w1, 0, (unsigned)(T1 * a.ks1 * 64 * 16), 0x00020000);
-            f32x4 xcur[NT], xnext[NT];
+            const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)a.w1, 0, (unsigned)(T1 * a.ks1 * FRAG), 0x00020000);
+            f32x4 xcur[2][NT], xnext[2][NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) xcur[nt] = gather4(0, nt);
+            for (int nt = 0; nt < NT; ++nt) { xcur[0][nt] = gather4(0, nt); xcur[1][nt] = gather4(1, nt); }
             for (int ks = 0; ks < a.ks1; ++ks) {
                 const bool more = ks + 1 < a.ks1;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) xnext[nt] = more ? gather4(ks + 1, nt) : xcur[nt];
-                h4 xhi[NT], xlo[NT];
+                for (int nt = 0; nt < NT; ++nt) {
+                    xnext[0][nt] = more ? gather4(2 * ks + 2, nt) : xcur[0][nt];
+                    xnext[1][nt] = more ? gather4(2 * ks + 3, nt) : xcur[1][nt];
+                }
+                h8 xhi[NT], xlo[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) split4(xcur[nt], xhi[nt], xlo[nt], bad);
-#pragma unroll
-                for (int t = 0; t < T1; ++t) {
-                    const WFrag w = wload_h(rs1, lane * 16, (t * a.ks1 + ks) * 1024);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc1[t][nt] = mfma16h(w.hi, xhi[nt], acc1[t][nt]);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc1[t][nt] = mfma16h(w.hi, xlo[nt], acc1[t][nt]);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc1[t][nt] = mfma16h(w.lo, xhi[nt], acc1[t][nt]);
+                for (int nt = 0; nt < NT; ++nt) {
+                    split4<0>(xcur[0][nt], xhi[nt], xlo[nt], bad);
+                    split4<4>(xcur[1][nt], xhi[nt], xlo[nt], bad);
                 }
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) xcur[nt] = xnext[nt];
+                for (int t = 0; t < T1; ++t) {
+                    const WFrag w = wload_h(rs1, lane * 16, (t * a.ks1 + ks) * FRAG);
+                    mac3<NT>(w, xhi, xlo, acc1[t]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { xcur[0][nt] = xnext[0][nt]; xcur[1][nt] = xnext[1][nt]; }
             }
-            h4 h1hi[T1][NT], h1lo[T1][NT];
+            h8 h1hi[S1][NT], h1lo[S1][NT];
 #pragma unroll
             for (int t = 0; t < T1; ++t)
 #pragma unroll
@@ -142,25 +160,26 @@ __global__ __launch_bounds__(256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
                     f32x4 v = acc1[t][nt];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                    split4(v, h1hi[t][nt], h1lo[t][nt], bad);
+                    if (t % 2 == 0) split4<0>(v, h1hi[t / 2][nt], h1lo[t / 2][nt], bad);
+                    else split4<4>(v, h1hi[t / 2][nt], h1lo[t / 2][nt], bad);
                 }
 
             // ---------------- layer 2 ----------------
             {
-                constexpr int KCH = (T1 % 4 == 0) ? 4 : ((T1 % 2 == 0) ? 2 : 1);  // k16-steps per prefetched chunk
-                constexpr int NCH = T1 / KCH;
+                constexpr int KCH = (S1 % 4 == 0) ? 4 : ((S1 % 2 == 0) ? 2 : 1);  // k32-steps per prefetched chunk
+                constexpr int NCH = S1 / KCH;
                 constexpr int G = T2 * NCH;
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.w2, 0, (unsigned)(T2 * T1 * 64 * 16), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.w2, 0, (unsigned)(T2 * S1 * FRAG), 0x00020000);
                 WFrag w[2][KCH];
 #pragma unroll
-                for (int u = 0; u < KCH; ++u) w[0][u] = wload_h(rs, lane * 16, u * 1024);
+                for (int u = 0; u < KCH; ++u) w[0][u] = wload_h(rs, lane * 16, u * FRAG);
                 f32x4 acc[NT];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const int mt = g / NCH, ch = g % NCH;
                     if (g + 1 < G) {
 #pragma unroll
-                        for (int u = 0; u < KCH; ++u) w[(g + 1) & 1][u] = wload_h(rs, lane * 16, ((g + 1) * KCH + u) * 1024);
+                        for (int u = 0; u < KCH; ++u) w[(g + 1) & 1][u] = wload_h(rs, lane * 16, ((g + 1) * KCH + u) * FRAG);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (ch == 0) {
@@ -169,22 +188,15 @@ __global__ __launch_bounds__(256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
                         for (int nt = 0; nt < NT; ++nt) acc[nt] = bias;
                     }
 #pragma unroll
-                    for (int u = 0; u < KCH; ++u) {
-                        const int t = ch * KCH + u;
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16h(w[g & 1][u].hi, h1hi[t][nt], acc[nt]);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16h(w[g & 1][u].hi, h1lo[t][nt], acc[nt]);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16h(w[g & 1][u].lo, h1hi[t][nt], acc[nt]);
-                    }
+                    for (int u = 0; u < KCH; ++u) mac3<NT>(w[g & 1][u], h1hi[ch * KCH + u], h1lo[ch * KCH + u], acc);
                     if (ch == NCH - 1) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
                             f32x4 v = acc[nt];
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                            split4(v, h2hi[mt][nt], h2lo[mt][nt], bad);
+                            if (mt % 2 == 0) split4<0>(v, h2hi[mt / 2][nt], h2lo[mt / 2][nt], bad);
+                            else split4<4>(v, h2hi[mt / 2][nt], h2lo[mt / 2][nt], bad);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -195,17 +207,17 @@ __global__ __launch_bounds__(256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
         // ---------------- layer 3 (runtime width) + max-pool ----------------
         const long long bj0 = col0 / NS;
         {
-            constexpr int KCH = (T2 % 4 == 0) ? 4 : ((T2 % 2 == 0) ? 2 : 1);
-            constexpr int NCH = T2 / KCH;
+            constexpr int KCH = (S2 % 4 == 0) ? 4 : ((S2 % 2 == 0) ? 2 : 1);
+            constexpr int NCH = S2 / KCH;
             const int MT3 = a.c3 / 16;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.w3, 0, (unsigned)(MT3 * T2 * 64 * 16), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.w3, 0, (unsigned)(MT3 * S2 * FRAG), 0x00020000);
             WFrag wfirst[KCH];
 #pragma unroll
-            for (int u = 0; u < KCH; ++u) wfirst[u] = wload_h(rs, lane * 16, u * 1024);
+            for (int u = 0; u < KCH; ++u) wfirst[u] = wload_h(rs, lane * 16, u * FRAG);
             for (int mt = 0; mt < MT3; ++mt) {
                 const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.b3 + 16 * mt + 4 * q);
-                const int tile_off = mt * T2 * 1024;
-                const int next_off = ((mt + 1 < MT3) ? mt + 1 : mt) * T2 * 1024;
+                const int tile_off = mt * S2 * FRAG;
+                const int next_off = ((mt + 1 < MT3) ? mt + 1 : mt) * S2 * FRAG;
                 WFrag w[2][KCH];
 #pragma unroll
                 for (int u = 0; u < KCH; ++u) w[0][u] = wfirst[u];
@@ -216,22 +228,14 @@ __global__ __launch_bounds__(256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
                 for (int ch = 0; ch < NCH; ++ch) {
                     if (ch + 1 < NCH) {
 #pragma unroll
-                        for (int u = 0; u < KCH; ++u) w[(ch + 1) & 1][u] = wload_h(rs, lane * 16, tile_off + ((ch + 1) * KCH + u) * 1024);
+                        for (int u = 0; u < KCH; ++u) w[(ch + 1) & 1][u] = wload_h(rs, lane * 16, tile_off + ((ch + 1) * KCH + u) * FRAG);
                     } else {
 #pragma unroll
-                        for (int u = 0; u < KCH; ++u) wfirst[u] = wload_h(rs, lane * 16, next_off + u * 1024);
+                        for (int u = 0; u < KCH; ++u) wfirst[u] = wload_h(rs, lane * 16, next_off + u * FRAG);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int u = 0; u < KCH; ++u) {
-                        const int t = ch * KCH + u;
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16h(w[ch & 1][u].hi, h2hi[t][nt], acc[nt]);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16h(w[ch & 1][u].hi, h2lo[t][nt], acc[nt]);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16h(w[ch & 1][u].lo, h2hi[t][nt], acc[nt]);
-                    }
+                    for (int u = 0; u < KCH; ++u) mac3<NT>(w[ch & 1][u], h2hi[ch * KCH + u], h2lo[ch * KCH + u], acc);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 f32x4 best[CPP];
@@ -273,7 +277,7 @@ static int launch_f16_variant(const SaMlpArgs &a, hipStream_t st) {
         return fail(SPS_ERR_INVALID, "sa_group_mlp(f16): centroids*nsample per scene (%lld) not a multiple of %d", cols_scene, UNIT);
     k.ups = (int)(cols_scene / UNIT);
     k.units = a.units * k.ups;
-    k.ks1 = (3 + a.c_feat + 15) / 16;
+    k.ks1 = (3 + a.c_feat + 31) / 32;
     int blocks = divup(k.units, 4);
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL((sa_group_mlp_f16_kernel<C1, C2, NT, NS>), dim3(blocks), dim3(256), 0, st, k);
@@ -283,13 +287,11 @@ static int launch_f16_variant(const SaMlpArgs &a, hipStream_t st) {
 int launch_sa_mlp_f16(const SaMlpArgs &a, int c1, int c2, int nsample, hipStream_t st) {
 #define SPS_MLPH_CASE(C1, C2, NT, NS) \
     if (c1 == C1 && c2 == C2 && nsample == NS) return launch_f16_variant<C1, C2, NT, NS>(a, st);
-    SPS_MLPH_CASE(16, 16, 2, 16)
     SPS_MLPH_CASE(32, 32, 2, 32)
     SPS_MLPH_CASE(64, 64, 2, 16)
     SPS_MLPH_CASE(64, 96, 2, 32)
     SPS_MLPH_CASE(128, 128, 2, 16)
     SPS_MLPH_CASE(128, 256, 2, 32)
-    SPS_MLPH_CASE(16, 16, 2, 32)
     SPS_MLPH_CASE(32, 32, 2, 16)
     SPS_MLPH_CASE(128, 64, 2, 16)
     SPS_MLPH_CASE(128, 96, 2, 32)

@@ -56,13 +56,23 @@ def _split_halves(frag_f32, lanes_inner=4):
     return torch.cat([hi, lo], dim=-1).contiguous().view(torch.int16).view(-1)
 
 
-def _pack_f16(w, cout_pad, cin_pad):
-    """[tile][k16][lane = q*16+i][jj]: W[16*tile + i][16*k16 + 4*q + jj], split into fp16 hi/lo."""
-    cout, cin = w.shape
+def _frags_k32(w, cout_pad, cin_pad):
+    """(cout, cin) fp32 -> split-fp16 K = 32 fragments as int16 [tile, k32, hi|lo, lane = 16 q + i, 8 halves]:
+    k-slot (q, j) of step s is input channel 32 s + 16 (j // 4) + 4 q + j % 4, row i of the tile."""
+    cout, cin_ = w.shape
     wp = w.new_zeros(cout_pad, cin_pad)
-    wp[:cout, :cin] = w
-    frag = wp.view(cout_pad // 16, 16, cin_pad // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()  # [tile,t,q,i,jj]
-    return _split_halves(frag)
+    wp[:cout, :cin_] = w
+    # channel = 32 s + 16 h + 4 q + r  ->  [tile, i, s, h, q, r] -> [tile, s, q, i, h, r] -> [tile, s, lane, j]
+    f = wp.view(cout_pad // 16, 16, cin_pad // 32, 2, 4, 4).permute(0, 2, 4, 1, 3, 5)
+    f = f.reshape(cout_pad // 16, cin_pad // 32, 64, 8)
+    hi = f.half()
+    lo = (f - hi.float()).half()
+    return torch.stack([hi, lo], dim=2).contiguous().view(torch.int16)
+
+
+def _pack_f16(w, cout_pad, cin_pad):
+    """[tile][k32] fragments of csrc/sa_mlp_f16.hip (2 KiB each)."""
+    return _frags_k32(w, cout_pad, cin_pad).reshape(-1)
 
 
 def _pack_stream(w1, w2, w3, c1, c2, c3, cin):
@@ -70,18 +80,8 @@ def _pack_stream(w1, w2, w3, c1, c2, c3, cin):
     layer 1 as [k32][tile]; then, for every k32-step s of layer 3, the layer-2 tiles 2s and 2s+1 as [tile][k32]
     followed by the layer-3 fragments (tile, s) of all tiles.  A fragment is 2 KiB: [lane][8 hi halves] then
     [lane][8 lo halves]; k-slot (q, j) of step s is input channel 32 s + 16 (j // 4) + 4 q + j % 4 (lane = 16 q + i)."""
-    def frags(w, cout_pad, cin_pad):
-        cout, cin_ = w.shape
-        wp = w.new_zeros(cout_pad, cin_pad)
-        wp[:cout, :cin_] = w
-        # channel = 32 s + 16 h + 4 q + r  ->  [tile, i, s, h, q, r] -> [tile, s, q, i, h, r] -> [tile, s, lane, j]
-        f = wp.view(cout_pad // 16, 16, cin_pad // 32, 2, 4, 4).permute(0, 2, 4, 1, 3, 5)
-        f = f.reshape(cout_pad // 16, cin_pad // 32, 64, 8)
-        hi = f.half()
-        lo = (f - hi.float()).half()
-        return torch.stack([hi, lo], dim=2).contiguous().view(torch.int16)  # [tile, s, hi|lo, lane, 8] (as int16)
     cin_pad = (cin + 31) // 32 * 32
-    f1, f2, f3 = frags(w1, c1, cin_pad), frags(w2, c2, c1), frags(w3, c3, c2)
+    f1, f2, f3 = _frags_k32(w1, c1, cin_pad), _frags_k32(w2, c2, c1), _frags_k32(w3, c3, c2)
     parts = [f1.permute(1, 0, 2, 3, 4).reshape(-1)]
     for s in range(c2 // 32):
         parts.append(f2[2 * s:2 * s + 2].reshape(-1))
@@ -186,7 +186,7 @@ def pack_scale(mlp, nsample):
         p.split = 0
         if PRECISION == "fp16x2" and c1 >= 32:
             p.split = 2 if (SHARE_WEIGHTS and _lds_stream_ok(c1, c2, c3)) else 1
-        cin_pad = (c1m.in_channels + 15) // 16 * 16
+        cin_pad = (c1m.in_channels + 31) // 32 * 32
         if p.split == 2:
             p.w1 = _pack_stream(w1, w2, w3, c1, c2, c3, c1m.in_channels)
             p.w2 = p.w3 = p.w1
