@@ -47,6 +47,26 @@ __device__ __forceinline__ WFrag wload_h(__amdgpu_buffer_rsrc_t r, int voff, int
     b.i = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff + 1024, 0);
     return WFrag{a.h, b.h};
 }
+// Weight source of a layer: a buffer resource (fragments streamed from L2 by every wave) or, when all three layers fit
+// (WLDS: the 64-wide scales, <= 96 KiB), a copy in LDS made once per workgroup -- the L1 scales moved 805 MB of
+// weights per launch through L2 (8.4 TB/s: that bandwidth, not the matrix cores, bounded them).
+template <bool WLDS>
+struct WSrc {
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned lds;  // byte address of the layer's first fragment in LDS
+    __device__ __forceinline__ WFrag load(int lane16, int soff) const {
+        if constexpr (WLDS) {
+            typedef const __attribute__((address_space(3))) i32x4 lds_v;
+            lds_v *p = (lds_v *)(size_t)(lds + (unsigned)soff + (unsigned)lane16);
+            union { i32x4 i; h8 h; } a, b;
+            a.i = p[0]; b.i = p[64];
+            return WFrag{a.h, b.h};
+        } else {
+            return wload_h(rs, lane16, soff);
+        }
+    }
+};
+
 template <int NT>
 __device__ __forceinline__ void mac3(const WFrag &w, const h8 (&xh)[NT], const h8 (&xl)[NT], f32x4 (&acc)[NT]) {
 #pragma unroll
@@ -71,8 +91,8 @@ __device__ __forceinline__ float row_allmax_h(float v) {
 }
 
 // a.ks1 = layer-1 k-steps of 32 grouped channels = ceil((3 + c_feat) / 32)
-template <int C1, int C2, int NT, int NS>
-__global__ __launch_bounds__(256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
+template <int C1, int C2, int NT, int NS, bool WLDS>
+__global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
     constexpr int T1 = C1 / 16, T2 = C2 / 16;
     constexpr int S1 = T1 / 2, S2 = T2 / 2;  // k32-steps over the previous layer's channels
     constexpr int UNIT = 16 * NT;
@@ -84,6 +104,27 @@ __global__ __launch_bounds__(256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
 
+    WSrc<WLDS> ws1, ws2, ws3;
+    {
+        const int MT3 = a.c3 / 16;
+        const unsigned n1 = (unsigned)(T1 * a.ks1 * FRAG), n2 = (unsigned)(T2 * S1 * FRAG), n3 = (unsigned)(MT3 * S2 * FRAG);
+        if constexpr (WLDS) {
+            extern __shared__ __attribute__((aligned(16))) char wlds[];
+            const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) void *)wlds;
+            ws1.lds = base; ws2.lds = base + n1; ws3.lds = base + n1 + n2;
+            i32x4 *dst = reinterpret_cast<i32x4 *>(wlds);
+            const i32x4 *s1 = reinterpret_cast<const i32x4 *>(a.w1), *s2 = reinterpret_cast<const i32x4 *>(a.w2),
+                        *s3 = reinterpret_cast<const i32x4 *>(a.w3);
+            for (unsigned i = threadIdx.x; i < n1 / 16; i += blockDim.x) dst[i] = s1[i];
+            for (unsigned i = threadIdx.x; i < n2 / 16; i += blockDim.x) dst[n1 / 16 + i] = s2[i];
+            for (unsigned i = threadIdx.x; i < n3 / 16; i += blockDim.x) dst[(n1 + n2) / 16 + i] = s3[i];
+            __syncthreads();
+        } else {
+            ws1.rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.w1, 0, n1, 0x00020000);
+            ws2.rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.w2, 0, n2, 0x00020000);
+            ws3.rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.w3, 0, n3, 0x00020000);
+        }
+    }
     bool bad = false;
     for (int unit = wave; unit < a.units; unit += nwaves) {
         const int ub = unit / a.ups;
@@ -127,7 +168,6 @@ __global__ __launch_bounds__(256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
                 }
                 return v;
             };
-            const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)a.w1, 0, (unsigned)(T1 * a.ks1 * FRAG), 0x00020000);
             f32x4 xcur[2][NT], xnext[2][NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { xcur[0][nt] = gather4(0, nt); xcur[1][nt] = gather4(1, nt); }
@@ -146,7 +186,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
                 }
 #pragma unroll
                 for (int t = 0; t < T1; ++t) {
-                    const WFrag w = wload_h(rs1, lane * 16, (t * a.ks1 + ks) * FRAG);
+                    const WFrag w = ws1.load(lane * 16, (t * a.ks1 + ks) * FRAG);
                     mac3<NT>(w, xhi, xlo, acc1[t]);
                 }
 #pragma unroll
@@ -169,17 +209,16 @@ __global__ __launch_bounds__(256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
                 constexpr int KCH = (S1 % 4 == 0) ? 4 : ((S1 % 2 == 0) ? 2 : 1);  // k32-steps per prefetched chunk
                 constexpr int NCH = S1 / KCH;
                 constexpr int G = T2 * NCH;
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.w2, 0, (unsigned)(T2 * S1 * FRAG), 0x00020000);
                 WFrag w[2][KCH];
 #pragma unroll
-                for (int u = 0; u < KCH; ++u) w[0][u] = wload_h(rs, lane * 16, u * FRAG);
+                for (int u = 0; u < KCH; ++u) w[0][u] = ws2.load(lane * 16, u * FRAG);
                 f32x4 acc[NT];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const int mt = g / NCH, ch = g % NCH;
                     if (g + 1 < G) {
 #pragma unroll
-                        for (int u = 0; u < KCH; ++u) w[(g + 1) & 1][u] = wload_h(rs, lane * 16, ((g + 1) * KCH + u) * FRAG);
+                        for (int u = 0; u < KCH; ++u) w[(g + 1) & 1][u] = ws2.load(lane * 16, ((g + 1) * KCH + u) * FRAG);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (ch == 0) {
@@ -210,10 +249,9 @@ __global__ __launch_bounds__(256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
             constexpr int KCH = (S2 % 4 == 0) ? 4 : ((S2 % 2 == 0) ? 2 : 1);
             constexpr int NCH = S2 / KCH;
             const int MT3 = a.c3 / 16;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.w3, 0, (unsigned)(MT3 * S2 * FRAG), 0x00020000);
             WFrag wfirst[KCH];
 #pragma unroll
-            for (int u = 0; u < KCH; ++u) wfirst[u] = wload_h(rs, lane * 16, u * FRAG);
+            for (int u = 0; u < KCH; ++u) wfirst[u] = ws3.load(lane * 16, u * FRAG);
             for (int mt = 0; mt < MT3; ++mt) {
                 const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.b3 + 16 * mt + 4 * q);
                 const int tile_off = mt * S2 * FRAG;
@@ -228,10 +266,10 @@ __global__ __launch_bounds__(256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
                 for (int ch = 0; ch < NCH; ++ch) {
                     if (ch + 1 < NCH) {
 #pragma unroll
-                        for (int u = 0; u < KCH; ++u) w[(ch + 1) & 1][u] = wload_h(rs, lane * 16, tile_off + ((ch + 1) * KCH + u) * FRAG);
+                        for (int u = 0; u < KCH; ++u) w[(ch + 1) & 1][u] = ws3.load(lane * 16, tile_off + ((ch + 1) * KCH + u) * FRAG);
                     } else {
 #pragma unroll
-                        for (int u = 0; u < KCH; ++u) wfirst[u] = wload_h(rs, lane * 16, next_off + u * FRAG);
+                        for (int u = 0; u < KCH; ++u) wfirst[u] = ws3.load(lane * 16, next_off + u * FRAG);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -278,9 +316,25 @@ static int launch_f16_variant(const SaMlpArgs &a, hipStream_t st) {
     k.ups = (int)(cols_scene / UNIT);
     k.units = a.units * k.ups;
     k.ks1 = (3 + a.c_feat + 31) / 32;
+    // all three layers' fragments in LDS when they fit beside nothing else (one workgroup of 8 waves per CU) and the
+    // launch is big enough to amortise the copy
+    const size_t wbytes = (size_t)FRAG * ((size_t)(C1 / 16) * k.ks1 + (size_t)(C2 / 16) * (C1 / 32) + (size_t)(a.c3 / 16) * (C2 / 32));
+    if (wbytes <= 128 * 1024 && k.units >= 2048) {
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute((const void *)sa_group_mlp_f16_kernel<C1, C2, NT, NS, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+                return fail(SPS_ERR_LAUNCH, "sa_group_mlp(f16): cannot raise the dynamic LDS limit");
+            raised = true;
+        }
+        int blocks = divup(k.units, 8);
+        if (blocks > 256) blocks = 256;
+        hipLaunchKernelGGL((sa_group_mlp_f16_kernel<C1, C2, NT, NS, true>), dim3(blocks), dim3(512), wbytes, st, k);
+        return check_launch("sa_group_mlp_f16_kernel<lds weights>");
+    }
     int blocks = divup(k.units, 4);
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL((sa_group_mlp_f16_kernel<C1, C2, NT, NS>), dim3(blocks), dim3(256), 0, st, k);
+    hipLaunchKernelGGL((sa_group_mlp_f16_kernel<C1, C2, NT, NS, false>), dim3(blocks), dim3(256), 0, st, k);
     return check_launch("sa_group_mlp_f16_kernel");
 }
 
