@@ -205,7 +205,9 @@ int sps_sa_group_mlp_range(int b, int n, int m, int j0, int jcount, int c_feat, 
 
 /* sps_sa_group_mlp_range with the arithmetic chosen per call (split_fp16 = 0: fp32 MFMA; 1: split-fp16, per-layer
  * fragment arrays; 2: split-fp16 with ONE concatenated fragment stream in w1 that a workgroup's waves share through
- * LDS -- first hidden width a multiple of 64; w2 / w3 are ignored; weights packed accordingly by the caller) and,
+ * LDS -- first hidden width a multiple of 64; w2 / w3 are ignored; weights packed accordingly by the caller; + 4:
+ * `features` is point-major (b, n, c_feat), c_feat % 4 == 0, and layer 1's input channels are ordered
+ * [features, xyz] instead of [xyz, features] -- a neighbour's channels are then contiguous 16-byte loads) and,
  * for the split-fp16 kernel, a device flag that is set to 1 if an operand left the exactly splittable range
  * (|x| > 131 000: the value was clamped).  overflow_flag may be NULL. */
 int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,
@@ -221,7 +223,7 @@ int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int c_feat, int
  * spsnet_amd/fused.py:_pack_pw.  Exact fp32 (MFMA f32). */
 int sps_pointwise_mlp(int b, int m, int cin, int c1, int c2, int classes, const float *x, const float *w1,
                       const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, float *y1,
-                      float *y3, sps_stream_t stream);
+                      float *y1_point_major /* optional (b, m, c1) copy of y1, or NULL */, float *y3, sps_stream_t stream);
 
 #ifdef __cplusplus
 }

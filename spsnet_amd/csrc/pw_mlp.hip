@@ -25,7 +25,7 @@ constexpr int PW_PAD = 17;  // LDS row pitch of the activation images (floats)
 struct PwArgs {
     int m, cin, c1, c2, c3, c3_real;
     const float *x, *w1, *b1, *w2, *b2, *w3, *b3;
-    float *y1, *y3;
+    float *y1, *y1t, *y3;
 };
 
 __device__ __forceinline__ f32x4 pw_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -79,11 +79,13 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void pw_mlp_kernel(PwArgs a) {
             acc = pw_tile(reinterpret_cast<const f32x4 *>(a.w1) + (size_t)t * k16n * 64 + lane, xt, k16n, q, c, acc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = fmaxf(acc[r], 0.f);
+                acc[r] = fmaxf(acc[r], 0.f);
                 const int row = 16 * t + 4 * q + r;
-                a.y1[((size_t)scene * a.c1 + row) * a.m + m0 + c] = v;
-                act1[row * PW_PAD + c] = v;
+                a.y1[((size_t)scene * a.c1 + row) * a.m + m0 + c] = acc[r];
+                act1[row * PW_PAD + c] = acc[r];
             }
+            // point-major twin (B, M, C1) for the next layer's grouped-MLP gathers: 16 bytes per lane, 64 per column
+            if (a.y1t) *reinterpret_cast<f32x4 *>(a.y1t + ((size_t)scene * a.m + m0 + c) * a.c1 + 16 * t + 4 * q) = acc;
         }
     }
     if (!a.w2) return;
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void pw_mlp_kernel(PwArgs a) {
 
 extern "C" int sps_pointwise_mlp(int b, int m, int cin, int c1, int c2, int c3_real, const float *x, const float *w1,
                                  const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
-                                 float *y1, float *y3, sps_stream_t stream) {
+                                 float *y1, float *y1_point_major, float *y3, sps_stream_t stream) {
     using namespace sps;
     if (b < 0 || m < 0 || cin <= 0 || c1 <= 0) return fail(SPS_ERR_INVALID, "pointwise_mlp: bad shape b=%d m=%d cin=%d c1=%d", b, m, cin, c1);
     if (b == 0 || m == 0) return SPS_OK;
@@ -129,7 +131,7 @@ extern "C" int sps_pointwise_mlp(int b, int m, int cin, int c1, int c2, int c3_r
     if (b > 65535) return fail(SPS_ERR_INVALID, "pointwise_mlp: batch %d exceeds the grid limit", b);
     PwArgs a;
     a.m = m; a.cin = cin; a.c1 = c1; a.c2 = deep ? c2 : 0; a.c3 = 16; a.c3_real = deep ? c3_real : 0;
-    a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = deep ? w2 : nullptr; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.y1 = y1; a.y3 = y3;
+    a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = deep ? w2 : nullptr; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.y1 = y1; a.y1t = y1_point_major; a.y3 = y3;
     const int wide = (deep && c2 > cin) ? c2 : cin;
     const size_t lds = sizeof(float) * (size_t)PW_PAD * ((size_t)wide + c1);
     if (lds > 150 * 1024) return fail(SPS_ERR_INVALID, "pointwise_mlp: widths (%d, %d, %d) need more LDS than a workgroup has", cin, c1, c2);

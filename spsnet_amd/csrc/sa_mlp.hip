@@ -330,9 +330,13 @@ extern "C" int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int 
     a.xyz = xyz; a.new_xyz = new_xyz; a.feat = features; a.idx = idx;
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.out = out;
     a.overflow = overflow_flag;
+    const int arith = split_fp16 & 3;
+    a.feat_pm = (split_fp16 & 4) ? 1 : 0;
+    if (a.feat_pm && (arith == 0 || c_feat < 4 || (c_feat % 4)))
+        return fail(SPS_ERR_INVALID, "sa_group_mlp: point-major features need a split-fp16 mode and c_feat %% 4 == 0 (got %d)", c_feat);
     hipStream_t st = as_stream(stream);
-    if (split_fp16 == 2) return launch_sa_mlp_f16_lds(a, c1, c2, nsample, st);
-    if (split_fp16) return launch_sa_mlp_f16(a, c1, c2, nsample, st);
+    if (arith == 2) return launch_sa_mlp_f16_lds(a, c1, c2, nsample, st);
+    if (arith) return launch_sa_mlp_f16(a, c1, c2, nsample, st);
 #define SPS_MLP_CASE(C1, C2, NT, NS) \
     if (c1 == C1 && c2 == C2 && nsample == NS) return launch_variant<C1, C2, NT, NS>(a, st);
     SPS_MLP_CASE(16, 16, 2, 16)    // IA-SSD L0 r=0.2 [4,16,16,32]

@@ -15,6 +15,7 @@ struct SaMlpArgs {
     const int *idx;
     const float *w1, *b1, *w2, *b2, *w3, *b3;
     float *out;
+    int feat_pm;                   // 1: `feat` is point-major (B, N, c_feat) and layer 1's channel order is [features, xyz]
     int *overflow;                 // split-fp16 kernel: set to 1 if an operand exceeded the exactly splittable range
 };
 

@@ -151,6 +151,21 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
             }
             auto gather4 = [&](int k16, int nt) -> f32x4 {
                 f32x4 v;
+                if (a.feat_pm) {
+                    // point-major features (B, N, C), C % 4 == 0, grouped channel order [features, xyz, pad]: a lane's
+                    // four channels are one 16-byte load, the four q-lanes of a column read 64 contiguous bytes
+                    const int ch0 = 16 * k16 + 4 * q;
+                    if (ch0 < a.c_feat) {
+                        v = *reinterpret_cast<const f32x4 *>(a.feat + ((size_t)bb[nt] * a.n + src[nt]) * a.c_feat + ch0);
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int ax = ch0 + jj - a.c_feat;
+                            v[jj] = ax < 3 ? a.xyz[((size_t)bb[nt] * a.n + src[nt]) * 3 + ax] - a.new_xyz[(size_t)bj[nt] * 3 + ax] : 0.f;
+                        }
+                    }
+                    return v;
+                }
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int ch = 16 * k16 + 4 * q + jj;  // grouped channel: 0..2 centred xyz, 3.. features

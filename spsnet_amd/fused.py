@@ -102,7 +102,7 @@ def _pad_bias(b, cpad):
 
 
 class PackedScale:
-    __slots__ = ("c1", "c2", "c3", "c3_real", "cin", "w1", "b1", "w2", "b2", "w3", "b3", "key", "split")
+    __slots__ = ("c1", "c2", "c3", "c3_real", "cin", "w1", "b1", "w2", "b2", "w3", "b3", "key", "split", "point_major")
 
 
 def _stack_layers(mlp):
@@ -165,8 +165,10 @@ def check_overflow():
     return bad
 
 
-def pack_scale(mlp, nsample):
-    """-> PackedScale (cached on the module) or None when the fused kernel has no variant for this scale."""
+def pack_scale(mlp, nsample, point_major=False):
+    """-> PackedScale (cached on the module) or None when the fused kernel has no variant for this scale.
+    point_major: layer 1's input channels ordered [features, xyz] for gathers from a (B, N, C) feature tensor
+    (only used, and only honoured, by the split-fp16 kernels with C % 4 == 0)."""
     pairs = _stack_layers(mlp)
     if pairs is None:
         return None
@@ -175,13 +177,19 @@ def pack_scale(mlp, nsample):
     if not _L.sps_sa_group_mlp_supported(c1, c2, nsample):
         return None
     device = c1m.weight.device
-    key = _version_key(pairs, device) + (PRECISION, SHARE_WEIGHTS)
-    cached = getattr(mlp, "_sps_packed", None)
+    c_feat = c1m.in_channels - 3
+    point_major = bool(point_major and PRECISION == "fp16x2" and c1 >= 32 and c_feat >= 4 and c_feat % 4 == 0)
+    key = _version_key(pairs, device) + (PRECISION, SHARE_WEIGHTS, point_major)
+    slot = "_sps_packed_pm" if point_major else "_sps_packed"
+    cached = getattr(mlp, slot, None)
     if cached is not None and cached.key == key:
         return cached
     with torch.no_grad():
         (w1, b1), (w2, b2), (w3, b3) = (_fold(c, b) for c, b in pairs)
+        if point_major:
+            w1 = torch.cat([w1[:, 3:], w1[:, :3]], dim=1)  # grouped channels as [features, xyz]
         p = PackedScale()
+        p.point_major = point_major
         p.c1, p.c2, p.c3, p.c3_real, p.cin = c1, c2, c3, c3m.out_channels, c1m.in_channels
         p.split = 0
         if PRECISION == "fp16x2" and c1 >= 32:
@@ -196,18 +204,36 @@ def pack_scale(mlp, nsample):
             p.w1, p.w2, p.w3 = _pack_first(w1, c1), _pack_next(w2, c2, c1), _pack_next(w3, c3, c2)
         p.b1, p.b2, p.b3 = _pad_bias(b1, c1), _pad_bias(b2, c2), _pad_bias(b3, c3)
         p.key = key
-    object.__setattr__(mlp, "_sps_packed", p)  # plain attribute: not a parameter/buffer, not in state_dict
+    object.__setattr__(mlp, slot, p)  # plain attribute: not a parameter/buffer, not in state_dict
     return p
+
+
+def point_major_twin(features):
+    """The (B, N, C) copy that pointwise_tail attached to a (B, C, N) feature tensor it produced, or None."""
+    t = getattr(features, "_sps_nc", None)
+    if t is None or features is None:
+        return None
+    B, C, N = features.shape
+    if t.shape != (B, N, C) or t.device != features.device or not t.is_contiguous() or C % 4:
+        return None
+    return t
 
 
 def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=0, jcount=None):
     """One launch: gather the nsample neighbours in `idx` (B,M,ns), run the packed 3-layer MLP, max-pool,
     and write channels [channel_offset, channel_offset + c3_real) of out (B, Ctot, M); optionally only for the
-    centroids [j0, j0+jcount) of every scene."""
+    centroids [j0, j0+jcount) of every scene.  A scale packed with point_major reads the features' (B, N, C) twin."""
     B, N, _ = xyz.shape
     M, ns = idx.shape[1], idx.shape[2]
     jcount = M if jcount is None else jcount
     c_feat = 0 if features is None else features.shape[1]
+    mode = int(packed.split)
+    if packed.point_major:
+        twin = point_major_twin(features)
+        if twin is None:
+            raise ValueError("scale packed for point-major features, but the feature tensor carries no (B, N, C) twin")
+        features = twin
+        mode |= 4
     if 3 + c_feat != packed.cin:
         raise ValueError(f"grouped input has {3 + c_feat} channels, the MLP expects {packed.cin}")
     stream = torch.cuda.current_stream(xyz.device).cuda_stream
@@ -215,7 +241,7 @@ def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=
         B, N, M, j0, jcount, c_feat, ns, xyz.data_ptr(), new_xyz.data_ptr(), 0 if features is None else features.data_ptr(),
         idx.data_ptr(), packed.c1, packed.c2, packed.c3, packed.c3_real, packed.w1.data_ptr(), packed.b1.data_ptr(),
         packed.w2.data_ptr(), packed.b2.data_ptr(), packed.w3.data_ptr(), packed.b3.data_ptr(), out.data_ptr(),
-        out.shape[1], channel_offset, int(packed.split),
+        out.shape[1], channel_offset, mode,
         _overflow_flag(xyz.device).data_ptr() if packed.split else 0, stream), "sa_group_mlp")
 
 
@@ -301,9 +327,11 @@ def pointwise_tail(agg, head, pooled):
         object.__setattr__(agg, "_sps_tail", packed)
     x = pooled.contiguous()
     y1 = torch.empty((B, c1, M), dtype=torch.float32, device=pooled.device)
+    y1t = torch.empty((B, M, c1), dtype=torch.float32, device=pooled.device)  # point-major twin for the next SA layer
     y3 = torch.empty((B, M, classes), dtype=torch.float32, device=pooled.device) if head is not None else None
     ptr = lambda t: 0 if t is None else t.data_ptr()
     _lib.check(_L.sps_pointwise_mlp(B, M, cin, c1, c2, classes, x.data_ptr(), ptr(packed.w1), ptr(packed.b1), ptr(packed.w2),
-                                    ptr(packed.b2), ptr(packed.w3), ptr(packed.b3), y1.data_ptr(), ptr(y3),
+                                    ptr(packed.b2), ptr(packed.w3), ptr(packed.b3), y1.data_ptr(), y1t.data_ptr(), ptr(y3),
                                     torch.cuda.current_stream(pooled.device).cuda_stream), "pointwise_mlp")
+    y1._sps_nc = y1t
     return y1, y3

@@ -78,7 +78,7 @@ class _PointnetSAModuleBase(nn.Module):
                 return None
             if (xyz.shape[0] * new_xyz.shape[1] * grouper.nsample) % 32 != 0:
                 return None
-            packed = _fused.pack_scale(mlp, grouper.nsample)
+            packed = _fused.pack_scale(mlp, grouper.nsample, point_major=_fused.point_major_twin(features) is not None)
             if packed is None:
                 return None
             plan.append(packed)
