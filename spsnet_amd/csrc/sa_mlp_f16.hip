@@ -334,7 +334,7 @@ static int launch_f16_variant(const SaMlpArgs &a, hipStream_t st) {
     // all three layers' fragments in LDS when they fit beside nothing else (one workgroup of 8 waves per CU) and the
     // launch is big enough to amortise the copy
     const size_t wbytes = (size_t)FRAG * ((size_t)(C1 / 16) * k.ks1 + (size_t)(C2 / 16) * (C1 / 32) + (size_t)(a.c3 / 16) * (C2 / 32));
-    if (wbytes <= 128 * 1024 && k.units >= 2048) {
+    if (C1 >= 64 && wbytes <= 128 * 1024 && k.units >= 2048) {  // (the 32-wide scale is faster streaming: measured)
         static bool raised = false;
         if (!raised) {
             if (hipFuncSetAttribute((const void *)sa_group_mlp_f16_kernel<C1, C2, NT, NS, true>,
