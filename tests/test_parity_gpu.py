@@ -460,6 +460,32 @@ def test_fused_full_width_stack_against_cpu_oracle(ext, G, dev):
     np.testing.assert_allclose(G.n(got[1][2]), want[1][2], rtol=1e-4, atol=1e-4)
 
 
+def test_full_size_stack_against_cpu_oracle(ext, G, dev):
+    """BASELINE config 2 at full size (16 384 points, IA-SSD widths; 2 scenes) against the CPU oracle stack: this is the
+    shape at which the streamed first layer, the multi-pick FPS rounds, the LDS-resident / shared-stream split-fp16
+    MLP kernels, the point-major gathers and the fused tails are all active."""
+    from oracle import cpu_stack
+    from spsnet_amd import fused, pointnet2_modules as M, sa_stack, scenes
+    layers = sa_stack.build_sa_layers(M, sa_stack.IASSD_KITTI, seed=9)
+    xyz, feats = scenes.make_batch("kitti-lidar-v1", 2, 16384, seed0=123, dup_fraction=0.005)
+    want = cpu_stack.sa_stack_cpu(cpu_stack.cpu_copy(layers), xyz, feats)
+    layers = layers.to(dev)
+    with torch.no_grad():
+        got = sa_stack.run_sa_layers(layers, G.t(xyz), G.t(feats))
+    assert not sa_stack.check_timeouts() and not fused.check_overflow()
+    for k in (0, 1):   # D-FPS layers: indices and centroids exact
+        np.testing.assert_array_equal(G.n(got[k][3]), want[k][3])
+        np.testing.assert_array_equal(G.n(got[k][0]), want[k][0])
+    for k in (0, 1):
+        ref = want[k][1]
+        assert float(np.abs(G.n(got[k][1]) - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(G.n(got[1][2]), want[1][2], rtol=1e-4, atol=1e-4)
+    # layer 2 samples by score: same set up to near-ties of the scores (which carry the 1e-4 feature tolerance)
+    gi, wi = G.n(got[2][3]), want[2][3]
+    overlap = np.mean([len(np.intersect1d(gi[b], wi[b])) / wi.shape[1] for b in range(gi.shape[0])])
+    assert overlap >= 0.99
+
+
 # ------------------------------------------------------------------ pruned vs brute-force FPS kernels
 @pytest.mark.parametrize("N,m,kind", [(6144, 512, "lattice"), (8192, 1024, "dup"), (7000, 700, "dup"), (16384, 4096, "kitti"),
                                       (16384, 600, "lattice"), (20480, 300, "dup"), (12345, 999, "uniform")])
