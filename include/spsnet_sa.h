@@ -209,7 +209,7 @@ int sps_sa_group_mlp_range(int b, int n, int m, int j0, int jcount, int c_feat, 
  * `features` is point-major (b, n, c_feat), c_feat % 4 == 0, and layer 1's input channels are ordered
  * [features, xyz] instead of [xyz, features] -- a neighbour's channels are then contiguous 16-byte loads) and,
  * for the split-fp16 kernel, a device flag that is set to 1 if an operand left the exactly splittable range
- * (|x| > 131 000: the value was clamped).  overflow_flag may be NULL. */
+ * (|x| > 65 504: the value was clamped).  overflow_flag may be NULL. */
 int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,
                         const float *new_xyz, const float *features, const int *idx, int c1, int c2, int c3,
                         int c3_real, const float *w1, const float *b1, const float *w2, const float *b2,

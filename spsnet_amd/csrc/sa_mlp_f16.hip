@@ -4,7 +4,7 @@
 // the dropped lo*lo term is 2^-22 relative, so features stay within ~1e-6 of the fp32 path -- far inside the
 // 1e-4 bar of BASELINE.json -- while v_mfma_f32_16x16x16_f16 runs at 16x the rate of the fp32 MFMA (which on
 // gfx950 is no faster than the VALU).  |x| is clamped to the fp16 range before the split, so an out-of-range
-// activation degrades gracefully (error grows beyond |x| ~ 1.3e5) instead of producing inf/NaN.
+// activation saturates (and is reported) instead of producing inf/NaN.
 //
 // Layout: v_mfma_f32_16x16x32_f16 wants 8 consecutive k per lane.  The D tiles of layer l (lane (q,c): rows 4q..4q+3 of
 // column c) of TWO consecutive 16-row tiles form the B operand of one k32-step of layer l+1 if k-slot (q, j) of step s
@@ -24,17 +24,20 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 // K = 32: the K = 16 form issues at 32 cycles on gfx950, this one at 16 for twice the work
 __device__ __forceinline__ f32x4 mfma32h(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
-// |x| <= 131008 splits exactly to 22 bits (hi saturates at 65504, lo carries the rest); beyond that the value is
-// clamped and `bad` is raised so that the host can tell (fused.check_overflow) -- never inf/NaN, never silent.
-template <int OFF>
-__device__ __forceinline__ void split4(const f32x4 v, h8 &hi, h8 &lo, bool &bad) {
+// Split 4 fp32 values into halves OFF..OFF+3 of the hi / lo operand vectors.  The value is clamped to the fp16 range
+// first (RELU: to [0, 65504], which is the layer's ReLU as well), so hi is finite and lo = fp16(c - hi) is tiny: no
+// inf/NaN can arise.  |x| <= 65504 splits exactly to 22 bits; `mx` tracks the largest magnitude seen so that the
+// launch can report operands beyond that (fused.check_overflow) -- never silent.
+template <int OFF, bool RELU>
+__device__ __forceinline__ void split4(const f32x4 v, h8 &hi, h8 &lo, float &mx) {
+    mx = __builtin_amdgcn_fmed3f(mx, INFINITY, fmaxf(fabsf(v[0]), fabsf(v[1])));  // max3(mx, |v0|, |v1|) for mx >= 0
+    mx = __builtin_amdgcn_fmed3f(mx, INFINITY, fmaxf(fabsf(v[2]), fabsf(v[3])));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        bad |= fabsf(v[r]) > 131000.f;
-        const float c = __builtin_amdgcn_fmed3f(v[r], -65504.f, 65504.f);
+        const float c = __builtin_amdgcn_fmed3f(v[r], RELU ? 0.f : -65504.f, 65504.f);
         const _Float16 h = (_Float16)c;
         hi[OFF + r] = h;
-        lo[OFF + r] = (_Float16)__builtin_amdgcn_fmed3f(v[r] - (float)h, -65504.f, 65504.f);
+        lo[OFF + r] = (_Float16)(c - (float)h);
     }
 }
 
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
             ws3.rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.w3, 0, n3, 0x00020000);
         }
     }
-    bool bad = false;
+    float mx = 0.f;  // largest operand magnitude this lane has split
     for (int unit = wave; unit < a.units; unit += nwaves) {
         const int ub = unit / a.ups;
         const long long col0 = ((long long)ub * a.m + a.j0) * NS + (long long)(unit - ub * a.ups) * UNIT;
@@ -196,8 +199,8 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
                 h8 xhi[NT], xlo[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    split4<0>(xcur[0][nt], xhi[nt], xlo[nt], bad);
-                    split4<4>(xcur[1][nt], xhi[nt], xlo[nt], bad);
+                    split4<0, false>(xcur[0][nt], xhi[nt], xlo[nt], mx);
+                    split4<4, false>(xcur[1][nt], xhi[nt], xlo[nt], mx);
                 }
 #pragma unroll
                 for (int t = 0; t < T1; ++t) {
@@ -212,11 +215,8 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
             for (int t = 0; t < T1; ++t)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    f32x4 v = acc1[t][nt];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                    if (t % 2 == 0) split4<0>(v, h1hi[t / 2][nt], h1lo[t / 2][nt], bad);
-                    else split4<4>(v, h1hi[t / 2][nt], h1lo[t / 2][nt], bad);
+                    if (t % 2 == 0) split4<0, true>(acc1[t][nt], h1hi[t / 2][nt], h1lo[t / 2][nt], mx);
+                    else split4<4, true>(acc1[t][nt], h1hi[t / 2][nt], h1lo[t / 2][nt], mx);
                 }
 
             // ---------------- layer 2 ----------------
@@ -246,11 +246,8 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
                     if (ch == NCH - 1) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            f32x4 v = acc[nt];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                            if (mt % 2 == 0) split4<0>(v, h2hi[mt / 2][nt], h2lo[mt / 2][nt], bad);
-                            else split4<4>(v, h2hi[mt / 2][nt], h2lo[mt / 2][nt], bad);
+                            if (mt % 2 == 0) split4<0, true>(acc[nt], h2hi[mt / 2][nt], h2lo[mt / 2][nt], mx);
+                            else split4<4, true>(acc[nt], h2hi[mt / 2][nt], h2lo[mt / 2][nt], mx);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -318,7 +315,7 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
             }
         }
     }
-    if (bad && a.overflow) *a.overflow = 1;
+    if (mx > 65504.f && a.overflow) *a.overflow = 1;
 }
 
 template <int C1, int C2, int NT, int NS>

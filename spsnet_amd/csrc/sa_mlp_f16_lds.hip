@@ -38,16 +38,20 @@ namespace {
 
 __device__ __forceinline__ f32x4 mfma32h(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
-// split 4 fp32 values into halves OFF..OFF+3 of the hi / lo operand vectors (see sa_mlp_f16.hip for the range rule)
-template <int OFF>
-__device__ __forceinline__ void split4(const f32x4 v, h8 &hi, h8 &lo, bool &bad) {
+// Split 4 fp32 values into halves OFF..OFF+3 of the hi / lo operand vectors.  The value is clamped to the fp16 range
+// first (RELU: to [0, 65504], which is the layer's ReLU as well), so hi is finite and lo = fp16(c - hi) is tiny: no
+// inf/NaN can arise.  |x| <= 65504 splits exactly to 22 bits; `mx` tracks the largest magnitude seen so that the
+// launch can report operands beyond that (fused.check_overflow) -- never silent.
+template <int OFF, bool RELU>
+__device__ __forceinline__ void split4(const f32x4 v, h8 &hi, h8 &lo, float &mx) {
+    mx = __builtin_amdgcn_fmed3f(mx, INFINITY, fmaxf(fabsf(v[0]), fabsf(v[1])));  // max3(mx, |v0|, |v1|) for mx >= 0
+    mx = __builtin_amdgcn_fmed3f(mx, INFINITY, fmaxf(fabsf(v[2]), fabsf(v[3])));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        bad |= fabsf(v[r]) > 131000.f;
-        const float c = __builtin_amdgcn_fmed3f(v[r], -65504.f, 65504.f);
+        const float c = __builtin_amdgcn_fmed3f(v[r], RELU ? 0.f : -65504.f, 65504.f);
         const _Float16 h = (_Float16)c;
         hi[OFF + r] = h;
-        lo[OFF + r] = (_Float16)__builtin_amdgcn_fmed3f(v[r] - (float)h, -65504.f, 65504.f);
+        lo[OFF + r] = (_Float16)(c - (float)h);
     }
 }
 
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(64 * WAVES) void sa_group_mlp_f16_lds_kernel(SaMlpA
         for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32h(w.lo, xh[nt], acc[nt]);
     };
 
-    bool bad = false;
+    float mx = 0.f;  // largest operand magnitude this lane has split
     // units are handed out per workgroup so that its four waves stay in lockstep on the shared stream; a wave without a
     // unit of its own recomputes the last one and writes nothing
     const int ngroups = (a.units + WAVES - 1) / WAVES;
@@ -244,8 +248,8 @@ __global__ __launch_bounds__(64 * WAVES) void sa_group_mlp_f16_lds_kernel(SaMlpA
                 h8 xhi[NT], xlo[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    split4<0>(xcur[0][nt], xhi[nt], xlo[nt], bad);
-                    split4<4>(xcur[1][nt], xhi[nt], xlo[nt], bad);
+                    split4<0, false>(xcur[0][nt], xhi[nt], xlo[nt], mx);
+                    split4<4, false>(xcur[1][nt], xhi[nt], xlo[nt], mx);
                 }
 #pragma unroll
                 for (int tc = 0; tc < T1 / 4; ++tc) {
@@ -262,11 +266,8 @@ __global__ __launch_bounds__(64 * WAVES) void sa_group_mlp_f16_lds_kernel(SaMlpA
             for (int t = 0; t < T1; ++t)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    f32x4 v = acc1[t][nt];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                    if (t % 2 == 0) split4<0>(v, h1hi[t / 2][nt], h1lo[t / 2][nt], bad);
-                    else split4<4>(v, h1hi[t / 2][nt], h1lo[t / 2][nt], bad);
+                    if (t % 2 == 0) split4<0, true>(acc1[t][nt], h1hi[t / 2][nt], h1lo[t / 2][nt], mx);
+                    else split4<4, true>(acc1[t][nt], h1hi[t / 2][nt], h1lo[t / 2][nt], mx);
                 }
 
             // ---------------- layers 2 and 3, interleaved by layer-3 k-step ----------------
@@ -296,11 +297,8 @@ __global__ __launch_bounds__(64 * WAVES) void sa_group_mlp_f16_lds_kernel(SaMlpA
                         if (s1 == S1 - 1) {
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt) {
-                                f32x4 v = acc[nt];
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                                if (half == 0) split4<0>(v, gh[nt], gl[nt], bad);
-                                else split4<4>(v, gh[nt], gl[nt], bad);
+                                if (half == 0) split4<0, true>(acc[nt], gh[nt], gl[nt], mx);
+                                else split4<4, true>(acc[nt], gh[nt], gl[nt], mx);
                             }
                         }
                     } else {
@@ -342,7 +340,7 @@ __global__ __launch_bounds__(64 * WAVES) void sa_group_mlp_f16_lds_kernel(SaMlpA
         wait_vm<0>();  // stores retire out of order with loads: let them (and the requests) finish before counting again
     }
     wait_vm<0>();
-    if (bad && a.overflow) *a.overflow = 1;
+    if (mx > 65504.f && a.overflow) *a.overflow = 1;
 }
 
 template <int C1, int C2, int C3, int NT, int NS>

@@ -156,7 +156,7 @@ def _overflow_flag(device):
 
 
 def check_overflow():
-    """True if a split-fp16 launch met an operand beyond the exactly splittable range (|x| > 131 000) since the last
+    """True if a split-fp16 launch met an operand beyond the exactly splittable range (|x| > 65 504) since the last
     call; such values were clamped.  Synchronises the device.  Use set_precision("fp32") for unbounded inputs."""
     bad = False
     for f in _OVERFLOW.values():
