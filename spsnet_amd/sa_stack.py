@@ -126,7 +126,7 @@ def check_timeouts():
     return bad
 
 
-def _streamed_first_layer(layer, nxt, xyz, features):
+def _streamed_first_layer(layer, nxt, xyz, features, stds=None):
     """Layer 0 with its grouping/MLP consuming the D-FPS output WHILE the FPS kernel is still running.
 
     FPS is a serial chain on one CU per scene (~2.9 ms for 8 x 16384 -> 4096); the ball queries and grouped MLPs of
@@ -214,7 +214,9 @@ def _streamed_first_layer(layer, nxt, xyz, features):
         _prefetch_dfps(nxt, new_xyz, True)
     main.wait_event(done)
     new_features, cls = layer._tail(out)
-    return new_xyz, new_features, cls, idx, None
+    if stds is not None:  # the layer's sampler thins the stability scores with its picks (reference :307-310)
+        stds = pointnet2_utils.gather_operation(stds.view(B, 1, -1).contiguous(), idx).squeeze()
+    return new_xyz, new_features, cls, idx, stds
 
 
 def _is_plain_dfps(layer, n_in):
@@ -238,10 +240,10 @@ def run_sa_layers(layers, xyz, features, stds=None, overlap=True, stream_first_l
     use_overlap = overlap and xyz.is_cuda and not torch.is_grad_enabled()
     for k, layer in enumerate(layers):
         nxt = layers[k + 1] if k + 1 < len(layers) else None
-        if use_overlap and k == 0 and stds is None and cls_pred is None and stream_first_layer:
-            res = _streamed_first_layer(layer, nxt, xyz, features)
+        if use_overlap and k == 0 and cls_pred is None and stream_first_layer:
+            res = _streamed_first_layer(layer, nxt, xyz, features, stds)
             if res is not None:
-                xyz, features, cls_pred, idx, _ = res
+                xyz, features, cls_pred, idx, stds = res
                 outs.append((xyz, features, cls_pred, idx))
                 continue
         if use_overlap and nxt is not None and _can_prefetch(layer, nxt):

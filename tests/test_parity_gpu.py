@@ -629,22 +629,28 @@ def test_ball_query_dual_radius(ext, G, oracle, N, M, ra, nsa, rb, nsb):
         np.testing.assert_array_equal(G.n(ib), oracle.ball_query(rb, nsb, xyz, new_xyz))
 
 
-def test_streamed_first_layer_equals_sequential(ext, G, dev):
+@pytest.mark.parametrize("with_stds", [False, True])
+def test_streamed_first_layer_equals_sequential(ext, G, dev, with_stds):
     """Layer 0 with its grouping/MLP consuming the FPS output while FPS runs (progress hand-off) against the plain
-    sequential schedule: every output of every layer bit-identical, no wait timed out."""
+    sequential schedule: every output of every layer bit-identical, no wait timed out.  with_stds = BASELINE config 4
+    (stability-score sampler at layer 2, stds thinned by every sampler on the way)."""
     from spsnet_amd import pointnet2_modules as M, sa_stack, scenes
-    layers = sa_stack.build_sa_layers(M, sa_stack.IASSD_KITTI, seed=2).to(dev)
+    cfg = sa_stack.scaled_config(sample_methods=['D-FPS', 'D-FPS', 'sss_aware']) if with_stds else sa_stack.IASSD_KITTI
+    layers = sa_stack.build_sa_layers(M, cfg, seed=2).to(dev)
     xyz, feats = scenes.make_batch("kitti-lidar-v1", 4, 16384, seed0=31, dup_fraction=0.01)
     x, f = G.t(xyz), G.t(feats)
+    sd = G.t(np.random.default_rng(5).uniform(0, 40, (4, 16384)).astype(np.float32)) if with_stds else None
+    _run = sa_stack.run_sa_layers
+    sa_stack_run = lambda *a, **k: _run(*a, stds=sd, **k)
     with torch.no_grad():
-        b = sa_stack.run_sa_layers(layers, x, f, overlap=False)
+        b = sa_stack_run(layers, x, f, overlap=False)
         for rep in range(3):
             # poison the caching allocator's free blocks with in-bounds but wrong values: a consumer that ran ahead
             # of the producer (or read a stale cache line) would then compute visibly wrong results, not fault
             junk_i = torch.full((32 << 20,), 1 + rep, dtype=torch.int32, device=dev)
             junk_f = torch.full((32 << 20,), 0.5 + rep, dtype=torch.float32, device=dev)
             del junk_i, junk_f
-            a = sa_stack.run_sa_layers(layers, x, f, stream_first_layer=True)
+            a = sa_stack_run(layers, x, f, stream_first_layer=True)
             torch.cuda.synchronize()
             assert not sa_stack.check_timeouts()
             for la, lb in zip(a, b):
