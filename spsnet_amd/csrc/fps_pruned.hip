@@ -59,16 +59,22 @@ __device__ __forceinline__ float fmin_raw(float a, float b) {
 }
 __device__ __forceinline__ int wave_min_i32_id(int v) { return ~wave_max_i32_id(~v); }
 
-__device__ __forceinline__ float wave_allmin_f32(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
+// wave-wide float min / max through DPP (rows, then row broadcasts; result read from lane 63): ~10 cycles per step
+// where the ds_bpermute behind __shfl_xor costs ~60 -- the bucket boxes need 6 x 32 of these reductions per wave
+template <bool MAX>
+__device__ __forceinline__ float wave_all_f32(float v) {
+    const int id = __float_as_int(MAX ? -INFINITY : INFINITY);
+    auto step = [&](float o) { v = MAX ? fmaxf(v, o) : fminf(v, o); };
+    step(__int_as_float(dpp_or<DPP_ROW_SHR1>(__float_as_int(v), id)));
+    step(__int_as_float(dpp_or<DPP_ROW_SHR2>(__float_as_int(v), id)));
+    step(__int_as_float(dpp_or<DPP_ROW_SHR4>(__float_as_int(v), id)));
+    step(__int_as_float(dpp_or<DPP_ROW_SHR8>(__float_as_int(v), id)));
+    step(__int_as_float(dpp_or<DPP_ROW_BCAST15, 0xA>(__float_as_int(v), id)));
+    step(__int_as_float(dpp_or<DPP_ROW_BCAST31, 0xC>(__float_as_int(v), id)));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-__device__ __forceinline__ float wave_allmax_f32(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
+__device__ __forceinline__ float wave_allmin_f32(float v) { return wave_all_f32<false>(v); }
+__device__ __forceinline__ float wave_allmax_f32(float v) { return wave_all_f32<true>(v); }
 
 // v[LANE] = value (wave-uniform), LANE a compile-time constant
 template <int LANE>
@@ -125,13 +131,23 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
 
     // ------------------------------------------------------------------ spatial sort (once)
     float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int k = tid; k < n; k += PF_THREADS) {
+    // eight points per trip: their 24 loads are in flight together (a plain strided loop waits ~1 us per iteration)
+    for (int k0 = tid; k0 < n; k0 += 8 * PF_THREADS) {
+        float v[8][3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float v = xyz[k * 3 + a];
-            lo3[a] = fminf(lo3[a], v);
-            hi3[a] = fmaxf(hi3[a], v);
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u * PF_THREADS;
+            const int kk = k < n ? k : k0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) v[u][a] = xyz[kk * 3 + a];
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                lo3[a] = fminf(lo3[a], v[u][a]);
+                hi3[a] = fmaxf(hi3[a], v[u][a]);
+            }
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -152,13 +168,25 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
     const PfGrid grid = pf_make_grid(glo, ghi);
     // cell keys of this thread's points stay in registers between the histogram and the scatter pass
     int ckey[P];
+    constexpr int KB = P % 8 == 0 ? 8 : 4;  // points per batch: loads first (unconditional, clamped), then keys + atomics
 #pragma unroll
-    for (int i = 0; i < P; ++i) {
-        const int k = tid + i * PF_THREADS;
-        ckey[i] = 0;
-        if (k < n) {
-            ckey[i] = pf_cell_key(grid, xyz[k * 3], xyz[k * 3 + 1], xyz[k * 3 + 2]);
-            atomicAdd(&sh.hist[ckey[i]], 1);
+    for (int i0 = 0; i0 < P; i0 += KB) {
+        float v[KB][3];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const int k = tid + (i0 + u) * PF_THREADS;
+            const int kk = k < n ? k : 0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) v[u][a] = xyz[kk * 3 + a];
+        }
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const int k = tid + (i0 + u) * PF_THREADS;
+            ckey[i0 + u] = 0;
+            if (k < n) {
+                ckey[i0 + u] = pf_cell_key(grid, v[u][0], v[u][1], v[u][2]);
+                atomicAdd(&sh.hist[ckey[i0 + u]], 1);
+            }
         }
     }
     __syncthreads();
