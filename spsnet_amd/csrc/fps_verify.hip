@@ -73,6 +73,7 @@ __global__ __launch_bounds__(FV_THREADS) void fps_prefix_check_kernel(
     int n, int m, int bs, int l2, int rb, const float *__restrict__ xyz, const float *__restrict__ temp,
     const float *__restrict__ T, float *__restrict__ temp_done, int *__restrict__ idx, int *__restrict__ bad) {
     __shared__ float4 step[FV_MAX_M];  // step j (1 <= j < m): {centre j-1, T[j]} at step[j-1]
+    __shared__ unsigned srank[FV_MAX_M];  // tie-break rank of point j, at srank[j-1]
     __shared__ float segmin[FV_SEG][64];
     const int scene = blockIdx.y;
     const int lane = threadIdx.x & 63, seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -80,7 +81,10 @@ __global__ __launch_bounds__(FV_THREADS) void fps_prefix_check_kernel(
     xyz += (size_t)scene * n * 3;
     T += (size_t)scene * m;
     const int steps = m - 1;
-    for (int i = threadIdx.x; i < steps; i += FV_THREADS) step[i] = make_float4(xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2], T[i + 1]);
+    for (int i = threadIdx.x; i < steps; i += FV_THREADS) {
+        step[i] = make_float4(xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2], T[i + 1]);
+        srank[i] = fv_rank((unsigned)(i + 1), bs, l2, rb);
+    }
     __syncthreads();
     const bool live = k < n;
     const int kk = live ? k : 0;
@@ -101,8 +105,7 @@ __global__ __launch_bounds__(FV_THREADS) void fps_prefix_check_kernel(
     for (int i = ibeg; i < iend; ++i) {  // step j = i + 1: centre i has been applied, the guess says point j is picked now
         const float4 c = step[i];
         t = fminf(sqdist(px, py, pz, c.x, c.y, c.z), t);
-        const unsigned rj = fv_rank((unsigned)(i + 1), bs, l2, rb);
-        violated |= (k != i + 1) && (t > c.w || (t == c.w && myrank < rj));
+        violated |= (k != i + 1) & ((t > c.w) | ((t == c.w) & (myrank < srank[i])));
     }
     if (live) {
         if (seg == FV_SEG - 1) {

@@ -114,7 +114,8 @@ def _can_prefetch(layer, nxt):
 
 
 # centroid chunks of the streamed first layer, as cumulative fractions of M in 1/16ths: big chunks while FPS still has a
-# long way to go, small ones at the end (what is left to do after the last pick is the last chunk's work)
+# long way to go, small ones at the end (what is left to do after the last pick is the last chunk's work; a chunk
+# costs ~70 us however small it is -- one wave scans the whole cloud per centroid -- so finer tails only add launches)
 _CHUNK_ENDS_16 = (4, 8, 12, 14, 15, 16)
 _TIMEOUT_FLAGS = []   # device flags of the bounded waits issued so far (see check_timeouts)
 
