@@ -286,7 +286,8 @@ __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG_DUAL) void ball_query_dual_ker
 // cannot exploit (it stops only when all 64 centroids of a wave are full) and whose per-hit divergent appends
 // cost more than its distance arithmetic (tools/bq_time.py: 353 us vs 150 us without hits at the layer-0 shape).
 constexpr int BQW_WAVES = 4;   // centroids per workgroup
-constexpr long long BQ_WAVE_MAX_CENTROIDS = 8192;  // b * centroids up to which sps_ball_query_full2_range prefers this kernel
+constexpr long long BQ_WAVE_MAX_CENTROIDS = 8192;
+constexpr long long BQ_SEG_MAX_CENTROIDS = 2048;   // ... and up to which four waves share a centroid  // b * centroids up to which sps_ball_query_full2_range prefers this kernel
 constexpr int BQW_UNROLL = 4;  // 64-point steps in flight per loop trip
 
 __global__ __launch_bounds__(64 * BQW_WAVES) void ball_query_wave_dual_kernel(
@@ -338,6 +339,76 @@ __global__ __launch_bounds__(64 * BQW_WAVES) void ball_query_wave_dual_kernel(
     const int ka = ca < nsa ? ca : nsa, kb = cb < nsb ? cb : nsb;
     for (int l = ka + lane; l < nsa; l += 64) row_a[l] = first_a;
     for (int l = kb + lane; l < nsb; l += 64) row_b[l] = first_b;
+}
+
+// The same with the four waves of a workgroup sharing ONE centroid (each scans a quarter of the cloud, ordered hit
+// lists meet in LDS): for launches of a few hundred centroids, where the scan of a whole cloud by one wave (~38 us at
+// 16 384 points) is the launch time.
+constexpr int BQS_SEG = 4;
+constexpr int BQS_MAX_NS = 64;
+__global__ __launch_bounds__(64 * BQS_SEG) void ball_query_wave_seg_kernel(
+    int n, int m, float r2a, float r2b, int nsa, int nsb, const float *__restrict__ new_xyz,
+    const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b, int jbeg) {
+    __shared__ int hits[2][BQS_SEG][BQS_MAX_NS];
+    __shared__ int cnt[2][BQS_SEG];
+    const int scene = blockIdx.y, j = jbeg + blockIdx.x;
+    const int lane = threadIdx.x & 63, seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    xyz += (size_t)scene * n * 3;
+    const float *ctr = new_xyz + ((size_t)scene * m + j) * 3;
+    const float cx = ctr[0], cy = ctr[1], cz = ctr[2];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int seg_len = ((n + BQS_SEG - 1) / BQS_SEG + 63) & ~63;
+    const int kbeg = seg * seg_len, kend = (kbeg + seg_len < n) ? kbeg + seg_len : n;
+    int ca = 0, cb = 0;
+    for (int base = kbeg; base < kend; base += 64 * BQW_UNROLL) {
+        float px[BQW_UNROLL], py[BQW_UNROLL], pz[BQW_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BQW_UNROLL; ++u) {
+            const int k = base + u * 64 + lane;
+            const int kk = k < n ? k : n - 1;
+            px[u] = xyz[kk * 3 + 0]; py[u] = xyz[kk * 3 + 1]; pz[u] = xyz[kk * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < BQW_UNROLL; ++u) {
+            const int k = base + u * 64 + lane;
+            const float d2 = sqdist(cx, cy, cz, px[u], py[u], pz[u]);
+            const bool in = k < kend;
+            const bool ha = in && d2 < r2a, hb = in && d2 < r2b;
+            const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
+            if (ma != 0ull && ca < nsa) {
+                const int pos = ca + __builtin_popcountll(ma & below);
+                if (ha && pos < nsa) hits[0][seg][pos] = k;
+                ca += __builtin_popcountll(ma);
+            }
+            if (mb != 0ull && cb < nsb) {
+                const int pos = cb + __builtin_popcountll(mb & below);
+                if (hb && pos < nsb) hits[1][seg][pos] = k;
+                cb += __builtin_popcountll(mb);
+            }
+        }
+        if (ca >= nsa && cb >= nsb) break;
+    }
+    if (lane == 0) { cnt[0][seg] = ca < nsa ? ca : nsa; cnt[1][seg] = cb < nsb ? cb : nsb; }
+    __syncthreads();
+    if (seg < 2) {  // wave 0 merges radius a, wave 1 radius b: segment order = index order
+        const int ns = seg ? nsb : nsa;
+        int *row = (seg ? idx_b : idx_a) + ((size_t)scene * m + j) * ns;
+        int c[BQS_SEG], total = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < BQS_SEG; ++s2) { c[s2] = cnt[seg][s2]; total += c[s2]; }
+        int first = 0;  // empty ball: zeros
+#pragma unroll
+        for (int s2 = BQS_SEG - 1; s2 >= 0; --s2) first = c[s2] > 0 ? hits[seg][s2][0] : first;
+        for (int p = lane; p < ns; p += 64) {
+            int v = first, q = p;
+#pragma unroll
+            for (int s2 = 0; s2 < BQS_SEG; ++s2) {
+                if (q >= 0 && q < c[s2]) v = hits[seg][s2][q];
+                q = (q >= 0 && q < c[s2]) ? -1 : q - c[s2];
+            }
+            row[p] = p < total ? v : first;
+        }
+    }
 }
 
 // perm[b, :] = the scene's centroids sorted by 12-bit cell key (counting sort in LDS, one workgroup per scene;
@@ -451,6 +522,12 @@ extern "C" int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcoun
     // segments are waves of one workgroup); one wave per centroid spreads the same work over the chip.
     bool per_wave = !perm_work && (long long)b * jcount <= BQ_WAVE_MAX_CENTROIDS;
     if (const char *force = getenv("SPS_BQ_WAVE")) per_wave = force[0] == '1';  // diagnostic override (tools/bq_time.py)
+    if (per_wave && (long long)b * jcount <= BQ_SEG_MAX_CENTROIDS && nsample_a <= BQS_MAX_NS && nsample_b <= BQS_MAX_NS &&
+        n >= 4096) {
+        hipLaunchKernelGGL(ball_query_wave_seg_kernel, dim3(jcount, b), dim3(64 * BQS_SEG), 0, as_stream(stream), n, m,
+                           radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, j0);
+        return check_launch("ball_query_wave_seg_kernel");
+    }
     if (per_wave) {
         hipLaunchKernelGGL(ball_query_wave_dual_kernel, dim3(divup(jcount, BQW_WAVES), b), dim3(64 * BQW_WAVES), 0,
                            as_stream(stream), n, m, radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz,

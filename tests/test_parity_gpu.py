@@ -768,3 +768,23 @@ def test_pointwise_tail_matches_torch(ext, G, dev, cin, cagg, conf, M):
     # module-level switch: training mode keeps the reference's op sequence
     mod.train()
     assert fused.pointwise_tail(mod.aggregation_layer, mod.confidence_layers, pooled) is None
+
+
+@pytest.mark.parametrize("N,M,j0,cnt,ra,nsa,rb,nsb", [(5000, 512, 128, 256, 0.4, 16, 1.5, 32), (16384, 4096, 3840, 256, 0.2, 16, 0.8, 32),
+                                                       (4099, 300, 0, 300, 0.05, 8, 6.0, 64), (8192, 1024, 1000, 24, 1.0, 16, 1.0, 16)])
+def test_ball_query_range_small_launch_kernels(ext, G, oracle, N, M, j0, cnt, ra, nsa, rb, nsb):
+    """Centroid ranges small enough for the wave-per-centroid kernels (one wave, or four waves sharing a centroid):
+    same rows as the oracle, rows outside the range untouched; includes empty balls and overfull balls."""
+    from spsnet_amd import scenes
+    xyz, _ = scenes.make_batch("kitti-lidar-v1", 2, N, seed0=N + M)
+    rng = np.random.default_rng(M)
+    new_xyz = xyz[:, rng.integers(0, N, M)].copy()
+    new_xyz[:, j0 + cnt - 1] = 500.0          # an empty ball inside the range
+    ia = torch.full((2, M, nsa), -7, dtype=torch.int32, device="cuda")
+    ib = torch.full((2, M, nsb), -7, dtype=torch.int32, device="cuda")
+    ext.ball_query_full2_range(ra, rb, G.t(xyz), G.t(new_xyz), ia, ib, j0, cnt)
+    wa, wb = oracle.ball_query(ra, nsa, xyz, new_xyz), oracle.ball_query(rb, nsb, xyz, new_xyz)
+    np.testing.assert_array_equal(G.n(ia)[:, j0:j0 + cnt], wa[:, j0:j0 + cnt])
+    np.testing.assert_array_equal(G.n(ib)[:, j0:j0 + cnt], wb[:, j0:j0 + cnt])
+    assert (G.n(ia)[:, :j0] == -7).all() and (G.n(ia)[:, j0 + cnt:] == -7).all()
+    assert (G.n(ib)[:, :j0] == -7).all() and (G.n(ib)[:, j0 + cnt:] == -7).all()
