@@ -70,10 +70,9 @@ __device__ __forceinline__ float row_allmax_h(float v) {
     return fmaxf(v, o);
 }
 
-constexpr int WAVES = 4;            // waves per workgroup = fragments per chunk
 constexpr int RING = 6;             // LDS slots of one chunk (8 KiB) each
 constexpr int FRAG_BYTES = 2048;    // [hi x8 | lo x8] per lane, as two lane-linear 1-KiB pieces
-constexpr int CHUNK_BYTES = WAVES * FRAG_BYTES;
+constexpr int CHUNK_BYTES = 4 * FRAG_BYTES;  // a chunk = 4 fragments = 8 pieces of 1 KiB, fetched by 4 or 8 waves
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -83,14 +82,17 @@ __device__ __forceinline__ void wait_vm() {
 }  // namespace
 
 // a.w1 = the concatenated fragment stream; a.ks1 = layer-1 k-steps of 32 grouped channels.
-template <int C1, int C2, int C3, int NT, int NS>
+template <int C1, int C2, int C3, int NT, int NS, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void sa_group_mlp_f16_lds_kernel(SaMlpArgs a) {
+    constexpr int PIECES = 8 / WAVES;  // 1-KiB pieces of a chunk each wave fetches
+    static_assert(WAVES == 4 || WAVES == 8, "4 waves x 2 pieces or 8 waves x 1 piece");
     constexpr int T1 = C1 / 16, T2 = C2 / 16, MT3 = C3 / 16;   // 16-row output tiles
     constexpr int S1 = T1 / 2, S2 = T2 / 2;                    // k32-steps over the previous layer's channels
     constexpr int UNIT = 16 * NT;
-    constexpr int CPP = UNIT / NS;
+    constexpr int CPP = UNIT >= NS ? UNIT / NS : 1;    // whole centroids per unit ...
+    constexpr int SPLIT = UNIT >= NS ? 1 : NS / UNIT;  // ... or consecutive waves (units) per centroid
     constexpr int BLOCK_FRAGS = 2 * S1 + MT3;                  // fragments of one (layer-2 pair, layer-3 k-step) block
-    static_assert(UNIT % NS == 0 && (NS % 16) == 0 && CPP >= 1, "a unit must hold whole centroids");
+    static_assert((UNIT % NS == 0 || NS % UNIT == 0) && (NS % 16) == 0 && WAVES % SPLIT == 0, "units and centroids must nest");
     static_assert(T1 % 4 == 0 && T2 % 2 == 0 && BLOCK_FRAGS % 4 == 0, "chunks of 4 fragments must tile the stream");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ring = smem;                                        // RING x 8 KiB
@@ -110,33 +112,44 @@ __global__ __launch_bounds__(64 * WAVES) void sa_group_mlp_f16_lds_kernel(SaMlpA
     float *my_stage = stage + (size_t)wv * CPP * C3;
 
     // ---- the fragment stream ----
-    const char *wsrc = reinterpret_cast<const char *>(a.w1) + (size_t)wv * FRAG_BYTES + lane * 16;  // my piece of chunk 0
+    const char *wsrc = reinterpret_cast<const char *>(a.w1) + (size_t)wv * (PIECES * 1024) + lane * 16;  // my pieces of chunk 0
     const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) void *)ring;
     int prod = 0, prod_slot = 0, cons_slot = 0;  // next chunk to request / its slot / slot of the next chunk to consume
     auto request = [&]() {
         // LDS-DMA as inline asm: through the builtin hipcc treats the pending LDS write as an alias of every later ring
         // read and drains it (vmcnt(0)) before each one.  M0 = wave-uniform LDS destination; saved and restored.
         const char *gsrc = wsrc + (size_t)prod * CHUNK_BYTES;
-        const unsigned dst = ring_base + (unsigned)(prod_slot * CHUNK_BYTES + wv * FRAG_BYTES);
-        const char *gsrc2 = gsrc + 1024;  // the lo piece (no instruction offset: it would also move the LDS address)
+        const unsigned dst = ring_base + (unsigned)(prod_slot * CHUNK_BYTES + wv * (PIECES * 1024));
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\t"
-                     "s_mov_b32 m0, %3\n\t"
-                     "s_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, off\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\t"
-                     "s_nop 0\n\t"
-                     "global_load_lds_dwordx4 %2, off\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(gsrc), "v"(gsrc2), "s"(dst)
-                     : "memory", "scc");
+        if constexpr (PIECES == 2) {
+            const char *gsrc2 = gsrc + 1024;  // (no instruction offset: it would also move the LDS address)
+            asm volatile("s_mov_b32 %0, m0\n\t"
+                         "s_mov_b32 m0, %3\n\t"
+                         "s_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, off\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\t"
+                         "s_nop 0\n\t"
+                         "global_load_lds_dwordx4 %2, off\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(gsrc), "v"(gsrc2), "s"(dst)
+                         : "memory", "scc");
+        } else {
+            asm volatile("s_mov_b32 %0, m0\n\t"
+                         "s_mov_b32 m0, %2\n\t"
+                         "s_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, off\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(gsrc), "s"(dst)
+                         : "memory");
+        }
         prod = (prod + 1 == nchunks) ? 0 : prod + 1;
         prod_slot = (prod_slot + 1 == RING) ? 0 : prod_slot + 1;
     };
     for (int i = 0; i < RING - 1; ++i) request();
     auto next_chunk = [&](WFrag (&w)[4]) {
-        wait_vm<2 * (RING - 2)>();                  // my pieces of the chunk about to be read have landed
+        wait_vm<PIECES * (RING - 2)>();             // my pieces of the chunk about to be read have landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();               // ... and everybody else's; everybody is done with the previous chunk
         asm volatile("" ::: "memory");
@@ -314,7 +327,7 @@ __global__ __launch_bounds__(64 * WAVES) void sa_group_mlp_f16_lds_kernel(SaMlpA
                 for (int cc = 0; cc < CPP; ++cc) best[cc] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int cc = (nt * 16) / NS;
+                    const int cc = SPLIT > 1 ? 0 : (nt * 16) / NS;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) best[cc][r] = fmaxf(best[cc][r], acc3[mt][nt][r]);
                 }
@@ -328,14 +341,28 @@ __global__ __launch_bounds__(64 * WAVES) void sa_group_mlp_f16_lds_kernel(SaMlpA
             }
         }
         // ---------------- write the unit's pooled rows; nothing of mine may be outstanding but the weight requests ------
-        if (valid) {
+        if constexpr (SPLIT > 1) {
+            // a centroid's samples are spread over SPLIT consecutive waves: the first of them combines the partial maxima
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        if (valid && wv % SPLIT == 0) {
             const long long bj0 = col0 / NS;
             for (int e = lane; e < CPP * a.c3_real; e += 64) {
                 const int cc = e / a.c3_real, row = e - cc * a.c3_real;
                 const long long cen = bj0 + cc;
                 const int b = (int)(cen / a.m), j = (int)(cen - (long long)b * a.m);
-                a.out[((size_t)b * a.out_c_total + a.out_c_off + row) * a.m + j] = my_stage[(size_t)cc * C3 + row];
+                float v = my_stage[(size_t)cc * C3 + row];
+#pragma unroll
+                for (int o = 1; o < SPLIT; ++o) v = fmaxf(v, my_stage[(size_t)(o * CPP + cc) * C3 + row]);
+                a.out[((size_t)b * a.out_c_total + a.out_c_off + row) * a.m + j] = v;
             }
+        }
+        if constexpr (SPLIT > 1) {  // the partner's stage is read above: nobody may overwrite it before everybody is here
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
         wait_vm<0>();  // stores retire out of order with loads: let them (and the requests) finish before counting again
     }
@@ -343,7 +370,7 @@ __global__ __launch_bounds__(64 * WAVES) void sa_group_mlp_f16_lds_kernel(SaMlpA
     if (mx > 65504.f && a.overflow) *a.overflow = 1;
 }
 
-template <int C1, int C2, int C3, int NT, int NS>
+template <int C1, int C2, int C3, int NT, int NS, int WAVES>
 static int launch_lds_variant(const SaMlpArgs &a, hipStream_t st) {
     constexpr int UNIT = 16 * NT;
     SaMlpArgs k = a;
@@ -355,19 +382,26 @@ static int launch_lds_variant(const SaMlpArgs &a, hipStream_t st) {
     k.ks1 = (3 + a.c_feat + 31) / 32;
     const int groups = divup(k.units, WAVES);
     int blocks = groups < 256 * 2 ? groups : 256 * 2;
-    const size_t lds = (size_t)RING * CHUNK_BYTES + sizeof(float) * ((size_t)C1 + C2 + C3 + (size_t)WAVES * (UNIT / NS) * C3);
-    hipLaunchKernelGGL((sa_group_mlp_f16_lds_kernel<C1, C2, C3, NT, NS>), dim3(blocks), dim3(64 * WAVES), lds, st, k);
+    const size_t lds = (size_t)RING * CHUNK_BYTES + sizeof(float) * ((size_t)C1 + C2 + C3 + (size_t)WAVES * (UNIT >= NS ? UNIT / NS : 1) * C3);
+    static bool raised = false;
+    if (lds > 64 * 1024 && !raised) {
+        if (hipFuncSetAttribute((const void *)sa_group_mlp_f16_lds_kernel<C1, C2, C3, NT, NS, WAVES>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return fail(SPS_ERR_LAUNCH, "sa_group_mlp(f16/lds): cannot raise the dynamic LDS limit");
+        raised = true;
+    }
+    hipLaunchKernelGGL((sa_group_mlp_f16_lds_kernel<C1, C2, C3, NT, NS, WAVES>), dim3(blocks), dim3(64 * WAVES), lds, st, k);
     return check_launch("sa_group_mlp_f16_lds_kernel");
 }
 
 // split_fp16 == 2: the weights are ONE concatenated stream in a.w1 (fused._pack_stream)
 int launch_sa_mlp_f16_lds(const SaMlpArgs &a, int c1, int c2, int nsample, hipStream_t st) {
-#define SPS_MLPL_CASE(C1, C2, C3, NT, NS) \
-    if (c1 == C1 && c2 == C2 && a.c3 == C3 && nsample == NS) return launch_lds_variant<C1, C2, C3, NT, NS>(a, st);
-    SPS_MLPL_CASE(64, 64, 128, 2, 16)
-    SPS_MLPL_CASE(64, 96, 128, 2, 32)
-    SPS_MLPL_CASE(128, 128, 256, 2, 16)
-    SPS_MLPL_CASE(128, 256, 256, 2, 32)
+#define SPS_MLPL_CASE(C1, C2, C3, NT, NS, W) \
+    if (c1 == C1 && c2 == C2 && a.c3 == C3 && nsample == NS) return launch_lds_variant<C1, C2, C3, NT, NS, W>(a, st);
+    SPS_MLPL_CASE(64, 64, 128, 2, 16, 4)
+    SPS_MLPL_CASE(64, 96, 128, 2, 32, 4)
+    SPS_MLPL_CASE(128, 128, 256, 1, 16, 8)
+    SPS_MLPL_CASE(128, 256, 256, 1, 32, 8)
 #undef SPS_MLPL_CASE
     return fail(SPS_ERR_INVALID, "sa_group_mlp(f16/lds): no kernel for widths (%d, %d, %d) nsample %d", c1, c2, a.c3, nsample);
 }
