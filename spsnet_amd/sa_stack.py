@@ -164,8 +164,13 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None):
     idx_b = torch.empty((B, M, gb.nsample), dtype=torch.int32, device=dev)
     out = torch.empty((B, sum(p.c3_real for p in plan), M), dtype=torch.float32, device=dev)
     _TIMEOUT_FLAGS.append(timed_out)
-    if len(_TIMEOUT_FLAGS) > 64:
-        del _TIMEOUT_FLAGS[:32]
+    if len(_TIMEOUT_FLAGS) > 8:
+        # the flags of passes issued long ago: reading them costs nothing by now, and a bounded wait that gave up means a
+        # consumer ran on samples that had not been written -- never let that pass silently
+        old, _TIMEOUT_FLAGS[:4] = _TIMEOUT_FLAGS[:4], []
+        if any(int(f.item()) != 0 for f in old):
+            raise RuntimeError("spsnet_amd.sa_stack: a device-side wait on FPS progress timed out in an earlier pass "
+                               "(results of that pass are invalid); use run_sa_layers(..., stream_first_layer=False)")
 
     start = torch.cuda.Event()
     start.record(main)
