@@ -170,7 +170,8 @@ int sps_ball_query_full2_wave(int b, int n, int m, float radius_a, int nsample_a
  *   c1, c2, c3: layer widths PADDED to multiples of 16; c3_real <= c3 channels are written
  *   w1/b1, w2/b2, w3/b3: folded weights in MFMA fragment order (spsnet_amd/fused.py) and padded biases
  *   out (B, out_c_total, M): channels [out_c_off, out_c_off + c3_real) receive the pooled features.
- * B*M*nsample must be a multiple of 32.  Returns SPS_ERR_INVALID when no kernel variant exists for
+ * B*M*nsample must be a multiple of 32.  nsample 64: `out` must be zero-filled by the caller (a centroid's samples
+ * span two kernel units whose maxima are combined with an atomic max; pooled values are >= 0 after the ReLU).  Returns SPS_ERR_INVALID when no kernel variant exists for
  * (c1, c2, nsample): ask sps_sa_group_mlp_supported first. */
 int sps_sa_group_mlp(int b, int n, int m, int c_feat, int nsample, const float *xyz, const float *new_xyz,
                      const float *features, const int *idx, int c1, int c2, int c3, int c3_real,

@@ -71,8 +71,9 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
     constexpr int T1 = C1 / 16, T2 = C2 / 16;
     constexpr int COLS = 16 * NT;
     constexpr int UNIT = COLS;
-    constexpr int CPP = COLS / NS;  // whole centroids per unit (1 or 2)
-    static_assert(COLS % NS == 0 && (NS % 16) == 0 && CPP >= 1, "a unit must hold whole centroids");
+    constexpr int CPP = COLS >= NS ? COLS / NS : 1;  // whole centroids per unit (1 or 2) ...
+    constexpr bool PART = COLS < NS;                  // ... or a unit is a slice of one centroid's samples (nsample 64)
+    static_assert((COLS % NS == 0 || NS % COLS == 0) && (NS % 16) == 0, "units and centroids must nest");
 
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, c = lane & 15;
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
                 for (int cc = 0; cc < CPP; ++cc) best[cc] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int cc = (nt * 16) / NS;  // which centroid of the unit this tile belongs to
+                    const int cc = PART ? 0 : (nt * 16) / NS;  // which centroid of the unit this tile belongs to
 #pragma unroll
                     for (int r = 0; r < 4; ++r) best[cc][r] = fmaxf(best[cc][r], acc[nt][r]);
                 }
@@ -247,8 +248,14 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int row = 16 * mt + 4 * q + r;
-                            if (row < a.c3_real)
-                                a.out[((size_t)b * a.out_c_total + a.out_c_off + row) * a.m + j] = v[r];
+                            if (row < a.c3_real) {
+                                float *dst = a.out + ((size_t)b * a.out_c_total + a.out_c_off + row) * a.m + j;
+                                // a slice of the centroid's samples: combine with the other slices.  Pooled values are
+                                // >= 0 after the ReLU, so their bit patterns order like ints and the caller's zero
+                                // fill is the identity (sps_sa_group_mlp_ex requires a zeroed `out` for nsample 64)
+                                if constexpr (PART) atomicMax(reinterpret_cast<int *>(dst), __float_as_int(v[r]));
+                                else *dst = v[r];
+                            }
                         }
                     }
                 }
@@ -349,6 +356,12 @@ extern "C" int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int 
     SPS_MLP_CASE(32, 32, 2, 16)
     SPS_MLP_CASE(128, 64, 2, 16)   // SPSNet L1 [127,124->128,64,128]
     SPS_MLP_CASE(128, 96, 2, 32)   // SPSNet L1 [127,124->128,96,128]
+    SPS_MLP_CASE(16, 16, 2, 64)    // nsample 64 (BASELINE config 5): a centroid spans two units, atomic max
+    SPS_MLP_CASE(32, 32, 2, 64)
+    SPS_MLP_CASE(64, 64, 2, 64)
+    SPS_MLP_CASE(64, 96, 2, 64)
+    SPS_MLP_CASE(128, 128, 2, 64)
+    SPS_MLP_CASE(128, 256, 2, 64)
 #undef SPS_MLP_CASE
     return fail(SPS_ERR_INVALID, "sa_group_mlp: no kernel for widths (%d, %d) nsample %d", c1, c2, nsample);
 }
@@ -356,7 +369,8 @@ extern "C" int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int 
 // 1 if sps_sa_group_mlp has a kernel for these padded widths / nsample
 extern "C" int sps_sa_group_mlp_supported(int c1, int c2, int nsample) {
     static const int tab[][3] = {{16, 16, 16}, {32, 32, 32}, {64, 64, 16}, {64, 96, 32}, {128, 128, 16}, {128, 256, 32},
-                                 {16, 16, 32}, {32, 32, 16}, {128, 64, 16}, {128, 96, 32}};
+                                 {16, 16, 32}, {32, 32, 16}, {128, 64, 16}, {128, 96, 32},
+                                 {16, 16, 64}, {32, 32, 64}, {64, 64, 64}, {64, 96, 64}, {128, 128, 64}, {128, 256, 64}};
     for (auto &t : tab)
         if (t[0] == c1 && t[1] == c2 && t[2] == nsample) return 1;
     return 0;

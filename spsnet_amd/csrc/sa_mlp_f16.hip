@@ -99,8 +99,9 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
     constexpr int T1 = C1 / 16, T2 = C2 / 16;
     constexpr int S1 = T1 / 2, S2 = T2 / 2;  // k32-steps over the previous layer's channels
     constexpr int UNIT = 16 * NT;
-    constexpr int CPP = UNIT / NS;
-    static_assert(UNIT % NS == 0 && (NS % 16) == 0 && CPP >= 1, "a unit must hold whole centroids");
+    constexpr int CPP = UNIT >= NS ? UNIT / NS : 1;  // whole centroids per unit ...
+    constexpr bool PART = UNIT < NS;                  // ... or a unit is a slice of one centroid's samples (nsample 64)
+    static_assert((UNIT % NS == 0 || NS % UNIT == 0) && (NS % 16) == 0, "units and centroids must nest");
     static_assert(T1 % 2 == 0 && T2 % 2 == 0, "two 16-row tiles chain into one K = 32 operand");
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, c = lane & 15;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
                 for (int cc = 0; cc < CPP; ++cc) best[cc] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int cc = (nt * 16) / NS;
+                    const int cc = PART ? 0 : (nt * 16) / NS;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) best[cc][r] = fmaxf(best[cc][r], acc[nt][r]);
                 }
@@ -308,7 +309,13 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int row = 16 * mt + 4 * q + r;
-                            if (row < a.c3_real) a.out[((size_t)b * a.out_c_total + a.out_c_off + row) * a.m + j] = v[r];
+                            if (row < a.c3_real) {
+                                float *dst = a.out + ((size_t)b * a.out_c_total + a.out_c_off + row) * a.m + j;
+                                // a slice of the centroid's samples: combine with the other slices (values >= 0 after
+                                // the ReLU order like ints; the caller zero-fills `out` for nsample 64)
+                                if constexpr (PART) atomicMax(reinterpret_cast<int *>(dst), __float_as_int(v[r]));
+                                else *dst = v[r];
+                            }
                         }
                     }
                 }
@@ -361,6 +368,11 @@ int launch_sa_mlp_f16(const SaMlpArgs &a, int c1, int c2, int nsample, hipStream
     SPS_MLPH_CASE(32, 32, 2, 16)
     SPS_MLPH_CASE(128, 64, 2, 16)
     SPS_MLPH_CASE(128, 96, 2, 32)
+    SPS_MLPH_CASE(32, 32, 2, 64)
+    SPS_MLPH_CASE(64, 64, 2, 64)
+    SPS_MLPH_CASE(64, 96, 2, 64)
+    SPS_MLPH_CASE(128, 128, 2, 64)
+    SPS_MLPH_CASE(128, 256, 2, 64)
 #undef SPS_MLPH_CASE
     return fail(SPS_ERR_INVALID, "sa_group_mlp(f16): no kernel for widths (%d, %d) nsample %d", c1, c2, nsample);
 }

@@ -402,6 +402,8 @@ int launch_sa_mlp_f16_lds(const SaMlpArgs &a, int c1, int c2, int nsample, hipSt
     SPS_MLPL_CASE(64, 96, 128, 2, 32, 4)
     SPS_MLPL_CASE(128, 128, 256, 1, 16, 8)
     SPS_MLPL_CASE(128, 256, 256, 1, 32, 8)
+    SPS_MLPL_CASE(128, 128, 256, 1, 64, 8)   // nsample 64: a centroid spans four waves
+    SPS_MLPL_CASE(128, 256, 256, 1, 64, 8)
 #undef SPS_MLPL_CASE
     return fail(SPS_ERR_INVALID, "sa_group_mlp(f16/lds): no kernel for widths (%d, %d, %d) nsample %d", c1, c2, a.c3, nsample);
 }

@@ -89,8 +89,10 @@ class _PointnetSAModuleBase(nn.Module):
         if plan:
             xyz_c, new_c = xyz.contiguous(), new_xyz.contiguous()
             feats_c = features.contiguous() if features is not None else None
-            out = torch.empty((xyz.shape[0], sum(p.c3_real for p in plan), new_xyz.shape[1]),
-                              dtype=torch.float32, device=xyz.device)
+            # nsample 64: a centroid's samples span several kernel units, combined by an atomic max onto zeros
+            alloc = torch.zeros if any(g.nsample > 32 for g in self.groupers) else torch.empty
+            out = alloc((xyz.shape[0], sum(p.c3_real for p in plan), new_xyz.shape[1]),
+                        dtype=torch.float32, device=xyz.device)
             offset = 0
             if len(plan) == 2:  # the usual two-scale layer: both ball queries share one scan
                 ga, gb = self.groupers

@@ -162,7 +162,8 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None):
     timed_out = torch.zeros((1,), dtype=torch.int32, device=dev)
     idx_a = torch.empty((B, M, ga.nsample), dtype=torch.int32, device=dev)
     idx_b = torch.empty((B, M, gb.nsample), dtype=torch.int32, device=dev)
-    out = torch.empty((B, sum(p.c3_real for p in plan), M), dtype=torch.float32, device=dev)
+    out = (torch.zeros if max(ga.nsample, gb.nsample) > 32 else torch.empty)(
+        (B, sum(p.c3_real for p in plan), M), dtype=torch.float32, device=dev)
     _TIMEOUT_FLAGS.append(timed_out)
     if len(_TIMEOUT_FLAGS) > 8:
         # the flags of passes issued long ago: reading them costs nothing by now, and a bounded wait that gave up means a

@@ -400,6 +400,8 @@ FUSED_CASES = [  # (c_feat, mlp widths, nsample, radius)
     (1, [16, 16, 32], 16, 0.4), (1, [32, 32, 64], 32, 0.9), (64, [64, 64, 128], 16, 0.8), (64, [64, 96, 128], 32, 1.6),
     (128, [128, 128, 256], 16, 1.6), (128, [128, 256, 256], 32, 3.0), (124, [124, 64, 128], 16, 0.8),
     (5, [16, 16, 20], 32, 1.0), (0, [32, 32, 64], 16, 0.7),
+    # nsample 64 (BASELINE config 5): a centroid's samples span two kernel units (four waves in the shared-stream kernel)
+    (1, [16, 16, 32], 64, 0.9), (64, [64, 96, 128], 64, 1.6), (128, [128, 256, 256], 64, 3.0), (128, [128, 128, 256], 64, 2.0),
 ]
 
 
