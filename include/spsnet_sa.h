@@ -226,6 +226,14 @@ int sps_pointwise_mlp(int b, int m, int cin, int c1, int c2, int classes, const 
                       const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, float *y1,
                       float *y1_point_major /* optional (b, m, c1) copy of y1, or NULL */, float *y3, sps_stream_t stream);
 
+/* farthest_point_sampling_kernel_launcher (sampling_gpu.cu:93-253) with an optional device workspace of
+ * b * sps_fps_workspace_floats(n) floats (0 for sizes that need none).  With it, scenes of 16 385 .. 262 144 points
+ * take the spatially pruned large-scene kernel (same indices and final `temp`, bit for bit; ~100x faster than the
+ * streaming brute-force sweep at Waymo sizes); without it this is sps_farthest_point_sampling_kernel_launcher. */
+long long sps_fps_workspace_floats(int n);
+int sps_fps_with_workspace(int b, int n, int m, const float *dataset, float *temp, int *idxs, float *work,
+                           sps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,7 @@ _PROTOS = {
                          _i, _i, _vp],
     "sps_sa_group_mlp_supported": [_i, _i, _i],
     "sps_set_mlp_precision": [_i],
+    "sps_fps_with_workspace": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_pointwise_mlp": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_sa_group_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                             _vp, _vp, _i, _i, _i, _vp, _vp],
@@ -81,6 +82,8 @@ def load():
     lib.sps_last_error.argtypes = []
     lib.sps_opt_n_threads.restype = _i
     lib.sps_opt_n_threads.argtypes = [_i]
+    lib.sps_fps_workspace_floats.restype = ctypes.c_longlong
+    lib.sps_fps_workspace_floats.argtypes = [_i]
     for name, args in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = _i

@@ -206,6 +206,7 @@ __global__ __launch_bounds__(FPS_MAX_THREADS) void fps_stream_kernel(
 }
 
 static int g_fps_mode = 0;  // 0 = auto (pruned where it applies), 1 = brute-force kernels only
+int fps_mode() { return g_fps_mode; }
 
 static int ilog2(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
 

@@ -64,9 +64,17 @@ def farthest_point_sampling_wrapper(b, n, m, points_tensor, temp_tensor, idx_ten
     """sampling.cpp:34-43.  points (B,N,3), temp (B,N) pre-filled 1e10, idx (B,M) -> 1."""
     p, t, i = _ptr(points_tensor, F32, "points"), _ptr(temp_tensor, F32, "temp"), _ptr(idx_tensor, I32, "idx")
     _need(points_tensor, b * n * 3, "points"); _need(temp_tensor, b * n, "temp"); _need(idx_tensor, b * m, "idx")
+    # scenes too large for the register-resident kernel (16 384 < n <= 262 144) take the pruned large-scene kernel,
+    # which sorts the points into a workspace (20 B per point) -- torch's caching allocator hands it out
+    work_floats = int(_L.sps_fps_workspace_floats(n)) if m > 1 else 0
     with _on(points_tensor):
-        _lib.check(_L.sps_farthest_point_sampling_kernel_launcher(b, n, m, p, t, i, _stream(points_tensor)),
-                   "farthest_point_sampling")
+        if work_floats:
+            work = torch.empty((b * work_floats,), dtype=F32, device=points_tensor.device)
+            _lib.check(_L.sps_fps_with_workspace(b, n, m, p, t, i, work.data_ptr(), _stream(points_tensor)),
+                       "farthest_point_sampling")
+        else:
+            _lib.check(_L.sps_farthest_point_sampling_kernel_launcher(b, n, m, p, t, i, _stream(points_tensor)),
+                       "farthest_point_sampling")
     return 1
 
 

@@ -790,3 +790,36 @@ def test_ball_query_range_small_launch_kernels(ext, G, oracle, N, M, j0, cnt, ra
     np.testing.assert_array_equal(G.n(ib)[:, j0:j0 + cnt], wb[:, j0:j0 + cnt])
     assert (G.n(ia)[:, :j0] == -7).all() and (G.n(ia)[:, j0 + cnt:] == -7).all()
     assert (G.n(ib)[:, :j0] == -7).all() and (G.n(ib)[:, j0 + cnt:] == -7).all()
+
+
+# ------------------------------------------------------------------ pruned FPS for scenes beyond one CU's registers
+@pytest.mark.parametrize("N,m,kind", [(20000, 700, "lattice"), (40000, 2000, "dup"), (65536, 4096, "kitti"),
+                                      (70001, 1500, "uniform"), (180000, 2500, "kitti"), (16385, 16385, "dup")])
+def test_fps_large_scene_kernel(ext, G, oracle, N, m, kind):
+    """fps_pruned_big.hip (points in a workspace, bucket metadata in registers, several picks per barrier) against the
+    oracle and against the brute-force streaming kernel: indices AND final running distances bit-exact.  Sizes cover
+    the three metadata-row variants (<= 65 536, <= 131 072, <= 262 144 points), ragged last buckets and m = n."""
+    from spsnet_amd import _lib, scenes
+    rng = np.random.default_rng(N + m)
+    if kind == "lattice":
+        xyz = cloud(rng, 2, N, lattice=True)
+    elif kind == "kitti":
+        xyz, _ = scenes.make_batch("kitti-lidar-v1", 2 if N < 100000 else 1, N, seed0=21, dup_fraction=0.01)
+    elif kind == "uniform":
+        xyz, _ = scenes.make_batch("uniform-v1", 2, N, seed0=22)
+    else:
+        xyz = cloud(rng, 2, N, dup=0.2)
+    L = _lib.load()
+    assert L.sps_fps_workspace_floats(N) > 0
+    got, got_t = G.fps(ext, xyz, m)
+    old = L.sps_set_fps_mode(1)
+    try:
+        brute, brute_t = G.fps(ext, xyz, m)
+    finally:
+        L.sps_set_fps_mode(old)
+    np.testing.assert_array_equal(got, brute)
+    np.testing.assert_array_equal(got_t, brute_t)
+    if N * m <= 300_000_000:
+        want, want_t = oracle.fps(xyz, m, return_temp=True)
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(got_t, want_t)
