@@ -198,11 +198,22 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_big_kernel(int n, int m
         r_vmax = vmax;
         r_keylo = (int)((0x0FFFFFFFu - (unsigned)rank) << 4);
     };
-    auto commit = [&](auto rc, int l) {
+    auto commit = [&](auto rc, int l) {  // metadata of (row R, lane l) <- the scalars refresh() left: six v_writelane, one M0 set-up
         constexpr int R = decltype(rc)::value;
         int a0 = bmax[R], a1 = bsec[R], a2 = bkeylo[R], a3 = __float_as_int(bpx[R]), a4 = __float_as_int(bpy[R]), a5 = __float_as_int(bpz[R]);
-        put_lane_rt(a0, r_vmax, l); put_lane_rt(a1, r_sec, l); put_lane_rt(a2, r_keylo, l);
-        put_lane_rt(a3, r_px, l); put_lane_rt(a4, r_py, l); put_lane_rt(a5, r_pz, l);
+        unsigned keep;
+        asm volatile("s_mov_b32 %6, m0\n\t"
+                     "s_mov_b32 m0, %13\n\t"
+                     "s_nop 3\n\t"
+                     "v_writelane_b32 %0, %7, m0\n\t"
+                     "v_writelane_b32 %1, %8, m0\n\t"
+                     "v_writelane_b32 %2, %9, m0\n\t"
+                     "v_writelane_b32 %3, %10, m0\n\t"
+                     "v_writelane_b32 %4, %11, m0\n\t"
+                     "v_writelane_b32 %5, %12, m0\n\t"
+                     "s_mov_b32 m0, %6"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "=&s"(keep)
+                     : "s"(r_vmax), "s"(r_sec), "s"(r_keylo), "s"(r_px), "s"(r_py), "s"(r_pz), "s"(__builtin_amdgcn_readfirstlane(l)));
         bmax[R] = a0; bsec[R] = a1; bkeylo[R] = a2; bpx[R] = __int_as_float(a3); bpy[R] = __int_as_float(a4); bpz[R] = __int_as_float(a5);
     };
     auto for_rows = [&](auto &&fn) { rows_each<0, ROWS>(fn); };  // fn(integral_constant row), unrolled
