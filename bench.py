@@ -229,7 +229,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.mlp_precision == "fp32" else "f32 (wide grouped-MLP scales as split-fp16 hi+lo pairs on MFMA, fp32 accumulate, <=2e-5 rel. vs fp32)",
             "data": "synthetic",
             "config": {"workload": f"batch={args.batch}/GPU x {args.points} pts ({args.dataset}), IA-SSD SA L0-L2 "
-                                   f"(4096/1024/512 centroids, nsample 16&32, layer-2 sampler {args.sampler}), fp32",
+                                   f"(4096/1024/512 centroids, nsample 16&32, layer-2 sampler {args.sampler}), fp32 tensors, "
+                                   f"grouped MLP {args.mlp_precision}",
                        "global_batch": world * args.batch, "points_per_scene": args.points,
                        "parallelism": f"scene-sharded x{world}, no data-path collective"},
         }
