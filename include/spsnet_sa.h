@@ -178,6 +178,9 @@ int sps_sa_group_mlp(int b, int n, int m, int c_feat, int nsample, const float *
                      const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                      const float *b3, float *out, int out_c_total, int out_c_off, sps_stream_t stream);
 int sps_sa_group_mlp_supported(int c1, int c2, int nsample);
+/* 1 if only the shared-stream split-fp16 kernel (sps_sa_group_mlp_ex mode 2) serves these padded widths
+ * (IA-SSD layer 5: 256-256-512 / 256-512-1024). */
+int sps_sa_group_mlp_supported_stream(int c1, int c2, int c3, int nsample);
 /* Arithmetic of sps_sa_group_mlp: 0 = exact fp32 MFMA (default), 1 = split-fp16: every operand as hi+lo halves,
  * three v_mfma_f32_16x16x16_f16 per product block, fp32 accumulate (~1e-6 relative, csrc/sa_mlp_f16.hip).  The
  * weight buffers passed afterwards must be packed for the selected mode (spsnet_amd/fused.py).  Returns the old mode. */

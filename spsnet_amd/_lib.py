@@ -46,6 +46,7 @@ _PROTOS = {
                          _i, _i, _vp],
     "sps_sa_group_mlp_supported": [_i, _i, _i],
     "sps_set_mlp_precision": [_i],
+    "sps_sa_group_mlp_supported_stream": [_i, _i, _i, _i],
     "sps_fps_with_workspace": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_pointwise_mlp": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_sa_group_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,

@@ -367,6 +367,14 @@ extern "C" int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int 
 }
 
 // 1 if sps_sa_group_mlp has a kernel for these padded widths / nsample
+// widths that only the shared-stream split-fp16 kernel (mode 2) serves
+extern "C" int sps_sa_group_mlp_supported_stream(int c1, int c2, int c3, int nsample) {
+    static const int tab[][4] = {{256, 256, 512, 16}, {256, 512, 1024, 32}};
+    for (auto &t : tab)
+        if (t[0] == c1 && t[1] == c2 && t[2] == c3 && t[3] == nsample) return 1;
+    return 0;
+}
+
 extern "C" int sps_sa_group_mlp_supported(int c1, int c2, int nsample) {
     static const int tab[][3] = {{16, 16, 16}, {32, 32, 32}, {64, 64, 16}, {64, 96, 32}, {128, 128, 16}, {128, 256, 32},
                                  {16, 16, 32}, {32, 32, 16}, {128, 64, 16}, {128, 96, 32},

@@ -92,7 +92,7 @@ def _pack_stream(w1, w2, w3, c1, c2, c3, cin):
 def _lds_stream_ok(c1, c2, c3):
     # measured (profiles/round1): the 64-wide scales are bound by their per-unit gathers, where four lockstep waves per
     # workgroup lose to independent ones; the shared stream pays from 128 channels on
-    return (c1, c2, c3) in ((128, 128, 256), (128, 256, 256))
+    return (c1, c2, c3) in ((128, 128, 256), (128, 256, 256), (256, 256, 512), (256, 512, 1024))
 
 
 def _pad_bias(b, cpad):
@@ -174,7 +174,10 @@ def pack_scale(mlp, nsample, point_major=False):
         return None
     (c1m, _), (c2m, _), (c3m, _) = pairs
     c1, c2, c3 = _pad16(c1m.out_channels), _pad16(c2m.out_channels), _pad16(c3m.out_channels)
-    if not _L.sps_sa_group_mlp_supported(c1, c2, nsample):
+    stream_only = bool(_L.sps_sa_group_mlp_supported_stream(c1, c2, c3, nsample))
+    if stream_only and not (PRECISION == "fp16x2" and SHARE_WEIGHTS):
+        return None
+    if not stream_only and not _L.sps_sa_group_mlp_supported(c1, c2, nsample):
         return None
     device = c1m.weight.device
     c_feat = c1m.in_channels - 3

@@ -402,6 +402,8 @@ FUSED_CASES = [  # (c_feat, mlp widths, nsample, radius)
     (5, [16, 16, 20], 32, 1.0), (0, [32, 32, 64], 16, 0.7),
     # nsample 64 (BASELINE config 5): a centroid's samples span two kernel units (four waves in the shared-stream kernel)
     (1, [16, 16, 32], 64, 0.9), (64, [64, 96, 128], 64, 1.6), (128, [128, 256, 256], 64, 3.0), (128, [128, 128, 256], 64, 2.0),
+    # IA-SSD layer 5 (vote centres): 512- and 1024-wide outputs, shared-stream kernel only
+    (256, [256, 256, 512], 16, 2.4), (256, [256, 512, 1024], 32, 3.2),
 ]
 
 
