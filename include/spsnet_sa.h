@@ -237,6 +237,15 @@ long long sps_fps_workspace_floats(int n);
 int sps_fps_with_workspace(int b, int n, int m, const float *dataset, float *temp, int *idxs, float *work,
                            sps_stream_t stream);
 
+/* Deterministic form of group_points_grad / gather_points_grad (group_points_gpu.cu:53-71, sampling_gpu.cu:46-63, which
+ * scatter with atomicAdd in an unspecified order): grad_points (b, c, n) += grad_out (b, c, cols) scattered by
+ * idx (b, cols), every target summed in ascending column order -- the order of a sequential loop, so the result is
+ * bit-identical from run to run.  cols = npoints * nsample (group) or npoints (gather); work = device ints,
+ * sps_index_add_workspace_ints(b, n, cols) of them. */
+long long sps_index_add_workspace_ints(int b, int n, int cols);
+int sps_index_add_deterministic(int b, int c, int n, int cols, const float *grad_out, const int *idx, float *grad_points,
+                                int *work, sps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,7 @@ _PROTOS = {
                          _i, _i, _vp],
     "sps_sa_group_mlp_supported": [_i, _i, _i],
     "sps_set_mlp_precision": [_i],
+    "sps_index_add_deterministic": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_sa_group_mlp_supported_stream": [_i, _i, _i, _i],
     "sps_fps_with_workspace": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_pointwise_mlp": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -85,6 +86,8 @@ def load():
     lib.sps_opt_n_threads.argtypes = [_i]
     lib.sps_fps_workspace_floats.restype = ctypes.c_longlong
     lib.sps_fps_workspace_floats.argtypes = [_i]
+    lib.sps_index_add_workspace_ints.restype = ctypes.c_longlong
+    lib.sps_index_add_workspace_ints.argtypes = [_i, _i, _i]
     for name, args in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = _i

@@ -119,3 +119,122 @@ extern "C" int sps_group_points_grad_kernel_launcher_fast(int b, int c, int n, i
     return sps::launch_group(true, "group_points_grad", b, c, n, npoints, nsample, grad_out, idx, grad_points,
                              sps::as_stream(stream));
 }
+
+// ---- deterministic gradients ---------------------------------------------------------------------------------
+// group_points_grad / gather_points_grad scatter with atomicAdd (reference group_points_gpu.cu:53-71,
+// sampling_gpu.cu:46-63): the fp32 summation order, hence the low bits of the gradient, change from run to run.
+// sps_index_add_deterministic computes the same sums in a FIXED order -- ascending column e = (j, s), which is the
+// order a sequential CPU loop (and the oracle) uses, so the result is bit-identical to the oracle:
+//   1. count the columns per target point (integer atomics are order-independent), prefix-sum to segment offsets;
+//   2. scatter the column numbers into their segments (arbitrary order), sort every segment ascending;
+//   3. one thread per point walks its segment for every channel.
+namespace sps {
+
+constexpr int IA_THREADS = 256;
+
+__global__ __launch_bounds__(IA_THREADS) void ia_count_kernel(int n, int cols, const int *__restrict__ idx, int *__restrict__ offs) {
+    const int scene = blockIdx.y, e = blockIdx.x * IA_THREADS + threadIdx.x;
+    if (e < cols) atomicAdd(&offs[(size_t)scene * (n + 1) + idx[(size_t)scene * cols + e] + 1], 1);
+}
+
+// in place: offs[scene][i] = number of columns whose target is < i (offs[scene][0] = 0 already)
+__global__ __launch_bounds__(1024) void ia_scan_kernel(int n, int *__restrict__ offs, int *__restrict__ cursor) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    int *o = offs + (size_t)blockIdx.x * (n + 1) + 1;
+    int *cur = cursor + (size_t)blockIdx.x * n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int v = i < n ? o[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (i < n) {
+            o[i] = before + incl;          // offs[i + 1] = end of segment i
+            cur[i] = before + incl - v;    // start of segment i: the fill cursor
+        }
+        __syncthreads();
+        if (tid == 1023) carry = before + incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(IA_THREADS) void ia_fill_kernel(int n, int cols, const int *__restrict__ idx, int *__restrict__ cursor,
+                                                             int *__restrict__ list) {
+    const int scene = blockIdx.y, e = blockIdx.x * IA_THREADS + threadIdx.x;
+    if (e >= cols) return;
+    const int pos = atomicAdd(&cursor[(size_t)scene * n + idx[(size_t)scene * cols + e]], 1);
+    list[(size_t)scene * cols + pos] = e;
+}
+
+__global__ __launch_bounds__(IA_THREADS) void ia_sort_kernel(int n, int cols, const int *__restrict__ offs, int *__restrict__ list) {
+    const int scene = blockIdx.y, p = blockIdx.x * IA_THREADS + threadIdx.x;
+    if (p >= n) return;
+    const int *o = offs + (size_t)scene * (n + 1);
+    int *seg = list + (size_t)scene * cols + o[p];
+    const int len = o[p + 1] - o[p];
+    for (int i = 1; i < len; ++i) {  // insertion sort: segments are short (columns per point ~ M*nsample/N)
+        const int v = seg[i];
+        int k = i - 1;
+        while (k >= 0 && seg[k] > v) { seg[k + 1] = seg[k]; --k; }
+        seg[k + 1] = v;
+    }
+}
+
+__global__ __launch_bounds__(IA_THREADS) void ia_sum_kernel(int c, int n, int cols, const float *__restrict__ grad_out,
+                                                            const int *__restrict__ offs, const int *__restrict__ list,
+                                                            float *__restrict__ grad_points) {
+    const int scene = blockIdx.y, p = blockIdx.x * IA_THREADS + threadIdx.x;
+    if (p >= n) return;
+    const int *o = offs + (size_t)scene * (n + 1);
+    const int beg = o[p], end = o[p + 1];
+    const int *seg = list + (size_t)scene * cols;
+    const int c0 = blockIdx.z * GG_CCHUNK;
+    const int c1 = (c0 + GG_CCHUNK < c) ? c0 + GG_CCHUNK : c;
+    for (int ch = c0; ch < c1; ++ch) {
+        const float *g = grad_out + ((size_t)scene * c + ch) * cols;
+        float *dst = grad_points + ((size_t)scene * c + ch) * n + p;
+        float acc = *dst;  // accumulate onto the caller's buffer, like the atomic kernels do
+        for (int k = beg; k < end; ++k) acc += g[seg[k]];
+        *dst = acc;
+    }
+}
+
+}  // namespace sps
+
+extern "C" long long sps_index_add_workspace_ints(int b, int n, int cols) {
+    return (long long)b * ((long long)(n + 1) + n + cols);
+}
+
+// grad_points (b, c, n) += scatter of grad_out (b, c, cols) by idx (b, cols), summed per target in ascending column
+// order (cols = npoints * nsample for group_points_grad, npoints for gather_points_grad).  work: device ints,
+// sps_index_add_workspace_ints(b, n, cols) of them.
+extern "C" int sps_index_add_deterministic(int b, int c, int n, int cols, const float *grad_out, const int *idx,
+                                           float *grad_points, int *work, sps_stream_t stream) {
+    using namespace sps;
+    if (b < 0 || c < 0 || n < 0 || cols < 0) return fail(SPS_ERR_INVALID, "index_add: bad shape b=%d c=%d n=%d cols=%d", b, c, n, cols);
+    if (b == 0 || c == 0 || cols == 0) return SPS_OK;
+    if (n == 0) return fail(SPS_ERR_INVALID, "index_add: indices into an empty tensor");
+    if (!grad_out || !idx || !grad_points || !work) return fail(SPS_ERR_INVALID, "index_add: null pointer");
+    if (b > 65535) return fail(SPS_ERR_INVALID, "index_add: batch %d exceeds the grid limit", b);
+    hipStream_t st = as_stream(stream);
+    int *offs = work, *cursor = work + (size_t)b * (n + 1), *list = cursor + (size_t)b * n;
+    if (hipMemsetAsync(offs, 0, sizeof(int) * (size_t)b * (n + 1), st) != hipSuccess) return fail(SPS_ERR_LAUNCH, "index_add: memset failed");
+    hipLaunchKernelGGL(ia_count_kernel, dim3(divup(cols, IA_THREADS), b), dim3(IA_THREADS), 0, st, n, cols, idx, offs);
+    hipLaunchKernelGGL(ia_scan_kernel, dim3(b), dim3(1024), 0, st, n, offs, cursor);
+    hipLaunchKernelGGL(ia_fill_kernel, dim3(divup(cols, IA_THREADS), b), dim3(IA_THREADS), 0, st, n, cols, idx, cursor, list);
+    hipLaunchKernelGGL(ia_sort_kernel, dim3(divup(n, IA_THREADS), b), dim3(IA_THREADS), 0, st, n, cols, offs, list);
+    hipLaunchKernelGGL(ia_sum_kernel, dim3(divup(n, IA_THREADS), b, divup(c, GG_CCHUNK)), dim3(IA_THREADS), 0, st, c, n, cols,
+                       grad_out, offs, list, grad_points);
+    return check_launch("index_add_deterministic");
+}

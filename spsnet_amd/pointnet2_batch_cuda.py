@@ -148,6 +148,20 @@ def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out_tensor, idx_te
     return 1
 
 
+def index_add_deterministic(grad_out, idx, grad_points):
+    """grad_points (B,C,N) += grad_out (B,C,cols) scattered by idx (B,cols) with every target summed in ascending column
+    order: the run-to-run reproducible form of group_points_grad / gather_points_grad (idx (B,M,ns) or (B,M) flattened)."""
+    B, C, N = grad_points.shape
+    cols = idx.numel() // max(B, 1)
+    g, i, o = _ptr(grad_out, F32, "grad_out"), _ptr(idx, I32, "idx"), _ptr(grad_points, F32, "grad_points")
+    _need(grad_out, B * C * cols, "grad_out")
+    work = torch.empty((int(_L.sps_index_add_workspace_ints(B, N, cols)),), dtype=I32, device=grad_out.device)
+    with _on(grad_out):
+        _lib.check(_L.sps_index_add_deterministic(B, C, N, cols, g, i, o, work.data_ptr(), _stream(grad_out)),
+                   "index_add_deterministic")
+    return grad_points
+
+
 def three_nn_wrapper(b, n, m, unknown_tensor, known_tensor, dist2_tensor, idx_tensor):
     """interpolate.cpp:21-30.  unknown (B,n,3), known (B,m,3) -> dist2, idx (B,n,3); returns None."""
     u, k = _ptr(unknown_tensor, F32, "unknown"), _ptr(known_tensor, F32, "known")

@@ -28,6 +28,16 @@ __all__ = [
 _FPS_TEMP_INIT = 1e10  # reference pointnet2_utils.py:26
 
 
+# Gradients of the gather / group ops: the reference scatters with atomicAdd (sum order unspecified, low bits vary from
+# run to run).  True, or torch.use_deterministic_algorithms(True), selects the fixed-order kernels instead
+# (csrc/group_gather.hip: sps_index_add_deterministic; bit-identical to a sequential CPU loop).
+DETERMINISTIC_BACKWARD = False
+
+
+def _deterministic():
+    return DETERMINISTIC_BACKWARD or torch.are_deterministic_algorithms_enabled()
+
+
 def _new(like: torch.Tensor, shape, dtype, zero=False):
     return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=like.device)
 
@@ -95,7 +105,10 @@ class GatherOperation(Function):
         batch, chans, n = ctx.src_shape
         grad_out = grad_out.contiguous()
         grad_features = _new(grad_out, (batch, chans, n), torch.float32, zero=True)
-        _ext.gather_points_grad_wrapper(batch, chans, n, idx.shape[1], grad_out, idx, grad_features)
+        if _deterministic():
+            _ext.index_add_deterministic(grad_out, idx, grad_features)
+        else:
+            _ext.gather_points_grad_wrapper(batch, chans, n, idx.shape[1], grad_out, idx, grad_features)
         return grad_features, None
 
 
@@ -177,7 +190,10 @@ class GroupingOperation(Function):
         batch, chans, m, ns = grad_out.shape
         grad_out = grad_out.contiguous()
         grad_features = _new(grad_out, (batch, chans, ctx.n), torch.float32, zero=True)
-        _ext.group_points_grad_wrapper(batch, chans, ctx.n, m, ns, grad_out, idx, grad_features)
+        if _deterministic():
+            _ext.index_add_deterministic(grad_out, idx, grad_features)
+        else:
+            _ext.group_points_grad_wrapper(batch, chans, ctx.n, m, ns, grad_out, idx, grad_features)
         return grad_features, None
 
 

@@ -825,3 +825,43 @@ def test_fps_large_scene_kernel(ext, G, oracle, N, m, kind):
         want, want_t = oracle.fps(xyz, m, return_temp=True)
         np.testing.assert_array_equal(got, want)
         np.testing.assert_array_equal(got_t, want_t)
+
+
+# ------------------------------------------------------------------ deterministic gradients
+@pytest.mark.parametrize("B,C,N,M,ns", [(2, 5, 700, 96, 16), (3, 67, 4096, 1024, 32), (1, 16, 300, 300, 1), (2, 8, 64, 512, 8)])
+def test_deterministic_group_and_gather_grads(ext, G, oracle, B, C, N, M, ns):
+    """sps_index_add_deterministic: the gradient of group_points / gather_points summed in ascending column order --
+    bit-identical to the oracle's sequential loop, identical from run to run, and within fp32 rounding of the atomic
+    kernels.  Includes heavily repeated targets (M*ns >> N)."""
+    from spsnet_amd import pointnet2_utils as U
+    rng = np.random.default_rng(B * 1000 + N)
+    if ns == 1:
+        idx = rng.integers(0, N, size=(B, M)).astype(np.int32)
+        go = rng.standard_normal((B, C, M)).astype(np.float32)
+        want = oracle.gather_points_grad(go, idx, N)
+    else:
+        idx = rng.integers(0, max(1, N // 4), size=(B, M, ns)).astype(np.int32)   # few targets, many hits each
+        go = rng.standard_normal((B, C, M, ns)).astype(np.float32)
+        want = oracle.group_points_grad(go, idx, N)
+    outs = []
+    for _ in range(2):
+        gp = torch.zeros((B, C, N), device="cuda")
+        ext.index_add_deterministic(G.t(go), G.t(idx), gp)
+        outs.append(G.n(gp))
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_array_equal(outs[0], want)
+    # through autograd, switched by the module flag
+    feats = torch.randn(B, C, N, device="cuda", requires_grad=True)
+    old = U.DETERMINISTIC_BACKWARD
+    try:
+        grads = []
+        for flag in (True, False):
+            U.DETERMINISTIC_BACKWARD = flag
+            feats.grad = None
+            out = U.gather_operation(feats, G.t(idx)) if ns == 1 else U.grouping_operation(feats, G.t(idx))
+            out.backward(G.t(go))
+            grads.append(G.n(feats.grad))
+    finally:
+        U.DETERMINISTIC_BACKWARD = old
+    np.testing.assert_array_equal(grads[0], want)
+    np.testing.assert_allclose(grads[1], want, rtol=1e-4, atol=1e-4)
