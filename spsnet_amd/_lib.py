@@ -59,7 +59,8 @@ _PROTOS = {
     "sps_sa_group_mlp_range": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _i, _i, _vp],
 }
-EXPORTS = ["sps_abi_version", "sps_last_error", "sps_opt_n_threads"] + list(_PROTOS)
+EXPORTS = ["sps_abi_version", "sps_last_error", "sps_opt_n_threads", "sps_fps_workspace_floats",
+           "sps_index_add_workspace_ints"] + list(_PROTOS)
 
 _lib = None
 
