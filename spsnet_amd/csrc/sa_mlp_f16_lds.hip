@@ -83,7 +83,7 @@ __device__ __forceinline__ void wait_vm() {
 
 // a.w1 = the concatenated fragment stream; a.ks1 = layer-1 k-steps of 32 grouped channels.
 template <int C1, int C2, int C3, int NT, int NS, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void sa_group_mlp_f16_lds_kernel(SaMlpArgs a) {
+__global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa_group_mlp_f16_lds_kernel(SaMlpArgs a) {
     constexpr int PIECES = 8 / WAVES;  // 1-KiB pieces of a chunk each wave fetches
     static_assert(WAVES == 4 || WAVES == 8, "4 waves x 2 pieces or 8 waves x 1 piece");
     constexpr int T1 = C1 / 16, T2 = C2 / 16, MT3 = C3 / 16;   // 16-row output tiles
@@ -400,8 +400,8 @@ int launch_sa_mlp_f16_lds(const SaMlpArgs &a, int c1, int c2, int nsample, hipSt
     if (c1 == C1 && c2 == C2 && a.c3 == C3 && nsample == NS) return launch_lds_variant<C1, C2, C3, NT, NS, W>(a, st);
     SPS_MLPL_CASE(64, 64, 128, 2, 16, 4)
     SPS_MLPL_CASE(64, 96, 128, 2, 32, 4)
-    SPS_MLPL_CASE(128, 128, 256, 1, 16, 8)
-    SPS_MLPL_CASE(128, 256, 256, 1, 32, 8)
+    SPS_MLPL_CASE(128, 128, 256, 1, 16, 4)
+    SPS_MLPL_CASE(128, 256, 256, 1, 32, 4)
     SPS_MLPL_CASE(256, 256, 512, 1, 16, 4)   // IA-SSD layer 5 [259,256,256,512]: 4 waves = 512 registers each
     SPS_MLPL_CASE(256, 512, 1024, 1, 32, 4)  // IA-SSD layer 5 [259,256,512,1024]
     SPS_MLPL_CASE(128, 128, 256, 1, 64, 8)   // nsample 64: a centroid spans four waves
