@@ -246,6 +246,22 @@ long long sps_index_add_workspace_ints(int b, int n, int cols);
 int sps_index_add_deterministic(int b, int c, int n, int cols, const float *grad_out, const int *idx, float *grad_points,
                                 int *work, sps_stream_t stream);
 
+/* DenseEdgeConv.forward (surface_feature.py:98-116) given the neighbour table of its radius query, as one kernel:
+ * x (b, n, d) point-major features, idx (b, n, k) from ball_query(radius, k, pos, pos) (:55, 84-89) ->
+ * out (b, n, d + 3*growth) = [max_k y3 | max_k y2 | max_k y1 | x], y1 = relu(W1 e + b1) over the edge features
+ * e = [x_i, x_j, x_j - x_i] (or x_j - x_i alone when relative_only, :71-80), y2 = relu(W2 [y1, x_i] + b2),
+ * y3 = W3 [y2, y1, x_i] + b3.  Built for the configuration the reference instantiates (FeatureExtraction defaults,
+ * :120-131: d = 24, k = 16, growth = 12, three FC layers, ReLU, max); weights in the fragment order of
+ * spsnet_amd/fused.py:pack_dense_edge_conv.  Exact fp32 (MFMA f32). */
+int sps_dense_edge_conv(int b, int n, int d, int k, int growth, int relative_only, const float *x, const int *idx,
+                        const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                        const float *b3, float *out, sps_stream_t stream);
+
+/* FCLayer (surface_feature.py:8-27) on point-major rows: out (rows, cout) = act(x (rows, cin) W^T + bias), W (cout, cin)
+ * as nn.Linear stores it, act = ReLU if relu != 0.  Built for cout = 24 (FeatureExtraction's conv_channels), cin <= 64. */
+int sps_linear_rows(long long rows, int cin, int cout, const float *x, const float *w, const float *bias, int relu,
+                    float *out, sps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

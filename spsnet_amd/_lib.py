@@ -50,6 +50,8 @@ _PROTOS = {
     "sps_sa_group_mlp_supported_stream": [_i, _i, _i, _i],
     "sps_fps_with_workspace": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_pointwise_mlp": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_dense_edge_conv": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_linear_rows": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "sps_sa_group_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                             _vp, _vp, _i, _i, _i, _vp, _vp],
     "sps_fps_publish": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],

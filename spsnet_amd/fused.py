@@ -338,3 +338,77 @@ def pointwise_tail(agg, head, pooled):
                                     torch.cuda.current_stream(pooled.device).cuda_stream), "pointwise_mlp")
     y1._sps_nc = y1t
     return y1, y3
+
+
+# ---- DenseEdgeConv / FeatureExtraction (surface_feature.py:45-187) ------------------------------------------------------
+class PackedEdgeConv:
+    __slots__ = ("key", "w1", "b1", "w2", "b2", "w3", "b3", "relative")
+
+
+def _dec_frag(w, cols):
+    """w (12, C) -> (len(cols), 64): element [ks][16 q + i] = w[i][cols[ks][q]] (rows >= 12 and column -1 read as zero)."""
+    g = w.shape[0]
+    wp = torch.zeros((16, w.shape[1] + 1), dtype=torch.float32, device=w.device)
+    wp[:g, :-1] = w
+    col = torch.as_tensor(cols, dtype=torch.long, device=w.device)          # (KS, 4), -1 -> the zero column
+    col = torch.where(col < 0, torch.full_like(col, w.shape[1]), col)
+    return wp[:, col].permute(1, 2, 0).reshape(len(cols), 64).contiguous()  # (16, KS, 4) -> (KS, 4, 16)
+
+
+def dense_edge_conv_supported(conv):
+    return (conv.in_channels == 24 and conv.knn == 16 and conv.growth_rate == 12 and conv.num_fc_layers == 3
+            and conv.aggr.oper == 'max' and isinstance(conv.layer_first.activation, nn.ReLU)
+            and isinstance(conv.layers[0].activation, nn.ReLU) and isinstance(conv.layer_last.activation, nn.Identity)
+            and all(l.linear.bias is not None for l in (conv.layer_first, conv.layers[0], conv.layer_last)))
+
+
+def pack_dense_edge_conv(conv):
+    """Weights of a DenseEdgeConv in the fragment order of csrc/dense_edge_conv.hip: input channel 6q + j of the 24 wide
+    blocks sits in k-slot q of k-step j; the 12 activation channels of a previous layer sit as 4q + r (q < 3)."""
+    lins = (conv.layer_first.linear, conv.layers[0].linear, conv.layer_last.linear)
+    key = tuple((t.data_ptr(), t._version) for l in lins for t in (l.weight, l.bias))
+    packed = getattr(conv, "_sps_packed", None)
+    if packed is not None and packed.key == key:
+        return packed
+    with torch.no_grad():
+        wide = lambda base: [[base + 6 * q + j for q in range(4)] for j in range(6)]
+        act = lambda base: [[base + 4 * q + r if q < 3 else -1 for q in range(4)] for r in range(4)]
+        packed = PackedEdgeConv()
+        packed.key, packed.relative = key, bool(conv.relative_feat_only)
+        w1, w2, w3 = (l.weight.detach().float() for l in lins)
+        packed.w1 = _dec_frag(w1, wide(0) if packed.relative else wide(0) + wide(24) + wide(48))
+        packed.w2 = _dec_frag(w2, act(0) + wide(12))
+        packed.w3 = _dec_frag(w3, act(0) + act(12) + wide(24))
+        packed.b1, packed.b2, packed.b3 = (_pad_bias(l.bias.detach().float(), 16) for l in lins)
+    object.__setattr__(conv, "_sps_packed", packed)
+    return packed
+
+
+def dense_edge_conv(conv, x, idx):
+    """x (B, N, 24) fp32, idx (B, N, 16) int32 -> (B, N, 60); one launch (sps_dense_edge_conv)."""
+    packed = pack_dense_edge_conv(conv)
+    B, N, d = x.shape
+    x = x.contiguous()
+    out = torch.empty((B, N, conv.out_channels), dtype=torch.float32, device=x.device)
+    _lib.check(_L.sps_dense_edge_conv(B, N, d, idx.shape[2], conv.growth_rate, int(packed.relative), x.data_ptr(),
+                                      idx.data_ptr(), packed.w1.data_ptr(), packed.b1.data_ptr(), packed.w2.data_ptr(),
+                                      packed.b2.data_ptr(), packed.w3.data_ptr(), packed.b3.data_ptr(), out.data_ptr(),
+                                      torch.cuda.current_stream(x.device).cuda_stream), "dense_edge_conv")
+    return out
+
+
+def linear_rows_supported(fc):
+    return (fc.linear.out_features == 24 and fc.linear.in_features <= 64
+            and isinstance(fc.activation, (nn.ReLU, nn.Identity)))
+
+
+def linear_rows(fc, x):
+    """FCLayer on point-major rows: x (..., cin) -> (..., 24); one launch (sps_linear_rows)."""
+    lin = fc.linear
+    x = x.contiguous()
+    rows = x.numel() // x.shape[-1]
+    out = torch.empty(x.shape[:-1] + (lin.out_features,), dtype=torch.float32, device=x.device)
+    _lib.check(_L.sps_linear_rows(rows, lin.in_features, lin.out_features, x.data_ptr(), lin.weight.data_ptr(),
+                                  0 if lin.bias is None else lin.bias.data_ptr(), int(isinstance(fc.activation, nn.ReLU)),
+                                  out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream), "linear_rows")
+    return out

@@ -11,6 +11,11 @@ points in index order inside radius 0.8 (QueryAndGroup(radius, knn, use_xyz=Fals
 Reference quirk kept on purpose: with dynamic_graph=True (the default) the d-channel feature tensor is
 passed as `pos`, and the ball query reads its memory as packed (x,y,z) triples (:167-170 with
 ball_query_gpu.cu:17-19) -- the build hands the same flat buffer to the same indexing, so results agree.
+
+Inference (no gradient needed, CUDA fp32, the configuration FeatureExtraction instantiates) takes two kernels per
+convolution: the radius query and `sps_dense_edge_conv` (csrc/dense_edge_conv.hip), which keeps the edge features and
+the three dense activations in registers; the transforms run on `sps_linear_rows`.  Training keeps the
+differentiable op-by-op form below.
 """
 import torch
 import torch.nn as nn
@@ -86,7 +91,24 @@ class DenseEdgeConv(nn.Module):
             return neigh - centre
         return torch.cat([centre, neigh, neigh - centre], dim=3)
 
-    def forward(self, x, pos):
+    def _fused(self, x, pos):
+        if not x.is_cuda or x.dtype != torch.float32 or pos.dtype != torch.float32:
+            return False
+        if pointnet2_utils._needs_grad(x, pos, *self.parameters()):
+            return False
+        from . import fused
+        return fused.dense_edge_conv_supported(self)
+
+    def neighbours(self, pos):
+        """(B,N,K) int32 table of the radius query the grouper runs (pos read as packed xyz triples)."""
+        pos = pos.contiguous()
+        return pointnet2_utils.ball_query(self.group.radius, self.knn, pos, pos)
+
+    def forward(self, x, pos, idx=None):
+        """`idx` (optional) = a neighbour table already computed for the same `pos` (static graphs share one)."""
+        if self._fused(x, pos):
+            from . import fused
+            return fused.dense_edge_conv(self, x, self.neighbours(pos) if idx is None else idx)
         y = torch.cat([self.layer_first(self.get_edge_feature(x, pos)),
                        x.unsqueeze(-2).repeat(1, 1, self.knn, 1)], dim=-1)
         for layer in self.layers:
@@ -116,16 +138,32 @@ class FeatureExtraction(nn.Module):
     def out_channels(self):
         return self.convs[-1].out_channels
 
+    @staticmethod
+    def _transform(fc, x):
+        if x.is_cuda and x.dtype == torch.float32 and not pointnet2_utils._needs_grad(x, *fc.parameters()):
+            from . import fused
+            if fused.linear_rows_supported(fc):
+                return fused.linear_rows(fc, x)
+        return fc(x)
+
     def dynamic_graph_forward(self, x):
         for transform, conv in zip(self.transforms, self.convs):
-            x = transform(x)
+            x = self._transform(transform, x)
             x = conv(x, x)
         return x
 
     def static_graph_forward(self, pos):
         x = pos
+        idx = None
         for transform, conv in zip(self.transforms, self.convs):
-            x = conv(transform(x), pos)
+            x = self._transform(transform, x)
+            if conv._fused(x, pos):
+                # every convolution queries the same positions with the same radius and K: one table serves all
+                if idx is None:
+                    idx = conv.neighbours(pos)
+                x = conv(x, pos, idx)
+            else:
+                x = conv(x, pos)
         return x
 
     def forward(self, x):

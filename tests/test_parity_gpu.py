@@ -569,21 +569,47 @@ def test_fps_pruned_degenerate_clouds(ext, G, oracle):
         np.testing.assert_array_equal(got_t, want_t)
 
 
+@pytest.mark.parametrize("path", ["fused", "op_by_op"])
 @pytest.mark.parametrize("mode", ["static", "dynamic"])
-def test_golden_surface_feature(ext, G, dev, mode):
+def test_golden_surface_feature(ext, G, dev, mode, path):
     """FeatureExtraction / DenseEdgeConv (surface_feature.py:45-187) against the reference's output, including
-    the dynamic-graph quirk where a d-channel feature tensor is read as packed xyz triples."""
+    the dynamic-graph quirk where a d-channel feature tensor is read as packed xyz triples.  `fused` = the inference
+    kernels (sps_linear_rows + sps_dense_edge_conv), `op_by_op` = the differentiable form (gradients enabled)."""
     from spsnet_amd import surface_feature as SF
     g = np.load(os.path.join(GOLD, "surface_feature.npz"))
     net = SF.FeatureExtraction(dynamic_graph=(mode == "dynamic"))
     pre = f"sd_{mode}."
     net.load_state_dict({k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}, strict=True)
     net = net.to(dev).eval()
-    with torch.no_grad():
-        out = net(G.t(g["xyz"]))
+    x = G.t(g["xyz"])
+    if path == "fused":
+        with torch.no_grad():
+            assert all(c._fused(torch.empty(1, 1, 24, device=dev), x) for c in net.convs)
+            out = net(x)
+    else:
+        out = net(x)
+        assert out.requires_grad
     ref = g["out_" + mode]
     assert out.shape == ref.shape
-    assert float(np.abs(G.n(out) - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+    assert float(np.abs(G.n(out.detach()) - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("mode", ["static", "dynamic"])
+def test_surface_feature_fused_matches_op_by_op(ext, G, dev, mode):
+    """The fused DenseEdgeConv kernels against the op-by-op form on LiDAR-like scenes (B=2, N=8192: many full and many
+    empty balls), random weights; 1e-4 relative to the largest feature."""
+    from spsnet_amd import scenes, surface_feature as SF
+    torch.manual_seed(5)
+    net = SF.FeatureExtraction(dynamic_graph=(mode == "dynamic")).to(dev).eval()
+    xyz, _ = scenes.make_batch("kitti-lidar-v1", 2, 8192, seed0=77)
+    x = G.t(xyz)
+    with torch.no_grad():
+        fused_out = net(x)
+    plain = net(x)
+    assert plain.requires_grad and not fused_out.requires_grad
+    a, b = G.n(fused_out), G.n(plain.detach())
+    assert a.shape == (2, 8192, 60)
+    assert float(np.abs(a - b).max()) <= 1e-4 * max(1.0, float(np.abs(b).max()))
 
 
 # ------------------------------------------------------------------ FPS of an FPS-ordered cloud (verified shortcut)
