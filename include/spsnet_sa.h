@@ -262,6 +262,16 @@ int sps_dense_edge_conv(int b, int n, int d, int k, int growth, int relative_onl
 int sps_linear_rows(long long rows, int cin, int cout, const float *x, const float *w, const float *bias, int relu,
                     float *out, sps_stream_t stream);
 
+/* ball_query_kernel_fast / ball_query_dilated_kernel_fast (ball_query_gpu.cu:9-45, 70-117) through a cell grid: the same
+ * rows as sps_ball_query_kernel_launcher_fast / ..._dilated_..., bit for bit, but only the points of the cells a group
+ * of 64 neighbouring centroids can reach are tested (visited in ascending index through an LDS bitmap), instead of
+ * all n.  work = device ints, sps_ball_query_grid_workspace_ints(b, n, m) of them (0 = size not supported: the call then
+ * runs the scan).  dilated != 0: hit if d2 == 0 or min_radius^2 <= d2 < max_radius^2.  fill_empty != 0: rows of empty
+ * balls are written as zeros instead of being left to the caller (pointnet2_utils.py:246). */
+long long sps_ball_query_grid_workspace_ints(int b, int n, int m);
+int sps_ball_query_grid(int b, int n, int m, float max_radius, float min_radius, int dilated, int nsample, int fill_empty,
+                        const float *new_xyz, const float *xyz, int *idx, int *work, sps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,7 @@ _PROTOS = {
     "sps_sa_group_mlp_supported_stream": [_i, _i, _i, _i],
     "sps_fps_with_workspace": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_pointwise_mlp": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_ball_query_grid": [_i, _i, _i, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_dense_edge_conv": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_linear_rows": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "sps_sa_group_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
@@ -62,7 +63,7 @@ _PROTOS = {
                                _vp, _vp, _i, _i, _vp],
 }
 EXPORTS = ["sps_abi_version", "sps_last_error", "sps_opt_n_threads", "sps_fps_workspace_floats",
-           "sps_index_add_workspace_ints"] + list(_PROTOS)
+           "sps_index_add_workspace_ints", "sps_ball_query_grid_workspace_ints"] + list(_PROTOS)
 
 _lib = None
 
@@ -90,6 +91,8 @@ def load():
     lib.sps_fps_workspace_floats.restype = ctypes.c_longlong
     lib.sps_fps_workspace_floats.argtypes = [_i]
     lib.sps_index_add_workspace_ints.restype = ctypes.c_longlong
+    lib.sps_ball_query_grid_workspace_ints.argtypes = [_i, _i, _i]
+    lib.sps_ball_query_grid_workspace_ints.restype = ctypes.c_longlong
     lib.sps_index_add_workspace_ints.argtypes = [_i, _i, _i]
     for name, args in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

@@ -3,15 +3,27 @@
 //
 // The reference materialises, per convolution, the grouped tensor (B, d, N, K), its (B, N, K, 3d) edge features and
 // three concatenated activations (B, N, K, d + i*c) through ~15 cuBLAS/elementwise launches; at B x N = 8 x 16384,
-// K = 16, d = 24 that is ~1.3 GB of traffic per convolution.  Here a wave owns one centre point: its K = 16
-// neighbours are the 16 columns of v_mfma_f32_16x16x4_f32, the growth-rate (12) output channels are the rows (padded
-// to 16), every activation stays in registers (a D fragment of layer i is directly the B operand of layer i+1: lane
-// (q, col) holds rows 4q..4q+3 of column col, which is k-slot q of k-step r for r = 0..3), and the only HBM traffic
-// is the 96-byte feature rows read (L2-resident) and the 240-byte output row written.
+// K = 16, d = 24 that is ~1.3 GB of traffic per convolution.  Here a wave owns a tile of 16 centre points and every
+// activation stays in registers:
+//   * the part of each layer that depends on the CENTRE only (W1[:, :d] x_i, W2[:, c:] x_i, W3[:, 2c:] x_i -- the edge
+//     feature and both dense concatenations repeat x_i for all K neighbours) is computed once per centre, for the 16
+//     centres of the tile at a time: they are the 16 columns of v_mfma_f32_16x16x4_f32, the three 12-row blocks (padded
+//     to 16) are three output tiles;
+//   * then, centre by centre, its K = 16 neighbours are the 16 columns: the centre terms enter as the accumulator (a row
+//     broadcast of the centre's column), the neighbour-dependent parts follow as MFMAs; a D fragment of layer i
+//     is directly the B operand of layer i+1 (lane (q, col) holds rows 4q..4q+3 of column col = k-slot q of k-steps
+//     r = 0..3), and the max over K is a DPP row reduction.
+// 18 MFMAs per centre instead of the 42 (30 for the first, difference-only convolution) of a per-centre GEMM chain;
+// the only HBM traffic is the 96-byte feature rows (L2-resident), the neighbour table and the 240-byte output row.
 //
-// Exact fp32 (MFMA fp32 = an fmaf chain per output), weights live in registers for the whole kernel (42 VGPRs).
-// Channel -> k-slot mapping of the d = 24 input channels: lane q of k-step j carries channel 6q + j, so that a lane
-// loads 24 contiguous bytes of a feature row.  The host packs the weights to match (fused.py: pack_dense_edge_conv).
+// fp32 throughout (MFMA fp32 = an fmaf chain per output).  The first layer of a full convolution is evaluated as
+// W1a x_i + W1b x_j + W1c (x_j - x_i) = (W1a - W1c) x_i + (W1b + W1c) x_j with the two weight sums formed on the host in
+// fp32 -- a third fewer MFMAs, and a rounding difference of the order of eps |W1c| |x| (measured < 2e-6 of the output
+// range on the golden network).  The difference-only first convolution keeps the reference's rounded x_j - x_i: its
+// inputs are raw coordinates, where the merged form would cancel.  Channel -> k-slot mapping of the d = 24 input channels: lane q of k-step j carries channel 6q + j, so
+// that a lane loads 24 contiguous bytes of a feature row.  The host packs the weights to match (fused.py:
+// pack_dense_edge_conv): w1 = [centre' | neighbour'] k-steps (the difference block alone when relative_only),
+// w2 = [y1 (4) | centre (6)], w3 = [y2 (4) | y1 (4) | centre (6)].
 //
 // Output row (reference order, surface_feature.py:98-116): [max_k y3 (12) | max_k y2 (12) | max_k y1 (12) | x (24)].
 #include "sps_common.h"
@@ -21,7 +33,7 @@ namespace sps {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int DEC_D = 24, DEC_K = 16, DEC_G = 12, DEC_OUT = DEC_D + 3 * DEC_G;
+constexpr int DEC_D = 24, DEC_K = 16, DEC_G = 12, DEC_OUT = DEC_D + 3 * DEC_G, DEC_TILE = 16;
 
 struct DecArgs {
     int n;
@@ -34,92 +46,160 @@ struct DecArgs {
 
 __device__ __forceinline__ f32x4 dec_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// max over the 16 lanes of a DPP row, valid in every lane (row rotations 8, 4, 2, 1)
-__device__ __forceinline__ float row_allmax(float v) {
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xF, 0xF, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xF, 0xF, false)));
-    return v;
+// y[r] = max over the 16 lanes of its DPP row, in every lane, for the three activations at once: one v_max_f32_dpp per
+// value and rotation (8, 4, 2, 1).  hipcc splits update_dpp + fmaxf into v_mov_dpp + v_max (and a v_mov for `old`), i.e.
+// three VALU slots per step; written out, the twelve independent chains also cover each other's DPP read-after-write
+// wait states (the leading s_nop covers the first).
+#define DEC_ROR_STEP(ROT)                                                                                            \
+    asm volatile("s_nop 1\n"                                                                                         \
+                 "v_max_f32_dpp %0, %0, %0 row_ror:" #ROT " row_mask:0xf bank_mask:0xf\n"                             \
+                 "v_max_f32_dpp %1, %1, %1 row_ror:" #ROT " row_mask:0xf bank_mask:0xf\n"                             \
+                 "v_max_f32_dpp %2, %2, %2 row_ror:" #ROT " row_mask:0xf bank_mask:0xf\n"                             \
+                 "v_max_f32_dpp %3, %3, %3 row_ror:" #ROT " row_mask:0xf bank_mask:0xf\n"                             \
+                 "v_max_f32_dpp %4, %4, %4 row_ror:" #ROT " row_mask:0xf bank_mask:0xf\n"                             \
+                 "v_max_f32_dpp %5, %5, %5 row_ror:" #ROT " row_mask:0xf bank_mask:0xf\n"                             \
+                 "v_max_f32_dpp %6, %6, %6 row_ror:" #ROT " row_mask:0xf bank_mask:0xf\n"                             \
+                 "v_max_f32_dpp %7, %7, %7 row_ror:" #ROT " row_mask:0xf bank_mask:0xf\n"                             \
+                 "v_max_f32_dpp %8, %8, %8 row_ror:" #ROT " row_mask:0xf bank_mask:0xf\n"                             \
+                 "v_max_f32_dpp %9, %9, %9 row_ror:" #ROT " row_mask:0xf bank_mask:0xf\n"                             \
+                 "v_max_f32_dpp %10, %10, %10 row_ror:" #ROT " row_mask:0xf bank_mask:0xf\n"                          \
+                 "v_max_f32_dpp %11, %11, %11 row_ror:" #ROT " row_mask:0xf bank_mask:0xf\n"                          \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(c0), "+v"(c1),    \
+                   "+v"(c2), "+v"(c3))
+__device__ __forceinline__ void row_allmax3(f32x4 &y1, f32x4 &y2, f32x4 &y3) {
+    float a0 = y1[0], a1 = y1[1], a2 = y1[2], a3 = y1[3], b0 = y2[0], b1 = y2[1], b2 = y2[2], b3 = y2[3], c0 = y3[0],
+          c1 = y3[1], c2 = y3[2], c3 = y3[3];
+    DEC_ROR_STEP(8);
+    DEC_ROR_STEP(4);
+    DEC_ROR_STEP(2);
+    DEC_ROR_STEP(1);
+    y1 = (f32x4){a0, a1, a2, a3};
+    y2 = (f32x4){b0, b1, b2, b3};
+    y3 = (f32x4){c0, c1, c2, c3};
 }
+#undef DEC_ROR_STEP
+__device__ __forceinline__ void dec_load6(const float *row, float (&v)[6]) {
+    const f32x2 *p = reinterpret_cast<const f32x2 *>(row);
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+        const f32x2 u = p[h];
+        v[2 * h] = u[0];
+        v[2 * h + 1] = u[1];
+    }
+}
+// lane `src` (0..15, wave-uniform) of every 16-lane row, broadcast to the row
+__device__ __forceinline__ float row_pick(float v, int addr) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); }
 
 template <bool REL>
-__global__ __launch_bounds__(256) void dense_edge_conv_kernel(DecArgs a) {
-    constexpr int KS1 = REL ? 6 : 18;
+__global__ __launch_bounds__(256, 4) void dense_edge_conv_kernel(DecArgs a) {
+    constexpr int CEN = REL ? 0 : 6;      // k-steps of w1 that multiply the centre
     const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
-    float w1r[KS1], w2r[10], w3r[14];
+    // weights of the per-centre steps live in registers; those of the per-tile centre terms (and the biases) are
+    // re-read from LDS once per tile, which keeps the kernel at four waves per SIMD
+    __shared__ float cw[18 + 12][64];
+    if (threadIdx.x < 64) {
 #pragma unroll
-    for (int k = 0; k < KS1; ++k) w1r[k] = a.w1[k * 64 + lane];
-#pragma unroll
-    for (int k = 0; k < 10; ++k) w2r[k] = a.w2[k * 64 + lane];
-#pragma unroll
-    for (int k = 0; k < 14; ++k) w3r[k] = a.w3[k * 64 + lane];
-    const f32x4 b1v = *reinterpret_cast<const f32x4 *>(a.b1 + 4 * q);
-    const f32x4 b2v = *reinterpret_cast<const f32x4 *>(a.b2 + 4 * q);
-    const f32x4 b3v = *reinterpret_cast<const f32x4 *>(a.b3 + 4 * q);
-
-    const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
-    for (long long p = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); p < a.units; p += nwaves) {
-        const long long scene = p / a.n;
-        const int nb = a.idx[p * DEC_K + c];
-        const f32x2 *xcp = reinterpret_cast<const f32x2 *>(a.x + p * DEC_D + 6 * q);
-        const f32x2 *xnp = reinterpret_cast<const f32x2 *>(a.x + (scene * a.n + nb) * DEC_D + 6 * q);
-        float xc[6], xn[6];
-#pragma unroll
-        for (int h = 0; h < 3; ++h) {
-            const f32x2 u = xcp[h], v = xnp[h];
-            xc[2 * h] = u[0]; xc[2 * h + 1] = u[1];
-            xn[2 * h] = v[0]; xn[2 * h + 1] = v[1];
+        for (int j = 0; j < 6; ++j) {
+            cw[j][lane] = REL ? 0.f : a.w1[j * 64 + lane];
+            cw[6 + j][lane] = a.w2[(4 + j) * 64 + lane];
+            cw[12 + j][lane] = a.w3[(8 + j) * 64 + lane];
         }
-        // ---- layer_first: [centre | neighbour | neighbour - centre] (or the difference only) -> 12, ReLU ----
-        f32x4 y1 = b1v;
-        if (!REL) {
-#pragma unroll
-            for (int j = 0; j < 6; ++j) y1 = dec_mfma(w1r[j], xc[j], y1);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) y1 = dec_mfma(w1r[6 + j], xn[j], y1);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) y1 = dec_mfma(w1r[12 + j], xn[j] - xc[j], y1);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 6; ++j) y1 = dec_mfma(w1r[j], xn[j] - xc[j], y1);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y1[r] = fmaxf(y1[r], 0.f);
-        // ---- layers.0: [y1 | centre] -> 12, ReLU ----
-        f32x4 y2 = b2v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y2 = dec_mfma(w2r[r], y1[r], y2);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) y2 = dec_mfma(w2r[4 + j], xc[j], y2);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y2[r] = fmaxf(y2[r], 0.f);
-        // ---- layer_last: [y2 | y1 | centre] -> 12, no activation ----
-        f32x4 y3 = b3v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y3 = dec_mfma(w3r[r], y2[r], y3);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y3 = dec_mfma(w3r[4 + r], y1[r], y3);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) y3 = dec_mfma(w3r[8 + j], xc[j], y3);
-        // ---- max over the K columns; lane (q, c) with c < 3 stores segment c of rows 4q..4q+3 ----
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            y1[r] = row_allmax(y1[r]);
-            y2[r] = row_allmax(y2[r]);
-            y3[r] = row_allmax(y3[r]);
+            cw[18 + r][lane] = a.b1[4 * q + r];
+            cw[22 + r][lane] = a.b2[4 * q + r];
+            cw[26 + r][lane] = a.b3[4 * q + r];
         }
-        float *o = a.out + p * DEC_OUT;
-        if (q < 3) {
-            if (c == 0) *reinterpret_cast<f32x4 *>(o + 4 * q) = y3;
-            if (c == 1) *reinterpret_cast<f32x4 *>(o + DEC_G + 4 * q) = y2;
-            if (c == 2) *reinterpret_cast<f32x4 *>(o + 2 * DEC_G + 4 * q) = y1;
+    }
+    float w1x[6], w2y[4], w3y[8];  // w1x multiplies x_j (merged blocks) or, for the difference-only layer, x_j - x_i
+#pragma unroll
+    for (int j = 0; j < 6; ++j) w1x[j] = a.w1[(CEN + j) * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w2y[r] = a.w2[r * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) w3y[r] = a.w3[r * 64 + lane];
+    __syncthreads();
+
+    const long long tiles = (a.units + DEC_TILE - 1) / DEC_TILE;
+    const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+    const long long last = a.units - 1;
+    for (long long tile = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < tiles; tile += nwaves) {
+        const long long p0 = tile * DEC_TILE;
+        const int count = (a.units - p0 < DEC_TILE) ? (int)(a.units - p0) : DEC_TILE;
+        const long long pc = (p0 + c < last) ? p0 + c : last;  // column c's centre (clamped in a short tile)
+        float xc[6];
+        dec_load6(a.x + pc * DEC_D + 6 * q, xc);
+        const int srow = (int)((pc / a.n) * a.n);  // first row of that centre's scene
+        // ---- centre terms of the three layers for the 16 centres of the tile: column c = centre c ----
+        f32x4 t0, t1, t2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            t0[r] = cw[18 + r][lane];
+            t1[r] = cw[22 + r][lane];
+            t2[r] = cw[26 + r][lane];
         }
-        if (c >= 3 && c < 6) {
-            f32x2 v;
-            v[0] = xc[2 * (c - 3)];
-            v[1] = xc[2 * (c - 3) + 1];
-            *reinterpret_cast<f32x2 *>(o + 3 * DEC_G + 6 * q + 2 * (c - 3)) = v;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            if (!REL) t0 = dec_mfma(cw[j][lane], xc[j], t0);
+            t1 = dec_mfma(cw[6 + j][lane], xc[j], t1);
+            t2 = dec_mfma(cw[12 + j][lane], xc[j], t2);
+        }
+        // the centre's own channels are the tail of its output row
+        if (p0 + c < a.units) {
+            f32x2 *o = reinterpret_cast<f32x2 *>(a.out + (p0 + c) * DEC_OUT + 3 * DEC_G + 6 * q);
+#pragma unroll
+            for (int h = 0; h < 3; ++h) o[h] = (f32x2){xc[2 * h], xc[2 * h + 1]};
+        }
+        // ---- centre by centre; the neighbour table runs two centres ahead, the neighbour rows one ----
+        const int *ip = a.idx + p0 * DEC_K + c;
+        int nb1 = ip[(count > 1 ? 1 : 0) * DEC_K];
+        float xn[6];
+        dec_load6(a.x + ((long long)__builtin_amdgcn_readlane(srow, 0) + ip[0]) * DEC_D + 6 * q, xn);
+        for (int cc = 0; cc < count; ++cc) {
+            const int c1 = (cc + 1 < count) ? cc + 1 : cc, c2 = (cc + 2 < count) ? cc + 2 : c1;
+            const int nb2 = ip[c2 * DEC_K];
+            float xnext[6];
+            dec_load6(a.x + ((long long)__builtin_amdgcn_readlane(srow, c1) + nb1) * DEC_D + 6 * q, xnext);
+            const int pick = ((lane & 48) | cc) << 2;
+            if (REL) {  // the reference's rounded difference x_j - x_i
+#pragma unroll
+                for (int j = 0; j < 6; ++j) xn[j] -= row_pick(xc[j], pick);
+            }
+            // ---- layer_first ----
+            f32x4 y1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y1[r] = row_pick(t0[r], pick);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) y1 = dec_mfma(w1x[j], xn[j], y1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y1[r] = fmaxf(y1[r], 0.f);
+            // ---- layers.0: [y1 | centre] ----
+            f32x4 y2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y2[r] = row_pick(t1[r], pick);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y2 = dec_mfma(w2y[r], y1[r], y2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y2[r] = fmaxf(y2[r], 0.f);
+            // ---- layer_last: [y2 | y1 | centre], no activation ----
+            f32x4 y3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y3[r] = row_pick(t2[r], pick);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y3 = dec_mfma(w3y[r], y2[r], y3);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y3 = dec_mfma(w3y[4 + r], y1[r], y3);
+            // ---- max over the K columns; three lanes of each row q < 3 store rows 4q..4q+3 of one segment each ----
+            row_allmax3(y1, y2, y3);
+            float *o = a.out + (p0 + cc) * DEC_OUT + 4 * q;
+            if (q < 3) {
+                if (c == 0) *reinterpret_cast<f32x4 *>(o) = y3;
+                if (c == 1) *reinterpret_cast<f32x4 *>(o + DEC_G) = y2;
+                if (c == 2) *reinterpret_cast<f32x4 *>(o + 2 * DEC_G) = y1;
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) xn[j] = xnext[j];
+            nb1 = nb2;
         }
     }
 }
@@ -175,8 +255,8 @@ extern "C" int sps_dense_edge_conv(int b, int n, int d, int k, int growth, int r
     DecArgs a;
     a.n = n; a.units = (long long)b * n; a.x = x; a.idx = idx;
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.out = out;
-    const long long want = (a.units + 3) / 4;
-    const int grid = (int)(want < 256 * 16 ? want : 256 * 16);
+    const long long want = ((a.units + DEC_TILE - 1) / DEC_TILE + 3) / 4;  // 4 waves per workgroup, one tile per wave and trip
+    const int grid = (int)(want < 256 * 8 ? want : 256 * 8);
     if (relative_only) hipLaunchKernelGGL(dense_edge_conv_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), a);
     else hipLaunchKernelGGL(dense_edge_conv_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), a);
     return check_launch("dense_edge_conv_kernel");

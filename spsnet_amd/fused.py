@@ -376,7 +376,11 @@ def pack_dense_edge_conv(conv):
         packed = PackedEdgeConv()
         packed.key, packed.relative = key, bool(conv.relative_feat_only)
         w1, w2, w3 = (l.weight.detach().float() for l in lins)
-        packed.w1 = _dec_frag(w1, wide(0) if packed.relative else wide(0) + wide(24) + wide(48))
+        if packed.relative:
+            packed.w1 = _dec_frag(w1, wide(0))
+        else:  # [x_i | x_j | x_j - x_i] -> [(W1a - W1c) x_i | (W1b + W1c) x_j]
+            merged = torch.cat([w1[:, 0:24] - w1[:, 48:72], w1[:, 24:48] + w1[:, 48:72]], dim=1)
+            packed.w1 = _dec_frag(merged, wide(0) + wide(24))
         packed.w2 = _dec_frag(w2, act(0) + wide(12))
         packed.w3 = _dec_frag(w3, act(0) + act(12) + wide(24))
         packed.b1, packed.b2, packed.b3 = (_pad_bias(l.bias.detach().float(), 16) for l in lins)

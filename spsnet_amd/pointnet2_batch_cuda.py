@@ -108,13 +108,30 @@ def gather_points_grad_wrapper(b, c, n, npoints, grad_out_tensor, idx_tensor, gr
     return 1
 
 
+# Launches with at least this many points AND centroids per scene go through the cell grid (csrc/ball_query_grid.hip:
+# same rows, far fewer pair tests); smaller ones are cheaper on the plain scan.  (0, 0) = always, None = never.
+BQ_GRID_MIN = (4096, 4096)
+
+
+def _grid_workspace(b, n, m, like):
+    if BQ_GRID_MIN is None or n < BQ_GRID_MIN[0] or m < BQ_GRID_MIN[1]:
+        return None
+    ints = _L.sps_ball_query_grid_workspace_ints(b, n, m)
+    return torch.empty(ints, dtype=I32, device=like.device) if ints > 0 else None
+
+
 def ball_query_wrapper(b, n, m, radius, nsample, new_xyz_tensor, xyz_tensor, idx_tensor):
     """ball_query.cpp:32-43.  new_xyz (B,M,3), xyz (B,N,3), idx (B,M,nsample) pre-zeroed -> 1."""
     q, p, i = _ptr(new_xyz_tensor, F32, "new_xyz"), _ptr(xyz_tensor, F32, "xyz"), _ptr(idx_tensor, I32, "idx")
     _need(new_xyz_tensor, b * m * 3, "new_xyz"); _need(xyz_tensor, b * n * 3, "xyz"); _need(idx_tensor, b * m * nsample, "idx")
     with _on(xyz_tensor):
-        _lib.check(_L.sps_ball_query_kernel_launcher_fast(b, n, m, radius, nsample, q, p, i, _stream(xyz_tensor)),
-                   "ball_query")
+        work = _grid_workspace(b, n, m, xyz_tensor)
+        if work is not None:
+            _lib.check(_L.sps_ball_query_grid(b, n, m, radius, 0.0, 0, nsample, 0, q, p, i, work.data_ptr(),
+                                              _stream(xyz_tensor)), "ball_query_grid")
+        else:
+            _lib.check(_L.sps_ball_query_kernel_launcher_fast(b, n, m, radius, nsample, q, p, i, _stream(xyz_tensor)),
+                       "ball_query")
     return 1
 
 
@@ -123,8 +140,13 @@ def ball_query_dilated_wrapper(b, n, m, max_radius, min_radius, nsample, new_xyz
     q, p, i = _ptr(new_xyz_tensor, F32, "new_xyz"), _ptr(xyz_tensor, F32, "xyz"), _ptr(idx_tensor, I32, "idx")
     _need(new_xyz_tensor, b * m * 3, "new_xyz"); _need(xyz_tensor, b * n * 3, "xyz"); _need(idx_tensor, b * m * nsample, "idx")
     with _on(xyz_tensor):
-        _lib.check(_L.sps_ball_query_dilated_kernel_launcher_fast(b, n, m, max_radius, min_radius, nsample, q, p, i,
-                                                                  _stream(xyz_tensor)), "ball_query_dilated")
+        work = _grid_workspace(b, n, m, xyz_tensor)
+        if work is not None:
+            _lib.check(_L.sps_ball_query_grid(b, n, m, max_radius, min_radius, 1, nsample, 0, q, p, i, work.data_ptr(),
+                                              _stream(xyz_tensor)), "ball_query_grid")
+        else:
+            _lib.check(_L.sps_ball_query_dilated_kernel_launcher_fast(b, n, m, max_radius, min_radius, nsample, q, p, i,
+                                                                      _stream(xyz_tensor)), "ball_query_dilated")
     return 1
 
 

@@ -150,6 +150,64 @@ def test_ball_query_dilated(ext, G, oracle, rmax, rmin):
                                   oracle.ball_query_dilated(rmax, rmin, 16, xyz, new_xyz))
 
 
+# ------------------------------------------------------------------ ball query through the cell grid
+@pytest.mark.parametrize("N,M,r,ns", [(1, 1, 1.0, 4), (7, 3, 0.5, 1), (100, 64, 0.8, 16), (1000, 65, 0.5, 32),
+                                      (4097, 1000, 1.5, 32), (16384, 4100, 0.2, 16), (20000, 3000, 0.01, 3),
+                                      (50, 200, 9.0, 64), (70000, 1500, 0.4, 16), (3000, 5000, 1e-4, 8),
+                                      (5000, 2000, 1e6, 16)])
+def test_ball_query_grid(ext, G, oracle, monkeypatch, N, M, r, ns):
+    """csrc/ball_query_grid.hip against the oracle's scan: every launch forced through the grid, including sizes it
+    would not normally take, radii far below / above the cloud's extent and a guaranteed-empty ball."""
+    monkeypatch.setattr(ext, "BQ_GRID_MIN", (0, 0))
+    rng = np.random.default_rng(N + M)
+    xyz = cloud(rng, 2, N, dup=0.05)
+    new_xyz = np.concatenate([xyz[:, rng.integers(0, N, M // 2 + 1)], cloud(rng, 2, M, 0)], 1)[:, :M].copy()
+    new_xyz[:, -1] = 100.0
+    np.testing.assert_array_equal(G.ball_query(ext, r, ns, xyz, new_xyz), oracle.ball_query(r, ns, xyz, new_xyz))
+
+
+@pytest.mark.parametrize("rmax,rmin", [(0.8, 0.0), (0.8, 0.3), (1.6, 0.8)])
+def test_ball_query_grid_dilated(ext, G, oracle, monkeypatch, rmax, rmin):
+    monkeypatch.setattr(ext, "BQ_GRID_MIN", (0, 0))
+    rng = np.random.default_rng(11)
+    xyz = cloud(rng, 2, 3000, dup=0.1)
+    new_xyz = xyz[:, rng.integers(0, 3000, 257)].copy()
+    np.testing.assert_array_equal(G.ball_query(ext, rmax, 16, xyz, new_xyz, dilated_min=rmin),
+                                  oracle.ball_query_dilated(rmax, rmin, 16, xyz, new_xyz))
+
+
+def test_ball_query_grid_self_query_lidar(ext, G, oracle, dev):
+    """The DenseEdgeConv launch (surface_feature.py:55): every point is a centroid (same tensor), r = 0.8, K = 16, on
+    LiDAR-like scenes -- the default route of ball_query_wrapper at this size; rows of empty balls stay untouched."""
+    from spsnet_amd import scenes
+    xyz, _ = scenes.make_batch("kitti-lidar-v1", 3, 16384, seed0=5, dup_fraction=0.01)
+    x = G.t(xyz)
+    idx = torch.zeros((3, 16384, 16), dtype=torch.int32, device=dev)
+    assert ext.BQ_GRID_MIN is not None and 16384 >= max(ext.BQ_GRID_MIN)
+    ext.ball_query_wrapper(3, 16384, 16384, 0.8, 16, x, x, idx)
+    np.testing.assert_array_equal(G.n(idx), oracle.ball_query(0.8, 16, xyz, xyz))
+    far = torch.full((1, 2048, 3), 500.0, device=dev)
+    keep = torch.full((1, 2048, 4), -7, dtype=torch.int32, device=dev)
+    ext.ball_query_wrapper(1, 16384, 2048, 0.8, 4, far, x[:1].contiguous(), keep)
+    assert (keep == -7).all()
+
+
+def test_ball_query_grid_degenerate_clouds(ext, G, oracle, monkeypatch):
+    """All points identical, points on a line, NaN / inf coordinates in points and centroids: same rows as the scan."""
+    monkeypatch.setattr(ext, "BQ_GRID_MIN", (0, 0))
+    rng = np.random.default_rng(3)
+    same = np.full((1, 3000, 3), 1.25, np.float32)
+    line = np.zeros((1, 3000, 3), np.float32); line[0, :, 1] = rng.permutation(3000) * 0.01
+    bad = cloud(rng, 1, 3000, dup=0.02)
+    bad[0, 5] = np.nan; bad[0, 17, 1] = np.inf; bad[0, 99, 2] = -np.inf; bad[0, 1234, 0] = np.nan
+    for xyz in (same, line, bad):
+        ctr = xyz[:, rng.integers(0, 3000, 700)].copy()
+        ctr[0, 3] = np.nan; ctr[0, 8, 0] = np.inf
+        with np.errstate(invalid="ignore", over="ignore"):
+            want = oracle.ball_query(0.3, 16, xyz, ctr)
+        np.testing.assert_array_equal(G.ball_query(ext, 0.3, 16, xyz, ctr), want)
+
+
 # ------------------------------------------------------------------ gather / group (+grad)
 @pytest.mark.parametrize("C,N,M,ns", [(1, 10, 4, 1), (3, 1000, 333, 16), (67, 4096, 1024, 32), (259, 512, 256, 16)])
 def test_group_and_gather(ext, G, oracle, C, N, M, ns):

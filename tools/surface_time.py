@@ -13,10 +13,11 @@ x = torch.from_numpy(xyz).to(dev)
 for mode in ("dynamic", "static"):
     torch.manual_seed(0)
     net = SF.FeatureExtraction(dynamic_graph=(mode == "dynamic")).to(dev).eval()
+    outs = {}
     for label, grad in (("fused", False), ("op_by_op", True)):
         ctx = torch.enable_grad() if grad else torch.no_grad()
         with ctx:
-            for _ in range(2):
+            for _ in range(5):
                 out = net(x)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -24,4 +25,7 @@ for mode in ("dynamic", "static"):
             for _ in range(reps):
                 out = net(x)
             torch.cuda.synchronize()
+        outs[label] = out.detach()
         print(f"{mode:8s} {label:9s} {1e3 * (time.perf_counter() - t0) / reps:8.3f} ms per forward ({B}x{N})", flush=True)
+    dev_ = (outs["fused"] - outs["op_by_op"]).abs().max().item() / outs["op_by_op"].abs().max().item()
+    print(f"{mode:8s} max |fused - op_by_op| / max |op_by_op| = {dev_:.2e}", flush=True)
