@@ -216,6 +216,75 @@ def surface_features():
     np.savez_compressed(os.path.join(OUT, "surface_feature.npz"), **d)
 
 
+class _AttrDict(dict):
+    """What the reference's backbones need of an EasyDict: attribute access over a dict."""
+    __getattr__ = dict.__getitem__
+
+
+def _attr(obj):
+    if isinstance(obj, dict):
+        return _AttrDict({k: _attr(v) for k, v in obj.items()})
+    return obj
+
+
+def _load_backbone(filename, cls):
+    """Execute ONE reference backbone file (pcdet/models/backbones_3d/<filename>) under its package name without
+    running pcdet/models/__init__.py, which imports spconv-based code that is not installed here."""
+    import importlib.util
+    import types
+    for name in ("pcdet.models", "pcdet.models.backbones_3d"):
+        if name not in sys.modules:
+            pkg = types.ModuleType(name)
+            pkg.__path__ = []
+            sys.modules[name] = pkg
+    modname = "pcdet.models.backbones_3d." + filename[:-3]
+    spec = importlib.util.spec_from_file_location(
+        modname, os.path.join(ref_harness.REFERENCE_ROOT, "pcdet", "models", "backbones_3d", filename))
+    mod = importlib.util.module_from_spec(spec)
+    mod.__package__ = "pcdet.models.backbones_3d"
+    sys.modules[modname] = mod
+    spec.loader.exec_module(mod)
+    return getattr(mod, cls)
+
+
+BACKBONE_NPOINTS = [1024, 256, 128, 64, -1, 64]
+BACKBONE_SEED = 77
+
+
+def backbones():
+    """IASSD_Backbone / PAGNet_Backbone end to end (IASSD_backbone.py:93-178, PAGNet_backbone.py:102-197) at the shipped
+    widths on 2 x 4096 points.  The weights are not stored: scenes.fill_parameters(seed) regenerates them by key name."""
+    from spsnet_amd import backbones as B
+    for tag, filename, cls, base in (("iassd", "IASSD_backbone.py", "IASSD_Backbone", B.IASSD_KITTI_CFG),
+                                     ("pagnet", "PAGNet_backbone.py", "PAGNet_Backbone", B.SPSNET_KITTI_CFG)):
+        cfg = B.scaled_cfg(base, BACKBONE_NPOINTS)
+        net = _load_backbone(filename, cls)(_attr(copy.deepcopy(cfg)), num_class=3, input_channels=4).eval()
+        scenes.fill_parameters(net, BACKBONE_SEED)
+        xyz, feats = scenes.make_batch("kitti-lidar-v1", 2, 4096, seed0=700, dup_fraction=0.01)
+        bidx = np.repeat(np.arange(2, dtype=np.float32), 4096)[:, None]
+        points = np.concatenate([bidx, xyz.reshape(-1, 3), feats.transpose(0, 2, 1).reshape(-1, 1)], 1).astype(np.float32)
+        batch = dict(batch_size=2, points=torch.from_numpy(points))
+        d = dict(points=points, npoints=np.asarray(BACKBONE_NPOINTS), seed=np.asarray(BACKBONE_SEED))
+        if tag == "pagnet":
+            stds = np.random.default_rng(9).uniform(0, 40, (2, 4096)).astype(np.float32)
+            batch['stds'] = torch.from_numpy(stds)
+            d['stds'] = stds
+        with torch.no_grad():
+            out = net(batch)
+        for key in ("ctr_offsets", "centers", "centers_origin", "centers_features", "ctr_batch_idx"):
+            d[key] = _np(out[key])
+        for k, t in enumerate(out["encoder_xyz"]):
+            d[f"encoder_xyz_{k}"] = _np(t)
+        for k, t in enumerate(out["encoder_features"]):
+            if t is not None and k > 0:
+                d[f"encoder_features_{k}"] = _np(t)
+        for k, t in enumerate(out["sa_ins_preds"]):
+            if isinstance(t, torch.Tensor):
+                d[f"sa_ins_preds_{k}"] = _np(t)
+        d["n_encoder_coords"] = np.asarray(len(out["encoder_coords"]))
+        np.savez_compressed(os.path.join(OUT, f"backbone_{tag}.npz"), **d)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     U, M = ref_harness.load_reference()
@@ -227,6 +296,7 @@ def main():
     generator_layer(M)
     fp_module(M)
     surface_features()
+    backbones()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -1,0 +1,281 @@
+"""IA-SSD / SPSNet point backbones over the gfx950 set-abstraction ops.
+
+Mirror of the reference's pcdet/models/backbones_3d/IASSD_backbone.py (IASSD_Backbone :7-191) and
+PAGNet_backbone.py (PAGNet_Backbone :7-212): same class names, constructor `(model_cfg, num_class, input_channels)`,
+YAML keys (SA_CONFIG: NPOINT_LIST, SAMPLE_RANGE_LIST, SAMPLE_METHOD_LIST, RADIUS_LIST, NSAMPLE_LIST, MLPS, LAYER_TYPE,
+DILATED_GROUP, AGGREGATION_MLPS, CONFIDENCE_MLPS, LAYER_INPUT, CTR_INDEX, MAX_TRANSLATE_RANGE, USE_SURFACE --
+tools/cfgs/kitti_models/IA-SSD.yaml:33-56, SPSNet.yaml:39-69), state_dict keys (`SA_modules.{k}...`, `SF_extract...`)
+and the keys written to `batch_dict` (:170-178 / :189-197).  `model_cfg` may be the reference's EasyDict or a plain dict.
+
+What differs is the schedule, not the arithmetic (inference on a GPU only; training runs layer by layer):
+  * layer 0 consumes its farthest-point picks while FPS is still running and layer 1's FPS starts as soon as layer 0's
+    centroids exist (sa_stack._streamed_first_layer / _prefetch_dfps);
+  * PAGNet's surface features (FeatureExtraction over all N points, PAGNet_backbone.py:154-157) run on a side stream
+    beside layer 0's FPS, which occupies one CU per scene.
+The debugging branch that dumps sampled points to a hard-coded path (SAVE_SAMPLE_LIST, :199-212) is not reproduced.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from . import pointnet2_modules, pointnet2_utils, sa_stack, surface_feature
+
+
+class _Cfg:
+    """Attribute + .get() access over a dict or an EasyDict-like object (the reference reads both ways)."""
+
+    def __init__(self, obj):
+        self._o = obj
+
+    def _raw(self, key):
+        if isinstance(self._o, dict):
+            return self._o[key]
+        return getattr(self._o, key)
+
+    def __getattr__(self, key):
+        if key.startswith('_'):
+            raise AttributeError(key)
+        try:
+            v = self._raw(key)
+        except KeyError:
+            raise AttributeError(key)
+        return _Cfg(v) if isinstance(v, dict) or (hasattr(v, 'keys') and hasattr(v, 'get')) else v
+
+    def get(self, key, default=None):
+        try:
+            return self.__getattr__(key)
+        except AttributeError:
+            return default
+
+
+class _PointBackbone(nn.Module):
+    """Common body: IASSD_backbone.py:10-84 / PAGNet_backbone.py:10-92 (constructor), :93-178 / :102-197 (forward)."""
+
+    _surface = False  # PAGNet: FeatureExtraction + stds
+
+    def __init__(self, model_cfg, num_class, input_channels, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_class = num_class
+        self.SA_modules = nn.ModuleList()
+        channel_in = input_channels - 3
+        channel_out_list = [channel_in]
+        self.num_points_each_layer = []
+
+        sa_config = _Cfg(model_cfg).SA_CONFIG
+        self.layer_types = list(sa_config.LAYER_TYPE)
+        self.ctr_idx_list = list(sa_config.CTR_INDEX)
+        self.layer_inputs = list(sa_config.LAYER_INPUT)
+        self.aggregation_mlps = sa_config.get('AGGREGATION_MLPS', None)
+        self.confidence_mlps = sa_config.get('CONFIDENCE_MLPS', None)
+        self.max_translate_range = sa_config.get('MAX_TRANSLATE_RANGE', None)
+        if self._surface and sa_config.get('USE_SURFACE', False):
+            self.SF_extract = surface_feature.FeatureExtraction()
+
+        for k in range(len(sa_config.NSAMPLE_LIST)):
+            src = self.layer_inputs[k]
+            channel_in = channel_out_list[src[-1] if isinstance(src, list) else src]
+            if self.layer_types[k] == 'SA_Layer':
+                mlps = [[channel_in] + list(m) for m in sa_config.MLPS[k]]
+                channel_out = sum(m[-1] for m in mlps)
+                aggregation_mlp = None
+                if self.aggregation_mlps and self.aggregation_mlps[k]:
+                    aggregation_mlp = list(self.aggregation_mlps[k])
+                    channel_out = aggregation_mlp[-1]
+                confidence_mlp = None
+                if self.confidence_mlps and self.confidence_mlps[k]:
+                    confidence_mlp = list(self.confidence_mlps[k])
+                self.SA_modules.append(pointnet2_modules.PointnetSAModuleMSG_WithSampling(
+                    npoint_list=sa_config.NPOINT_LIST[k], sample_range_list=sa_config.SAMPLE_RANGE_LIST[k],
+                    sample_type_list=sa_config.SAMPLE_METHOD_LIST[k], radii=sa_config.RADIUS_LIST[k],
+                    nsamples=sa_config.NSAMPLE_LIST[k], mlps=mlps, use_xyz=True,
+                    dilated_group=sa_config.DILATED_GROUP[k], aggregation_mlp=aggregation_mlp,
+                    confidence_mlp=confidence_mlp, num_class=self.num_class, **self._sampler_kwargs(sa_config, k)))
+            elif self.layer_types[k] == 'Vote_Layer':
+                self.SA_modules.append(pointnet2_modules.Vote_layer(
+                    mlp_list=sa_config.MLPS[k], pre_channel=channel_out_list[self.layer_inputs[k]],
+                    max_translate_range=self.max_translate_range))
+                # channel_out keeps the previous layer's value, as in the reference (:76-84)
+            if hasattr(self, 'SF_extract') and k == 3:
+                channel_out += 60  # the voting layer sees [surface features | layer-3 features] (PAGNet_backbone.py:88-89)
+            channel_out_list.append(channel_out)
+        self.num_point_features = channel_out
+
+    def _sampler_kwargs(self, sa_config, k):
+        return {}
+
+    def break_up_pc(self, pc):
+        batch_idx = pc[:, 0]
+        xyz = pc[:, 1:4].contiguous()
+        features = (pc[:, 4:].contiguous() if pc.size(-1) > 4 else None)
+        return batch_idx, xyz, features
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _sa_layer(self, i, xyz_input, feature_input, cls_pred, ctr_xyz, stds, fast):
+        """One SA layer; on the fast path layer 0 is streamed against its own FPS and the next plain D-FPS layer is
+        started early.  -> (li_xyz, li_features, li_cls_pred, sampled_idx, stds)"""
+        layer = self.SA_modules[i]
+        nxt = None
+        if (fast and i + 1 < len(self.SA_modules) and self.layer_types[i + 1] == 'SA_Layer'
+                and self.layer_inputs[i + 1] == i + 1 and self.ctr_idx_list[i + 1] == -1):
+            nxt = self.SA_modules[i + 1]
+        if fast and i == 0 and cls_pred is None and ctr_xyz is None and self.layer_inputs[0] == 0:
+            res = sa_stack._streamed_first_layer(layer, nxt, xyz_input, feature_input, stds)
+            if res is not None:
+                return res
+        if nxt is not None and ctr_xyz is None and sa_stack._can_prefetch(layer, nxt):
+            ordered = sa_stack._is_plain_dfps(layer, xyz_input.shape[1])
+            layer._on_new_xyz = lambda nx, _n=nxt, _o=ordered: sa_stack._prefetch_dfps(_n, nx, _o)
+        kw = {}
+        if self._surface:
+            kw['stds'] = stds
+        try:
+            return layer(xyz_input, feature_input, cls_pred, ctr_xyz=ctr_xyz, **kw)
+        finally:
+            layer._on_new_xyz = None
+
+    def forward(self, batch_dict):
+        """batch_dict: batch_size, points (B*N, 4 + C) [batch_idx, x, y, z, ...] (+ stds for PAGNet) -> batch_dict with
+        ctr_offsets, centers, centers_origin, centers_features, ctr_batch_idx, encoder_xyz, encoder_coords,
+        sa_ins_preds, encoder_features."""
+        batch_size = batch_dict['batch_size']
+        points = batch_dict['points']
+        batch_idx, xyz, features = self.break_up_pc(points)
+        stds = batch_dict.get('stds', None) if self._surface else None
+
+        # every scene must hold the same number of points (reference :109-113): one bincount instead of B syncs
+        counts = torch.bincount(batch_idx.long(), minlength=batch_size)
+        assert int(counts.min()) == int(counts.max())
+        xyz = xyz.view(batch_size, -1, 3)
+        features = (features.view(batch_size, -1, features.shape[-1]).permute(0, 2, 1).contiguous()
+                    if features is not None else None)
+
+        fast = xyz.is_cuda and not torch.is_grad_enabled()
+        encoder_xyz, encoder_features, sa_ins_preds = [xyz], [features], []
+        encoder_coords = [torch.cat([batch_idx.view(batch_size, -1, 1), xyz], dim=-1)]
+        sample_list = []
+        surface = None
+        surface_done = None
+        if self._surface and hasattr(self, 'SF_extract') and fast:
+            # all-N surface features on a side stream: they are first needed after layer 0 has sampled
+            main = torch.cuda.current_stream(xyz.device)
+            side = _surface_stream(xyz.device)
+            start = torch.cuda.Event()
+            start.record(main)
+            xyz.record_stream(side)
+            with torch.cuda.stream(side):
+                side.wait_event(start)
+                surface = self.SF_extract(xyz).permute(0, 2, 1).contiguous()
+                surface_done = torch.cuda.Event()
+                surface_done.record(side)
+
+        li_cls_pred = None
+        centers = centers_origin = ctr_offsets = None
+        for i in range(len(self.SA_modules)):
+            xyz_input = encoder_xyz[self.layer_inputs[i]]
+            feature_input = encoder_features[self.layer_inputs[i]]
+            if self.layer_types[i] == 'SA_Layer':
+                ctr_xyz = encoder_xyz[self.ctr_idx_list[i]] if self.ctr_idx_list[i] != -1 else None
+                li_xyz, li_features, li_cls_pred, sampled_idx_list, stds = self._sa_layer(
+                    i, xyz_input, feature_input, li_cls_pred, ctr_xyz, stds, fast)
+                sample_list.append(sampled_idx_list)
+                if self._surface and hasattr(self, 'SF_extract') and i <= 4:
+                    if i == 0 and surface is None:
+                        surface = self.SF_extract(xyz).permute(0, 2, 1).contiguous()
+                    if surface_done is not None:
+                        torch.cuda.current_stream(xyz.device).wait_event(surface_done)
+                        surface.record_stream(torch.cuda.current_stream(xyz.device))
+                        surface_done = None
+                    surface = pointnet2_utils.gather_operation(surface, sampled_idx_list)
+            elif self.layer_types[i] == 'Vote_Layer':
+                kw = {'center_surface_futures': surface} if self._surface else {}
+                li_xyz, li_features, xyz_select, ctr_offsets = self.SA_modules[i](xyz_input, feature_input, **kw)
+                centers = li_xyz
+                centers_origin = xyz_select
+                origin_idx = batch_idx.view(batch_size, -1)[:, :centers_origin.shape[1]]
+                encoder_coords.append(torch.cat([origin_idx[..., None].float(), centers_origin.view(batch_size, -1, 3)], dim=-1))
+            encoder_xyz.append(li_xyz)
+            li_batch_idx = batch_idx.view(batch_size, -1)[:, :li_xyz.shape[1]]
+            encoder_coords.append(torch.cat([li_batch_idx[..., None].float(), li_xyz.view(batch_size, -1, 3)], dim=-1))
+            encoder_features.append(li_features)
+            if li_cls_pred is not None:
+                cls_idx = batch_idx.view(batch_size, -1)[:, :li_cls_pred.shape[1]]
+                sa_ins_preds.append(torch.cat([cls_idx[..., None].float(),
+                                               li_cls_pred.view(batch_size, -1, li_cls_pred.shape[-1])], dim=-1))
+            else:
+                sa_ins_preds.append([])
+
+        ctr_batch_idx = batch_idx.view(batch_size, -1)[:, :li_xyz.shape[1]].contiguous().view(-1)
+        col = ctr_batch_idx[:, None].float()
+        batch_dict['ctr_offsets'] = torch.cat((col, ctr_offsets.contiguous().view(-1, 3)), dim=1)
+        batch_dict['centers'] = torch.cat((col, centers.contiguous().view(-1, 3)), dim=1)
+        batch_dict['centers_origin'] = torch.cat((col, centers_origin.contiguous().view(-1, 3)), dim=1)
+        last = encoder_features[-1]
+        batch_dict['centers_features'] = last.permute(0, 2, 1).contiguous().view(-1, last.shape[1])
+        batch_dict['ctr_batch_idx'] = ctr_batch_idx
+        batch_dict['encoder_xyz'] = encoder_xyz
+        batch_dict['encoder_coords'] = encoder_coords
+        batch_dict['sa_ins_preds'] = sa_ins_preds
+        batch_dict['encoder_features'] = encoder_features
+        return batch_dict
+
+
+_SURFACE_STREAMS = {}
+
+
+def _surface_stream(device):
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    if key not in _SURFACE_STREAMS:
+        _SURFACE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SURFACE_STREAMS[key]
+
+
+class IASSD_Backbone(_PointBackbone):
+    """Backbone for IA-SSD (reference IASSD_backbone.py:7-191)."""
+
+
+class PAGNet_Backbone(_PointBackbone):
+    """Backbone for SPSNet: IA-SSD's stack + stability-driven sampling (`stds`) + surface features for the voting layer
+    (reference PAGNet_backbone.py:7-212)."""
+    _surface = True
+
+    def _sampler_kwargs(self, sa_config, k):  # stable-sampling balls (PAGNet_backbone.py:76-78)
+        ss_r, ss_n = sa_config.get('SS_RADIUS_LIST', None), sa_config.get('SS_NSAMPLE_LIST', None)
+        return dict(ss_radii=ss_r[k] if ss_r is not None else None, ss_nsamples=ss_n[k] if ss_n is not None else None)
+
+
+# the shipped KITTI configurations, as plain dicts (tools/cfgs/kitti_models/IA-SSD.yaml:33-56, SPSNet.yaml:39-69)
+IASSD_KITTI_CFG = dict(SA_CONFIG=dict(
+    NPOINT_LIST=[[4096], [1024], [512], [256], [-1], [256]],
+    SAMPLE_RANGE_LIST=[[-1], [-1], [-1], [-1], [-1], [-1]],
+    SAMPLE_METHOD_LIST=[['D-FPS'], ['D-FPS'], ['ctr_aware'], ['ctr_aware'], [], []],
+    RADIUS_LIST=[[0.2, 0.8], [0.8, 1.6], [1.6, 4.8], [], [], [4.8, 6.4]],
+    NSAMPLE_LIST=[[16, 32], [16, 32], [16, 32], [], [], [16, 32]],
+    MLPS=[[[16, 16, 32], [32, 32, 64]], [[64, 64, 128], [64, 96, 128]], [[128, 128, 256], [128, 256, 256]], [], [128],
+          [[256, 256, 512], [256, 512, 1024]]],
+    LAYER_TYPE=['SA_Layer', 'SA_Layer', 'SA_Layer', 'SA_Layer', 'Vote_Layer', 'SA_Layer'],
+    DILATED_GROUP=[False, False, False, False, False, False],
+    AGGREGATION_MLPS=[[64], [128], [256], [256], [], [512]],
+    CONFIDENCE_MLPS=[[], [128], [256], [], [], []],
+    LAYER_INPUT=[0, 1, 2, 3, 4, 3],
+    CTR_INDEX=[-1, -1, -1, -1, -1, 5],
+    MAX_TRANSLATE_RANGE=[3.0, 3.0, 2.0],
+))
+
+
+SPSNET_KITTI_CFG = copy.deepcopy(IASSD_KITTI_CFG)
+SPSNET_KITTI_CFG['SA_CONFIG'].update(
+    SAMPLE_METHOD_LIST=[['D-FPS'], ['D-FPS'], ['sss_aware'], ['sss_aware'], [], []],
+    SS_RADIUS_LIST=[[0.05], [0.2], [], [], [], []],
+    SS_NSAMPLE_LIST=[[16], [16], [], [], [], [1]],
+    USE_SURFACE=True,
+)
+SPSNET_KITTI_CFG['SA_CONFIG']['MLPS'][1] = [[124, 64, 128], [124, 96, 128]]
+
+
+def scaled_cfg(base, npoints):
+    """The same stack on a smaller cloud: NPOINT_LIST replaced (entries of -1 kept)."""
+    cfg = copy.deepcopy(base)
+    cfg['SA_CONFIG']['NPOINT_LIST'] = [[p] for p in npoints]
+    return cfg

@@ -93,3 +93,27 @@ def make_batch(kind, batch, n, seed0=0, dup_fraction=0.0):
         xs.append(x)
         fs.append(f)
     return np.stack(xs), np.stack(fs)[:, None, :]
+
+
+def fill_parameters(module, seed):
+    """Deterministic, name-keyed values for every parameter and buffer of `module` (a torch.nn.Module): the same
+    state for the reference's module and the build's mirror without shipping a state_dict -- they share key names
+    and shapes.  Convolution / linear weights ~ N(0, 2 / fan_in), one-dimensional `weight` and `running_var` in
+    [0.5, 1.5), `bias` / `running_mean` ~ 0.1 N(0, 1)."""
+    import zlib
+    import torch
+    with torch.no_grad():
+        for name, t in module.state_dict().items():
+            if not t.dtype.is_floating_point:
+                continue
+            rng = np.random.default_rng([int(seed), zlib.crc32(name.encode())])
+            leaf = name.rsplit('.', 1)[-1]
+            if t.dim() >= 2:
+                fan_in = int(np.prod(t.shape[1:]))
+                v = rng.normal(size=tuple(t.shape)) * np.sqrt(2.0 / max(fan_in, 1))
+            elif leaf in ('weight', 'running_var'):
+                v = rng.uniform(0.5, 1.5, size=tuple(t.shape))
+            else:
+                v = rng.normal(size=tuple(t.shape)) * 0.1
+            t.copy_(torch.from_numpy(np.asarray(v, dtype=np.float32)))
+    return module

@@ -949,3 +949,57 @@ def test_deterministic_group_and_gather_grads(ext, G, oracle, B, C, N, M, ns):
         U.DETERMINISTIC_BACKWARD = old
     np.testing.assert_array_equal(grads[0], want)
     np.testing.assert_allclose(grads[1], want, rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------ whole backbones (IASSD_backbone.py / PAGNet_backbone.py)
+@pytest.mark.parametrize("tag", ["iassd", "pagnet"])
+@pytest.mark.parametrize("schedule", ["overlapped", "layer_by_layer"])
+def test_golden_backbone(ext, G, dev, tag, schedule):
+    """IASSD_Backbone / PAGNet_Backbone.forward on 2 x 4096 points at the shipped widths against the reference's own
+    forward (run over the C oracle, oracle/gen_golden.py:backbones): sampled centres bit-exact at every level, features,
+    votes and class scores to 1e-4.  `overlapped` = the inference schedule (streamed layer 0, early FPS, surface features
+    on a side stream), `layer_by_layer` = the reference's order (gradients enabled)."""
+    from spsnet_amd import backbones as BB, scenes
+    g = np.load(os.path.join(GOLD, f"backbone_{tag}.npz"))
+    base = BB.IASSD_KITTI_CFG if tag == "iassd" else BB.SPSNET_KITTI_CFG
+    cls = BB.IASSD_Backbone if tag == "iassd" else BB.PAGNet_Backbone
+    net = cls(BB.scaled_cfg(base, [int(v) for v in g["npoints"]]), num_class=3, input_channels=4)
+    scenes.fill_parameters(net, int(g["seed"]))
+    net = net.to(dev).eval()
+    batch = dict(batch_size=2, points=G.t(g["points"]))
+    if tag == "pagnet":
+        batch["stds"] = G.t(g["stds"])
+    if schedule == "overlapped":
+        with torch.no_grad():
+            out = net(batch)
+    else:
+        out = net(batch)
+        assert out["centers_features"].requires_grad
+
+    def close(a, ref, what):
+        a = G.n(a)
+        assert a.shape == ref.shape, what
+        if ref.size == 0:   # the voting layer's (B, M, 0) "features"
+            return
+        tol = 1e-4 * max(1.0, float(np.abs(ref).max()))
+        assert float(np.abs(a - ref).max()) <= tol, what
+
+    for k in range(len(out["encoder_xyz"])):
+        want = g[f"encoder_xyz_{k}"]
+        if k >= 5:         # votes (centre + clamped regression output) and the last layer, which is centred on them
+            close(out["encoder_xyz"][k], want, f"encoder_xyz[{k}]")
+        else:              # sampled subsets of the input cloud: exact
+            np.testing.assert_array_equal(G.n(out["encoder_xyz"][k]), want, err_msg=f"encoder_xyz[{k}]")
+    for k, t in enumerate(out["encoder_features"]):
+        key = f"encoder_features_{k}"
+        if key in g.files:
+            close(t, g[key], key)
+    for k, t in enumerate(out["sa_ins_preds"]):
+        key = f"sa_ins_preds_{k}"
+        assert (key in g.files) == isinstance(t, torch.Tensor)
+        if key in g.files:
+            close(t, g[key], key)
+    for key in ("ctr_offsets", "centers", "centers_origin", "centers_features"):
+        close(out[key], g[key], key)
+    np.testing.assert_array_equal(G.n(out["ctr_batch_idx"]), g["ctr_batch_idx"])
+    assert len(out["encoder_coords"]) == int(g["n_encoder_coords"])

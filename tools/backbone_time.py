@@ -1,0 +1,33 @@
+"""Time IASSD_Backbone / PAGNet_Backbone.forward (spsnet_amd/backbones.py) at the KITTI configuration.
+usage: python tools/backbone_time.py [B] [N] [reps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from spsnet_amd import backbones as BB, scenes
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+dev = torch.device("cuda:0")
+xyz, feats = scenes.make_batch("kitti-lidar-v1", B, N, seed0=1)
+bidx = np.repeat(np.arange(B, dtype=np.float32), N)[:, None]
+points = torch.from_numpy(np.concatenate([bidx, xyz.reshape(-1, 3), feats.transpose(0, 2, 1).reshape(-1, 1)], 1).astype(np.float32)).to(dev)
+stds = torch.from_numpy(np.random.default_rng(0).uniform(0, 40, (B, N)).astype(np.float32)).to(dev)
+for tag, cls, cfg in (("IASSD_Backbone", BB.IASSD_Backbone, BB.IASSD_KITTI_CFG), ("PAGNet_Backbone", BB.PAGNet_Backbone, BB.SPSNET_KITTI_CFG)):
+    net = scenes.fill_parameters(cls(cfg, num_class=3, input_channels=4), 5).to(dev).eval()
+    def batch():
+        d = dict(batch_size=B, points=points)
+        if tag.startswith("PAG"):
+            d["stds"] = stds
+        return d
+    with torch.no_grad():
+        for _ in range(5):
+            net(batch())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            net(batch())
+        torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / reps
+    print(f"{tag:16s} {B}x{N}: {ms:7.3f} ms per forward  ({B * N / ms / 1e3:.1f} M points/s)", flush=True)
