@@ -92,3 +92,38 @@ def test_surface_feature_mirror_has_reference_state_dict_keys():
     mine = {k: tuple(v.shape) for k, v in net.state_dict().items()}
     assert mine == {k: tuple(v) for k, v in ref.items()}
     assert net.out_channels == 60  # the "surface feature C=60" of SURVEY.md 8a-3
+
+
+def test_backbone_mirrors_have_reference_state_dict_keys():
+    """IASSD_Backbone / PAGNet_Backbone: same parameter names and shapes as the reference's classes (so checkpoints
+    load, and so scenes.fill_parameters gives both the same weights).  Needs /root/reference: build container only."""
+    import copy
+    import pytest
+    from oracle import ref_harness
+    if not ref_harness.available():
+        pytest.skip("reference tree not present (GPU box)")
+    from oracle import gen_golden
+    from spsnet_amd import backbones as BB
+    ref_harness.load_reference()
+    for filename, cls, mine_cls, cfg in (("IASSD_backbone.py", "IASSD_Backbone", BB.IASSD_Backbone, BB.IASSD_KITTI_CFG),
+                                         ("PAGNet_backbone.py", "PAGNet_Backbone", BB.PAGNet_Backbone, BB.SPSNET_KITTI_CFG)):
+        ref = gen_golden._load_backbone(filename, cls)(gen_golden._attr(copy.deepcopy(cfg)), num_class=3, input_channels=4)
+        mine = mine_cls(copy.deepcopy(cfg), num_class=3, input_channels=4)
+        want = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+        got = {k: tuple(v.shape) for k, v in mine.state_dict().items()}
+        assert got == want
+        assert mine.num_point_features == ref.num_point_features
+
+
+def test_fill_parameters_is_deterministic_and_name_keyed():
+    import torch
+    from spsnet_amd import scenes
+    a = torch.nn.Sequential(torch.nn.Conv1d(4, 8, 1), torch.nn.BatchNorm1d(8))
+    b = torch.nn.Sequential(torch.nn.Conv1d(4, 8, 1), torch.nn.BatchNorm1d(8))
+    scenes.fill_parameters(a, 3)
+    scenes.fill_parameters(b, 3)
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    assert float(a[1].running_var.min()) >= 0.5
+    scenes.fill_parameters(b, 4)
+    assert not torch.equal(a[0].weight, b[0].weight)
