@@ -271,6 +271,10 @@ int sps_linear_rows(long long rows, int cin, int cout, const float *x, const flo
 long long sps_ball_query_grid_workspace_ints(int b, int n, int m);
 int sps_ball_query_grid(int b, int n, int m, float max_radius, float min_radius, int dilated, int nsample, int fill_empty,
                         const float *new_xyz, const float *xyz, int *idx, int *work, sps_stream_t stream);
+/* The two grouping radii of an SA layer (pointnet2_modules.py:429-447 calls ball_query once per scale) from one walk
+ * of the grid: same rows as sps_ball_query_full2 (every row written, zeros for empty balls), same workspace. */
+int sps_ball_query_grid2(int b, int n, int m, float radius_a, int nsample_a, float radius_b, int nsample_b,
+                         const float *new_xyz, const float *xyz, int *idx_a, int *idx_b, int *work, sps_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -309,47 +309,60 @@ __device__ __forceinline__ int wave_min_i(int v) { return -wave_max_i32(-v); }  
 __device__ __forceinline__ int wave_max_i(int v) { return wave_max_i32(v); }
 
 constexpr int BQG_MAX_SEG = 4;  // 8 measured slower at N = 16384: the per-wave set-up is replicated
-// LDS of a workgroup (ints): bitmap[words] | cnts[S][64] | final[64][nsample + 1] | jrow[64] |
-//                            per wave: list (u16 x 2048 = 1024 ints) | stage[2][64] float4 (512 ints) | hits (u16 x nsample x 64)
-__host__ __device__ inline size_t bqg_shared_ints(int words, int nsample, int S) {
-    return (size_t)words + (size_t)S * 64 + (size_t)64 * (nsample + 1) + 64;
-}
-__host__ __device__ inline size_t bqg_wave_ints(int nsample) { return (size_t)1024 + 512 + (size_t)nsample * 32; }
 
-// One workgroup = 64 centroids adjacent in cell order; its S waves fill the candidate bitmap together, then each scans
+struct BqgQuery {
+    int n, m, fill_empty, words;
+    float radius;          // largest radius: the box of a group
+    float r2[2], r2min;    // squared radii (r2min: dilated form, single radius only)
+    int ns[2], vec4[2];
+    const float *new_xyz, *xyz;
+    int *idx[2];
+    const int *work;
+    long long stride;
+    BqgLayout lay;
+};
+// LDS of a workgroup (ints): bitmap[words] | cnts[R][S][64] | final[64][max nsample + 1] | jrow[64] |
+//       per wave: list (u16 x 2048 = 1024 ints) | stage[2][64] float4 (512 ints) | hits per radius (u16 x nsample x 64)
+__host__ __device__ inline size_t bqg_shared_ints(int words, int nsmax, int S, int R) {
+    return (size_t)words + (size_t)R * S * 64 + (size_t)64 * (nsmax + 1) + 64;
+}
+__host__ __device__ inline size_t bqg_wave_ints(int ns_total) { return (size_t)1024 + 512 + (size_t)ns_total * 32; }
+
+// One workgroup = 64 centroids adjacent on the Z curve; its S waves fill the candidate bitmap together, then each scans
 // one S-th of the index range (lane = centroid) and the segments are concatenated in order, as in ball_query_seg_kernel.
-template <bool DILATED>
-__global__ __launch_bounds__(64 * BQG_MAX_SEG) void bqg_query_kernel(int n, int m, float r2max, float r2min, float radius,
-                                                                      int nsample, int fill_empty,
-                                                                      const float *__restrict__ new_xyz,
-                                                                      const float *__restrict__ xyz, int *__restrict__ idx,
-                                                                      const int *__restrict__ work, long long stride,
-                                                                      BqgLayout lay, int words, int vec4) {
+// R = 2: the two grouping radii of an SA layer from ONE walk (distance evaluated once, two ordered hit lists).
+template <bool DILATED, int R>
+__global__ __launch_bounds__(64 * BQG_MAX_SEG) void bqg_query_kernel(BqgQuery a) {
     extern __shared__ __attribute__((aligned(16))) int bqg_lds[];
     const int S = blockDim.x >> 6;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int scene = blockIdx.y, group = blockIdx.x;
+    const int n = a.n, m = a.m, words = a.words;
+    const int nsmax = (R == 2 && a.ns[1] > a.ns[0]) ? a.ns[1] : a.ns[0];
+    const int nstot = a.ns[0] + (R == 2 ? a.ns[1] : 0);
     unsigned *bitmap = reinterpret_cast<unsigned *>(bqg_lds);
     int *cnts = bqg_lds + words;
-    int *final_img = cnts + S * 64;
-    int *jrow = final_img + 64 * (nsample + 1);
-    int *mine_base = jrow + 64 + (size_t)wv * bqg_wave_ints(nsample);
+    int *final_img = cnts + R * S * 64;
+    int *jrow = final_img + 64 * (nsmax + 1);
+    int *mine_base = jrow + 64 + (size_t)wv * bqg_wave_ints(nstot);
     unsigned short *list = reinterpret_cast<unsigned short *>(mine_base);
     f32x4 *stage = reinterpret_cast<f32x4 *>(mine_base + 1024);
-    unsigned short *hits = reinterpret_cast<unsigned short *>(mine_base + 1024 + 512);
+    unsigned short *hits[2];
+    hits[0] = reinterpret_cast<unsigned short *>(mine_base + 1024 + 512);
+    hits[1] = hits[0] + a.ns[0] * 64;
 
-    const int *w = work + (size_t)scene * stride;
+    const int *w = a.work + (size_t)scene * a.stride;
     const BqgGrid g = bqg_load(w);
-    const int *sorted = w + lay.sorted;
-    const int *pstart = w + lay.pstart;
-    const int *perm = w + lay.perm;
-    xyz += (size_t)scene * n * 3;
+    const int *sorted = w + a.lay.sorted;
+    const int *pstart = w + a.lay.pstart;
+    const int *perm = w + a.lay.perm;
+    const float *xyz = a.xyz + (size_t)scene * n * 3;
 
     const int slot = group * 64 + lane;
     const bool active = slot < m;
     const int j = perm[active ? slot : group * 64];
-    const float *ctr = new_xyz + ((size_t)scene * m + j) * 3;
+    const float *ctr = a.new_xyz + ((size_t)scene * m + j) * 3;
     const float cx = ctr[0], cy = ctr[1], cz = ctr[2];
     if (wv == 0) jrow[lane] = active ? j : -1;
 
@@ -358,20 +371,21 @@ __global__ __launch_bounds__(64 * BQG_MAX_SEG) void bqg_query_kernel(int n, int 
     {
         const float c3[3] = {cx, cy, cz};
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float pad = radius * 1.0001f + fabsf(c3[a]) * 1.0e-6f;
-            const int l = bqg_axis(c3[a] - pad, g.lo[a], g.inv, g.dim[a] - 1);
-            const int h = bqg_axis(c3[a] + pad, g.lo[a], g.inv, g.dim[a] - 1);
-            lo_c[a] = wave_min_i(l < h ? l : h);
-            hi_c[a] = wave_max_i(l < h ? h : l);
+        for (int ax = 0; ax < 3; ++ax) {
+            const float pad = a.radius * 1.0001f + fabsf(c3[ax]) * 1.0e-6f;
+            const int l = bqg_axis(c3[ax] - pad, g.lo[ax], g.inv, g.dim[ax] - 1);
+            const int h = bqg_axis(c3[ax] + pad, g.lo[ax], g.inv, g.dim[ax] - 1);
+            lo_c[ax] = wave_min_i(l < h ? l : h);
+            hi_c[ax] = wave_max_i(l < h ? h : l);
         }
     }
-    // ---- bitmap of the candidate ids: the (y, z) rows of the box are dealt out to the lanes of all waves, a lane fetches
-    //      its row's [start, end) in the sorted id array, then the wave sets the bits row by row ----
+    // ---- bitmap of the candidate ids: the (y, z) rows of the box are dealt out to the lanes, a lane fetches its row's
+    //      [start, end) in the sorted id array, then the waves set the bits row by row ----
     for (int i = threadIdx.x; i < words; i += blockDim.x) bitmap[i] = 0u;
     __syncthreads();
     {
         const int ny = hi_c[1] - lo_c[1] + 1, nz = hi_c[2] - lo_c[2] + 1, rows = ny * nz;
+        int turn = 0;
         for (int r0 = 0; r0 < rows; r0 += 64) {
             const int rr = r0 + lane;
             int s = 0, e = 0;
@@ -383,7 +397,6 @@ __global__ __launch_bounds__(64 * BQG_MAX_SEG) void bqg_query_kernel(int n, int 
             }
             // short rows are dealt out to the waves whole (all the loads of a row are issued before its bits are set, so
             // a wave pays one memory latency per row it owns); long rows are sliced across all the waves
-            int turn = 0;
             for (unsigned long long left = __ballot(e > s); left; left &= left - 1) {
                 const int l = __builtin_ctzll(left);
                 const int sl = __builtin_amdgcn_readlane(s, l), el = __builtin_amdgcn_readlane(e, l);
@@ -420,8 +433,14 @@ __global__ __launch_bounds__(64 * BQG_MAX_SEG) void bqg_query_kernel(int n, int 
     // ---- this wave's share of the index range, 2048 points (one bitmap word per lane) at a time, in index order ----
     const int wps = words / S;  // multiple of 64 (host)
     const int segbase = wv * wps * 32;
-    int cnt = active ? 0 : nsample;
-    float thr = (cnt < nsample) ? r2max : -1.f;
+    int cnt[2];
+    float thr_r[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        cnt[r] = (active && r < R) ? 0 : (r < R ? a.ns[r] : 0);
+        thr_r[r] = (r < R && cnt[r] < a.ns[r]) ? a.r2[r] : -1.f;
+    }
+    float thr = R == 2 ? fmaxf(thr_r[0], thr_r[1]) : thr_r[0];  // full / inactive lanes can no longer be hit
     const f32x4 nanp = {__builtin_nanf(""), 0.f, 0.f, 0.f};
     for (int w0 = wv * wps; w0 < (wv + 1) * wps; w0 += 64) {
         unsigned word = bitmap[w0 + lane];
@@ -481,13 +500,17 @@ __global__ __launch_bounds__(64 * BQG_MAX_SEG) void bqg_query_kernel(int n, int 
                     for (int u = 0; u < 8; ++u) {
                         const unsigned short k = (unsigned short)__float_as_int(p[u][3]);
                         if (DILATED) {
-                            if (d2[u] == 0.f && cnt < nsample) { hits[cnt * 64 + lane] = k; ++cnt; }
-                            if (d2[u] >= r2min && d2[u] < r2max && cnt < nsample) { hits[cnt * 64 + lane] = k; ++cnt; }
+                            if (d2[u] == 0.f && cnt[0] < a.ns[0]) { hits[0][cnt[0] * 64 + lane] = k; ++cnt[0]; }
+                            if (d2[u] >= a.r2min && d2[u] < a.r2[0] && cnt[0] < a.ns[0]) { hits[0][cnt[0] * 64 + lane] = k; ++cnt[0]; }
                         } else {
-                            if (d2[u] < r2max && cnt < nsample) { hits[cnt * 64 + lane] = k; ++cnt; }
+#pragma unroll
+                            for (int r = 0; r < R; ++r)
+                                if (d2[u] < a.r2[r] && cnt[r] < a.ns[r]) { hits[r][cnt[r] * 64 + lane] = k; ++cnt[r]; }
                         }
                     }
-                    thr = (cnt < nsample) ? r2max : -1.f;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) thr_r[r] = (cnt[r] < a.ns[r]) ? a.r2[r] : -1.f;
+                    thr = R == 2 ? fmaxf(thr_r[0], thr_r[1]) : thr_r[0];
                 }
             }
             buf ^= 1;
@@ -495,44 +518,94 @@ __global__ __launch_bounds__(64 * BQG_MAX_SEG) void bqg_query_kernel(int n, int 
         }
         if (__all(thr < 0.f)) break;
     }
-    // ---- ordered concatenation of the segments, padding with the first hit, coalesced rows ----
-    cnts[wv * 64 + lane] = active ? cnt : 0;
-    __syncthreads();
-    int before = 0, total_hits = 0;
-    for (int s = 0; s < S; ++s) {
-        const int c = cnts[s * 64 + lane];
-        before += (s < wv) ? c : 0;
-        total_hits += c;
-    }
-    const int mine = active ? cnt : 0;
-    for (int i = 0; i < mine && before + i < nsample; ++i) final_img[lane * (nsample + 1) + before + i] = segbase + hits[i * 64 + lane];
-    __syncthreads();
-    if (wv == 0) {
-        const int kept = total_hits < nsample ? total_hits : nsample;
-        const int pad = kept > 0 ? final_img[lane * (nsample + 1)] : 0;
-        for (int i = kept; i < nsample; ++i) final_img[lane * (nsample + 1) + i] = pad;
-        cnts[lane] = total_hits;  // every wave has read its prefix: the first row of cnts is free
-    }
-    __syncthreads();
-    if (vec4) {
-        const int q4 = nsample >> 2;
-        for (int e = threadIdx.x; e < 64 * q4; e += blockDim.x) {
-            const int c = e / q4, i = (e - c * q4) * 4;
-            const int jc = jrow[c];
-            if (jc < 0 || !(fill_empty || cnts[c] > 0)) continue;
-            i32x4 v;
+    // ---- per radius: ordered concatenation of the segments, padding with the first hit, coalesced rows ----
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = final_img[c * (nsample + 1) + i + u];
-            *reinterpret_cast<i32x4 *>(idx + ((size_t)scene * m + jc) * nsample + i) = v;
+    for (int r = 0; r < R; ++r) cnts[(r * S + wv) * 64 + lane] = active ? cnt[r] : 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int nsample = a.ns[r];
+        int before = 0, total_hits = 0;
+        for (int s = 0; s < S; ++s) {
+            const int c = cnts[(r * S + s) * 64 + lane];
+            before += (s < wv) ? c : 0;
+            total_hits += c;
         }
-    } else {
-        for (int e = threadIdx.x; e < 64 * nsample; e += blockDim.x) {
-            const int c = e / nsample, i = e - c * nsample;
-            const int jc = jrow[c];
-            if (jc < 0 || !(fill_empty || cnts[c] > 0)) continue;
-            idx[((size_t)scene * m + jc) * nsample + i] = final_img[c * (nsample + 1) + i];
+        const int mine = active ? cnt[r] : 0;
+        for (int i = 0; i < mine && before + i < nsample; ++i)
+            final_img[lane * (nsmax + 1) + before + i] = segbase + hits[r][i * 64 + lane];
+        __syncthreads();
+        if (wv == 0) {
+            const int kept = total_hits < nsample ? total_hits : nsample;
+            const int pad = kept > 0 ? final_img[lane * (nsmax + 1)] : 0;
+            for (int i = kept; i < nsample; ++i) final_img[lane * (nsmax + 1) + i] = pad;
+            jrow[lane] = (active && (a.fill_empty || total_hits > 0)) ? j : -1;  // rows of empty balls: the caller's zeros
         }
+        __syncthreads();
+        int *idx = a.idx[r];
+        if (a.vec4[r]) {
+            const int q4 = nsample >> 2;
+            for (int e = threadIdx.x; e < 64 * q4; e += blockDim.x) {
+                const int c = e / q4, i = (e - c * q4) * 4;
+                const int jc = jrow[c];
+                if (jc < 0) continue;
+                i32x4 v;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = final_img[c * (nsmax + 1) + i + u];
+                *reinterpret_cast<i32x4 *>(idx + ((size_t)scene * m + jc) * nsample + i) = v;
+            }
+        } else {
+            for (int e = threadIdx.x; e < 64 * nsample; e += blockDim.x) {
+                const int c = e / nsample, i = e - c * nsample;
+                const int jc = jrow[c];
+                if (jc < 0) continue;
+                idx[((size_t)scene * m + jc) * nsample + i] = final_img[c * (nsmax + 1) + i];
+            }
+        }
+        if (R == 2) __syncthreads();  // final_img / jrow are reused by the second radius
     }
+}
+
+// set-up launches + query; shared by the one- and two-radius entry points
+static int bqg_run(int R, bool dilated, int b, int n, int m, float ra, float rb, float rmin, int nsa, int nsb, int fill_empty,
+                   const float *new_xyz, const float *xyz, int *idx_a, int *idx_b, int *work, hipStream_t st) {
+    const BqgLayout lay = bqg_layout(n, m);
+    // S waves per group of 64 centroids (a power of two, one 2048-point bitmap chunk per wave at least)
+    const int chunks = divup(divup(n, 32), 64);
+    int S = 1;
+    static const int seg_cap = [] { const char *e = getenv("SPS_BQG_SEG"); const int v = e ? atoi(e) : 0; return v > 0 ? v : BQG_MAX_SEG; }();
+    while (S < BQG_MAX_SEG && S < seg_cap && 2 * S <= chunks) S <<= 1;
+    const int words = divup(chunks, S) * S * 64;
+    const int nsmax = (R == 2 && nsb > nsa) ? nsb : nsa, nstot = nsa + (R == 2 ? nsb : 0);
+    const size_t lds = 4 * (bqg_shared_ints(words, nsmax, S, R) + (size_t)S * bqg_wave_ints(nstot));
+    if (lds > 150 * 1024) return -1;  // caller falls back to the scan kernels
+    const void *fn = R == 2 ? (const void *)bqg_query_kernel<false, 2>
+                            : (dilated ? (const void *)bqg_query_kernel<true, 1> : (const void *)bqg_query_kernel<false, 1>);
+    static bool raised[3] = {false, false, false};
+    const int which = R == 2 ? 2 : (dilated ? 1 : 0);
+    if (lds > 64 * 1024 && !raised[which]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return fail(SPS_ERR_LAUNCH, "ball_query_grid: cannot raise the dynamic LDS limit");
+        raised[which] = true;
+    }
+    const int big = n > m ? n : m;
+    const float rbox = (R == 2 && rb > ra) ? rb : ra;
+    hipLaunchKernelGGL(bqg_setup_kernel, dim3(b), dim3(1024), 0, st, n, xyz, rbox, work, lay.stride, lay);
+    hipLaunchKernelGGL(bqg_count_kernel, dim3(divup(big, 256), b), dim3(256), 0, st, n, m, xyz, new_xyz, work, lay.stride, lay);
+    hipLaunchKernelGGL(bqg_scan_kernel, dim3(2, b), dim3(1024), 0, st, work, lay.stride, lay);
+    hipLaunchKernelGGL(bqg_scatter_kernel, dim3(divup(big, 256), b), dim3(256), 0, st, n, m, work, lay.stride, lay);
+    BqgQuery q;
+    q.n = n; q.m = m; q.fill_empty = fill_empty; q.words = words; q.radius = rbox;
+    q.r2[0] = ra * ra; q.r2[1] = rb * rb; q.r2min = rmin * rmin;  // fp32 products, as the reference forms them (ball_query_gpu.cu:23, 84-85)
+    q.ns[0] = nsa; q.ns[1] = nsb;
+    q.vec4[0] = (nsa % 4 == 0 && (reinterpret_cast<uintptr_t>(idx_a) & 15) == 0) ? 1 : 0;
+    q.vec4[1] = (R == 2 && nsb % 4 == 0 && (reinterpret_cast<uintptr_t>(idx_b) & 15) == 0) ? 1 : 0;
+    q.new_xyz = new_xyz; q.xyz = xyz; q.idx[0] = idx_a; q.idx[1] = idx_b; q.work = work; q.stride = lay.stride; q.lay = lay;
+    const dim3 grid(divup(m, 64), b), block(64 * S);
+    if (R == 2) hipLaunchKernelGGL((bqg_query_kernel<false, 2>), grid, block, lds, st, q);
+    else if (dilated) hipLaunchKernelGGL((bqg_query_kernel<true, 1>), grid, block, lds, st, q);
+    else hipLaunchKernelGGL((bqg_query_kernel<false, 1>), grid, block, lds, st, q);
+    return check_launch("bqg_query_kernel");
 }
 
 }  // namespace sps
@@ -550,40 +623,29 @@ extern "C" int sps_ball_query_grid(int b, int n, int m, float max_radius, float 
         return fail(SPS_ERR_INVALID, "ball_query_grid: bad shape b=%d n=%d m=%d nsample=%d", b, n, m, nsample);
     if (b == 0 || m == 0 || nsample == 0) return SPS_OK;
     hipStream_t st = as_stream(stream);
-    if (!work || n == 0 || n > BQG_MAX_N || !(max_radius > 0.f) || !(max_radius < 3.0e38f))
-        return launch_ball_query(dilated != 0, fill_empty != 0, b, n, m, max_radius, min_radius, nsample, new_xyz, xyz, idx, st);
-    if (!new_xyz || !xyz || !idx) return fail(SPS_ERR_INVALID, "ball_query_grid: null pointer");
-    if (b > 65535) return fail(SPS_ERR_INVALID, "ball_query_grid: batch %d exceeds the grid limit", b);
-    const BqgLayout lay = bqg_layout(n, m);
-    // S waves per group of 64 centroids (a power of two, one 2048-point bitmap chunk per wave at least)
-    const int chunks = divup(divup(n, 32), 64);
-    int S = 1;
-    static const int seg_cap = [] { const char *e = getenv("SPS_BQG_SEG"); const int v = e ? atoi(e) : 0; return v > 0 ? v : BQG_MAX_SEG; }();
-    while (S < BQG_MAX_SEG && S < seg_cap && 2 * S <= chunks) S <<= 1;
-    const int words = divup(chunks, S) * S * 64;
-    const size_t lds = 4 * (bqg_shared_ints(words, nsample, S) + (size_t)S * bqg_wave_ints(nsample));
-    if (lds > 150 * 1024)  // very large nsample: the scan kernel's limits apply instead
-        return launch_ball_query(dilated != 0, fill_empty != 0, b, n, m, max_radius, min_radius, nsample, new_xyz, xyz, idx, st);
-    static bool raised[2] = {false, false};
-    if (lds > 64 * 1024 && !raised[dilated ? 1 : 0]) {
-        const void *fn = dilated ? (const void *)bqg_query_kernel<true> : (const void *)bqg_query_kernel<false>;
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-            return fail(SPS_ERR_LAUNCH, "ball_query_grid: cannot raise the dynamic LDS limit");
-        raised[dilated ? 1 : 0] = true;
+    const bool usable = work && n > 0 && n <= BQG_MAX_N && max_radius > 0.f && max_radius < 3.0e38f && b <= 65535;
+    if (usable) {
+        if (!new_xyz || !xyz || !idx) return fail(SPS_ERR_INVALID, "ball_query_grid: null pointer");
+        const int rc = bqg_run(1, dilated != 0, b, n, m, max_radius, 0.f, min_radius, nsample, 0, fill_empty, new_xyz, xyz, idx,
+                               nullptr, work, st);
+        if (rc >= 0) return rc;
     }
-    const int big = n > m ? n : m;
-    hipLaunchKernelGGL(bqg_setup_kernel, dim3(b), dim3(1024), 0, st, n, xyz, max_radius, work, lay.stride, lay);
-    hipLaunchKernelGGL(bqg_count_kernel, dim3(divup(big, 256), b), dim3(256), 0, st, n, m, xyz, new_xyz, work, lay.stride, lay);
-    hipLaunchKernelGGL(bqg_scan_kernel, dim3(2, b), dim3(1024), 0, st, work, lay.stride, lay);
-    hipLaunchKernelGGL(bqg_scatter_kernel, dim3(divup(big, 256), b), dim3(256), 0, st, n, m, work, lay.stride, lay);
-    const int vec4 = (nsample % 4 == 0 && (reinterpret_cast<uintptr_t>(idx) & 15) == 0) ? 1 : 0;
-    const float r2max = max_radius * max_radius, r2min = min_radius * min_radius;
-    const dim3 grid(divup(m, 64), b), block(64 * S);
-    if (dilated)
-        hipLaunchKernelGGL(bqg_query_kernel<true>, grid, block, lds, st, n, m, r2max, r2min, max_radius, nsample, fill_empty, new_xyz,
-                           xyz, idx, work, lay.stride, lay, words, vec4);
-    else
-        hipLaunchKernelGGL(bqg_query_kernel<false>, grid, block, lds, st, n, m, r2max, r2min, max_radius, nsample, fill_empty, new_xyz,
-                           xyz, idx, work, lay.stride, lay, words, vec4);
-    return check_launch("bqg_query_kernel");
+    return launch_ball_query(dilated != 0, fill_empty != 0, b, n, m, max_radius, min_radius, nsample, new_xyz, xyz, idx, st);
+}
+
+extern "C" int sps_ball_query_grid2(int b, int n, int m, float radius_a, int nsample_a, float radius_b, int nsample_b,
+                                    const float *new_xyz, const float *xyz, int *idx_a, int *idx_b, int *work,
+                                    sps_stream_t stream) {
+    using namespace sps;
+    if (b < 0 || n <= 0 || m < 0 || nsample_a <= 0 || nsample_b <= 0)
+        return fail(SPS_ERR_INVALID, "ball_query_grid2: bad shape b=%d n=%d m=%d ns=(%d,%d)", b, n, m, nsample_a, nsample_b);
+    if (b == 0 || m == 0) return SPS_OK;
+    if (!new_xyz || !xyz || !idx_a || !idx_b) return fail(SPS_ERR_INVALID, "ball_query_grid2: null pointer");
+    const bool usable = work && n <= BQG_MAX_N && radius_a > 0.f && radius_a < 3.0e38f && radius_b > 0.f && radius_b < 3.0e38f && b <= 65535;
+    if (usable) {
+        const int rc = bqg_run(2, false, b, n, m, radius_a, radius_b, 0.f, nsample_a, nsample_b, 1, new_xyz, xyz, idx_a, idx_b,
+                               work, as_stream(stream));
+        if (rc >= 0) return rc;
+    }
+    return sps_ball_query_full2(b, n, m, radius_a, nsample_a, radius_b, nsample_b, new_xyz, xyz, idx_a, idx_b, nullptr, stream);
 }

@@ -360,6 +360,12 @@ def ball_query_full2(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz, spa
             _lib.check(_L.sps_ball_query_full2_wave(B, N, M, radius_a, nsample_a, radius_b, nsample_b, q, p, ia.data_ptr(),
                                                     ib.data_ptr(), _stream(xyz)), "ball_query_full2_wave")
         return ia, ib
+    grid_work = None if spatial_groups else _grid_workspace(B, N, M, xyz)
+    if grid_work is not None:  # large cloud AND many centroids: cell grid + bitmap (csrc/ball_query_grid.hip), same rows
+        with _on(xyz):
+            _lib.check(_L.sps_ball_query_grid2(B, N, M, radius_a, nsample_a, radius_b, nsample_b, q, p, ia.data_ptr(),
+                                               ib.data_ptr(), grid_work.data_ptr(), _stream(xyz)), "ball_query_grid2")
+        return ia, ib
     work = torch.empty((B, M), dtype=I32, device=xyz.device) if spatial_groups else None
     with _on(xyz):
         _lib.check(_L.sps_ball_query_full2(B, N, M, radius_a, nsample_a, radius_b, nsample_b, q, p, ia.data_ptr(),
