@@ -1054,3 +1054,70 @@ def test_stability_generator_stds(ext, G, dev):
     assert float(np.abs(stds - want_stds).max()) <= 1e-4 * max(1.0, float(np.abs(want_stds).max()))
     with pytest.raises(NotImplementedError):
         net.train()(dict(batch_size=2, points=G.t(points)))
+
+
+# ------------------------------------------------------------------ training mode: forward, BatchNorm statistics, gradients
+def _sa_layer_train_reference(mod_cpu, xyz, feats, oracle):
+    """Pure-PyTorch fp32 restatement of PointnetSAModuleMSG_WithSampling.forward in train() mode on the CPU
+    (pointnet2_modules.py:399-460): FPS / ball-query indices from the C oracle, grouping by advanced indexing so that
+    autograd supplies the scatter-add the reference implements in group_points_grad_kernel."""
+    B, N, _ = xyz.shape
+    idx = torch.from_numpy(oracle.fps(xyz.numpy(), mod_cpu.npoint_list[0]).astype(np.int64))          # (B, M)
+    new_xyz = torch.gather(xyz, 1, idx[..., None].expand(-1, -1, 3))
+    bsel = torch.arange(B)[:, None, None]
+    pooled = []
+    for grouper, mlp in zip(mod_cpu.groupers, mod_cpu.mlps):
+        bq = torch.from_numpy(oracle.ball_query(grouper.radius, grouper.nsample, xyz.numpy(), new_xyz.numpy()).astype(np.int64))
+        rel = xyz[bsel, bq] - new_xyz[:, :, None, :]                       # (B, M, ns, 3)
+        grouped = torch.cat([rel.permute(0, 3, 1, 2), feats.permute(0, 2, 1)[bsel, bq].permute(0, 3, 1, 2)], dim=1)
+        y = mlp(grouped)
+        pooled.append(torch.nn.functional.max_pool2d(y, kernel_size=[1, y.size(3)]).squeeze(-1))
+    nf = mod_cpu.aggregation_layer(torch.cat(pooled, dim=1))
+    cls = mod_cpu.confidence_layers(nf).transpose(1, 2)
+    return new_xyz, nf, cls, idx
+
+
+def test_training_mode_matches_torch_reference(ext, G, dev, oracle):
+    """An SA layer in train() mode (BatchNorm on batch statistics): outputs, updated running statistics and the
+    gradients w.r.t. the input features and every parameter against the CPU restatement above.  Distinct coordinates
+    (no exact ties in the max-pool) and a loss that reaches both heads."""
+    import copy
+    from spsnet_amd import pointnet2_modules as M, scenes
+    torch.manual_seed(1)
+    mod = M.PointnetSAModuleMSG_WithSampling(
+        npoint_list=[256], sample_range_list=[-1], sample_type_list=['D-FPS'], radii=[0.6, 1.2], nsamples=[8, 16],
+        mlps=[[4, 8, 16], [4, 16, 24]], use_xyz=True, dilated_group=False, aggregation_mlp=[32], confidence_mlp=[16],
+        num_class=3)
+    scenes.fill_parameters(mod, 8)
+    ref = copy.deepcopy(mod).train()
+    mod = mod.to(dev).train()
+    rng = np.random.default_rng(4)
+    xyz = torch.from_numpy(rng.uniform(-3, 3, (2, 2048, 3)).astype(np.float32))
+    feats0 = torch.from_numpy(rng.normal(size=(2, 4, 2048)).astype(np.float32))
+    wn = torch.from_numpy(rng.normal(size=(2, 32, 256)).astype(np.float32))
+    wc = torch.from_numpy(rng.normal(size=(2, 256, 3)).astype(np.float32))
+
+    f_ref = feats0.clone().requires_grad_(True)
+    _, nf_r, cls_r, idx_r = _sa_layer_train_reference(ref, xyz, f_ref, oracle)
+    ((nf_r * wn).sum() + (cls_r * wc).sum()).backward()
+
+    f_gpu = feats0.clone().to(dev).requires_grad_(True)
+    new_xyz, nf, cls, idx, _ = mod(xyz.to(dev), f_gpu)
+    ((nf * wn.to(dev)).sum() + (cls * wc.to(dev)).sum()).backward()
+
+    np.testing.assert_array_equal(G.n(idx), idx_r.numpy().astype(np.int32))
+
+    def close(a, b, what, tol=2e-4):
+        a, b = G.n(a), b.detach().numpy()
+        assert a.shape == b.shape, what
+        assert float(np.abs(a - b).max()) <= tol * max(1.0, float(np.abs(b).max())), what
+
+    close(nf, nf_r, "new_features")
+    close(cls, cls_r, "cls")
+    close(f_gpu.grad, f_ref.grad, "d/d features")
+    gpu_sd, ref_sd = dict(mod.named_parameters()), dict(ref.named_parameters())
+    for name, p in ref_sd.items():
+        close(gpu_sd[name].grad, p.grad, "d/d " + name)
+    for (name, bg), (_, br) in zip(mod.named_buffers(), ref.named_buffers()):
+        if bg.dtype.is_floating_point:
+            close(bg, br, "buffer " + name)
