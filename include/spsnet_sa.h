@@ -276,6 +276,40 @@ int sps_ball_query_grid(int b, int n, int m, float max_radius, float min_radius,
 int sps_ball_query_grid2(int b, int n, int m, float radius_a, int nsample_a, float radius_b, int nsample_b,
                          const float *new_xyz, const float *xyz, int *idx_a, int *idx_b, int *work, sps_stream_t stream);
 
+/* ---- pcdet/ops/pointnet2/pointnet2_stack: ragged batches (scenes concatenated along the point axis, per-scene counts).
+ * Argument order = the reference launchers' (+ stream).  The vector-pool family (vector_pool_gpu.cu) is not built. ---- */
+/* ball_query_kernel_launcher_stack (pointnet2_stack/src/ball_query_gpu.cu:15-90): new_xyz (M,3), xyz (N,3), idx (M,nsample)
+ * pre-zeroed by the caller; first nsample hits in index order (indices local to the scene), idx[row][0] = -1 if empty. */
+int sps_ball_query_kernel_launcher_stack(int b, int m, float radius, int nsample, const float *new_xyz,
+                                         const int *new_xyz_batch_cnt, const float *xyz, const int *xyz_batch_cnt, int *idx,
+                                         sps_stream_t stream);
+/* voxel_query_kernel_launcher_stack (voxel_query_gpu.cu:12-113): neighbours through point_indices (B,R1,R2,R3) within
+ * +-range voxels of new_coords (M,4) [b,z,y,x]; hit if d2 <= radius^2; global point indices; idx[row][0] = -1 if empty. */
+int sps_voxel_query_kernel_launcher_stack(int m, int r1, int r2, int r3, int nsample, float radius, int z_range, int y_range,
+                                          int x_range, const float *new_xyz, const float *xyz, const int *new_coords,
+                                          const int *point_indices, int *idx, sps_stream_t stream);
+/* stack_farthest_point_sampling_kernel_launcher (sampling_gpu.cu:187-348): per-scene FPS, global indices, temp (N)
+ * pre-filled with 1e10, tie rule of the fixed 1024-thread block. */
+int sps_stack_farthest_point_sampling_kernel_launcher(int n_total, int batch_size, const float *dataset, float *temp,
+                                                      const int *xyz_batch_cnt, int *idxs, const int *num_sampled_points,
+                                                      sps_stream_t stream);
+/* group_points(_grad)_kernel_launcher_stack (group_points_gpu.cu:14-125): features (N,C), idx (M,nsample) local to the
+ * scene -> out (M,C,nsample); grad: atomicAdd scatter into grad_features (N,C). */
+int sps_group_points_kernel_launcher_stack(int b, int m, int c, int nsample, const float *features,
+                                           const int *features_batch_cnt, const int *idx, const int *idx_batch_cnt, float *out,
+                                           sps_stream_t stream);
+int sps_group_points_grad_kernel_launcher_stack(int b, int m, int c, int n, int nsample, const float *grad_out, const int *idx,
+                                                const int *idx_batch_cnt, const int *features_batch_cnt, float *grad_features,
+                                                sps_stream_t stream);
+/* three_nn / three_interpolate(_grad)_kernel_launcher_stack (interpolate_gpu.cu:14-194): global indices into `known`. */
+int sps_three_nn_kernel_launcher_stack(int batch_size, int n, int m, const float *unknown, const int *unknown_batch_cnt,
+                                       const float *known, const int *known_batch_cnt, float *dist2, int *idx,
+                                       sps_stream_t stream);
+int sps_three_interpolate_kernel_launcher_stack(int n, int channels, const float *features, const int *idx,
+                                                const float *weight, float *out, sps_stream_t stream);
+int sps_three_interpolate_grad_kernel_launcher_stack(int n, int channels, const float *grad_out, const int *idx,
+                                                     const float *weight, float *grad_features, sps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -195,3 +195,75 @@ def topk_desc(score, k):
     idx = np.empty((B, k), np.int32)
     lib().orc_topk_desc(B, N, k, ps, idx.ctypes.data_as(_I))
     return idx
+
+
+# ---- stacked (ragged-batch) variants: pcdet/ops/pointnet2/pointnet2_stack/src (parity unpinned, see sa_oracle.c) ----
+def stack_ball_query(radius, nsample, xyz, xyz_cnt, new_xyz, new_cnt):
+    """-> raw idx (M, nsample) as the kernel leaves it on a zeroed buffer: local indices, [row, 0] = -1 if empty."""
+    xyz, px = _f(xyz); new_xyz, pq = _f(new_xyz)
+    xyz_cnt, pxc = _i(xyz_cnt); new_cnt, pqc = _i(new_cnt)
+    M = new_xyz.shape[0]
+    idx = np.zeros((M, nsample), np.int32)
+    lib().orc_stack_ball_query(len(xyz_cnt), M, ctypes.c_float(radius), nsample, pq, pqc, px, pxc, idx.ctypes.data_as(_I))
+    return idx
+
+
+def stack_voxel_query(max_range, radius, nsample, xyz, new_xyz, new_coords, point_indices):
+    xyz, px = _f(xyz); new_xyz, pq = _f(new_xyz)
+    new_coords, pc = _i(new_coords); point_indices, pp = _i(point_indices)
+    M = new_xyz.shape[0]
+    B, Z, Y, X = point_indices.shape
+    idx = np.zeros((M, nsample), np.int32)
+    lib().orc_stack_voxel_query(M, Z, Y, X, nsample, ctypes.c_float(radius), int(max_range[0]), int(max_range[1]),
+                                int(max_range[2]), pq, px, pc, pp, idx.ctypes.data_as(_I))
+    return idx
+
+
+def stack_fps(xyz, xyz_cnt, npoint):
+    xyz, px = _f(xyz); xyz_cnt, pc = _i(xyz_cnt); npoint, pn = _i(npoint)
+    temp = np.full((xyz.shape[0],), 1e10, np.float32)
+    out = np.zeros((int(npoint.sum()),), np.int32)
+    lib().orc_stack_fps(len(xyz_cnt), px, temp.ctypes.data_as(_F), pc, out.ctypes.data_as(_I), pn)
+    return out
+
+
+def stack_group_points(features, features_cnt, idx, idx_cnt):
+    features, pf = _f(features); features_cnt, pfc = _i(features_cnt); idx, pi = _i(idx); idx_cnt, pic = _i(idx_cnt)
+    M, ns = idx.shape
+    C = features.shape[1]
+    out = np.empty((M, C, ns), np.float32)
+    lib().orc_stack_group_points(len(idx_cnt), M, C, ns, pf, pfc, pi, pic, out.ctypes.data_as(_F))
+    return out
+
+
+def stack_group_points_grad(grad_out, idx, idx_cnt, features_cnt, N):
+    grad_out, pg = _f(grad_out); idx, pi = _i(idx); idx_cnt, pic = _i(idx_cnt); features_cnt, pfc = _i(features_cnt)
+    M, C, ns = grad_out.shape
+    out = np.zeros((N, C), np.float32)
+    lib().orc_stack_group_points_grad(len(idx_cnt), M, C, ns, pg, pi, pic, pfc, out.ctypes.data_as(_F))
+    return out
+
+
+def stack_three_nn(unknown, unknown_cnt, known, known_cnt):
+    unknown, pu = _f(unknown); known, pk = _f(known); unknown_cnt, puc = _i(unknown_cnt); known_cnt, pkc = _i(known_cnt)
+    N = unknown.shape[0]
+    d2 = np.empty((N, 3), np.float32)
+    idx = np.empty((N, 3), np.int32)
+    lib().orc_stack_three_nn(len(unknown_cnt), N, pu, puc, pk, pkc, d2.ctypes.data_as(_F), idx.ctypes.data_as(_I))
+    return d2, idx
+
+
+def stack_three_interpolate(features, idx, weight):
+    features, pf = _f(features); idx, pi = _i(idx); weight, pw = _f(weight)
+    N, C = idx.shape[0], features.shape[1]
+    out = np.empty((N, C), np.float32)
+    lib().orc_stack_three_interpolate(N, C, pf, pi, pw, out.ctypes.data_as(_F))
+    return out
+
+
+def stack_three_interpolate_grad(grad_out, idx, weight, M):
+    grad_out, pg = _f(grad_out); idx, pi = _i(idx); weight, pw = _f(weight)
+    N, C = grad_out.shape
+    out = np.zeros((M, C), np.float32)
+    lib().orc_stack_three_interpolate_grad(N, C, pg, pi, pw, out.ctypes.data_as(_F))
+    return out

@@ -52,6 +52,14 @@ _PROTOS = {
     "sps_pointwise_mlp": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_ball_query_grid": [_i, _i, _i, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_ball_query_grid2": [_i, _i, _i, _f, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_ball_query_kernel_launcher_stack": [_i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_voxel_query_kernel_launcher_stack": [_i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_stack_farthest_point_sampling_kernel_launcher": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_group_points_kernel_launcher_stack": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_group_points_grad_kernel_launcher_stack": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_three_nn_kernel_launcher_stack": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_three_interpolate_kernel_launcher_stack": [_i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sps_three_interpolate_grad_kernel_launcher_stack": [_i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_dense_edge_conv": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_linear_rows": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "sps_sa_group_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,

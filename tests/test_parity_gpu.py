@@ -1121,3 +1121,118 @@ def test_training_mode_matches_torch_reference(ext, G, dev, oracle):
     for (name, bg), (_, br) in zip(mod.named_buffers(), ref.named_buffers()):
         if bg.dtype.is_floating_point:
             close(bg, br, "buffer " + name)
+
+
+# ------------------------------------------------------------------ pointnet2_stack: ragged batches (parity unpinned by the reference)
+def _ragged(rng, sizes, dup=0.03):
+    parts = []
+    for n in sizes:
+        p = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+        k = int(n * dup)
+        if k:
+            p[rng.choice(n, k, replace=False)] = p[rng.integers(0, n, k)]
+        parts.append(p)
+    return np.concatenate(parts, 0), np.asarray(sizes, np.int32)
+
+
+@pytest.mark.parametrize("sizes,qsizes,r,ns", [([1000, 37, 2500], [200, 5, 300], 0.5, 16), ([1], [1], 1.0, 4),
+                                               ([5000, 5000], [1024, 1000], 0.2, 32), ([300, 300, 300, 300], [64, 1, 64, 7], 9.0, 8)])
+def test_stack_ball_query_and_group(dev, G, oracle, sizes, qsizes, r, ns):
+    """sps_ball_query_kernel_launcher_stack / sps_group_points(_grad)_kernel_launcher_stack through the extension mirror and
+    the autograd layer (pointnet2_stack/pointnet2_utils.py), against the oracle's restatement of the CUDA kernels."""
+    from spsnet_amd.pointnet2_stack import pointnet2_stack_cuda as SC, pointnet2_utils as SU
+    rng = np.random.default_rng(sum(sizes))
+    xyz, cnt = _ragged(rng, sizes)
+    starts = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    q = np.concatenate([np.concatenate([xyz[s + rng.integers(0, n, (m + 1) // 2)], rng.uniform(-3, 3, (m // 2, 3)).astype(np.float32)])
+                        for s, n, m in zip(starts, sizes, qsizes)]).astype(np.float32)
+    q[-1] = 100.0                                        # an empty ball
+    qc = np.asarray(qsizes, np.int32)
+    raw = torch.zeros((len(q), ns), dtype=torch.int32, device=dev)
+    SC.ball_query_wrapper(len(sizes), len(q), r, ns, G.t(q), G.t(qc), G.t(xyz), G.t(cnt), raw)
+    want_raw = oracle.stack_ball_query(r, ns, xyz, cnt, q, qc)
+    np.testing.assert_array_equal(G.n(raw), want_raw)
+    idx, empty = SU.ball_query(r, ns, G.t(xyz), G.t(cnt), G.t(q), G.t(qc))
+    want_idx = want_raw.copy(); want_idx[want_raw[:, 0] == -1] = 0
+    np.testing.assert_array_equal(G.n(idx), want_idx)
+    np.testing.assert_array_equal(G.n(empty), want_raw[:, 0] == -1)
+    feats = rng.normal(size=(len(xyz), 7)).astype(np.float32)
+    f = G.t(feats).requires_grad_(True)
+    out = SU.grouping_operation(f, G.t(cnt), idx, G.t(qc))
+    np.testing.assert_array_equal(G.n(out), oracle.stack_group_points(feats, cnt, want_idx, qc))
+    go = rng.normal(size=out.shape).astype(np.float32)
+    out.backward(G.t(go))
+    np.testing.assert_allclose(G.n(f.grad), oracle.stack_group_points_grad(go, want_idx, qc, cnt, len(xyz)), rtol=1e-4, atol=1e-5)
+    nf, idx2 = SU.QueryAndGroup(r, ns, use_xyz=True)(G.t(xyz), G.t(cnt), G.t(q), G.t(qc), G.t(feats))
+    assert nf.shape == (len(q), 3 + 7, ns) and torch.equal(idx2, idx)
+    assert float(nf[empty].abs().max()) == 0.0 if bool(empty.any()) else True
+
+
+@pytest.mark.parametrize("sizes,npoints", [([1000, 37, 2500], [100, 37, 512]), ([4096, 4096], [1024, 1]), ([9000], [2000])])
+def test_stack_fps(dev, G, oracle, sizes, npoints):
+    """stack_farthest_point_sampling (1024-thread tie rule, global indices) incl. lattice clouds with masses of equal
+    distances, and the batch-form FPS of the stack module."""
+    from spsnet_amd.pointnet2_stack import pointnet2_utils as SU
+    rng = np.random.default_rng(sum(sizes))
+    for lattice in (False, True):
+        if lattice:
+            xyz = np.concatenate([rng.integers(-4, 5, (n, 3)).astype(np.float32) * 0.25 for n in sizes])
+        else:
+            xyz, _ = _ragged(rng, sizes)
+        cnt = np.asarray(sizes, np.int32)
+        got = SU.stack_farthest_point_sample(G.t(xyz), G.t(cnt), list(npoints))
+        np.testing.assert_array_equal(G.n(got), oracle.stack_fps(xyz, cnt, np.asarray(npoints, np.int32)))
+    dense = rng.uniform(-3, 3, (2, 3000, 3)).astype(np.float32)
+    np.testing.assert_array_equal(G.n(SU.farthest_point_sample(G.t(dense), 300)), oracle.fps(dense, 300))
+
+
+def test_stack_three_nn_interpolate_and_voxel_query(dev, G, oracle):
+    from spsnet_amd.pointnet2_stack import pointnet2_utils as SU, voxel_query_utils as VU
+    rng = np.random.default_rng(17)
+    known, kc = _ragged(rng, [700, 2, 1500])
+    unknown, uc = _ragged(rng, [300, 50, 999], dup=0.0)
+    unknown[:40] = known[:40]                            # exact matches -> zero distances and ties
+    dist, idx = SU.three_nn(G.t(unknown), G.t(uc), G.t(known), G.t(kc))
+    d2, widx = oracle.stack_three_nn(unknown, uc, known, kc)
+    np.testing.assert_array_equal(G.n(idx), widx)
+    np.testing.assert_array_equal(G.n(dist), np.sqrt(d2))
+    feats = rng.normal(size=(len(known), 9)).astype(np.float32)
+    w = rng.uniform(0, 1, (len(unknown), 3)).astype(np.float32)
+    w /= w.sum(1, keepdims=True)
+    f = G.t(feats).requires_grad_(True)
+    out = SU.three_interpolate(f, idx, G.t(w))
+    np.testing.assert_array_equal(G.n(out), oracle.stack_three_interpolate(feats, widx, w))
+    go = rng.normal(size=out.shape).astype(np.float32)
+    out.backward(G.t(go))
+    np.testing.assert_allclose(G.n(f.grad), oracle.stack_three_interpolate_grad(go, widx, w, len(known)), rtol=1e-4, atol=1e-5)
+
+    # voxel query: two scenes of 2000 points in a 0.5 m grid; the table keeps the last point written to a voxel
+    B, n, vs = 2, 2000, 0.5
+    xyz = rng.uniform(0, 8, (B * n, 3)).astype(np.float32)
+    xyz[:, 2] *= 0.25
+    grid = (4, 16, 16)                                   # Z, Y, X
+    coords = np.floor(xyz / vs).astype(np.int32)[:, ::-1]  # z, y, x
+    pi = -np.ones((B,) + grid, np.int32)
+    for i in range(B * n):
+        pi[i // n, coords[i, 0], coords[i, 1], coords[i, 2]] = i
+    sel = np.concatenate([rng.choice(n, 300, replace=False) + b * n for b in range(B)])
+    new_xyz = (xyz[sel] + rng.normal(scale=0.05, size=(len(sel), 3))).astype(np.float32)
+    new_coords = np.concatenate([(sel // n)[:, None].astype(np.int32), coords[sel]], 1).astype(np.int32)
+    idx, empty = VU.voxel_query((1, 2, 2), 0.8, 16, G.t(xyz), G.t(new_xyz), G.t(new_coords), G.t(pi))
+    want = oracle.stack_voxel_query((1, 2, 2), 0.8, 16, xyz, new_xyz, new_coords, pi)
+    wempty = want[:, 0] == -1
+    want[wempty] = 0
+    np.testing.assert_array_equal(G.n(idx), want)
+    np.testing.assert_array_equal(G.n(empty), wempty)
+    cnt = np.full((B,), n, np.int32)
+    gf, gx, em = VU.VoxelQueryAndGrouping((1, 2, 2), 0.8, 16)(
+        G.t(new_coords), G.t(xyz), G.t(cnt), G.t(new_xyz), G.t(np.full((B,), 300, np.int32)), G.t(xyz.copy()), G.t(pi))
+    assert gf.shape == (600, 3, 16) and torch.equal(gf, gx)
+
+
+def test_stack_vector_pool_is_reported_missing(dev):
+    from spsnet_amd.pointnet2_stack import pointnet2_stack_cuda as SC, pointnet2_utils as SU
+    with pytest.raises(NotImplementedError):
+        SC.vector_pool_wrapper()
+    with pytest.raises(NotImplementedError):
+        SU.vector_pool_with_voxel_query_op()
