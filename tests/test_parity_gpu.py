@@ -1236,3 +1236,62 @@ def test_stack_vector_pool_is_reported_missing(dev):
         SC.vector_pool_wrapper()
     with pytest.raises(NotImplementedError):
         SU.vector_pool_with_voxel_query_op()
+
+
+def test_stack_modules_against_torch_reference(dev, G, oracle):
+    """StackSAModuleMSG / StackPointnetFPModule (pointnet2_stack/pointnet2_modules.py:30-157) on ragged scenes, train mode,
+    forward and the gradient w.r.t. the features, against a CPU restatement with oracle indices and torch indexing."""
+    import copy
+    from spsnet_amd import scenes
+    from spsnet_amd.pointnet2_stack import pointnet2_modules as SM
+    rng = np.random.default_rng(23)
+    xyz, cnt = _ragged(rng, [900, 40, 1500], dup=0.0)
+    starts = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    qs = [128, 16, 200]
+    q = np.concatenate([xyz[s + rng.choice(n, m, replace=False)] for s, n, m in zip(starts, cnt, qs)]).astype(np.float32)
+    qc = np.asarray(qs, np.int32)
+    feats = rng.normal(size=(len(xyz), 5)).astype(np.float32)
+    mod = scenes.fill_parameters(SM.StackSAModuleMSG(radii=[0.5, 1.0], nsamples=[8, 16], mlps=[[5, 8, 16], [5, 8, 24]]), 3)
+    ref = copy.deepcopy(mod).train()
+    mod = mod.to(dev).train()
+    f_gpu = G.t(feats).requires_grad_(True)
+    _, out = mod(G.t(xyz), G.t(cnt), G.t(q), G.t(qc), f_gpu)
+    # CPU restatement
+    f_ref = torch.from_numpy(feats).requires_grad_(True)
+    xt, qt = torch.from_numpy(xyz), torch.from_numpy(q)
+    scene_start = torch.from_numpy(np.repeat(starts, qs).astype(np.int64))
+    pooled = []
+    for grouper, mlp in zip(ref.groupers, ref.mlps):
+        raw = oracle.stack_ball_query(grouper.radius, grouper.nsample, xyz, cnt, q, qc)
+        empty = torch.from_numpy(raw[:, 0] == -1)
+        raw[raw[:, 0] == -1] = 0
+        gi = torch.from_numpy(raw.astype(np.int64)) + scene_start[:, None]            # global rows (M, ns)
+        gx = (xt[gi] - qt[:, None, :]).permute(0, 2, 1)                                # (M, 3, ns)
+        gf = f_ref[gi].permute(0, 2, 1)
+        grouped = torch.cat([gx, gf], dim=1)
+        grouped = torch.where(empty[:, None, None], torch.zeros_like(grouped), grouped)
+        y = mlp(grouped.permute(1, 0, 2).unsqueeze(0))
+        pooled.append(torch.nn.functional.max_pool2d(y, kernel_size=[1, y.size(3)]).squeeze(-1).squeeze(0).permute(1, 0))
+    want = torch.cat(pooled, dim=1)
+    wsum = torch.from_numpy(rng.normal(size=tuple(want.shape)).astype(np.float32))
+    (want * wsum).sum().backward()
+    (out * wsum.to(dev)).sum().backward()
+    tol = lambda b: 2e-4 * max(1.0, float(np.abs(b).max()))
+    assert float(np.abs(G.n(out) - want.detach().numpy()).max()) <= tol(want.detach().numpy())
+    assert float(np.abs(G.n(f_gpu.grad) - f_ref.grad.numpy()).max()) <= tol(f_ref.grad.numpy())
+
+    fp = scenes.fill_parameters(SM.StackPointnetFPModule(mlp=[16 + 5, 12]), 4)
+    fp_ref = copy.deepcopy(fp).eval()
+    fp = fp.to(dev).eval()
+    kf = rng.normal(size=(len(q), 16)).astype(np.float32)
+    with torch.no_grad():
+        got = fp(G.t(xyz), G.t(cnt), G.t(q), G.t(qc), G.t(feats), G.t(kf))
+        d2, idx = oracle.stack_three_nn(xyz, cnt, q, qc)
+        rec = 1.0 / (torch.from_numpy(np.sqrt(d2)) + 1e-8)
+        w = rec / rec.sum(-1, keepdim=True)
+        interp = torch.from_numpy(oracle.stack_three_interpolate(kf, idx, w.numpy()))
+        x = torch.cat([interp, torch.from_numpy(feats)], dim=1)
+        want = fp_ref.mlp(x.permute(1, 0)[None, :, :, None]).squeeze(0).squeeze(-1).permute(1, 0).numpy()
+    assert float(np.abs(G.n(got) - want).max()) <= tol(want)
+    with pytest.raises(NotImplementedError):
+        SM.VectorPoolAggregationModule()
