@@ -112,7 +112,7 @@ class _PointBackbone(nn.Module):
         return batch_idx, xyz, features
 
     # ------------------------------------------------------------------------------------------------------------------
-    def _sa_layer(self, i, xyz_input, feature_input, cls_pred, ctr_xyz, stds, fast):
+    def _sa_layer(self, i, xyz_input, feature_input, cls_pred, ctr_xyz, stds, fast, beside_fps=None):
         """One SA layer; on the fast path layer 0 is streamed against its own FPS and the next plain D-FPS layer is
         started early.  -> (li_xyz, li_features, li_cls_pred, sampled_idx, stds)"""
         layer = self.SA_modules[i]
@@ -121,9 +121,11 @@ class _PointBackbone(nn.Module):
                 and self.layer_inputs[i + 1] == i + 1 and self.ctr_idx_list[i + 1] == -1):
             nxt = self.SA_modules[i + 1]
         if fast and i == 0 and cls_pred is None and ctr_xyz is None and self.layer_inputs[0] == 0:
-            res = sa_stack._streamed_first_layer(layer, nxt, xyz_input, feature_input, stds)
+            res = sa_stack._streamed_first_layer(layer, nxt, xyz_input, feature_input, stds, after_producer=beside_fps)
             if res is not None:
                 return res
+        if beside_fps is not None:
+            beside_fps()   # no streamed layer 0: at least ahead of its kernels
         if nxt is not None and ctr_xyz is None and sa_stack._can_prefetch(layer, nxt):
             ordered = sa_stack._is_plain_dfps(layer, xyz_input.shape[1])
             layer._on_new_xyz = lambda nx, _n=nxt, _o=ordered: sa_stack._prefetch_dfps(_n, nx, _o)
@@ -157,18 +159,34 @@ class _PointBackbone(nn.Module):
         sample_list = []
         surface = None
         surface_done = None
-        if self._surface and hasattr(self, 'SF_extract') and fast:
-            # all-N surface features on a side stream: they are first needed after layer 0 has sampled
-            main = torch.cuda.current_stream(xyz.device)
+        pending_gathers = []   # fast path: the per-layer gathers of the surface features are deferred to their consumer
+        xyz_ready = None
+        if fast and self._surface and hasattr(self, 'SF_extract'):
+            xyz_ready = torch.cuda.Event()
+            xyz_ready.record(torch.cuda.current_stream(xyz.device))
+
+        def launch_surface():
+            # all-N surface features on a side stream, enqueued right after layer 0's FPS kernel (which occupies one CU
+            # per scene for ~1.9 ms) and before the chunk pipeline that consumes its picks
+            nonlocal surface, surface_done
             side = _surface_stream(xyz.device)
-            start = torch.cuda.Event()
-            start.record(main)
             xyz.record_stream(side)
             with torch.cuda.stream(side):
-                side.wait_event(start)
+                side.wait_event(xyz_ready)
                 surface = self.SF_extract(xyz).permute(0, 2, 1).contiguous()
                 surface_done = torch.cuda.Event()
                 surface_done.record(side)
+
+        def gathered_surface():
+            nonlocal surface, surface_done
+            if surface_done is not None:
+                torch.cuda.current_stream(xyz.device).wait_event(surface_done)
+                surface.record_stream(torch.cuda.current_stream(xyz.device))
+                surface_done = None
+            for sampled in pending_gathers:
+                surface = pointnet2_utils.gather_operation(surface, sampled)
+            pending_gathers.clear()
+            return surface
 
         li_cls_pred = None
         centers = centers_origin = ctr_offsets = None
@@ -177,19 +195,19 @@ class _PointBackbone(nn.Module):
             feature_input = encoder_features[self.layer_inputs[i]]
             if self.layer_types[i] == 'SA_Layer':
                 ctr_xyz = encoder_xyz[self.ctr_idx_list[i]] if self.ctr_idx_list[i] != -1 else None
+                hook = launch_surface if (fast and i == 0 and xyz_ready is not None) else None
                 li_xyz, li_features, li_cls_pred, sampled_idx_list, stds = self._sa_layer(
-                    i, xyz_input, feature_input, li_cls_pred, ctr_xyz, stds, fast)
+                    i, xyz_input, feature_input, li_cls_pred, ctr_xyz, stds, fast, hook)
                 sample_list.append(sampled_idx_list)
                 if self._surface and hasattr(self, 'SF_extract') and i <= 4:
-                    if i == 0 and surface is None:
-                        surface = self.SF_extract(xyz).permute(0, 2, 1).contiguous()
-                    if surface_done is not None:
-                        torch.cuda.current_stream(xyz.device).wait_event(surface_done)
-                        surface.record_stream(torch.cuda.current_stream(xyz.device))
-                        surface_done = None
-                    surface = pointnet2_utils.gather_operation(surface, sampled_idx_list)
+                    if fast:
+                        pending_gathers.append(sampled_idx_list)
+                    else:
+                        if i == 0:
+                            surface = self.SF_extract(xyz).permute(0, 2, 1).contiguous()
+                        surface = pointnet2_utils.gather_operation(surface, sampled_idx_list)
             elif self.layer_types[i] == 'Vote_Layer':
-                kw = {'center_surface_futures': surface} if self._surface else {}
+                kw = {'center_surface_futures': gathered_surface() if fast else surface} if self._surface else {}
                 li_xyz, li_features, xyz_select, ctr_offsets = self.SA_modules[i](xyz_input, feature_input, **kw)
                 centers = li_xyz
                 centers_origin = xyz_select

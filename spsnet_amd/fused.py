@@ -340,6 +340,60 @@ def pointwise_tail(agg, head, pooled):
     return y1, y3
 
 
+def vote_offsets(mlp, ctr_reg, parts):
+    """Vote_layer's regression (pointnet2_modules.py:488-496: [Conv1d + BatchNorm1d + ReLU], Conv1d(C, 3, bias)) on the
+    channel-wise concatenation of `parts` (each (B, Ci, M)) as ONE kernel -> offsets (B, M, 3), or None when the fused
+    path does not apply.  Reuses the aggregation/confidence kernel (csrc/pw_mlp.hip) with an identity middle layer:
+    the hidden activation is a ReLU output, so relu(I h + 0) = h exactly, in fp32."""
+    mods = list(mlp) if mlp is not None else []
+    if len(mods) != 3 or not (isinstance(mods[0], nn.Conv1d) and isinstance(mods[1], nn.BatchNorm1d) and isinstance(mods[2], nn.ReLU)):
+        return None
+    conv, bn = mods[0], mods[1]
+    x0 = parts[0]
+    if mlp.training or ctr_reg.training or not x0.is_cuda or any(p.dtype != torch.float32 for p in parts):
+        return None
+    if torch.is_grad_enabled() and (any(p.requires_grad for p in parts) or any(p.requires_grad for p in mlp.parameters())
+                                    or any(p.requires_grad for p in ctr_reg.parameters())):
+        return None
+    if conv.kernel_size != (1,) or ctr_reg.kernel_size != (1,) or not bn.track_running_stats:
+        return None
+    B, M = x0.shape[0], x0.shape[2]
+    cin = sum(p.shape[1] for p in parts)
+    c1, classes = conv.out_channels, ctr_reg.out_channels
+    cin_pad = _pad16(cin)
+    if cin != conv.in_channels or c1 % 16 or M % 16 or classes > 16 or ctr_reg.in_channels != c1:
+        return None
+    if 17 * 4 * (max(cin_pad, c1) + c1) > 150 * 1024:
+        return None
+    key = _version_key([(conv, bn)], x0.device) + tuple(
+        (t.data_ptr(), t._version) for t in (ctr_reg.weight, ctr_reg.bias) if t is not None)
+    packed = getattr(mlp, "_sps_vote", None)
+    if packed is None or packed.key != key:
+        with torch.no_grad():
+            packed = PackedTail()
+            packed.key, packed.cin, packed.c1, packed.c2, packed.classes = key, cin_pad, c1, c1, classes
+            w, b = _fold(conv, bn)
+            wp = w.new_zeros(c1, cin_pad)
+            wp[:, :cin] = w                      # padded input channels read zeros and weigh nothing
+            packed.w1, packed.b1 = _pack_pw(wp, c1), b.contiguous()
+            packed.w2, packed.b2 = _pack_pw(torch.eye(c1, dtype=torch.float32, device=w.device), c1), b.new_zeros(c1)
+            w3 = ctr_reg.weight.detach().reshape(classes, c1).float()
+            b3 = ctr_reg.bias.detach().float() if ctr_reg.bias is not None else w3.new_zeros(classes)
+            packed.w3, packed.b3 = _pack_pw(w3, 16), _pad_bias(b3, 16)
+        object.__setattr__(mlp, "_sps_vote", packed)
+    pieces = list(parts)
+    if cin_pad != cin:
+        pieces.append(x0.new_zeros((B, cin_pad - cin, M)))
+    x = torch.cat(pieces, dim=1) if len(pieces) > 1 else x0.contiguous()
+    y1 = torch.empty((B, c1, M), dtype=torch.float32, device=x.device)
+    y3 = torch.empty((B, M, classes), dtype=torch.float32, device=x.device)
+    _lib.check(_L.sps_pointwise_mlp(B, M, cin_pad, c1, c1, classes, x.data_ptr(), packed.w1.data_ptr(), packed.b1.data_ptr(),
+                                    packed.w2.data_ptr(), packed.b2.data_ptr(), packed.w3.data_ptr(), packed.b3.data_ptr(),
+                                    y1.data_ptr(), 0, y3.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream),
+               "pointwise_mlp (vote)")
+    return y3
+
+
 # ---- DenseEdgeConv / FeatureExtraction (surface_feature.py:45-187) ------------------------------------------------------
 class PackedEdgeConv:
     __slots__ = ("key", "w1", "b1", "w2", "b2", "w3", "b3", "relative")

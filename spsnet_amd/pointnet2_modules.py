@@ -445,22 +445,33 @@ class Vote_layer(nn.Module):
         self.max_offset_limit = (torch.tensor(max_translate_range).float()
                                  if max_translate_range is not None else None)
 
+    def _limit_on(self, device):
+        cached = getattr(self, '_limit_cache', None)
+        if cached is None or cached.device != device:
+            cached = self.max_offset_limit.to(device).view(1, 1, 3)
+            object.__setattr__(self, '_limit_cache', cached)
+        return cached
+
     def forward(self, xyz, features, **kwargs):
         if kwargs.get('center_surface_futures', None) is not None:
             self.center_surface_futures = kwargs['center_surface_futures']
-        hidden = features
-        if self.mlp_modules is not None:
-            if hasattr(self, 'center_surface_futures'):
-                hidden = torch.cat([self.center_surface_futures, hidden], dim=1)
-            hidden = self.mlp_modules(hidden)
-        offsets = self.ctr_reg(hidden).transpose(1, 2)      # (B, M, 3)
+        surface = getattr(self, 'center_surface_futures', None) if self.mlp_modules is not None else None
+        offsets = None
+        if self.mlp_modules is not None:   # inference: regression stack as one kernel (fused.vote_offsets)
+            offsets = _fused.vote_offsets(self.mlp_modules, self.ctr_reg, [features] if surface is None else [surface, features])
+        if offsets is None:
+            hidden = features
+            if self.mlp_modules is not None:
+                if surface is not None:
+                    hidden = torch.cat([surface, hidden], dim=1)
+                hidden = self.mlp_modules(hidden)
+            offsets = self.ctr_reg(hidden).transpose(1, 2)      # (B, M, 3)
         new_features = offsets[..., 3:]                      # empty: ctr_reg has exactly 3 outputs
         ctr_offsets = offsets[..., :3]
         if self.max_offset_limit is not None:
-            limit = self.max_offset_limit.to(xyz.device).view(1, 1, 3).expand_as(ctr_offsets)
-            clamped = torch.where(ctr_offsets > limit, limit, ctr_offsets)
-            clamped = torch.where(clamped < -limit, -limit, clamped)
-            vote_xyz = xyz + clamped
+            limit = self._limit_on(xyz.device)
+            # where(o > l, l, o) then where(. < -l, -l, .) of the reference (:505-507) in one op; NaN stays NaN either way
+            vote_xyz = xyz + torch.clamp(ctr_offsets, min=-limit, max=limit)
         else:
             vote_xyz = xyz + ctr_offsets
         return vote_xyz, new_features, xyz, ctr_offsets

@@ -127,14 +127,17 @@ def check_timeouts():
     return bad
 
 
-def _streamed_first_layer(layer, nxt, xyz, features, stds=None):
+def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=None):
     """Layer 0 with its grouping/MLP consuming the D-FPS output WHILE the FPS kernel is still running.
 
     FPS is a serial chain on one CU per scene (~2.9 ms for 8 x 16384 -> 4096); the ball queries and grouped MLPs of
     the centroids it has already produced need nothing else, so they run chunk by chunk on a second stream, each
     chunk gated by a bounded device-side wait on the kernel's published progress counter (csrc: sps_fps_publish /
     sps_wait_progress, the write-through hand-off of the CDNA guide).  Same kernels, same results; only the
-    schedule differs.  Returns None when the layer does not qualify (caller falls back to layer.forward)."""
+    schedule differs.  Returns None when the layer does not qualify (caller falls back to layer.forward).
+    after_producer: called on the host right after the FPS kernel has been enqueued -- the place for independent work
+    that should run beside it (PAGNet's surface features): enqueued earlier it delays the FPS launch by its own host
+    time, enqueued after this function it starts ~1.7 ms late (the host time of the chunk pipeline below)."""
     from . import fused as _fused
     from . import pointnet2_batch_cuda as _ext
     from . import pointnet2_utils
@@ -176,6 +179,8 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None):
     start = torch.cuda.Event()
     start.record(main)
     _ext.fps_publish(xyz, temp, idx, progress)          # producer, on the main stream
+    if after_producer is not None:
+        after_producer()
     for t in (xyz, features, idx, progress, timed_out, new_xyz, idx_a, idx_b, out):
         t.record_stream(side)
     ends = [M * e // 16 for e in _CHUNK_ENDS_16]
