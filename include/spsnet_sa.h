@@ -228,6 +228,11 @@ int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int c_feat, int
 int sps_pointwise_mlp(int b, int m, int cin, int c1, int c2, int classes, const float *x, const float *w1,
                       const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, float *y1,
                       float *y1_point_major /* optional (b, m, c1) copy of y1, or NULL */, float *y3, sps_stream_t stream);
+/* The same for the points [j0, j0 + jcount) of every scene only (multiples of 16): lets a caller that produces x chunk by
+ * chunk (the streamed first layer) run the tail chunk by chunk too. */
+int sps_pointwise_mlp_range(int b, int m, int j0, int jcount, int cin, int c1, int c2, int classes, const float *x,
+                            const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                            const float *b3, float *y1, float *y1_point_major, float *y3, sps_stream_t stream);
 
 /* farthest_point_sampling_kernel_launcher (sampling_gpu.cu:93-253) with an optional device workspace of
  * b * sps_fps_workspace_floats(n) floats (0 for sizes that need none).  With it, scenes of 16 385 .. 262 144 points

@@ -338,12 +338,13 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
             int v1, v2;
             const int wl1 = best_bucket(mine, v1);
             const int wl2 = best_bucket(mine && lane != wl1, v2);
-            const int v3 = wave_max_i32_id((mine && lane != wl1 && lane != wl2) ? bmax : IMIN);
-            // runner-up inside each of the two buckets
+            // the best of the other buckets, and the runner-up inside each of the two buckets: one interleaved reduction
             const int hl1 = __builtin_amdgcn_readlane(bhold, wl1), hl2 = __builtin_amdgcn_readlane(bhold, wl2);
             const float tw1 = t[wl1], tw2 = t[wl2];
-            const int t21 = wave_max_i32_id(lane != hl1 ? __float_as_int(tw1) : IMIN);
-            const int t22 = wave_max_i32_id(lane != hl2 ? __float_as_int(tw2) : IMIN);
+            int v3 = (mine && lane != wl1 && lane != wl2) ? bmax : IMIN;
+            int t21 = lane != hl1 ? __float_as_int(tw1) : IMIN;
+            int t22 = lane != hl2 ? __float_as_int(tw2) : IMIN;
+            wave_max_i32_id3(v3, t21, t22);
             auto record = [&](int wl, int vmax, int others, auto r) {
                 constexpr int R = decltype(r)::value;
                 const int klo = __builtin_amdgcn_readlane((int)bkeylo, wl);
@@ -402,8 +403,9 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
         pair(id.w, ik.w, ixv.w, iyv.w, izv.w, ibv.w);
         // sum over the four lanes of record j: its position in the order, and whether it may follow
         int cnt = nbef | (nbad << 8);
-        cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
-        cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+        asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                     : "+v"(cnt));
         const int pos = cnt & 0xFF;
         const int firstbad = -wave_max_i32_id((cnt >> 8) ? -pos : -2 * PF_WAVES);
         int L = firstbad < m - j ? firstbad : m - j;

@@ -225,8 +225,8 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_big_kernel(int n, int m
             const size_t p = (size_t)g * 64 + lane;
             const float xv = sx[p], yv = sy[p], zv = sz[p], tv = st[p];
             const int rv = srk[p];
-            const float lx = wave_allmin_f32(xv), ly = wave_allmin_f32(yv), lz = wave_allmin_f32(zv);
-            const float hx = wave_allmax_f32(xv), hy = wave_allmax_f32(yv), hz = wave_allmax_f32(zv);
+            float lx = xv, ly = yv, lz = zv, hx = xv, hy = yv, hz = zv;
+            wave_box6(lx, ly, lz, hx, hy, hz);
             if (lane == l) { blo_x[R] = lx; blo_y[R] = ly; blo_z[R] = lz; bhi_x[R] = hx; bhi_y[R] = hy; bhi_z[R] = hz; }
             refresh(tv, rv, xv, yv, zv);
             commit(rc, l);

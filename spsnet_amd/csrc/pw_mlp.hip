@@ -23,7 +23,7 @@ constexpr int PW_MAX_WAVES = 16;
 constexpr int PW_PAD = 17;  // LDS row pitch of the activation images (floats)
 
 struct PwArgs {
-    int m, cin, c1, c2, c3, c3_real;
+    int m, j0, cin, c1, c2, c3, c3_real;  // j0: first point of the launch (a multiple of 16)
     const float *x, *w1, *b1, *w2, *b2, *w3, *b3;
     float *y1, *y1t, *y3;
 };
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void pw_mlp_kernel(PwArgs a) {
     float *xt = pw_lds, *act2 = pw_lds, *act1 = pw_lds + r0;
     const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
-    const int scene = blockIdx.y, m0 = blockIdx.x * 16;
+    const int scene = blockIdx.y, m0 = a.j0 + blockIdx.x * 16;
 
     // ---- stage the 16 input columns: cin rows of 64 bytes, coalesced ----
     {
@@ -115,12 +115,14 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void pw_mlp_kernel(PwArgs a) {
 
 }  // namespace sps
 
-extern "C" int sps_pointwise_mlp(int b, int m, int cin, int c1, int c2, int c3_real, const float *x, const float *w1,
-                                 const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
-                                 float *y1, float *y1_point_major, float *y3, sps_stream_t stream) {
+extern "C" int sps_pointwise_mlp_range(int b, int m, int j0, int jcount, int cin, int c1, int c2, int c3_real, const float *x,
+                                       const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                                       const float *b3, float *y1, float *y1_point_major, float *y3, sps_stream_t stream) {
     using namespace sps;
     if (b < 0 || m < 0 || cin <= 0 || c1 <= 0) return fail(SPS_ERR_INVALID, "pointwise_mlp: bad shape b=%d m=%d cin=%d c1=%d", b, m, cin, c1);
-    if (b == 0 || m == 0) return SPS_OK;
+    if (j0 < 0 || jcount < 0 || j0 + jcount > m || j0 % 16 || jcount % 16)
+        return fail(SPS_ERR_INVALID, "pointwise_mlp: range [%d, +%d) must lie in [0, %d) on multiples of 16", j0, jcount, m);
+    if (b == 0 || jcount == 0) return SPS_OK;
     if (m % 16 || cin % 16 || c1 % 16) return fail(SPS_ERR_INVALID, "pointwise_mlp: m, cin, c1 (%d, %d, %d) must be multiples of 16", m, cin, c1);
     if (!x || !w1 || !b1 || !y1) return fail(SPS_ERR_INVALID, "pointwise_mlp: null pointer");
     const bool deep = w2 != nullptr;
@@ -130,7 +132,7 @@ extern "C" int sps_pointwise_mlp(int b, int m, int cin, int c1, int c2, int c3_r
     }
     if (b > 65535) return fail(SPS_ERR_INVALID, "pointwise_mlp: batch %d exceeds the grid limit", b);
     PwArgs a;
-    a.m = m; a.cin = cin; a.c1 = c1; a.c2 = deep ? c2 : 0; a.c3 = 16; a.c3_real = deep ? c3_real : 0;
+    a.m = m; a.j0 = j0; a.cin = cin; a.c1 = c1; a.c2 = deep ? c2 : 0; a.c3 = 16; a.c3_real = deep ? c3_real : 0;
     a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = deep ? w2 : nullptr; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.y1 = y1; a.y1t = y1_point_major; a.y3 = y3;
     const int wide = (deep && c2 > cin) ? c2 : cin;
     const size_t lds = sizeof(float) * (size_t)PW_PAD * ((size_t)wide + c1);
@@ -146,6 +148,12 @@ extern "C" int sps_pointwise_mlp(int b, int m, int cin, int c1, int c2, int c3_r
     int tiles = c1 / 16;
     if (deep && c2 / 16 > tiles) tiles = c2 / 16;
     const int waves = tiles < 4 ? 4 : (tiles > PW_MAX_WAVES ? PW_MAX_WAVES : tiles);
-    hipLaunchKernelGGL(pw_mlp_kernel, dim3(m / 16, b), dim3(64 * waves), lds, as_stream(stream), a);
+    hipLaunchKernelGGL(pw_mlp_kernel, dim3(jcount / 16, b), dim3(64 * waves), lds, as_stream(stream), a);
     return check_launch("pw_mlp_kernel");
+}
+
+extern "C" int sps_pointwise_mlp(int b, int m, int cin, int c1, int c2, int c3_real, const float *x, const float *w1,
+                                 const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
+                                 float *y1, float *y1_point_major, float *y3, sps_stream_t stream) {
+    return sps_pointwise_mlp_range(b, m, 0, m, cin, c1, c2, c3_real, x, w1, b1, w2, b2, w3, b3, y1, y1_point_major, y3, stream);
 }

@@ -239,9 +239,10 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
                 }
 #pragma unroll
                 for (int cc = 0; cc < CPP; ++cc) {
+                    const f32x4 pooled4 = row_allmax4(best[cc]);  // pool, then ReLU
                     float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(row_allmax(best[cc][r]), 0.f);  // pool, then ReLU
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(pooled4[r], 0.f);
                     if (c == 0) {
                         const long long cen = bj0 + cc;
                         const int b = (int)(cen / a.m), j = (int)(cen - (long long)b * a.m);

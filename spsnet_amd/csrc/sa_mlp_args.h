@@ -20,6 +20,27 @@ struct SaMlpArgs {
 };
 
 
+// max over the 16 lanes of each DPP row (= the 16 columns of an MFMA tile) for the four rows a lane holds, valid in
+// every lane: xor butterfly quad_perm [1,0,3,2] / [2,3,0,1] / row_half_mirror / row_mirror.  Written as v_max_f32_dpp:
+// hipcc emits v_mov_b32_dpp + v_max_f32 per step from update_dpp + fmaxf (twice the VALU slots, and on this chip VALU
+// work is not hidden behind other waves' MFMAs); the four independent chains cover each other's DPP wait states.
+#ifdef __HIPCC__
+typedef float sps_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ sps_f32x4 row_allmax4(sps_f32x4 v) {
+    float a = v[0], b = v[1], c = v[2], d = v[3];
+#define SPS_DPP_MAX4(CTRL)                                                    \
+    "v_max_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n"           \
+    "v_max_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n"           \
+    "v_max_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n"           \
+    "v_max_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n"
+    asm volatile("s_nop 1\n" SPS_DPP_MAX4("quad_perm:[1,0,3,2]") SPS_DPP_MAX4("quad_perm:[2,3,0,1]")
+                 SPS_DPP_MAX4("row_half_mirror") SPS_DPP_MAX4("row_mirror")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef SPS_DPP_MAX4
+    return (sps_f32x4){a, b, c, d};
+}
+#endif
+
 extern int g_mlp_f16;
 // sa_mlp_f16.hip: split-fp16 variant; same argument block (units = scenes, ups = centroids per scene on entry)
 int launch_sa_mlp_f16(const SaMlpArgs &a, int c1, int c2, int nsample, hipStream_t st);

@@ -333,9 +333,9 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa
                 }
 #pragma unroll
                 for (int cc = 0; cc < CPP; ++cc) {
-                    f32x4 v;
+                    f32x4 v = row_allmax4(best[cc]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(row_allmax_h(best[cc][r]), 0.f);
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                     if (c == 0) *reinterpret_cast<f32x4 *>(my_stage + (size_t)cc * C3 + 16 * mt + 4 * q) = v;
                 }
             }

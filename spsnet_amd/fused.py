@@ -284,16 +284,43 @@ def _tail_layers(agg, head):
     return out
 
 
-def pointwise_tail(agg, head, pooled):
-    """Aggregation stack (+ confidence head) of an SA layer on `pooled` (B, C, M) as one kernel ->
-    (new_features (B, Cagg, M), cls (B, M, K) | None), or None when the fused path does not apply (training, gradients
-    wanted, widths that are not multiples of 16, more than 16 classes, ...)."""
-    if agg.training or (head is not None and head.training) or not pooled.is_cuda or pooled.dtype != torch.float32:
+class TailRunner:
+    """The aggregation stack (+ confidence head) of an SA layer on `pooled` (B, C, M), launched for the whole layer or
+    range by range (`run(j0, jcount)`, on torch's current stream); `result()` -> (new_features (B, Cagg, M), cls | None)."""
+
+    def __init__(self, packed, pooled, with_head):
+        B, _, M = pooled.shape
+        dev = pooled.device
+        self.packed, self.x, self.B, self.M = packed, pooled, B, M
+        self.y1 = torch.empty((B, packed.c1, M), dtype=torch.float32, device=dev)
+        self.y1t = torch.empty((B, M, packed.c1), dtype=torch.float32, device=dev)  # point-major twin for the next SA layer
+        self.y3 = torch.empty((B, M, packed.classes), dtype=torch.float32, device=dev) if with_head else None
+
+    def tensors(self):
+        return tuple(t for t in (self.y1, self.y1t, self.y3) if t is not None)
+
+    def run(self, j0=0, jcount=None):
+        p = self.packed
+        ptr = lambda t: 0 if t is None else t.data_ptr()
+        _lib.check(_L.sps_pointwise_mlp_range(self.B, self.M, j0, self.M - j0 if jcount is None else jcount, p.cin, p.c1, p.c2,
+                                              p.classes, self.x.data_ptr(), ptr(p.w1), ptr(p.b1), ptr(p.w2), ptr(p.b2),
+                                              ptr(p.w3), ptr(p.b3), self.y1.data_ptr(), self.y1t.data_ptr(), ptr(self.y3),
+                                              torch.cuda.current_stream(self.x.device).cuda_stream), "pointwise_mlp")
+
+    def result(self):
+        self.y1._sps_nc = self.y1t
+        return self.y1, self.y3
+
+
+def tail_runner(agg, head, pooled):
+    """-> TailRunner, or None when the fused path does not apply (training, gradients wanted, widths that are not
+    multiples of 16, more than 16 classes, ...).  `pooled` must be contiguous and may still be being filled."""
+    if agg is None or agg.training or (head is not None and head.training) or not pooled.is_cuda or pooled.dtype != torch.float32:
         return None
     if torch.is_grad_enabled() and (pooled.requires_grad or any(p.requires_grad for p in agg.parameters())):
         return None
     layers = _tail_layers(agg, head)
-    if layers is None:
+    if layers is None or not pooled.is_contiguous():
         return None
     (c_agg, bn_agg) = layers[0]
     B, cin, M = pooled.shape
@@ -328,16 +355,17 @@ def pointwise_tail(agg, head, pooled):
                 b3 = c_out.bias.detach().float() if c_out.bias is not None else w3.new_zeros(classes)
                 packed.w3, packed.b3 = _pack_pw(w3, 16), _pad_bias(b3, 16)
         object.__setattr__(agg, "_sps_tail", packed)
-    x = pooled.contiguous()
-    y1 = torch.empty((B, c1, M), dtype=torch.float32, device=pooled.device)
-    y1t = torch.empty((B, M, c1), dtype=torch.float32, device=pooled.device)  # point-major twin for the next SA layer
-    y3 = torch.empty((B, M, classes), dtype=torch.float32, device=pooled.device) if head is not None else None
-    ptr = lambda t: 0 if t is None else t.data_ptr()
-    _lib.check(_L.sps_pointwise_mlp(B, M, cin, c1, c2, classes, x.data_ptr(), ptr(packed.w1), ptr(packed.b1), ptr(packed.w2),
-                                    ptr(packed.b2), ptr(packed.w3), ptr(packed.b3), y1.data_ptr(), y1t.data_ptr(), ptr(y3),
-                                    torch.cuda.current_stream(pooled.device).cuda_stream), "pointwise_mlp")
-    y1._sps_nc = y1t
-    return y1, y3
+    return TailRunner(packed, pooled, head is not None)
+
+
+def pointwise_tail(agg, head, pooled):
+    """Aggregation stack (+ confidence head) of an SA layer on `pooled` (B, C, M) as one kernel ->
+    (new_features (B, Cagg, M), cls (B, M, K) | None), or None when the fused path does not apply."""
+    runner = tail_runner(agg, head, pooled.contiguous())
+    if runner is None:
+        return None
+    runner.run()
+    return runner.result()
 
 
 def vote_offsets(mlp, ctr_reg, parts):

@@ -181,7 +181,10 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
     _ext.fps_publish(xyz, temp, idx, progress)          # producer, on the main stream
     if after_producer is not None:
         after_producer()
-    for t in (xyz, features, idx, progress, timed_out, new_xyz, idx_a, idx_b, out):
+    # the aggregation / confidence tail runs chunk by chunk behind the grouped MLPs (its 16-point tiles are independent),
+    # so that only the last chunk's share of it is left when FPS ends
+    tail = _fused.tail_runner(layer.aggregation_layer, getattr(layer, "confidence_layers", None), out)
+    for t in (xyz, features, idx, progress, timed_out, new_xyz, idx_a, idx_b, out) + (tail.tensors() if tail else ()):
         t.record_stream(side)
     ends = [M * e // 16 for e in _CHUNK_ENDS_16]
     # the next layer's D-FPS over these centroids is the verified identity prefix (fps_verify.hip): its first pass
@@ -209,6 +212,8 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
             for ix, packed in zip((idx_a, idx_b), plan):
                 _fused.group_mlp_pool(xyz, new_xyz, features, ix, packed, out, off, j0, chunk)
                 off += packed.c3_real
+            if tail is not None:
+                tail.run(j0, chunk)
         done = torch.cuda.Event()
         done.record(side)
     main.wait_event(xyz_ready)                           # all centroids exist: the next layer's FPS check can finish
@@ -225,7 +230,7 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
     elif nxt is not None and _can_prefetch(layer, nxt):
         _prefetch_dfps(nxt, new_xyz, True)
     main.wait_event(done)
-    new_features, cls = layer._tail(out)
+    new_features, cls = tail.result() if tail is not None else layer._tail(out)
     if stds is not None:  # the layer's sampler thins the stability scores with its picks (reference :307-310)
         stds = pointnet2_utils.gather_operation(stds.view(B, 1, -1).contiguous(), idx).squeeze()
     return new_xyz, new_features, cls, idx, stds
