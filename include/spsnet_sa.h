@@ -254,7 +254,8 @@ int sps_index_add_deterministic(int b, int c, int n, int cols, const float *grad
 /* DenseEdgeConv.forward (surface_feature.py:98-116) given the neighbour table of its radius query, as one kernel:
  * x (b, n, d) point-major features, idx (b, n, k) from ball_query(radius, k, pos, pos) (:55, 84-89) ->
  * out (b, n, d + 3*growth) = [max_k y3 | max_k y2 | max_k y1 | x], y1 = relu(W1 e + b1) over the edge features
- * e = [x_i, x_j, x_j - x_i] (or x_j - x_i alone when relative_only, :71-80), y2 = relu(W2 [y1, x_i] + b2),
+ * e = [x_i, x_j, x_j - x_i] (relative_only = 0; = 1: x_j - x_i alone, :71-80; = 2: as 0 with the centre / neighbour /
+ * difference weight blocks merged into two on the host, w1 = [(W1a - W1c) | (W1b + W1c)], ~1e-6 relative off), y2 = relu(W2 [y1, x_i] + b2),
  * y3 = W3 [y2, y1, x_i] + b3.  Built for the configuration the reference instantiates (FeatureExtraction defaults,
  * :120-131: d = 24, k = 16, growth = 12, three FC layers, ReLU, max); weights in the fragment order of
  * spsnet_amd/fused.py:pack_dense_edge_conv.  Exact fp32 (MFMA f32). */

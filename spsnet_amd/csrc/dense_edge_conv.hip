@@ -13,16 +13,16 @@
 //     broadcast of the centre's column), the neighbour-dependent parts follow as MFMAs; a D fragment of layer i
 //     is directly the B operand of layer i+1 (lane (q, col) holds rows 4q..4q+3 of column col = k-slot q of k-steps
 //     r = 0..3), and the max over K is a DPP row reduction.
-// 18 MFMAs per centre instead of the 42 (30 for the first, difference-only convolution) of a per-centre GEMM chain;
+// 24 MFMAs per centre (18 for the first, difference-only convolution) instead of the 42 (30) of a per-centre GEMM chain;
 // the only HBM traffic is the 96-byte feature rows (L2-resident), the neighbour table and the 240-byte output row.
 //
-// fp32 throughout (MFMA fp32 = an fmaf chain per output).  The first layer of a full convolution is evaluated as
-// W1a x_i + W1b x_j + W1c (x_j - x_i) = (W1a - W1c) x_i + (W1b + W1c) x_j with the two weight sums formed on the host in
-// fp32 -- a third fewer MFMAs, and a rounding difference of the order of eps |W1c| |x| (measured < 2e-6 of the output
-// range on the golden network).  The difference-only first convolution keeps the reference's rounded x_j - x_i: its
-// inputs are raw coordinates, where the merged form would cancel.  Channel -> k-slot mapping of the d = 24 input channels: lane q of k-step j carries channel 6q + j, so
+// fp32 throughout (MFMA fp32 = an fmaf chain per output); the difference x_j - x_i is rounded before it is multiplied,
+// as in the reference.  An optional merged form of the first layer, (W1a - W1c) x_i + (W1b + W1c) x_j with the weight
+// sums formed on the host (18 MFMAs, ~1e-6 relative off), exists for static graphs (fused.DEC_MERGED); it is OFF by
+// default because in a DYNAMIC graph the features are the next convolution's query positions, and every last-bit
+// change moves some point across a ball's boundary.  Channel -> k-slot mapping of the d = 24 input channels: lane q of k-step j carries channel 6q + j, so
 // that a lane loads 24 contiguous bytes of a feature row.  The host packs the weights to match (fused.py:
-// pack_dense_edge_conv): w1 = [centre' | neighbour'] k-steps (the difference block alone when relative_only),
+// pack_dense_edge_conv): w1 = [centre | neighbour | difference] k-steps (the difference block alone when relative_only),
 // w2 = [y1 (4) | centre (6)], w3 = [y2 (4) | y1 (4) | centre (6)].
 //
 // Output row (reference order, surface_feature.py:98-116): [max_k y3 (12) | max_k y2 (12) | max_k y1 (12) | x (24)].
@@ -90,8 +90,11 @@ __device__ __forceinline__ void dec_load6(const float *row, float (&v)[6]) {
 // lane `src` (0..15, wave-uniform) of every 16-lane row, broadcast to the row
 __device__ __forceinline__ float row_pick(float v, int addr) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); }
 
-template <bool REL>
+// FORM 0: layer_first on [x_i | x_j | x_j - x_i] as the reference forms it (w1 = 18 k-steps); 1: on x_j - x_i only (6);
+// 2: the algebraically merged (W1a - W1c) x_i + (W1b + W1c) x_j (12 k-steps, a third fewer MFMAs, ~1e-6 relative off)
+template <int FORM>
 __global__ __launch_bounds__(256, 4) void dense_edge_conv_kernel(DecArgs a) {
+    constexpr bool REL = FORM == 1;
     constexpr int CEN = REL ? 0 : 6;      // k-steps of w1 that multiply the centre
     const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
     // weights of the per-centre steps live in registers; those of the per-tile centre terms (and the biases) are
@@ -111,9 +114,13 @@ __global__ __launch_bounds__(256, 4) void dense_edge_conv_kernel(DecArgs a) {
             cw[26 + r][lane] = a.b3[4 * q + r];
         }
     }
-    float w1x[6], w2y[4], w3y[8];  // w1x multiplies x_j (merged blocks) or, for the difference-only layer, x_j - x_i
+    float w1x[6], w1d[FORM == 0 ? 6 : 1], w2y[4], w3y[8];  // w1x multiplies x_j (or x_j - x_i when REL), w1d the difference
 #pragma unroll
     for (int j = 0; j < 6; ++j) w1x[j] = a.w1[(CEN + j) * 64 + lane];
+    if (FORM == 0) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) w1d[j] = a.w1[(12 + j) * 64 + lane];
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) w2y[r] = a.w2[r * 64 + lane];
 #pragma unroll
@@ -161,16 +168,21 @@ __global__ __launch_bounds__(256, 4) void dense_edge_conv_kernel(DecArgs a) {
             float xnext[6];
             dec_load6(a.x + ((long long)__builtin_amdgcn_readlane(srow, c1) + nb1) * DEC_D + 6 * q, xnext);
             const int pick = ((lane & 48) | cc) << 2;
-            if (REL) {  // the reference's rounded difference x_j - x_i
+            float xd[6];
+            if (FORM != 2) {  // the reference's rounded difference x_j - x_i
 #pragma unroll
-                for (int j = 0; j < 6; ++j) xn[j] -= row_pick(xc[j], pick);
+                for (int j = 0; j < 6; ++j) xd[j] = xn[j] - row_pick(xc[j], pick);
             }
             // ---- layer_first ----
             f32x4 y1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) y1[r] = row_pick(t0[r], pick);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) y1 = dec_mfma(w1x[j], xn[j], y1);
+            for (int j = 0; j < 6; ++j) y1 = dec_mfma(w1x[j], REL ? xd[j] : xn[j], y1);
+            if (FORM == 0) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) y1 = dec_mfma(w1d[j], xd[j], y1);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) y1[r] = fmaxf(y1[r], 0.f);
             // ---- layers.0: [y1 | centre] ----
@@ -257,8 +269,9 @@ extern "C" int sps_dense_edge_conv(int b, int n, int d, int k, int growth, int r
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.out = out;
     const long long want = ((a.units + DEC_TILE - 1) / DEC_TILE + 3) / 4;  // 4 waves per workgroup, one tile per wave and trip
     const int grid = (int)(want < 256 * 8 ? want : 256 * 8);
-    if (relative_only) hipLaunchKernelGGL(dense_edge_conv_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), a);
-    else hipLaunchKernelGGL(dense_edge_conv_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), a);
+    if (relative_only == 1) hipLaunchKernelGGL(dense_edge_conv_kernel<1>, dim3(grid), dim3(256), 0, as_stream(stream), a);
+    else if (relative_only == 2) hipLaunchKernelGGL(dense_edge_conv_kernel<2>, dim3(grid), dim3(256), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL(dense_edge_conv_kernel<0>, dim3(grid), dim3(256), 0, as_stream(stream), a);
     return check_launch("dense_edge_conv_kernel");
 }
 

@@ -424,7 +424,12 @@ def vote_offsets(mlp, ctr_reg, parts):
 
 # ---- DenseEdgeConv / FeatureExtraction (surface_feature.py:45-187) ------------------------------------------------------
 class PackedEdgeConv:
-    __slots__ = ("key", "w1", "b1", "w2", "b2", "w3", "b3", "relative")
+    __slots__ = ("key", "w1", "b1", "w2", "b2", "w3", "b3", "relative", "form")
+
+
+# True: evaluate a full convolution's first layer with merged weight blocks (a third fewer MFMAs, ~1e-6 relative off).
+# Off by default: dynamic graphs feed the features back as query positions, where last-bit changes flip neighbours.
+DEC_MERGED = False
 
 
 def _dec_frag(w, cols):
@@ -448,7 +453,7 @@ def pack_dense_edge_conv(conv):
     """Weights of a DenseEdgeConv in the fragment order of csrc/dense_edge_conv.hip: input channel 6q + j of the 24 wide
     blocks sits in k-slot q of k-step j; the 12 activation channels of a previous layer sit as 4q + r (q < 3)."""
     lins = (conv.layer_first.linear, conv.layers[0].linear, conv.layer_last.linear)
-    key = tuple((t.data_ptr(), t._version) for l in lins for t in (l.weight, l.bias))
+    key = tuple((t.data_ptr(), t._version) for l in lins for t in (l.weight, l.bias)) + (DEC_MERGED,)
     packed = getattr(conv, "_sps_packed", None)
     if packed is not None and packed.key == key:
         return packed
@@ -459,10 +464,12 @@ def pack_dense_edge_conv(conv):
         packed.key, packed.relative = key, bool(conv.relative_feat_only)
         w1, w2, w3 = (l.weight.detach().float() for l in lins)
         if packed.relative:
-            packed.w1 = _dec_frag(w1, wide(0))
-        else:  # [x_i | x_j | x_j - x_i] -> [(W1a - W1c) x_i | (W1b + W1c) x_j]
+            packed.w1, packed.form = _dec_frag(w1, wide(0)), 1
+        elif DEC_MERGED:  # [x_i | x_j | x_j - x_i] -> [(W1a - W1c) x_i | (W1b + W1c) x_j]
             merged = torch.cat([w1[:, 0:24] - w1[:, 48:72], w1[:, 24:48] + w1[:, 48:72]], dim=1)
-            packed.w1 = _dec_frag(merged, wide(0) + wide(24))
+            packed.w1, packed.form = _dec_frag(merged, wide(0) + wide(24)), 2
+        else:
+            packed.w1, packed.form = _dec_frag(w1, wide(0) + wide(24) + wide(48)), 0
         packed.w2 = _dec_frag(w2, act(0) + wide(12))
         packed.w3 = _dec_frag(w3, act(0) + act(12) + wide(24))
         packed.b1, packed.b2, packed.b3 = (_pad_bias(l.bias.detach().float(), 16) for l in lins)
@@ -476,7 +483,7 @@ def dense_edge_conv(conv, x, idx):
     B, N, d = x.shape
     x = x.contiguous()
     out = torch.empty((B, N, conv.out_channels), dtype=torch.float32, device=x.device)
-    _lib.check(_L.sps_dense_edge_conv(B, N, d, idx.shape[2], conv.growth_rate, int(packed.relative), x.data_ptr(),
+    _lib.check(_L.sps_dense_edge_conv(B, N, d, idx.shape[2], conv.growth_rate, packed.form, x.data_ptr(),
                                       idx.data_ptr(), packed.w1.data_ptr(), packed.b1.data_ptr(), packed.w2.data_ptr(),
                                       packed.b2.data_ptr(), packed.w3.data_ptr(), packed.b3.data_ptr(), out.data_ptr(),
                                       torch.cuda.current_stream(x.device).cuda_stream), "dense_edge_conv")
