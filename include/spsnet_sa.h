@@ -316,6 +316,13 @@ int sps_three_interpolate_kernel_launcher_stack(int n, int channels, const float
 int sps_three_interpolate_grad_kernel_launcher_stack(int n, int channels, const float *grad_out, const int *idx,
                                                      const float *weight, float *grad_features, sps_stream_t stream);
 
+/* F.max_pool2d(x, kernel_size=[1, nsample]) of the SA modules (pointnet2_modules.py:441-444) and its gradient on a
+ * contiguous (rows, nsample) view, rows = B*C*M, nsample <= 255: out (rows) = row maxima, arg (rows) u8 = position of the
+ * FIRST maximum (a NaN wins and propagates), grad_in (rows, nsample) = grad_out at arg, zero elsewhere. */
+int sps_pool_max_fwd(long long rows, int nsample, const float *x, float *out, unsigned char *arg, sps_stream_t stream);
+int sps_pool_max_bwd(long long rows, int nsample, const float *grad_out, const unsigned char *arg, float *grad_in,
+                     sps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,8 @@ _PROTOS = {
     "sps_three_nn_kernel_launcher_stack": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_three_interpolate_kernel_launcher_stack": [_i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_three_interpolate_grad_kernel_launcher_stack": [_i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sps_pool_max_fwd": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
+    "sps_pool_max_bwd": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
     "sps_dense_edge_conv": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_linear_rows": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "sps_sa_group_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,

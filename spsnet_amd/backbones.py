@@ -117,8 +117,8 @@ class _PointBackbone(nn.Module):
         started early.  -> (li_xyz, li_features, li_cls_pred, sampled_idx, stds)"""
         layer = self.SA_modules[i]
         nxt = None
-        if (fast and i + 1 < len(self.SA_modules) and self.layer_types[i + 1] == 'SA_Layer'
-                and self.layer_inputs[i + 1] == i + 1 and self.ctr_idx_list[i + 1] == -1):
+        if (xyz_input.is_cuda and i + 1 < len(self.SA_modules) and self.layer_types[i + 1] == 'SA_Layer'
+                and self.layer_inputs[i + 1] == i + 1 and self.ctr_idx_list[i + 1] == -1):  # sampling has no gradient
             nxt = self.SA_modules[i + 1]
         if fast and i == 0 and cls_pred is None and ctr_xyz is None and self.layer_inputs[0] == 0:
             res = sa_stack._streamed_first_layer(layer, nxt, xyz_input, feature_input, stds, after_producer=beside_fps)

@@ -184,6 +184,27 @@ def index_add_deterministic(grad_out, idx, grad_points):
     return grad_points
 
 
+def pool_max_fwd(x, out, arg):
+    """x (..., ns) contiguous -> out (...) row maxima, arg (...) uint8 position of the first maximum."""
+    ns = x.shape[-1]
+    rows = x.numel() // ns
+    _need(out, rows, "out"); _need(arg, rows, "arg")
+    if arg.dtype != torch.uint8 or not arg.is_contiguous():
+        raise TypeError("arg must be a contiguous uint8 tensor")
+    with _on(x):
+        _lib.check(_L.sps_pool_max_fwd(rows, ns, _ptr(x, F32, "x"), _ptr(out, F32, "out"), arg.data_ptr(), _stream(x)),
+                   "pool_max_fwd")
+
+
+def pool_max_bwd(grad_out, arg, grad_in):
+    ns = grad_in.shape[-1]
+    rows = grad_in.numel() // ns
+    _need(grad_out, rows, "grad_out"); _need(arg, rows, "arg")
+    with _on(grad_out):
+        _lib.check(_L.sps_pool_max_bwd(rows, ns, _ptr(grad_out, F32, "grad_out"), arg.data_ptr(),
+                                       _ptr(grad_in, F32, "grad_in"), _stream(grad_out)), "pool_max_bwd")
+
+
 def three_nn_wrapper(b, n, m, unknown_tensor, known_tensor, dist2_tensor, idx_tensor):
     """interpolate.cpp:21-30.  unknown (B,n,3), known (B,m,3) -> dist2, idx (B,n,3); returns None."""
     u, k = _ptr(unknown_tensor, F32, "unknown"), _ptr(known_tensor, F32, "known")

@@ -32,10 +32,35 @@ def _conv_bn_relu_stack(widths: List[int], conv, norm) -> nn.Sequential:
     return nn.Sequential(*layers)
 
 
+class _MaxOverSamples(torch.autograd.Function):
+    """F.max_pool2d(x, [1, ns]).squeeze(-1) on (B,C,M,ns) with the same gradient routing (first maximum of a row):
+    csrc/group_gather.hip sps_pool_max_fwd / _bwd instead of torch's generic pooling kernels."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, C, M, ns = x.shape
+        out = torch.empty((B, C, M), dtype=torch.float32, device=x.device)
+        arg = torch.empty((B, C, M), dtype=torch.uint8, device=x.device)
+        _ext.pool_max_fwd(x, out, arg)
+        ctx.save_for_backward(arg)
+        ctx.ns = ns
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (arg,) = ctx.saved_tensors
+        grad_in = torch.empty(tuple(arg.shape) + (ctx.ns,), dtype=torch.float32, device=grad_out.device)
+        _ext.pool_max_bwd(grad_out.contiguous(), arg, grad_in)
+        return grad_in
+
+
 def _pool_over_samples(grouped: torch.Tensor, method: str) -> torch.Tensor:
     """(B,C,M,ns) -> (B,C,M) (reference :66-75, :434-443)."""
     window = [1, grouped.size(3)]
     if method == 'max_pool':
+        if grouped.is_cuda and grouped.dtype == torch.float32 and grouped.dim() == 4 and 0 < grouped.size(3) <= 255:
+            return _MaxOverSamples.apply(grouped)
         pooled = F.max_pool2d(grouped, kernel_size=window)
     elif method == 'avg_pool':
         pooled = F.avg_pool2d(grouped, kernel_size=window)

@@ -90,7 +90,7 @@ def _prefetch_dfps(next_layer, new_xyz, fps_ordered=False):
     ready = torch.cuda.Event()
     ready.record(main)
     new_xyz.record_stream(side)
-    with torch.cuda.stream(side):
+    with torch.cuda.stream(side), torch.no_grad():
         side.wait_event(ready)
         if fps_ordered:
             # new_xyz is a D-FPS pick sequence: its own D-FPS is the identity prefix up to distance ties, which
@@ -255,6 +255,7 @@ def run_sa_layers(layers, xyz, features, stds=None, overlap=True, stream_first_l
     outs = []
     cls_pred = None
     use_overlap = overlap and xyz.is_cuda and not torch.is_grad_enabled()
+    prefetch = overlap and xyz.is_cuda   # sampling carries no gradient: the next layer's D-FPS may start early in training too
     for k, layer in enumerate(layers):
         nxt = layers[k + 1] if k + 1 < len(layers) else None
         if use_overlap and k == 0 and cls_pred is None and stream_first_layer:
@@ -263,7 +264,7 @@ def run_sa_layers(layers, xyz, features, stds=None, overlap=True, stream_first_l
                 xyz, features, cls_pred, idx, stds = res
                 outs.append((xyz, features, cls_pred, idx))
                 continue
-        if use_overlap and nxt is not None and _can_prefetch(layer, nxt):
+        if prefetch and nxt is not None and _can_prefetch(layer, nxt):
             ordered = _is_plain_dfps(layer, xyz.shape[1])
             layer._on_new_xyz = lambda nx, _n=nxt, _o=ordered: _prefetch_dfps(_n, nx, _o)
         kw = {} if stds is None else {'stds': stds}

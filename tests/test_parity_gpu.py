@@ -1295,3 +1295,24 @@ def test_stack_modules_against_torch_reference(dev, G, oracle):
     assert float(np.abs(G.n(got) - want).max()) <= tol(want)
     with pytest.raises(NotImplementedError):
         SM.VectorPoolAggregationModule()
+
+
+def test_pool_max_matches_torch_max_pool2d(ext, dev):
+    """sps_pool_max_fwd / _bwd against F.max_pool2d(x, [1, ns]) forward and backward, with ties (repeated first hits, ReLU
+    zeros) and NaNs: same values, same gradient routing."""
+    from spsnet_amd import pointnet2_modules as M
+    g = torch.Generator(device=dev).manual_seed(2)
+    for shape in ((2, 5, 33, 16), (1, 3, 7, 1), (2, 4, 20, 32), (1, 2, 9, 7)):
+        x = torch.randn(shape, generator=g, device=dev)
+        x = torch.relu(x)                                  # masses of equal zeros
+        x[..., shape[-1] // 2:] = x[..., :1]               # repeated first hit
+        if shape[-1] > 2:
+            x[0, 0, 0, 1] = float("nan")
+        a = x.clone().requires_grad_(True)
+        b = x.clone().requires_grad_(True)
+        ya = M._pool_over_samples(a, 'max_pool')
+        yb = torch.nn.functional.max_pool2d(b, kernel_size=[1, shape[-1]]).squeeze(-1)
+        assert torch.equal(torch.nan_to_num(ya, nan=-7.0), torch.nan_to_num(yb, nan=-7.0))
+        go = torch.randn(ya.shape, generator=g, device=dev)
+        ya.backward(go); yb.backward(go)
+        assert torch.equal(a.grad, b.grad)
