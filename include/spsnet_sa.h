@@ -323,6 +323,19 @@ int sps_pool_max_fwd(long long rows, int nsample, const float *x, float *out, un
 int sps_pool_max_bwd(long long rows, int nsample, const float *grad_out, const unsigned char *arg, float *grad_in,
                      sps_stream_t stream);
 
+/* BatchNorm2d on batch statistics + ReLU (the [Conv2d, BatchNorm2d, ReLU] stacks of pointnet2_modules.py:203-209 in
+ * train() mode), forward and backward, on a contiguous (b, c, l) tensor, l = M * nsample.  torch semantics: biased variance
+ * to normalise, unbiased for running_var, running = (1 - momentum) running + momentum batch; weight / bias /
+ * running_* may be NULL.  mean, invstd (c) are outputs of the forward and inputs of the backward; work = doubles,
+ * sps_bn_train_workspace_doubles(b, c, l) of them; scratch2c = 2 c floats.  Fixed-order reductions (reproducible). */
+long long sps_bn_train_workspace_doubles(int b, int c, long long l);
+int sps_bn_relu_train_fwd(int b, int c, long long l, const float *x, const float *weight, const float *bias, float eps,
+                          float momentum, float *running_mean, float *running_var, float *mean, float *invstd, float *y,
+                          double *work, sps_stream_t stream);
+int sps_bn_relu_train_bwd(int b, int c, long long l, const float *x, const float *dy, const float *mean,
+                          const float *invstd, const float *weight, const float *bias, float *dx, float *dweight,
+                          float *dbias, float *scratch2c, double *work, sps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

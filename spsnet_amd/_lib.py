@@ -63,6 +63,8 @@ _PROTOS = {
     "sps_three_interpolate_grad_kernel_launcher_stack": [_i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_pool_max_fwd": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
     "sps_pool_max_bwd": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
+    "sps_bn_relu_train_fwd": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_bn_relu_train_bwd": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_dense_edge_conv": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_linear_rows": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "sps_sa_group_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
@@ -75,7 +77,7 @@ _PROTOS = {
                                _vp, _vp, _i, _i, _vp],
 }
 EXPORTS = ["sps_abi_version", "sps_last_error", "sps_opt_n_threads", "sps_fps_workspace_floats",
-           "sps_index_add_workspace_ints", "sps_ball_query_grid_workspace_ints"] + list(_PROTOS)
+           "sps_index_add_workspace_ints", "sps_ball_query_grid_workspace_ints", "sps_bn_train_workspace_doubles"] + list(_PROTOS)
 
 _lib = None
 
@@ -105,6 +107,8 @@ def load():
     lib.sps_index_add_workspace_ints.restype = ctypes.c_longlong
     lib.sps_ball_query_grid_workspace_ints.argtypes = [_i, _i, _i]
     lib.sps_ball_query_grid_workspace_ints.restype = ctypes.c_longlong
+    lib.sps_bn_train_workspace_doubles.argtypes = [_i, _i, ctypes.c_longlong]
+    lib.sps_bn_train_workspace_doubles.restype = ctypes.c_longlong
     lib.sps_index_add_workspace_ints.argtypes = [_i, _i, _i]
     for name, args in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

@@ -184,6 +184,39 @@ def index_add_deterministic(grad_out, idx, grad_points):
     return grad_points
 
 
+def bn_relu_train_fwd(x, weight, bias, eps, momentum, running_mean, running_var):
+    """x (B,C,...) contiguous -> (y, mean (C), invstd (C)); running_* updated in place (None = not tracked)."""
+    B, C = x.shape[0], x.shape[1]
+    L = x.numel() // max(B * C, 1)
+    y = torch.empty_like(x)
+    mean = torch.empty((C,), dtype=F32, device=x.device)
+    invstd = torch.empty((C,), dtype=F32, device=x.device)
+    work = torch.empty((int(_L.sps_bn_train_workspace_doubles(B, C, L)),), dtype=torch.float64, device=x.device)
+    opt = lambda t: 0 if t is None else _ptr(t, F32, "parameter")
+    with _on(x):
+        _lib.check(_L.sps_bn_relu_train_fwd(B, C, L, _ptr(x, F32, "x"), opt(weight), opt(bias), float(eps), float(momentum),
+                                            opt(running_mean), opt(running_var), mean.data_ptr(), invstd.data_ptr(),
+                                            y.data_ptr(), work.data_ptr(), _stream(x)), "bn_relu_train_fwd")
+    return y, mean, invstd
+
+
+def bn_relu_train_bwd(x, dy, mean, invstd, weight, bias):
+    """-> (dx, dweight (C), dbias (C))"""
+    B, C = x.shape[0], x.shape[1]
+    L = x.numel() // max(B * C, 1)
+    dx = torch.empty_like(x)
+    dweight = torch.empty((C,), dtype=F32, device=x.device)
+    dbias = torch.empty((C,), dtype=F32, device=x.device)
+    scratch = torch.empty((2 * C,), dtype=F32, device=x.device)
+    work = torch.empty((int(_L.sps_bn_train_workspace_doubles(B, C, L)),), dtype=torch.float64, device=x.device)
+    with _on(x):
+        _lib.check(_L.sps_bn_relu_train_bwd(B, C, L, _ptr(x, F32, "x"), _ptr(dy, F32, "dy"), mean.data_ptr(),
+                                            invstd.data_ptr(), 0 if weight is None else _ptr(weight, F32, "weight"),
+                                            0 if bias is None else _ptr(bias, F32, "bias"), dx.data_ptr(), dweight.data_ptr(), dbias.data_ptr(), scratch.data_ptr(),
+                                            work.data_ptr(), _stream(x)), "bn_relu_train_bwd")
+    return dx, dweight, dbias
+
+
 def pool_max_fwd(x, out, arg):
     """x (..., ns) contiguous -> out (...) row maxima, arg (...) uint8 position of the first maximum."""
     ns = x.shape[-1]

@@ -55,6 +55,45 @@ class _MaxOverSamples(torch.autograd.Function):
         return grad_in
 
 
+class _BatchNormReLUTrain(torch.autograd.Function):
+    """relu(batch_norm(x)) on batch statistics (training), forward and backward in csrc/bn_relu_train.hip; updates the
+    module's running statistics like nn.BatchNorm2d.forward does."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn):
+        x = x.contiguous()
+        y, mean, invstd = _ext.bn_relu_train_fwd(x, weight.detach(), bias.detach(), bn.eps, bn.momentum,
+                                                 bn.running_mean, bn.running_var)
+        bn.num_batches_tracked.add_(1)
+        ctx.save_for_backward(x, mean, invstd, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, invstd, weight, bias = ctx.saved_tensors
+        dx, dweight, dbias = _ext.bn_relu_train_bwd(x, dy.contiguous(), mean, invstd, weight.detach(), bias.detach())
+        return dx, dweight, dbias, None
+
+
+def _shared_mlp(mlp: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """mlp(x) for a [Conv2d, BatchNorm2d, ReLU]* stack; in training on the GPU each BatchNorm2d + ReLU pair runs as the
+    fused batch-statistics kernels instead of MIOpen's BatchNorm and a separate ReLU (same arithmetic, 1e-6)."""
+    if not (mlp.training and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()):
+        return mlp(x)
+    mods = list(mlp)
+    triples = list(zip(mods[0::3], mods[1::3], mods[2::3]))
+    if len(mods) % 3 or not triples:
+        return mlp(x)
+    for conv, bn, act in triples:
+        if not (isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and isinstance(act, nn.ReLU) and bn.affine
+                and bn.track_running_stats and bn.momentum is not None and bn.training
+                and bn.weight.dtype == torch.float32):
+            return mlp(x)
+    for conv, bn, _ in triples:
+        x = _BatchNormReLUTrain.apply(conv(x), bn.weight, bn.bias, bn)
+    return x
+
+
 def _pool_over_samples(grouped: torch.Tensor, method: str) -> torch.Tensor:
     """(B,C,M,ns) -> (B,C,M) (reference :66-75, :434-443)."""
     window = [1, grouped.size(3)]
@@ -131,7 +170,7 @@ class _PointnetSAModuleBase(nn.Module):
         scales = []
         for grouper, mlp in zip(self.groupers, self.mlps):
             grouped = grouper(xyz, new_xyz, features)      # (B, C, M, ns)
-            scales.append(_pool_over_samples(mlp(grouped), self.pool_method))
+            scales.append(_pool_over_samples(_shared_mlp(mlp, grouped), self.pool_method))
         return torch.cat(scales, dim=1)
 
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, new_xyz=None):

@@ -1316,3 +1316,31 @@ def test_pool_max_matches_torch_max_pool2d(ext, dev):
         go = torch.randn(ya.shape, generator=g, device=dev)
         ya.backward(go); yb.backward(go)
         assert torch.equal(a.grad, b.grad)
+
+
+def test_bn_relu_train_matches_torch(ext, dev):
+    """sps_bn_relu_train_fwd / _bwd against nn.BatchNorm2d (train mode) + ReLU: output, running statistics,
+    num_batches_tracked and the gradients w.r.t. input, weight and bias."""
+    import copy
+    from spsnet_amd import pointnet2_modules as M
+    g = torch.Generator(device=dev).manual_seed(6)
+    for shape in ((2, 5, 33, 16), (3, 16, 300, 32), (1, 1, 1, 2), (2, 7, 600, 16)):
+        conv = torch.nn.Conv2d(shape[1], shape[1], 1, bias=False)
+        bn = torch.nn.BatchNorm2d(shape[1])
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+        seq = torch.nn.Sequential(conv, bn, torch.nn.ReLU()).to(dev).train()
+        ref = copy.deepcopy(seq)
+        x = torch.randn(shape, generator=g, device=dev) * 3 + 1
+        a = x.clone().requires_grad_(True)
+        b = x.clone().requires_grad_(True)
+        ya = M._shared_mlp(seq, a)
+        yb = ref(b)
+        go = torch.randn(shape, generator=g, device=dev)
+        ya.backward(go); yb.backward(go)
+        close = lambda p, q, tol=1e-4: float((p.detach() - q.detach()).abs().max()) <= tol * max(1.0, float(q.detach().abs().max()))
+        assert close(ya, yb) and close(a.grad, b.grad)
+        assert close(seq[1].running_mean, ref[1].running_mean, 1e-5) and close(seq[1].running_var, ref[1].running_var, 1e-5)
+        assert int(seq[1].num_batches_tracked) == int(ref[1].num_batches_tracked) == 1
+        assert close(seq[1].weight.grad, ref[1].weight.grad) and close(seq[1].bias.grad, ref[1].bias.grad)
+        assert close(seq[0].weight.grad, ref[0].weight.grad)
