@@ -33,17 +33,6 @@ struct PbShared {
     int wsum[PF_WAVES];
 };
 
-// writelane with a runtime lane (M0) -- see fps_pruned.hip commit()
-__device__ __forceinline__ void put_lane_rt(int &v, int value, int lane_sel) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %1, m0\n\t"
-                 "s_mov_b32 m0, %3\n\t"
-                 "s_nop 3\n\t"
-                 "v_writelane_b32 %0, %2, m0\n\t"
-                 "s_mov_b32 m0, %1"
-                 : "+v"(v), "=&s"(keep)
-                 : "s"(__builtin_amdgcn_readfirstlane(value)), "s"(lane_sel));
-}
 
 template <int R, int ROWS, class F>
 __device__ __forceinline__ void rows_each(F &fn) {

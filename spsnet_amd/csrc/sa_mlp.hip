@@ -48,21 +48,6 @@ __device__ __forceinline__ f32x4 wload4(__amdgpu_buffer_rsrc_t r, int voff, int 
     return (f32x4){__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])};
 }
 
-// max over the 16 lanes of each DPP row (= the 16 columns of a tile), result valid in every lane
-__device__ __forceinline__ float row_allmax(float v) {
-    // xor-butterfly inside a row via quad_perm / row_half_mirror / row_mirror
-    int x = __float_as_int(v);
-    float o;
-    o = __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
-    v = fmaxf(v, o); x = __float_as_int(v);
-    o = __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
-    v = fmaxf(v, o); x = __float_as_int(v);
-    o = __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false));  // row_half_mirror
-    v = fmaxf(v, o); x = __float_as_int(v);
-    o = __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false));  // row_mirror
-    v = fmaxf(v, o);
-    return v;
-}
 
 // C1, C2: padded widths of layers 1 and 2 (multiples of 16).  NT: 16-column tiles per MFMA pass.
 // NS: nsample (16, 32 or 64), with 16*NT >= NS: a unit is 16*NT columns = 16*NT/NS whole centroids.

@@ -80,18 +80,6 @@ __device__ __forceinline__ void mac3(const WFrag &w, const h8 (&xh)[NT], const h
     for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32h(w.lo, xh[nt], acc[nt]);
 }
 
-__device__ __forceinline__ float row_allmax_h(float v) {
-    int x = __float_as_int(v);
-    float o;
-    o = __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));
-    v = fmaxf(v, o); x = __float_as_int(v);
-    o = __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));
-    v = fmaxf(v, o); x = __float_as_int(v);
-    o = __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false));
-    v = fmaxf(v, o); x = __float_as_int(v);
-    o = __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false));
-    return fmaxf(v, o);
-}
 
 // a.ks1 = layer-1 k-steps of 32 grouped channels = ceil((3 + c_feat) / 32)
 template <int C1, int C2, int NT, int NS, bool WLDS>

@@ -57,18 +57,6 @@ __device__ __forceinline__ void split4(const f32x4 v, h8 &hi, h8 &lo, float &mx)
 
 struct WFrag { h8 hi, lo; };
 
-__device__ __forceinline__ float row_allmax_h(float v) {
-    int x = __float_as_int(v);
-    float o;
-    o = __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));
-    v = fmaxf(v, o); x = __float_as_int(v);
-    o = __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));
-    v = fmaxf(v, o); x = __float_as_int(v);
-    o = __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false));
-    v = fmaxf(v, o); x = __float_as_int(v);
-    o = __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false));
-    return fmaxf(v, o);
-}
 
 constexpr int RING = 6;             // LDS slots of one chunk (8 KiB) each
 constexpr int FRAG_BYTES = 2048;    // [hi x8 | lo x8] per lane, as two lane-linear 1-KiB pieces
