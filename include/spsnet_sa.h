@@ -283,7 +283,7 @@ int sps_ball_query_grid2(int b, int n, int m, float radius_a, int nsample_a, flo
                          const float *new_xyz, const float *xyz, int *idx_a, int *idx_b, int *work, sps_stream_t stream);
 
 /* ---- pcdet/ops/pointnet2/pointnet2_stack: ragged batches (scenes concatenated along the point axis, per-scene counts).
- * Argument order = the reference launchers' (+ stream).  The vector-pool family (vector_pool_gpu.cu) is not built. ---- */
+ * Argument order = the reference launchers' (+ stream; device counters where the reference returns a count). ---- */
 /* ball_query_kernel_launcher_stack (pointnet2_stack/src/ball_query_gpu.cu:15-90): new_xyz (M,3), xyz (N,3), idx (M,nsample)
  * pre-zeroed by the caller; first nsample hits in index order (indices local to the scene), idx[row][0] = -1 if empty. */
 int sps_ball_query_kernel_launcher_stack(int b, int m, float radius, int nsample, const float *new_xyz,
@@ -335,6 +335,35 @@ int sps_bn_relu_train_fwd(int b, int c, long long l, const float *x, const float
 int sps_bn_relu_train_bwd(int b, int c, long long l, const float *x, const float *dy, const float *mean,
                           const float *invstd, const float *weight, const float *bias, float *dx, float *dweight,
                           float *dbias, float *scratch2c, double *work, sps_stream_t stream);
+
+/* Vector-pool family (pointnet2_stack/src/vector_pool_gpu.cu): one thread per new_xyz walks its scene in index order.
+ * query_stacked_local_neighbor_idxs (:117-187): per centre, the support points inside a ball (neighbor_type 1) or cube of
+ * max_neighbour_distance (first nsample if > 0, at most 1000), packed into stack_neighbor_idxs at a position taken from
+ * *cumsum (device counter, caller-zeroed); start_len (M,2) = [start, length].  Lists are truncated at avg_length * M. */
+int sps_query_stacked_local_neighbor_idxs_kernel_launcher_stack(
+    const float *support_xyz, const int *xyz_batch_cnt, const float *new_xyz, const int *new_xyz_batch_cnt,
+    int *stack_neighbor_idxs, int *start_len, int *cumsum, int avg_length_of_neighbor_idxs, float max_neighbour_distance,
+    int batch_size, int m, int nsample, int neighbor_type, sps_stream_t stream);
+/* query_three_nn_by_stacked_local_idxs (:14-72): three nearest of each centre's local list for every grid centre
+ * (M, num_total_grids, 3); missing neighbours repeat the first, an empty list gives -1. */
+int sps_query_three_nn_by_stacked_local_idxs_kernel_launcher_stack(
+    const float *support_xyz, const float *new_xyz, const float *new_xyz_grid_centers, int *new_xyz_grid_idxs,
+    float *new_xyz_grid_dist2, const int *stack_neighbor_idxs, const int *start_len, int m, int num_total_grids,
+    sps_stream_t stream);
+/* vector_pool_kernel_launcher_stack (:239-381): sums (pooling_type 0) or first-point picks (1) of the support features per
+ * local grid cell; outputs pre-zeroed by the caller; grouped_idxs (num_max_sum_points, 3) rows in arbitrary order;
+ * *cum_sum (device counter, caller-zeroed) ends as the value the reference returns. */
+int sps_vector_pool_kernel_launcher_stack(
+    const float *support_xyz, const float *support_features, const int *xyz_batch_cnt, const float *new_xyz,
+    float *new_features, float *new_local_xyz, const int *new_xyz_batch_cnt, int *point_cnt_of_grid, int *grouped_idxs,
+    int num_grid_x, int num_grid_y, int num_grid_z, float max_neighbour_distance, int batch_size, int n, int m, int num_c_in,
+    int num_c_out, int num_total_grids, int use_xyz, int num_max_sum_points, int nsample, int neighbor_type, int pooling_type,
+    int *cum_sum, sps_stream_t stream);
+/* vector_pool_grad_kernel_launcher_stack (:383-431) */
+int sps_vector_pool_grad_kernel_launcher_stack(const float *grad_new_features, const int *point_cnt_of_grid,
+                                               const int *grouped_idxs, float *grad_support_features, int n, int m,
+                                               int num_c_out, int num_c_in, int num_total_grids, int num_max_sum_points,
+                                               sps_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -267,3 +267,47 @@ def stack_three_interpolate_grad(grad_out, idx, weight, M):
     out = np.zeros((M, C), np.float32)
     lib().orc_stack_three_interpolate_grad(N, C, pg, pi, pw, out.ctypes.data_as(_F))
     return out
+
+
+def vp_local_neighbors(support_xyz, xyz_cnt, new_xyz, new_cnt, dist, nsample, neighbor_type):
+    """-> list of int32 arrays: per centre, the global rows of its local neighbours in index order."""
+    support_xyz, ps = _f(support_xyz); new_xyz, pq = _f(new_xyz); xyz_cnt, pc = _i(xyz_cnt); new_cnt, pqc = _i(new_cnt)
+    M = new_xyz.shape[0]
+    cap = 1000
+    lists = np.zeros((M, cap), np.int32)
+    lens = np.zeros((M,), np.int32)
+    lib().orc_vp_local_neighbors(len(xyz_cnt), M, ps, pc, pq, pqc, ctypes.c_float(dist), int(nsample), int(neighbor_type), cap,
+                                 lists.ctypes.data_as(_I), lens.ctypes.data_as(_I))
+    return lists, lens
+
+
+def vp_three_nn_local(support_xyz, grid_centers, lists, lens):
+    support_xyz, ps = _f(support_xyz); grid_centers, pg = _f(grid_centers); lists, pl = _i(lists); lens, pn = _i(lens)
+    M, G, _ = grid_centers.shape
+    idx = np.empty((M, G, 3), np.int32)
+    d2 = np.empty((M, G, 3), np.float32)
+    lib().orc_vp_three_nn_local(M, G, lists.shape[1], ps, pg, pl, pn, idx.ctypes.data_as(_I), d2.ctypes.data_as(_F))
+    return d2, idx
+
+
+def vp_pool(support_xyz, xyz_cnt, support_features, new_xyz, new_cnt, grid, dist, c_each, use_xyz, max_sum, nsample,
+            neighbor_type, pooling_type):
+    support_xyz, ps = _f(support_xyz); support_features, pf = _f(support_features); new_xyz, pq = _f(new_xyz)
+    xyz_cnt, pc = _i(xyz_cnt); new_cnt, pqc = _i(new_cnt)
+    M, total = new_xyz.shape[0], grid[0] * grid[1] * grid[2]
+    c_in, c_out = support_features.shape[1], c_each * total
+    nf = np.zeros((M, c_out), np.float32); nl = np.zeros((M, 3 * total), np.float32)
+    cg = np.zeros((M, total), np.int32); grouped = np.zeros((max(max_sum, 1), 3), np.int32)
+    lib().orc_vp_pool.restype = ctypes.c_int
+    cum = lib().orc_vp_pool(len(xyz_cnt), M, ps, pf, pc, pq, pqc, grid[0], grid[1], grid[2], ctypes.c_float(dist), c_in, c_out,
+                            int(use_xyz), int(max_sum), int(nsample), int(neighbor_type), int(pooling_type),
+                            nf.ctypes.data_as(_F), nl.ctypes.data_as(_F), cg.ctypes.data_as(_I), grouped.ctypes.data_as(_I))
+    return cum, nf, nl, cg, grouped[:min(cum, max_sum)]
+
+
+def vp_pool_grad(grad_new_features, cnt_of_grid, grouped, N, c_in):
+    grad_new_features, pg = _f(grad_new_features); cnt_of_grid, pc = _i(cnt_of_grid); grouped, pr = _i(grouped)
+    out = np.zeros((N, c_in), np.float32)
+    lib().orc_vp_pool_grad(grouped.shape[0], c_in, grad_new_features.shape[1], cnt_of_grid.shape[1], pg, pc, pr,
+                           out.ctypes.data_as(_F))
+    return out

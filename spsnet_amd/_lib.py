@@ -65,6 +65,11 @@ _PROTOS = {
     "sps_pool_max_bwd": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
     "sps_bn_relu_train_fwd": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_bn_relu_train_bwd": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_query_stacked_local_neighbor_idxs_kernel_launcher_stack": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _i, _vp],
+    "sps_query_three_nn_by_stacked_local_idxs_kernel_launcher_stack": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "sps_vector_pool_kernel_launcher_stack": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i,
+                                              _i, _i, _i, _i, _i, _vp, _vp],
+    "sps_vector_pool_grad_kernel_launcher_stack": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "sps_dense_edge_conv": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_linear_rows": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "sps_sa_group_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,

@@ -1,7 +1,6 @@
 """Drop-in for the reference's pybind extension `pointnet2_stack_cuda`
 (pcdet/ops/pointnet2/pointnet2_stack/src/pointnet2_api.cpp:12-31): same function names, positional signatures and
-return values for the ten functions of the ball-query / voxel-query / FPS / group / interpolate families, forwarded to
-libspsnet_sa.so (csrc/pointnet2_stack.hip).  The four vector-pool functions raise NotImplementedError.
+return values for all fourteen functions, forwarded to libspsnet_sa.so (csrc/pointnet2_stack.hip).
 Like the batch module: failed checks raise instead of exit(-1); kernels run on torch's current stream."""
 import torch
 
@@ -97,14 +96,63 @@ def three_interpolate_grad_wrapper(grad_out, idx, weight, grad_features):
     return 1
 
 
-def _not_built(name):
-    def fn(*args, **kwargs):
-        raise NotImplementedError(f"pointnet2_stack_cuda.{name}: the vector-pool family (vector_pool_gpu.cu) is not built")
-    fn.__name__ = name
-    return fn
+def query_stacked_local_neighbor_idxs_wrapper_stack(support_xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, stack_neighbor_idxs,
+                                                    start_len, cumsum, avg_length_of_neighbor_idxs, max_neighbour_distance,
+                                                    nsample, neighbor_type):
+    """vector_pool.cpp: per-centre local neighbour lists, packed; cumsum (1,) int32 zeroed by the caller."""
+    B, M = xyz_batch_cnt.shape[0], new_xyz.shape[0]
+    with _on(support_xyz):
+        _lib.check(_L.sps_query_stacked_local_neighbor_idxs_kernel_launcher_stack(
+            _ptr(support_xyz, F32, "support_xyz"), _ptr(xyz_batch_cnt, I32, "xyz_batch_cnt"), _ptr(new_xyz, F32, "new_xyz"),
+            _ptr(new_xyz_batch_cnt, I32, "new_xyz_batch_cnt"), _ptr(stack_neighbor_idxs, I32, "stack_neighbor_idxs"),
+            _ptr(start_len, I32, "start_len"), _ptr(cumsum, I32, "cumsum"), int(avg_length_of_neighbor_idxs),
+            float(max_neighbour_distance), B, M, int(nsample), int(neighbor_type), _stream(support_xyz)),
+            "query_stacked_local_neighbor_idxs")
+    return 0
 
 
-query_stacked_local_neighbor_idxs_wrapper_stack = _not_built("query_stacked_local_neighbor_idxs_wrapper_stack")
-query_three_nn_by_stacked_local_idxs_wrapper_stack = _not_built("query_three_nn_by_stacked_local_idxs_wrapper_stack")
-vector_pool_wrapper = _not_built("vector_pool_wrapper")
-vector_pool_grad_wrapper = _not_built("vector_pool_grad_wrapper")
+def query_three_nn_by_stacked_local_idxs_wrapper_stack(support_xyz, new_xyz, new_xyz_grid_centers, new_xyz_grid_idxs,
+                                                       new_xyz_grid_dist2, stack_neighbor_idxs, start_len, M, num_total_grids):
+    with _on(support_xyz):
+        _lib.check(_L.sps_query_three_nn_by_stacked_local_idxs_kernel_launcher_stack(
+            _ptr(support_xyz, F32, "support_xyz"), _ptr(new_xyz, F32, "new_xyz"),
+            _ptr(new_xyz_grid_centers, F32, "new_xyz_grid_centers"), _ptr(new_xyz_grid_idxs, I32, "new_xyz_grid_idxs"),
+            _ptr(new_xyz_grid_dist2, F32, "new_xyz_grid_dist2"), _ptr(stack_neighbor_idxs, I32, "stack_neighbor_idxs"),
+            _ptr(start_len, I32, "start_len"), int(M), int(num_total_grids), _stream(support_xyz)),
+            "query_three_nn_by_stacked_local_idxs")
+    return 0
+
+
+def vector_pool_wrapper(support_xyz, xyz_batch_cnt, support_features, new_xyz, new_xyz_batch_cnt, new_features, new_local_xyz,
+                        point_cnt_of_grid, grouped_idxs, num_grid_x, num_grid_y, num_grid_z, max_neighbour_distance, use_xyz,
+                        num_max_sum_points, nsample, neighbor_type, pooling_type):
+    """vector_pool.cpp:vector_pool_wrapper_stack -> the number of (point, centre, grid) triples found (may exceed
+    num_max_sum_points: the caller then retries with a larger buffer).  Reads the device counter: synchronises, like the
+    reference's cudaMemcpy."""
+    B, N, M = xyz_batch_cnt.shape[0], support_xyz.shape[0], new_xyz.shape[0]
+    c_in, c_out = support_features.shape[1], new_features.shape[1]
+    total = num_grid_x * num_grid_y * num_grid_z
+    counter = torch.zeros((1,), dtype=I32, device=support_xyz.device)
+    with _on(support_xyz):
+        _lib.check(_L.sps_vector_pool_kernel_launcher_stack(
+            _ptr(support_xyz, F32, "support_xyz"), _ptr(support_features, F32, "support_features"),
+            _ptr(xyz_batch_cnt, I32, "xyz_batch_cnt"), _ptr(new_xyz, F32, "new_xyz"), _ptr(new_features, F32, "new_features"),
+            _ptr(new_local_xyz, F32, "new_local_xyz"), _ptr(new_xyz_batch_cnt, I32, "new_xyz_batch_cnt"),
+            _ptr(point_cnt_of_grid, I32, "point_cnt_of_grid"), _ptr(grouped_idxs, I32, "grouped_idxs"), int(num_grid_x),
+            int(num_grid_y), int(num_grid_z), float(max_neighbour_distance), B, N, M, c_in, c_out, total, int(use_xyz),
+            int(num_max_sum_points), int(nsample), int(neighbor_type), int(pooling_type), counter.data_ptr(),
+            _stream(support_xyz)), "vector_pool")
+    return int(counter.item())
+
+
+def vector_pool_grad_wrapper(grad_new_features, point_cnt_of_grid, grouped_idxs, grad_support_features):
+    M, c_out = grad_new_features.shape
+    N, c_in = grad_support_features.shape
+    total = point_cnt_of_grid.shape[1]
+    rows = grouped_idxs.shape[0]
+    with _on(grad_new_features):
+        _lib.check(_L.sps_vector_pool_grad_kernel_launcher_stack(
+            _ptr(grad_new_features, F32, "grad_new_features"), _ptr(point_cnt_of_grid, I32, "point_cnt_of_grid"),
+            _ptr(grouped_idxs, I32, "grouped_idxs"), _ptr(grad_support_features, F32, "grad_support_features"), N, M, c_out,
+            c_in, total, rows, _stream(grad_new_features)), "vector_pool_grad")
+    return 0

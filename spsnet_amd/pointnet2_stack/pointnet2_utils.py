@@ -1,7 +1,7 @@
 """Autograd layer over the stack extension: mirror of pcdet/ops/pointnet2/pointnet2_stack/pointnet2_utils.py
 (BallQuery :9-48, GroupingOperation :51-108, QueryAndGroup :111-158, FarthestPointSampling :161-185,
-StackFarthestPointSampling :188-222, ThreeNN :225-256, ThreeInterpolate :259-298) -- same names, argument order and
-return values.  The two vector-pool Functions (:301-452) are not built and raise when called.
+StackFarthestPointSampling :188-222, ThreeNN :225-256, ThreeInterpolate :259-298, ThreeNNForVectorPoolByTwoStep :301-358,
+VectorPoolWithVoxelQuery :361-446) -- same names, argument order and return values.
 
 Stacked layout: rows of all scenes concatenated, `*_batch_cnt` (batch_size,) int32 gives the rows per scene.
 """
@@ -193,9 +193,94 @@ class ThreeInterpolate(Function):
 three_interpolate = ThreeInterpolate.apply
 
 
-def three_nn_for_vector_pool_by_two_step(*args, **kwargs):
-    raise NotImplementedError("pointnet2_stack: the vector-pool family (pointnet2_utils.py:301-452) is not built")
+class ThreeNNForVectorPoolByTwoStep(Function):
+    """Three nearest support points of every local grid centre, in two steps (reference :301-358): (1) per new_xyz, the
+    support points inside max_neighbour_distance * multiplier (cube, or ball when neighbor_type == 1), packed into one
+    stacked list -- retried with a larger buffer while it overflows; (2) three-NN of each grid centre inside that list.
+    -> (dist (M, G, 3) l2, idx (M, G, 3) global rows or -1, avg_length_of_neighbor_idxs tensor)"""
+
+    @staticmethod
+    def forward(ctx, support_xyz, xyz_batch_cnt, new_xyz, new_xyz_grid_centers, new_xyz_batch_cnt, max_neighbour_distance,
+                nsample, neighbor_type, avg_length_of_neighbor_idxs, num_total_grids, neighbor_distance_multiplier):
+        num_new_xyz = new_xyz.shape[0]
+        new_xyz_grid_dist2 = new_xyz_grid_centers.new_zeros(new_xyz_grid_centers.shape)
+        new_xyz_grid_idxs = new_xyz_grid_centers.new_zeros(new_xyz_grid_centers.shape).int().fill_(-1)
+        while True:
+            num_max_sum_points = avg_length_of_neighbor_idxs * num_new_xyz
+            stack_neighbor_idxs = new_xyz_grid_idxs.new_zeros(num_max_sum_points)
+            start_len = new_xyz_grid_idxs.new_zeros(num_new_xyz, 2).int()
+            cumsum = new_xyz_grid_idxs.new_zeros(1)
+            pointnet2.query_stacked_local_neighbor_idxs_wrapper_stack(
+                support_xyz.contiguous(), xyz_batch_cnt.contiguous(), new_xyz.contiguous(), new_xyz_batch_cnt.contiguous(),
+                stack_neighbor_idxs.contiguous(), start_len.contiguous(), cumsum, avg_length_of_neighbor_idxs,
+                max_neighbour_distance * neighbor_distance_multiplier, nsample, neighbor_type)
+            found = int(cumsum[0].item())
+            avg_length_of_neighbor_idxs = found // num_new_xyz + int(found % num_new_xyz > 0)
+            if found <= num_max_sum_points:
+                break
+        stack_neighbor_idxs = stack_neighbor_idxs[:found]
+        pointnet2.query_three_nn_by_stacked_local_idxs_wrapper_stack(
+            support_xyz.contiguous(), new_xyz.contiguous(), new_xyz_grid_centers.contiguous(), new_xyz_grid_idxs,
+            new_xyz_grid_dist2, stack_neighbor_idxs.contiguous(), start_len, num_new_xyz, num_total_grids)
+        return torch.sqrt(new_xyz_grid_dist2), new_xyz_grid_idxs, torch.tensor(avg_length_of_neighbor_idxs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return (None,) * 11
 
 
-def vector_pool_with_voxel_query_op(*args, **kwargs):
-    raise NotImplementedError("pointnet2_stack: the vector-pool family (pointnet2_utils.py:301-452) is not built")
+three_nn_for_vector_pool_by_two_step = ThreeNNForVectorPoolByTwoStep.apply
+
+
+class VectorPoolWithVoxelQuery(Function):
+    """Per-grid-cell pooling of the support features around every new_xyz (reference :361-446): sums divided by the cell's
+    point count (pooling_type 0) or the first point of a cell (1).
+    -> (new_features (M, G * c_each), new_local_xyz (M, 3 G), num_mean_points_per_grid, point_cnt_of_grid (M, G))"""
+
+    @staticmethod
+    def forward(ctx, support_xyz, xyz_batch_cnt, support_features, new_xyz, new_xyz_batch_cnt, num_grid_x, num_grid_y,
+                num_grid_z, max_neighbour_distance, num_c_out_each_grid, use_xyz, num_mean_points_per_grid=100, nsample=-1,
+                neighbor_type=0, pooling_type=0):
+        assert support_xyz.is_contiguous() and support_features.is_contiguous() and xyz_batch_cnt.is_contiguous()
+        assert new_xyz.is_contiguous() and new_xyz_batch_cnt.is_contiguous()
+        num_total_grids = num_grid_x * num_grid_y * num_grid_z
+        num_c_out = num_c_out_each_grid * num_total_grids
+        N, num_c_in = support_features.shape
+        M = new_xyz.shape[0]
+        assert num_c_in % num_c_out_each_grid == 0, \
+            f'the input channels ({num_c_in}) should be an integral multiple of num_c_out_each_grid({num_c_out_each_grid})'
+        while True:
+            new_features = support_features.new_zeros((M, num_c_out))
+            new_local_xyz = support_features.new_zeros((M, 3 * num_total_grids))
+            point_cnt_of_grid = xyz_batch_cnt.new_zeros((M, num_total_grids))
+            num_max_sum_points = num_mean_points_per_grid * M
+            grouped_idxs = xyz_batch_cnt.new_zeros((num_max_sum_points, 3))
+            num_cum_sum = pointnet2.vector_pool_wrapper(
+                support_xyz, xyz_batch_cnt, support_features, new_xyz, new_xyz_batch_cnt, new_features, new_local_xyz,
+                point_cnt_of_grid, grouped_idxs, num_grid_x, num_grid_y, num_grid_z, max_neighbour_distance, use_xyz,
+                num_max_sum_points, nsample, neighbor_type, pooling_type)
+            num_mean_points_per_grid = num_cum_sum // M + int(num_cum_sum % M > 0)
+            if num_cum_sum <= num_max_sum_points:
+                break
+        grouped_idxs = grouped_idxs[:num_cum_sum]
+        normalizer = torch.clamp_min(point_cnt_of_grid[:, :, None].float(), min=1e-6)
+        new_features = (new_features.view(-1, num_total_grids, num_c_out_each_grid) / normalizer).view(-1, num_c_out)
+        if use_xyz:
+            new_local_xyz = (new_local_xyz.view(-1, num_total_grids, 3) / normalizer).view(-1, num_total_grids * 3)
+        num_mean_points_per_grid = torch.Tensor([num_mean_points_per_grid]).int()
+        nsample = torch.Tensor([nsample]).int()
+        ctx.vector_pool_for_backward = (point_cnt_of_grid, grouped_idxs, N, num_c_in)
+        ctx.mark_non_differentiable(new_local_xyz, num_mean_points_per_grid, nsample, point_cnt_of_grid)
+        return new_features, new_local_xyz, num_mean_points_per_grid, point_cnt_of_grid
+
+    @staticmethod
+    def backward(ctx, grad_new_features, grad_local_xyz, grad_num_cum_sum, grad_point_cnt_of_grid):
+        point_cnt_of_grid, grouped_idxs, N, num_c_in = ctx.vector_pool_for_backward
+        grad_support_features = grad_new_features.new_zeros((N, num_c_in))
+        if grouped_idxs.shape[0] > 0:
+            pointnet2.vector_pool_grad_wrapper(grad_new_features.contiguous(), point_cnt_of_grid, grouped_idxs.contiguous(),
+                                               grad_support_features)
+        return (None, None, grad_support_features) + (None,) * 12
+
+
+vector_pool_with_voxel_query_op = VectorPoolWithVoxelQuery.apply

@@ -1230,14 +1230,6 @@ def test_stack_three_nn_interpolate_and_voxel_query(dev, G, oracle):
     assert gf.shape == (600, 3, 16) and torch.equal(gf, gx)
 
 
-def test_stack_vector_pool_is_reported_missing(dev):
-    from spsnet_amd.pointnet2_stack import pointnet2_stack_cuda as SC, pointnet2_utils as SU
-    with pytest.raises(NotImplementedError):
-        SC.vector_pool_wrapper()
-    with pytest.raises(NotImplementedError):
-        SU.vector_pool_with_voxel_query_op()
-
-
 def test_stack_modules_against_torch_reference(dev, G, oracle):
     """StackSAModuleMSG / StackPointnetFPModule (pointnet2_stack/pointnet2_modules.py:30-157) on ragged scenes, train mode,
     forward and the gradient w.r.t. the features, against a CPU restatement with oracle indices and torch indexing."""
@@ -1293,8 +1285,6 @@ def test_stack_modules_against_torch_reference(dev, G, oracle):
         x = torch.cat([interp, torch.from_numpy(feats)], dim=1)
         want = fp_ref.mlp(x.permute(1, 0)[None, :, :, None]).squeeze(0).squeeze(-1).permute(1, 0).numpy()
     assert float(np.abs(G.n(got) - want).max()) <= tol(want)
-    with pytest.raises(NotImplementedError):
-        SM.VectorPoolAggregationModule()
 
 
 def test_pool_max_matches_torch_max_pool2d(ext, dev):
@@ -1344,3 +1334,83 @@ def test_bn_relu_train_matches_torch(ext, dev):
         assert int(seq[1].num_batches_tracked) == int(ref[1].num_batches_tracked) == 1
         assert close(seq[1].weight.grad, ref[1].weight.grad) and close(seq[1].bias.grad, ref[1].bias.grad)
         assert close(seq[0].weight.grad, ref[0].weight.grad)
+
+
+@pytest.mark.parametrize("neighbor_type,nsample", [(0, -1), (1, -1), (0, 12)])
+def test_stack_vector_pool_family(dev, G, oracle, neighbor_type, nsample):
+    """The four vector-pool functions (vector_pool_gpu.cu) against the oracle's restatement: local neighbour lists (per
+    centre, whatever position the atomic counter gave them), three-NN of the grid centres inside them, pooled features /
+    local xyz / counts for both pooling types, the set of grouped triples, the retry protocol and the gradient."""
+    from spsnet_amd.pointnet2_stack import pointnet2_stack_cuda as SC, pointnet2_utils as SU
+    rng = np.random.default_rng(31 + neighbor_type)
+    xyz, cnt = _ragged(rng, [900, 30, 1400], dup=0.02)
+    starts = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    qs = [40, 3, 60]
+    q = np.concatenate([xyz[s + rng.choice(n, m, replace=False)] + rng.normal(scale=0.05, size=(m, 3))
+                        for s, n, m in zip(starts, cnt, qs)]).astype(np.float32)
+    q[-1] = 50.0                                         # a centre without neighbours
+    qc = np.asarray(qs, np.int32)
+    M, dist = len(q), 0.9
+    # --- local neighbour lists + three-NN of grid centres
+    want_lists, want_lens = oracle.vp_local_neighbors(xyz, cnt, q, qc, dist * 2.0, nsample, neighbor_type)
+    grid = (2, 2, 2)
+    from spsnet_amd.pointnet2_stack.pointnet2_modules import VectorPoolAggregationModule as VPA
+    centres = G.n(VPA.get_dense_voxels_by_center(G.t(q), dist, grid)).astype(np.float32)
+    d, idx, avg = SU.three_nn_for_vector_pool_by_two_step(G.t(xyz), G.t(cnt), G.t(q), G.t(centres), G.t(qc), dist, nsample,
+                                                          neighbor_type, 5, 8, 2.0)   # avg length 5: forces a retry
+    wd2, widx = oracle.vp_three_nn_local(xyz, centres, want_lists, want_lens)
+    np.testing.assert_array_equal(G.n(idx), widx)
+    np.testing.assert_array_equal(G.n(d), np.sqrt(wd2))
+    assert int(avg) == -(-int(want_lens.sum()) // M)
+    assert (widx[-1] == -1).all()
+    # --- pooling, both types
+    feats = rng.normal(size=(len(xyz), 6)).astype(np.float32)
+    for pooling_type in (0, 1):
+        f = G.t(feats).requires_grad_(True)
+        nf, nl, mean_pts, cg = SU.vector_pool_with_voxel_query_op(G.t(xyz), G.t(cnt), f, G.t(q), G.t(qc), 2, 2, 2, dist, 3, 1,
+                                                                 2, nsample, neighbor_type, pooling_type)   # 2 per centre: retry
+        cum, wnf, wnl, wcg, wgrouped = oracle.vp_pool(xyz, cnt, feats, q, qc, grid, dist, 3, 1, 10 ** 6, nsample,
+                                                      neighbor_type, pooling_type)
+        np.testing.assert_array_equal(G.n(cg), wcg)
+        norm = np.maximum(wcg[:, :, None].astype(np.float32), 1e-6)
+        np.testing.assert_array_equal(G.n(nf), (wnf.reshape(M, 8, 3) / norm).reshape(M, -1))
+        np.testing.assert_array_equal(G.n(nl), (wnl.reshape(M, 8, 3) / norm).reshape(M, -1))
+        assert int(mean_pts) == -(-cum // M)
+        go = rng.normal(size=tuple(nf.shape)).astype(np.float32)
+        nf.backward(G.t(go))
+        want_grad = oracle.vp_pool_grad(go, wcg, wgrouped, len(xyz), 6)
+        np.testing.assert_allclose(G.n(f.grad), want_grad, rtol=1e-4, atol=1e-5)
+    # --- raw kernel: rows of grouped_idxs as a set, counter beyond the buffer
+    nfb = torch.zeros((M, 24), device=dev); nlb = torch.zeros((M, 24), device=dev)
+    cgb = torch.zeros((M, 8), dtype=torch.int32, device=dev); gi = torch.zeros((cum + 5, 3), dtype=torch.int32, device=dev)
+    got = SC.vector_pool_wrapper(G.t(xyz), G.t(cnt), G.t(feats), G.t(q), G.t(qc), nfb, nlb, cgb, gi, 2, 2, 2, dist, 1, cum + 5,
+                                 nsample, neighbor_type, 1)
+    assert got == cum
+    assert sorted(map(tuple, G.n(gi)[:cum].tolist())) == sorted(map(tuple, wgrouped.tolist()))
+
+
+def test_stack_vector_pool_modules_run(dev, G):
+    """VectorPoolAggregationModule (all three aggregation types) and the MSG wrapper: forward + backward, finite, shapes."""
+    from spsnet_amd.pointnet2_stack import pointnet2_modules as SM
+    rng = np.random.default_rng(5)
+    xyz, cnt = _ragged(rng, [800, 1200], dup=0.0)
+    q = np.concatenate([xyz[:50], xyz[800:870]]).astype(np.float32)
+    qc = np.asarray([50, 70], np.int32)
+    feats = G.t(rng.normal(size=(len(xyz), 32)).astype(np.float32)).requires_grad_(True)
+    for kind in ("local_interpolation", "voxel_avg_pool", "voxel_random_choice"):
+        mod = SM.VectorPoolAggregationModule(32, (2, 2, 2), kind, 16, 8, (24,), 0.8, -1, 0).to(dev).train()
+        _, out = mod(xyz=G.t(xyz), xyz_batch_cnt=G.t(cnt), new_xyz=G.t(q), new_xyz_batch_cnt=G.t(qc), features=feats)
+        assert out.shape == (120, 24) and torch.isfinite(out).all()
+        feats.grad = None
+        out.square().mean().backward()
+        assert feats.grad is not None and torch.isfinite(feats.grad).all() and float(feats.grad.abs().sum()) > 0
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+    group = Cfg(NUM_LOCAL_VOXEL=(2, 2, 2), POST_MLPS=(16,), MAX_NEIGHBOR_DISTANCE=0.8, NEIGHBOR_NSAMPLE=-1)
+    cfg = Cfg(NUM_GROUPS=2, GROUP_CFG_0=group, GROUP_CFG_1=Cfg(group, MAX_NEIGHBOR_DISTANCE=1.6),
+              LOCAL_AGGREGATION_TYPE='voxel_avg_pool', NUM_REDUCED_CHANNELS=16, NUM_CHANNELS_OF_LOCAL_AGGREGATION=8,
+              MSG_POST_MLPS=(20,))
+    msg = SM.VectorPoolAggregationModuleMSG(32, cfg).to(dev).train()
+    _, out = msg(xyz=G.t(xyz), xyz_batch_cnt=G.t(cnt), new_xyz=G.t(q), new_xyz_batch_cnt=G.t(qc), features=feats)
+    assert out.shape == (120, 20) and torch.isfinite(out).all()
