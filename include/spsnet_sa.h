@@ -365,6 +365,20 @@ int sps_vector_pool_grad_kernel_launcher_stack(const float *grad_new_features, c
                                                int num_c_out, int num_c_in, int num_total_grids, int num_max_sum_points,
                                                sps_stream_t stream);
 
+/* Gradient of sps_dense_edge_conv (DenseEdgeConv.forward, surface_feature.py:98-116) for training: recomputes the
+ * convolution per centre and back-propagates through it.  relative_only as in the forward (0 or 1).  w_fwd = the forward's
+ * fragments [w1 | w2 | w3] concatenated, w_transposed = 44 x 64 fragments of the transposed blocks (fused.py:
+ * pack_dense_edge_conv_bwd).  Outputs: dx_centre (b, n, 24) = gradient through a point's role as centre (+ the
+ * pass-through channels of the output), dx_neighbour (b, 24, n*16) = gradient per (centre, neighbour column), to be
+ * scattered by idx (sps_group_points_grad_kernel_launcher_fast), grad_tiles (13 | 9 tiles of 16 x 16) = weight / bias
+ * gradients in tile form (fused.py unpacks them); partial = scratch of sps_dense_edge_conv_bwd_blocks() * tiles * 256
+ * floats.  Fixed-order reductions: reproducible. */
+int sps_dense_edge_conv_bwd_blocks(void);
+int sps_dense_edge_conv_bwd(int b, int n, int d, int k, int growth, int relative_only, const float *x, const int *idx,
+                            const float *grad_out, const float *w_fwd, const float *w_transposed, const float *b1,
+                            const float *b2, const float *b3, float *dx_centre, float *dx_neighbour, float *partial,
+                            float *grad_tiles, sps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

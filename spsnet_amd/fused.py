@@ -505,3 +505,91 @@ def linear_rows(fc, x):
                                   0 if lin.bias is None else lin.bias.data_ptr(), int(isinstance(fc.activation, nn.ReLU)),
                                   out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream), "linear_rows")
     return out
+
+
+def _dec_frag_t(mt):
+    """mt (rows <= 32, k <= 12): a transposed weight block -> (4 * tiles, 64) fragments, element [4 t + r][16 q + i] =
+    mt[16 t + i][4 q + r] (zero outside): the A operand of `mt @ dZ` with dZ in the accumulator layout."""
+    rows, k = mt.shape
+    tiles = (rows + 15) // 16
+    pad = mt.new_zeros((16 * tiles, 16))
+    pad[:rows, :k] = mt
+    # [t, i, q, r] -> [t, r, q, i]
+    return pad.view(tiles, 16, 4, 4).permute(0, 3, 2, 1).reshape(4 * tiles, 64).contiguous()
+
+
+def pack_dense_edge_conv_bwd(conv):
+    """Fragments of csrc/dense_edge_conv_bwd.hip: (w_fwd, w_transposed, b1, b2, b3); the forward part is the reference
+    form of the first layer ([x_i | x_j | x_j - x_i]), whatever DEC_MERGED says."""
+    lins = (conv.layer_first.linear, conv.layers[0].linear, conv.layer_last.linear)
+    w1, w2, w3 = (l.weight.detach().float() for l in lins)
+    wide = lambda base: [[base + 6 * q + j for q in range(4)] for j in range(6)]
+    act = lambda base: [[base + 4 * q + r if q < 3 else -1 for q in range(4)] for r in range(4)]
+    rel = bool(conv.relative_feat_only)
+    f1 = _dec_frag(w1, wide(0) if rel else wide(0) + wide(24) + wide(48))
+    wf = torch.cat([f1, _dec_frag(w2, act(0) + wide(12)), _dec_frag(w3, act(0) + act(12) + wide(24))], dim=0).contiguous()
+    if rel:
+        t1c, t1n = (-w1[:, 0:24]).t(), w1[:, 0:24].t()
+    else:
+        t1c, t1n = (w1[:, 0:24] - w1[:, 48:72]).t(), (w1[:, 24:48] + w1[:, 48:72]).t()
+    wt = torch.cat([_dec_frag_t(w3[:, 0:12].t()), _dec_frag_t(w3[:, 12:24].t()), _dec_frag_t(w2[:, 0:12].t()),
+                    _dec_frag_t(w3[:, 24:48].t()), _dec_frag_t(w2[:, 12:36].t()), _dec_frag_t(t1c), _dec_frag_t(t1n)],
+                   dim=0).contiguous()
+    assert wt.shape == (44, 64)
+    return (wf, wt) + tuple(_pad_bias(l.bias.detach().float(), 16) for l in lins)
+
+
+def dense_edge_conv_backward(conv, x, idx, grad_out, packed):
+    """-> (dx (B, N, 24), dW1, db1, dW2, db2, dW3, db3) of dense_edge_conv(conv, x, idx)."""
+    from . import pointnet2_batch_cuda as _ext
+    wf, wt, b1, b2, b3 = packed
+    B, N, d = x.shape
+    rel = bool(conv.relative_feat_only)
+    tiles = 9 if rel else 13
+    dev = x.device
+    dxc = torch.empty((B, N, d), dtype=torch.float32, device=dev)
+    dxn = torch.empty((B, d, N, 16), dtype=torch.float32, device=dev)
+    blocks = int(_L.sps_dense_edge_conv_bwd_blocks())
+    partial = torch.empty((blocks, tiles * 256), dtype=torch.float32, device=dev)
+    gt = torch.empty((tiles, 16, 16), dtype=torch.float32, device=dev)
+    _lib.check(_L.sps_dense_edge_conv_bwd(B, N, d, 16, conv.growth_rate, int(rel), x.data_ptr(), idx.data_ptr(),
+                                          grad_out.data_ptr(), wf.data_ptr(), wt.data_ptr(), b1.data_ptr(), b2.data_ptr(),
+                                          b3.data_ptr(), dxc.data_ptr(), dxn.data_ptr(), partial.data_ptr(), gt.data_ptr(),
+                                          torch.cuda.current_stream(dev).cuda_stream), "dense_edge_conv_bwd")
+    scat = torch.zeros((B, d, N), dtype=torch.float32, device=dev)
+    _ext.group_points_grad_wrapper(B, d, N, N, 16, dxn, idx, scat)
+    dx = dxc + scat.transpose(1, 2)
+    g = 12
+    dw3 = torch.cat([gt[0, :g, :12], gt[1, :g, :12], gt[2, :g, :16], gt[3, :g, :8]], dim=1)
+    dw2 = torch.cat([gt[4, :g, :12], gt[5, :g, :16], gt[6, :g, :8]], dim=1)
+    if rel:
+        dw1 = torch.cat([gt[7, :g, :16], gt[8, :g, :8]], dim=1)
+    else:
+        dw1 = torch.cat([gt[7, :g, :16], gt[8, :g, :8], gt[9, :g, :16], gt[10, :g, :8], gt[11, :g, :16], gt[12, :g, :8]], dim=1)
+    return dx, dw1, gt[8, :g, 8].clone(), dw2, gt[6, :g, 8].clone(), dw3, gt[3, :g, 8].clone()
+
+
+class DenseEdgeConvTrain(torch.autograd.Function):
+    """DenseEdgeConv.forward with gradients: fused forward kernel, fused recompute-and-backpropagate kernel."""
+
+    @staticmethod
+    def forward(ctx, x, idx, w1, b1, w2, b2, w3, b3, conv):
+        x = x.contiguous()
+        packed = pack_dense_edge_conv_bwd(conv)
+        wf, _, pb1, pb2, pb3 = packed
+        ks1 = 6 if conv.relative_feat_only else 18
+        B, N, d = x.shape
+        out = torch.empty((B, N, conv.out_channels), dtype=torch.float32, device=x.device)
+        _lib.check(_L.sps_dense_edge_conv(B, N, d, idx.shape[2], conv.growth_rate, 1 if conv.relative_feat_only else 0,
+                                          x.data_ptr(), idx.data_ptr(), wf[:ks1].data_ptr(), pb1.data_ptr(),
+                                          wf[ks1:ks1 + 10].data_ptr(), pb2.data_ptr(), wf[ks1 + 10:].data_ptr(), pb3.data_ptr(),
+                                          out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream), "dense_edge_conv")
+        ctx.save_for_backward(x, idx)
+        ctx.packed, ctx.conv = packed, conv
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, idx = ctx.saved_tensors
+        dx, dw1, db1, dw2, db2, dw3, db3 = dense_edge_conv_backward(ctx.conv, x, idx, grad_out.contiguous(), ctx.packed)
+        return dx, None, dw1, db1, dw2, db2, dw3, db3, None

@@ -22,6 +22,9 @@ import torch.nn as nn
 
 from . import pointnet2_utils
 
+# training (gradients wanted) through the fused kernels; False = the differentiable op-by-op form
+FUSED_TRAINING = True
+
 _ACTIVATIONS = {
     None: lambda: nn.Identity(),
     'relu': lambda: nn.ReLU(),
@@ -104,11 +107,26 @@ class DenseEdgeConv(nn.Module):
         pos = pos.contiguous()
         return pointnet2_utils.ball_query(self.group.radius, self.knn, pos, pos)
 
+    def _fused_train(self, x, pos):
+        """Gradients wanted: the fused forward + recompute-and-backpropagate kernels (fused.DenseEdgeConvTrain)."""
+        if not FUSED_TRAINING or not x.is_cuda or x.dtype != torch.float32 or pos.dtype != torch.float32:
+            return False
+        if not torch.is_grad_enabled():
+            return False
+        from . import fused
+        return fused.dense_edge_conv_supported(self)
+
     def forward(self, x, pos, idx=None):
         """`idx` (optional) = a neighbour table already computed for the same `pos` (static graphs share one)."""
         if self._fused(x, pos):
             from . import fused
             return fused.dense_edge_conv(self, x, self.neighbours(pos) if idx is None else idx)
+        if self._fused_train(x, pos):
+            from . import fused
+            with torch.no_grad():
+                table = self.neighbours(pos.detach()) if idx is None else idx
+            lf, l0, ll = self.layer_first.linear, self.layers[0].linear, self.layer_last.linear
+            return fused.DenseEdgeConvTrain.apply(x, table, lf.weight, lf.bias, l0.weight, l0.bias, ll.weight, ll.bias, self)
         y = torch.cat([self.layer_first(self.get_edge_feature(x, pos)),
                        x.unsqueeze(-2).repeat(1, 1, self.knn, 1)], dim=-1)
         for layer in self.layers:
@@ -157,7 +175,7 @@ class FeatureExtraction(nn.Module):
         idx = None
         for transform, conv in zip(self.transforms, self.convs):
             x = self._transform(transform, x)
-            if conv._fused(x, pos):
+            if conv._fused(x, pos) or conv._fused_train(x, pos):
                 # every convolution queries the same positions with the same radius and K: one table serves all
                 if idx is None:
                     idx = conv.neighbours(pos)

@@ -642,9 +642,9 @@ def test_fps_pruned_degenerate_clouds(ext, G, oracle):
         np.testing.assert_array_equal(got_t, want_t)
 
 
-@pytest.mark.parametrize("path", ["fused", "op_by_op"])
+@pytest.mark.parametrize("path", ["fused", "op_by_op", "fused_train"])
 @pytest.mark.parametrize("mode", ["static", "dynamic"])
-def test_golden_surface_feature(ext, G, dev, mode, path):
+def test_golden_surface_feature(ext, G, dev, mode, path, monkeypatch):
     """FeatureExtraction / DenseEdgeConv (surface_feature.py:45-187) against the reference's output, including
     the dynamic-graph quirk where a d-channel feature tensor is read as packed xyz triples.  `fused` = the inference
     kernels (sps_linear_rows + sps_dense_edge_conv), `op_by_op` = the differentiable form (gradients enabled)."""
@@ -659,16 +659,20 @@ def test_golden_surface_feature(ext, G, dev, mode, path):
         with torch.no_grad():
             assert all(c._fused(torch.empty(1, 1, 24, device=dev), x) for c in net.convs)
             out = net(x)
-    else:
+    elif path == "op_by_op":
+        monkeypatch.setattr(SF, "FUSED_TRAINING", False)
         out = net(x)
         assert out.requires_grad
+    else:   # fused_train: gradients wanted, fused forward + backward kernels
+        out = net(x)
+        assert out.requires_grad and type(out.grad_fn).__name__ == "DenseEdgeConvTrainBackward"
     ref = g["out_" + mode]
     assert out.shape == ref.shape
     assert float(np.abs(G.n(out.detach()) - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
 
 
 @pytest.mark.parametrize("mode", ["static", "dynamic"])
-def test_surface_feature_fused_matches_op_by_op(ext, G, dev, mode):
+def test_surface_feature_fused_matches_op_by_op(ext, G, dev, mode, monkeypatch):
     """The fused DenseEdgeConv kernels against the op-by-op form on LiDAR-like scenes (B=2, N=8192: many full and many
     empty balls), random weights; 1e-4 relative to the largest feature."""
     from spsnet_amd import scenes, surface_feature as SF
@@ -678,6 +682,7 @@ def test_surface_feature_fused_matches_op_by_op(ext, G, dev, mode):
     x = G.t(xyz)
     with torch.no_grad():
         fused_out = net(x)
+    monkeypatch.setattr(SF, "FUSED_TRAINING", False)
     plain = net(x)
     assert plain.requires_grad and not fused_out.requires_grad
     a, b = G.n(fused_out), G.n(plain.detach())
@@ -1414,3 +1419,73 @@ def test_stack_vector_pool_modules_run(dev, G):
     msg = SM.VectorPoolAggregationModuleMSG(32, cfg).to(dev).train()
     _, out = msg(xyz=G.t(xyz), xyz_batch_cnt=G.t(cnt), new_xyz=G.t(q), new_xyz_batch_cnt=G.t(qc), features=feats)
     assert out.shape == (120, 20) and torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("mode", ["static", "dynamic"])
+def test_surface_feature_training_gradients(ext, G, dev, mode, monkeypatch):
+    """FeatureExtraction with gradients through the fused kernels (sps_dense_edge_conv + sps_dense_edge_conv_bwd) against
+    autograd over the op-by-op form: output, the gradient w.r.t. the input cloud and every parameter.  2 x 2048 dense points
+    (full and padded balls); the loss reaches all 60 output channels."""
+    from spsnet_amd import scenes, surface_feature as SF
+    torch.manual_seed(9)
+    net = SF.FeatureExtraction(dynamic_graph=(mode == "dynamic")).to(dev).train()
+    xyz, _ = scenes.make_batch("kitti-lidar-v1", 2, 2048, seed0=13)
+    xyz = ((xyz - xyz.mean(1, keepdims=True)) * 0.15).astype(np.float32)
+    wsum = torch.randn((2, 2048, 60), generator=torch.Generator().manual_seed(1)).to(dev)
+
+    def run(fused_training):
+        monkeypatch.setattr(SF, "FUSED_TRAINING", fused_training)
+        for p in net.parameters():
+            p.grad = None
+        x = G.t(xyz).requires_grad_(True)
+        out = net(x)
+        (out * wsum).sum().backward()
+        return out.detach(), x.grad.detach(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+
+    out_a, dx_a, gp_a = run(True)
+    out_b, dx_b, gp_b = run(False)
+
+    def close(a, b, what, tol=2e-4):
+        a, b = G.n(a), G.n(b)
+        assert float(np.abs(a - b).max()) <= tol * max(1.0, float(np.abs(b).max())), what
+
+    if mode == "static":
+        close(out_a, out_b, "output")
+        # the subgradient of max is discontinuous: where two neighbours' values agree to the last bits, the two forward
+        # implementations may pick different ones -- a handful of points, visible in d/d xyz only
+        off = ((dx_a - dx_b).abs().amax(-1) > 2e-4 * float(dx_b.abs().max())).float().mean()
+        assert float(off) < 5e-3
+        for k in gp_b:   # one flipped argmax moves a bias gradient by one point's share: a few 1e-3 of the largest entry
+            close(gp_a[k], gp_b[k], "d/d " + k, tol=5e-3)
+    else:
+        # dynamic graph: a neighbour can flip with the last bit of the previous convolution's output (DESIGN 4.5b), so
+        # compare where the outputs agree: all but a handful of points, and gradients in aggregate
+        rows = (out_a - out_b).abs().amax(-1) <= 1e-4 * float(out_b.abs().max())
+        assert float(rows.float().mean()) > 0.999
+        for k in gp_b:
+            rel = float((gp_a[k] - gp_b[k]).abs().max()) / max(1.0, float(gp_b[k].abs().max()))
+            assert rel <= 2e-2, k
+
+
+@pytest.mark.parametrize("relative", [True, False])
+def test_dense_edge_conv_backward_kernel(ext, G, dev, relative, monkeypatch):
+    """One DenseEdgeConv in isolation (same input for both paths, so the argmax choices agree): output and every gradient
+    of sps_dense_edge_conv_bwd against autograd over the op-by-op form, 1e-5 relative."""
+    from spsnet_amd import scenes, surface_feature as SF
+    torch.manual_seed(4)
+    xyz, _ = scenes.make_batch("kitti-lidar-v1", 2, 2048, seed0=13)
+    pos = G.t(((xyz - xyz.mean(1, keepdims=True)) * 0.15).astype(np.float32))
+    conv = SF.DenseEdgeConv(24, 3, 12, knn=16, relative_feat_only=relative).to(dev).train()
+    x0 = torch.randn(2, 2048, 24, device=dev)
+    w = torch.randn(2, 2048, 60, device=dev)
+    res = {}
+    for fused_training in (True, False):
+        monkeypatch.setattr(SF, "FUSED_TRAINING", fused_training)
+        for p in conv.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        out = conv(x, pos)
+        (out * w).sum().backward()
+        res[fused_training] = [out.detach(), x.grad.detach()] + [p.grad.detach().clone() for p in conv.parameters()]
+    for a, b in zip(res[True], res[False]):
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
