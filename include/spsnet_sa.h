@@ -379,6 +379,13 @@ int sps_dense_edge_conv_bwd(int b, int n, int d, int k, int growth, int relative
                             const float *b2, const float *b3, float *dx_centre, float *dx_neighbour, float *partial,
                             float *grad_tiles, sps_stream_t stream);
 
+/* Gradient of sps_linear_rows: dx (rows, cin) = dy' w, grad_w_b (cout * cin + cout) = [dy'^T x | column sums of dy'], where
+ * dy' = dy masked by y > 0 when relu != 0.  partial = scratch of sps_linear_rows_bwd_blocks() * (cout * cin + cout) floats.
+ * Fixed-order reductions. */
+int sps_linear_rows_bwd_blocks(void);
+int sps_linear_rows_bwd(long long rows, int cin, int cout, const float *x, const float *y, const float *dy, const float *w,
+                        int relu, float *dx, float *partial, float *grad_w_b, sps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,8 @@ _PROTOS = {
     "sps_vector_pool_grad_kernel_launcher_stack": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "sps_dense_edge_conv_bwd": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_dense_edge_conv_bwd_blocks": [],
+    "sps_linear_rows_bwd": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "sps_linear_rows_bwd_blocks": [],
     "sps_dense_edge_conv": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_linear_rows": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "sps_sa_group_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,

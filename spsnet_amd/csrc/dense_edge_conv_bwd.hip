@@ -263,13 +263,87 @@ __global__ __launch_bounds__(64 * DB_WAVES, 2) void dense_edge_conv_bwd_kernel(D
     for (int e = threadIdx.x; e < TILES * 256; e += blockDim.x) out[e] = red[e];
 }
 
-// sum of the workgroups' partial tiles, fixed order
+// sum of the workgroups' partial tiles, fixed order: one wave per element, lane l adds blocks l, l + 64, ... and the 64
+// lane sums meet in a butterfly (the order does not depend on timing: reproducible)
 __global__ __launch_bounds__(256) void dec_bwd_reduce_kernel(int blocks, int count, const float *__restrict__ partial, float *__restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (e >= count) return;
     float s = 0.f;
-    for (int b = 0; b < blocks; ++b) s += partial[(size_t)b * count + e];
-    out[e] = s;
+    for (int b = lane; b < blocks; b += 64) s += partial[(size_t)b * count + e];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) out[e] = s;
+}
+
+// ---- gradient of the row-wise Linear (+ ReLU) of FCLayer (sps_linear_rows): dX = dY' W, dW = dY'^T X, db = sum dY' -------
+// (torch hands the weight gradient, a 24 x cin product over 131 072 rows, to a GEMM kernel that takes 0.4 ms for it.)
+// A workgroup stages 64 rows of x and dY' (= dY where the output was positive, if ReLU) in LDS; four threads per row form
+// dX, every thread accumulates its share of the 24 x cin + 24 weight / bias gradient entries over the 64 rows; workgroup
+// partials are summed by dec_bwd_reduce_kernel in a fixed order.
+constexpr int LB_ROWS = 64, LB_COUT = 24, LB_MAX_CIN = 64, LB_SLOTS = (LB_COUT * LB_MAX_CIN + 255) / 256;
+__global__ __launch_bounds__(256) void linear_rows24_bwd_kernel(long long rows, int cin, const float *__restrict__ x,
+                                                                const float *__restrict__ y, const float *__restrict__ dy,
+                                                                const float *__restrict__ w, int relu, float *__restrict__ dx,
+                                                                float *__restrict__ partial) {
+    __shared__ float ws[LB_COUT * LB_MAX_CIN];          // [o][i]
+    __shared__ float xs[LB_ROWS * (LB_MAX_CIN + 1)];
+    __shared__ float ds[LB_ROWS * (LB_COUT + 1)];
+    const int px = cin + 1, pd = LB_COUT + 1;
+    for (int e = threadIdx.x; e < LB_COUT * cin; e += blockDim.x) ws[e] = w[e];
+    float acc[LB_SLOTS], accb = 0.f;
+#pragma unroll
+    for (int k = 0; k < LB_SLOTS; ++k) acc[k] = 0.f;
+    const int entries = LB_COUT * cin;
+    for (long long r0 = (long long)blockIdx.x * LB_ROWS; r0 < rows; r0 += (long long)gridDim.x * LB_ROWS) {
+        const int here = (rows - r0 < LB_ROWS) ? (int)(rows - r0) : LB_ROWS;
+        __syncthreads();
+        for (int e = threadIdx.x; e < LB_ROWS * cin; e += blockDim.x) {
+            const int r = e / cin, i = e - r * cin;
+            xs[r * px + i] = r < here ? x[r0 * cin + e] : 0.f;
+        }
+        for (int e = threadIdx.x; e < LB_ROWS * LB_COUT; e += blockDim.x) {
+            const int r = e / LB_COUT, o = e - r * LB_COUT;
+            float g = 0.f;
+            if (r < here) {
+                g = dy[r0 * LB_COUT + e];
+                if (relu && !(y[r0 * LB_COUT + e] > 0.f)) g = 0.f;
+            }
+            ds[r * pd + o] = g;
+        }
+        __syncthreads();
+        {   // dX: four threads per row, outputs part, part + 4, ...
+            const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
+            if (r < here) {
+                for (int i = part; i < cin; i += 4) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int o = 0; o < LB_COUT; ++o) s = __builtin_fmaf(ds[r * pd + o], ws[o * cin + i], s);
+                    dx[(r0 + r) * cin + i] = s;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < LB_SLOTS; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            if (e < entries) {
+                const int o = e / cin, i = e - o * cin;
+                float s = acc[k];
+                for (int r = 0; r < LB_ROWS; ++r) s = __builtin_fmaf(ds[r * pd + o], xs[r * px + i], s);
+                acc[k] = s;
+            }
+        }
+        if (threadIdx.x < LB_COUT) {
+            float s = accb;
+            for (int r = 0; r < LB_ROWS; ++r) s += ds[r * pd + threadIdx.x];
+            accb = s;
+        }
+    }
+    float *out = partial + (size_t)blockIdx.x * (entries + LB_COUT);
+#pragma unroll
+    for (int k = 0; k < LB_SLOTS; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        if (e < entries) out[e] = acc[k];
+    }
+    if (threadIdx.x < LB_COUT) out[entries + threadIdx.x] = accb;
 }
 
 }  // namespace sps
@@ -306,6 +380,25 @@ extern "C" int sps_dense_edge_conv_bwd(int b, int n, int d, int k, int growth, i
     }
     if (relative_only) hipLaunchKernelGGL(dense_edge_conv_bwd_kernel<true>, dim3(blocks), dim3(64 * DB_WAVES), lds, st, a);
     else hipLaunchKernelGGL(dense_edge_conv_bwd_kernel<false>, dim3(blocks), dim3(64 * DB_WAVES), lds, st, a);
-    hipLaunchKernelGGL(dec_bwd_reduce_kernel, dim3(divup(tiles * 256, 256)), dim3(256), 0, st, blocks, tiles * 256, partial, grad_tiles);
+    hipLaunchKernelGGL(dec_bwd_reduce_kernel, dim3(divup(tiles * 256, 4)), dim3(256), 0, st, blocks, tiles * 256, partial, grad_tiles);
     return check_launch("dense_edge_conv_bwd_kernel");
+}
+
+extern "C" int sps_linear_rows_bwd_blocks(void) { return 512; }
+
+extern "C" int sps_linear_rows_bwd(long long rows, int cin, int cout, const float *x, const float *y, const float *dy,
+                                   const float *w, int relu, float *dx, float *partial, float *grad_w_b, sps_stream_t stream) {
+    using namespace sps;
+    if (rows < 0 || cin <= 0) return fail(SPS_ERR_INVALID, "linear_rows_bwd: bad shape rows=%lld cin=%d", rows, cin);
+    if (cout != LB_COUT || cin > LB_MAX_CIN) return fail(SPS_ERR_INVALID, "linear_rows_bwd: built for cout=%d, cin<=%d (got %d, %d)", LB_COUT, LB_MAX_CIN, cout, cin);
+    if (!x || !dy || !w || !dx || !partial || !grad_w_b || (relu && !y)) return fail(SPS_ERR_INVALID, "linear_rows_bwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int count = LB_COUT * cin + LB_COUT, blocks = sps_linear_rows_bwd_blocks();
+    if (rows == 0) {
+        hipMemsetAsync(grad_w_b, 0, sizeof(float) * count, st);
+        return SPS_OK;
+    }
+    hipLaunchKernelGGL(linear_rows24_bwd_kernel, dim3(blocks), dim3(256), 0, st, rows, cin, x, y, dy, w, relu, dx, partial);
+    hipLaunchKernelGGL(dec_bwd_reduce_kernel, dim3(divup(count, 4)), dim3(256), 0, st, blocks, count, partial, grad_w_b);
+    return check_launch("linear_rows24_bwd_kernel");
 }

@@ -593,3 +593,34 @@ class DenseEdgeConvTrain(torch.autograd.Function):
         x, idx = ctx.saved_tensors
         dx, dw1, db1, dw2, db2, dw3, db3 = dense_edge_conv_backward(ctx.conv, x, idx, grad_out.contiguous(), ctx.packed)
         return dx, None, dw1, db1, dw2, db2, dw3, db3, None
+
+
+class LinearRowsTrain(torch.autograd.Function):
+    """FCLayer (Linear + optional ReLU) on point-major rows with gradients: sps_linear_rows / sps_linear_rows_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        x = x.contiguous()
+        rows, cin = x.numel() // x.shape[-1], x.shape[-1]
+        out = torch.empty(x.shape[:-1] + (weight.shape[0],), dtype=torch.float32, device=x.device)
+        _lib.check(_L.sps_linear_rows(rows, cin, weight.shape[0], x.data_ptr(), weight.data_ptr(),
+                                      0 if bias is None else bias.data_ptr(), int(relu), out.data_ptr(),
+                                      torch.cuda.current_stream(x.device).cuda_stream), "linear_rows")
+        ctx.save_for_backward(x, out, weight)
+        ctx.relu, ctx.has_bias = bool(relu), bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        cout, cin = weight.shape
+        rows = x.numel() // cin
+        dx = torch.empty_like(x)
+        blocks = int(_L.sps_linear_rows_bwd_blocks())
+        partial = torch.empty((blocks, cout * cin + cout), dtype=torch.float32, device=x.device)
+        gwb = torch.empty((cout * cin + cout,), dtype=torch.float32, device=x.device)
+        _lib.check(_L.sps_linear_rows_bwd(rows, cin, cout, x.data_ptr(), y.data_ptr(), dy.data_ptr(), weight.data_ptr(),
+                                          int(ctx.relu), dx.data_ptr(), partial.data_ptr(), gwb.data_ptr(),
+                                          torch.cuda.current_stream(x.device).cuda_stream), "linear_rows_bwd")
+        return dx, gwb[:cout * cin].view(cout, cin), (gwb[cout * cin:] if ctx.has_bias else None), None

@@ -162,6 +162,10 @@ class FeatureExtraction(nn.Module):
             from . import fused
             if fused.linear_rows_supported(fc):
                 return fused.linear_rows(fc, x)
+        elif FUSED_TRAINING and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled():
+            from . import fused
+            if fused.linear_rows_supported(fc) and fc.linear.weight.dtype == torch.float32:
+                return fused.LinearRowsTrain.apply(x, fc.linear.weight, fc.linear.bias, isinstance(fc.activation, nn.ReLU))
         return fc(x)
 
     def dynamic_graph_forward(self, x):

@@ -1489,3 +1489,24 @@ def test_dense_edge_conv_backward_kernel(ext, G, dev, relative, monkeypatch):
         res[fused_training] = [out.detach(), x.grad.detach()] + [p.grad.detach().clone() for p in conv.parameters()]
     for a, b in zip(res[True], res[False]):
         assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("cin,relu", [(3, False), (60, True), (17, True)])
+def test_linear_rows_training(ext, dev, cin, relu):
+    """sps_linear_rows + sps_linear_rows_bwd (fused.LinearRowsTrain) against nn.Linear (+ ReLU) autograd."""
+    from spsnet_amd import fused
+    g = torch.Generator(device=dev).manual_seed(cin)
+    lin = torch.nn.Linear(cin, 24).to(dev)
+    x0 = torch.randn((3, 1000, cin), generator=g, device=dev)
+    go = torch.randn((3, 1000, 24), generator=g, device=dev)
+    a = x0.clone().requires_grad_(True)
+    ya = fused.LinearRowsTrain.apply(a, lin.weight, lin.bias, relu)
+    ya.backward(go)
+    got = (ya.detach(), a.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    lin.weight.grad = None; lin.bias.grad = None
+    b = x0.clone().requires_grad_(True)
+    yb = lin(b)
+    yb = torch.relu(yb) if relu else yb
+    yb.backward(go)
+    for p, q in zip(got, (yb.detach(), b.grad, lin.weight.grad, lin.bias.grad)):
+        assert float((p - q).abs().max()) <= 1e-4 * max(1.0, float(q.abs().max()))
