@@ -1510,3 +1510,35 @@ def test_linear_rows_training(ext, dev, cin, relu):
     yb.backward(go)
     for p, q in zip(got, (yb.detach(), b.grad, lin.weight.grad, lin.bias.grad)):
         assert float((p - q).abs().max()) <= 1e-4 * max(1.0, float(q.abs().max()))
+
+
+@pytest.mark.parametrize("tag", ["iassd", "pagnet"])
+def test_backbone_training_step_runs(ext, G, dev, tag):
+    """tools/train.py-style use of the backbone mirrors: train() mode, forward + backward through the fused training
+    kernels (BatchNorm+ReLU, max-pool, LDS scatter, DenseEdgeConv / FCLayer backward); finite gradients on every parameter
+    that takes part, running statistics updated."""
+    from spsnet_amd import backbones as BB, scenes
+    base = BB.IASSD_KITTI_CFG if tag == "iassd" else BB.SPSNET_KITTI_CFG
+    cls = BB.IASSD_Backbone if tag == "iassd" else BB.PAGNet_Backbone
+    net = scenes.fill_parameters(cls(BB.scaled_cfg(base, [1024, 256, 128, 64, -1, 64]), num_class=3, input_channels=4), 2)
+    net = net.to(dev).train()
+    xyz, feats = scenes.make_batch("kitti-lidar-v1", 2, 4096, seed0=77)
+    bidx = np.repeat(np.arange(2, dtype=np.float32), 4096)[:, None]
+    points = np.concatenate([bidx, xyz.reshape(-1, 3), feats.transpose(0, 2, 1).reshape(-1, 1)], 1).astype(np.float32)
+    batch = dict(batch_size=2, points=G.t(points))
+    if tag == "pagnet":
+        batch["stds"] = G.t(np.random.default_rng(1).uniform(0, 40, (2, 4096)).astype(np.float32))
+    before = {k: v.clone() for k, v in net.state_dict().items() if k.endswith("running_mean")}
+    out = net(batch)
+    loss = out["centers_features"].square().mean() + out["ctr_offsets"][:, 1:].square().mean()
+    for t in out["sa_ins_preds"]:
+        if isinstance(t, torch.Tensor):
+            loss = loss + t[..., 1:].square().mean()
+    loss.backward()
+    grads = [(k, p.grad) for k, p in net.named_parameters() if p.grad is not None]
+    assert len(grads) > 40 and all(torch.isfinite(g).all() for _, g in grads)
+    assert any(float(g.abs().sum()) > 0 for _, g in grads)
+    if tag == "pagnet":
+        assert any(k.startswith("SF_extract") and float(g.abs().sum()) > 0 for k, g in grads)
+    after = net.state_dict()
+    assert any(not torch.equal(before[k], after[k]) for k in before)
