@@ -518,25 +518,54 @@ def _dec_frag_t(mt):
     return pad.view(tiles, 16, 4, 4).permute(0, 3, 2, 1).reshape(4 * tiles, 64).contiguous()
 
 
+def _dec_bwd_maps(conv, device):
+    """Index maps that turn the flat parameter vector [0, w1, w2, w3] into the forward and transposed fragments of
+    csrc/dense_edge_conv_bwd.hip (built once per module by running the packing on matrices of indices): in training the
+    weights change every step, and packing them with ~40 small torch ops cost more host time than the kernels."""
+    maps = getattr(conv, "_sps_bwd_maps", None)
+    if maps is not None and maps[0].device == device:
+        return maps
+    lins = (conv.layer_first.linear, conv.layers[0].linear, conv.layer_last.linear)
+    shapes = [tuple(l.weight.shape) for l in lins]
+    sizes = [a * b for a, b in shapes]
+    offs = [1, 1 + sizes[0], 1 + sizes[0] + sizes[1]]   # index 0 is a zero
+    i1, i2, i3 = (torch.arange(n, dtype=torch.float32, device=device).add_(o).view(sh) for n, o, sh in zip(sizes, offs, shapes))
+    wide = lambda base: [[base + 6 * q + j for q in range(4)] for j in range(6)]
+    act = lambda base: [[base + 4 * q + r if q < 3 else -1 for q in range(4)] for r in range(4)]
+    rel = bool(conv.relative_feat_only)
+    f1 = _dec_frag(i1, wide(0) if rel else wide(0) + wide(24) + wide(48))
+    perm_f = torch.cat([f1, _dec_frag(i2, act(0) + wide(12)), _dec_frag(i3, act(0) + act(12) + wide(24))], dim=0)
+    zero = lambda like: torch.zeros_like(like)
+    blocks = [(i3[:, 0:12].t(), 1.0, None, 0.0), (i3[:, 12:24].t(), 1.0, None, 0.0), (i2[:, 0:12].t(), 1.0, None, 0.0),
+              (i3[:, 24:48].t(), 1.0, None, 0.0), (i2[:, 12:36].t(), 1.0, None, 0.0)]
+    if rel:
+        blocks += [(i1[:, 0:24].t(), -1.0, None, 0.0), (i1[:, 0:24].t(), 1.0, None, 0.0)]
+    else:
+        blocks += [(i1[:, 0:24].t(), 1.0, i1[:, 48:72].t(), -1.0), (i1[:, 24:48].t(), 1.0, i1[:, 48:72].t(), 1.0)]
+    pa = torch.cat([_dec_frag_t(a.contiguous()) for a, _, _, _ in blocks], dim=0)
+    pb = torch.cat([_dec_frag_t((b if b is not None else zero(a)).contiguous()) for a, _, b, _ in blocks], dim=0)
+    sa = torch.cat([torch.full_like(_dec_frag_t(a.contiguous()), s) for a, s, _, _ in blocks], dim=0)
+    sb = torch.cat([torch.full_like(_dec_frag_t(a.contiguous()), s) for a, _, _, s in blocks], dim=0)
+    maps = (perm_f.round().long().reshape(-1), pa.round().long().reshape(-1), sa.reshape(-1), pb.round().long().reshape(-1),
+            sb.reshape(-1))
+    object.__setattr__(conv, "_sps_bwd_maps", maps)
+    return maps
+
+
 def pack_dense_edge_conv_bwd(conv):
     """Fragments of csrc/dense_edge_conv_bwd.hip: (w_fwd, w_transposed, b1, b2, b3); the forward part is the reference
     form of the first layer ([x_i | x_j | x_j - x_i]), whatever DEC_MERGED says."""
     lins = (conv.layer_first.linear, conv.layers[0].linear, conv.layer_last.linear)
-    w1, w2, w3 = (l.weight.detach().float() for l in lins)
-    wide = lambda base: [[base + 6 * q + j for q in range(4)] for j in range(6)]
-    act = lambda base: [[base + 4 * q + r if q < 3 else -1 for q in range(4)] for r in range(4)]
-    rel = bool(conv.relative_feat_only)
-    f1 = _dec_frag(w1, wide(0) if rel else wide(0) + wide(24) + wide(48))
-    wf = torch.cat([f1, _dec_frag(w2, act(0) + wide(12)), _dec_frag(w3, act(0) + act(12) + wide(24))], dim=0).contiguous()
-    if rel:
-        t1c, t1n = (-w1[:, 0:24]).t(), w1[:, 0:24].t()
-    else:
-        t1c, t1n = (w1[:, 0:24] - w1[:, 48:72]).t(), (w1[:, 24:48] + w1[:, 48:72]).t()
-    wt = torch.cat([_dec_frag_t(w3[:, 0:12].t()), _dec_frag_t(w3[:, 12:24].t()), _dec_frag_t(w2[:, 0:12].t()),
-                    _dec_frag_t(w3[:, 24:48].t()), _dec_frag_t(w2[:, 12:36].t()), _dec_frag_t(t1c), _dec_frag_t(t1n)],
-                   dim=0).contiguous()
-    assert wt.shape == (44, 64)
-    return (wf, wt) + tuple(_pad_bias(l.bias.detach().float(), 16) for l in lins)
+    dev = lins[0].weight.device
+    perm_f, pa, sa, pb, sb = _dec_bwd_maps(conv, dev)
+    with torch.no_grad():
+        flat = torch.cat([lins[0].weight.new_zeros(1)] + [l.weight.detach().float().reshape(-1) for l in lins])
+        wf = flat[perm_f].view(-1, 64)
+        wt = (flat[pa] * sa + flat[pb] * sb).view(44, 64)
+        bias = flat.new_zeros(48)
+        for k, l in enumerate(lins):
+            bias[16 * k:16 * k + l.bias.numel()] = l.bias.detach()
+    return wf, wt, bias[0:16], bias[16:32], bias[32:48]
 
 
 def dense_edge_conv_backward(conv, x, idx, grad_out, packed):
