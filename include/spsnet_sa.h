@@ -386,6 +386,18 @@ int sps_linear_rows_bwd_blocks(void);
 int sps_linear_rows_bwd(long long rows, int cin, int cout, const float *x, const float *y, const float *dy, const float *w,
                         int relu, float *dx, float *partial, float *grad_w_b, sps_stream_t stream);
 
+/* The 1x1 convolutions of the grouped MLPs in training (Conv2d(k=1, bias=False), pointnet2_modules.py:203-209) on
+ * channel-major activations (b, c, l), l = M * nsample, exact fp32 on the matrix cores.
+ * sps_conv1x1_apply: out (b, co, l) = A (co x ci) in (b, ci, l) -- the forward with A = W, the data gradient with A = W^T;
+ * afrag = A in fragment order [ceil(co/16)][ceil(ci/4)][64 lanes] = A[16 t + (lane & 15)][4 ks + (lane >> 4)], zero padded
+ * (pointnet2_modules.py packs it); l % 4 == 0.
+ * sps_conv1x1_wgrad: dw (co, ci) = sum over scenes and columns of dy (b, co, l) x (b, ci, l)^T; l % 16 == 0; work =
+ * sps_conv1x1_wgrad_workspace_floats(b, ci, co, l) floats.  Fixed-order reductions. */
+int sps_conv1x1_apply(int b, int ci, int co, long long l, const float *in, const float *afrag, float *out, sps_stream_t stream);
+long long sps_conv1x1_wgrad_workspace_floats(int b, int ci, int co, long long l);
+int sps_conv1x1_wgrad(int b, int ci, int co, long long l, const float *x, const float *dy, float *dw, float *work,
+                      sps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,8 @@ _PROTOS = {
     "sps_dense_edge_conv_bwd_blocks": [],
     "sps_linear_rows_bwd": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "sps_linear_rows_bwd_blocks": [],
+    "sps_conv1x1_apply": [_i, _i, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp],
+    "sps_conv1x1_wgrad": [_i, _i, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp],
     "sps_dense_edge_conv": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_linear_rows": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "sps_sa_group_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
@@ -86,7 +88,7 @@ _PROTOS = {
                                _vp, _vp, _i, _i, _vp],
 }
 EXPORTS = ["sps_abi_version", "sps_last_error", "sps_opt_n_threads", "sps_fps_workspace_floats",
-           "sps_index_add_workspace_ints", "sps_ball_query_grid_workspace_ints", "sps_bn_train_workspace_doubles"] + list(_PROTOS)
+           "sps_index_add_workspace_ints", "sps_ball_query_grid_workspace_ints", "sps_bn_train_workspace_doubles", "sps_conv1x1_wgrad_workspace_floats"] + list(_PROTOS)
 
 _lib = None
 
@@ -118,6 +120,8 @@ def load():
     lib.sps_ball_query_grid_workspace_ints.restype = ctypes.c_longlong
     lib.sps_bn_train_workspace_doubles.argtypes = [_i, _i, ctypes.c_longlong]
     lib.sps_bn_train_workspace_doubles.restype = ctypes.c_longlong
+    lib.sps_conv1x1_wgrad_workspace_floats.argtypes = [_i, _i, _i, ctypes.c_longlong]
+    lib.sps_conv1x1_wgrad_workspace_floats.restype = ctypes.c_longlong
     lib.sps_index_add_workspace_ints.argtypes = [_i, _i, _i]
     for name, args in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

@@ -217,6 +217,55 @@ def bn_relu_train_bwd(x, dy, mean, invstd, weight, bias):
     return dx, dweight, dbias
 
 
+_CONV_MAPS = {}
+
+
+def _conv_frag_map(co, ci, transposed, device):
+    """Gather indices into [0, W.flatten()] that give the fragment order of csrc/conv1x1_train.hip for A = W (co x ci) or
+    A = W^T (ci x co); cached per shape."""
+    key = (co, ci, transposed, device)
+    m = _CONV_MAPS.get(key)
+    if m is None:
+        rows, cols = (ci, co) if transposed else (co, ci)          # A is rows x cols
+        t = torch.arange((rows + 15) // 16, device=device).view(-1, 1, 1, 1)
+        ks = torch.arange((cols + 3) // 4, device=device).view(1, -1, 1, 1)
+        q = torch.arange(4, device=device).view(1, 1, 4, 1)
+        i = torch.arange(16, device=device).view(1, 1, 1, 16)
+        r, k = 16 * t + i, 4 * ks + q                               # A[r][k], lane = 16 q + i
+        flat = (k * ci + r) if transposed else (r * ci + k)         # W[k][r] or W[r][k]
+        m = torch.where((r < rows) & (k < cols), flat + 1, torch.zeros_like(flat)).reshape(-1)
+        _CONV_MAPS[key] = m
+    return m
+
+
+def conv1x1_apply(x, weight2d, transposed):
+    """x (B, Cin, ...) contiguous -> (B, Cout, ...): W x (transposed=False, W (Cout, Cin)) or W^T x (True, W (Cin_of_W...))."""
+    co, ci = weight2d.shape
+    B = x.shape[0]
+    cin_x = ci if not transposed else co
+    cout = co if not transposed else ci
+    L = x.numel() // max(B * cin_x, 1)
+    flat = torch.cat([weight2d.new_zeros(1), weight2d.reshape(-1)])
+    frag = flat[_conv_frag_map(co, ci, transposed, x.device)]
+    out = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=F32, device=x.device)
+    with _on(x):
+        _lib.check(_L.sps_conv1x1_apply(B, cin_x, cout, L, _ptr(x, F32, "x"), frag.data_ptr(), out.data_ptr(), _stream(x)),
+                   "conv1x1_apply")
+    return out
+
+
+def conv1x1_wgrad(x, dy):
+    """x (B, Cin, ...), dy (B, Cout, ...) -> dW (Cout, Cin)"""
+    B, ci, co = x.shape[0], x.shape[1], dy.shape[1]
+    L = x.numel() // max(B * ci, 1)
+    dw = torch.empty((co, ci), dtype=F32, device=x.device)
+    work = torch.empty((int(_L.sps_conv1x1_wgrad_workspace_floats(B, ci, co, L)),), dtype=F32, device=x.device)
+    with _on(x):
+        _lib.check(_L.sps_conv1x1_wgrad(B, ci, co, L, _ptr(x, F32, "x"), _ptr(dy, F32, "dy"), dw.data_ptr(), work.data_ptr(),
+                                        _stream(x)), "conv1x1_wgrad")
+    return dw
+
+
 def pool_max_fwd(x, out, arg):
     """x (..., ns) contiguous -> out (...) row maxima, arg (...) uint8 position of the first maximum."""
     ns = x.shape[-1]

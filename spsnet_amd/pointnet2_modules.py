@@ -75,6 +75,30 @@ class _BatchNormReLUTrain(torch.autograd.Function):
         return dx, dweight, dbias, None
 
 
+class _Conv1x1Train(torch.autograd.Function):
+    """Conv2d(kernel 1, no bias) on (B, C, M, ns) with gradients: csrc/conv1x1_train.hip (forward, data and weight
+    gradient on fp32 MFMA, channel-major throughout) instead of MIOpen's NHWC implicit-GEMM kernels and their transposes."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous()
+        w2 = weight.detach().reshape(weight.shape[0], weight.shape[1])
+        ctx.save_for_backward(x, weight)
+        return _ext.conv1x1_apply(x, w2, False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        w2 = weight.detach().reshape(weight.shape[0], weight.shape[1])
+        dx = _ext.conv1x1_apply(dy, w2, True) if ctx.needs_input_grad[0] else None
+        dw = _ext.conv1x1_wgrad(x, dy).view_as(weight) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+FUSED_CONV_TRAINING = True
+
+
 def _shared_mlp(mlp: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
     """mlp(x) for a [Conv2d, BatchNorm2d, ReLU]* stack; in training on the GPU each BatchNorm2d + ReLU pair runs as the
     fused batch-statistics kernels instead of MIOpen's BatchNorm and a separate ReLU (same arithmetic, 1e-6)."""
@@ -90,7 +114,12 @@ def _shared_mlp(mlp: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
                 and bn.weight.dtype == torch.float32):
             return mlp(x)
     for conv, bn, _ in triples:
-        x = _BatchNormReLUTrain.apply(conv(x), bn.weight, bn.bias, bn)
+        if (FUSED_CONV_TRAINING and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1
+                and conv.bias is None and conv.weight.dtype == torch.float32 and (x.shape[2] * x.shape[3]) % 16 == 0):
+            z = _Conv1x1Train.apply(x, conv.weight)
+        else:
+            z = conv(x)
+        x = _BatchNormReLUTrain.apply(z, bn.weight, bn.bias, bn)
     return x
 
 

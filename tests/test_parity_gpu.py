@@ -1542,3 +1542,26 @@ def test_backbone_training_step_runs(ext, G, dev, tag):
         assert any(k.startswith("SF_extract") and float(g.abs().sum()) > 0 for k, g in grads)
     after = net.state_dict()
     assert any(not torch.equal(before[k], after[k]) for k in before)
+
+
+@pytest.mark.parametrize("B,ci,co,M,ns", [(2, 4, 16, 128, 16), (2, 67, 64, 96, 32), (1, 131, 256, 48, 16), (3, 96, 128, 20, 16),
+                                          (2, 256, 256, 64, 32), (2, 19, 22, 10, 8)])
+def test_conv1x1_training_kernels(ext, dev, B, ci, co, M, ns):
+    """sps_conv1x1_apply / sps_conv1x1_wgrad (pointnet2_modules._Conv1x1Train) against nn.Conv2d(kernel 1, no bias)
+    autograd: output, input gradient, weight gradient; channel counts that are not multiples of 4 / 16 / 64 included."""
+    from spsnet_amd import pointnet2_modules as M_
+    g = torch.Generator(device=dev).manual_seed(ci * 1000 + co)
+    conv = torch.nn.Conv2d(ci, co, 1, bias=False).to(dev)
+    x0 = torch.randn((B, ci, M, ns), generator=g, device=dev)
+    go = torch.randn((B, co, M, ns), generator=g, device=dev)
+    a = x0.clone().requires_grad_(True)
+    ya = M_._Conv1x1Train.apply(a, conv.weight)
+    ya.backward(go)
+    got = (ya.detach(), a.grad.clone(), conv.weight.grad.clone())
+    conv.weight.grad = None
+    b = x0.clone().requires_grad_(True)
+    yb = conv(b)
+    yb.backward(go)
+    for p, q, tol in zip(got, (yb.detach(), b.grad, conv.weight.grad), (1e-4, 1e-4, 2e-4)):
+        assert p.shape == q.shape
+        assert float((p - q).abs().max()) <= tol * max(1.0, float(q.abs().max()))
