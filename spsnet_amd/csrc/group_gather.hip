@@ -47,7 +47,9 @@ __global__ __launch_bounds__(GG_THREADS) void group_grad_kernel(
 // The same sums through LDS: a workgroup owns one (scene, channel) row of grad_points (n floats: 64 KiB at 16 384 points),
 // streams that row's grad_out columns coalesced (16 bytes per lane), merges runs of equal targets inside a lane (a ball
 // with fewer than nsample points repeats its first hit) and adds with ds_add_f32; the finished row is written once.
-// Global fp32 atomics ran at ~20 G/s here (885 us for the 16.8 M elements of IA-SSD layer 1); this is bound by the
+// Global fp32 atomics ran at ~20 G/s here (885 us for the 16.8 M elements of IA-SSD layer 1).  Measured bound: ds_add_f32 retires
+// about one lane per 3 cycles per CU whatever the address pattern (hot targets, uniform targets and 4x deeper load pipelining
+// all give 340 us for B=8, C=24, 16 384 x 16 columns), i.e. ~200 G adds/s chip-wide -- 10x the global rate, 3x below the
 // coalesced read of grad_out.  Summation order is unspecified, as with the reference's atomicAdd.
 constexpr int GGL_THREADS = 512;
 __global__ __launch_bounds__(GGL_THREADS) void group_grad_lds_kernel(int c, int n, int cols, const float *__restrict__ grad_out,

@@ -6,7 +6,7 @@ import torch
 from spsnet_amd import pointnet2_batch_cuda as ext
 
 dev = torch.device("cuda:0")
-for (B, C, N, M, ns) in ((8, 1, 16384, 4096, 32), (8, 64, 4096, 1024, 32), (8, 64, 4096, 1024, 16), (8, 128, 1024, 512, 32)):
+for (B, C, N, M, ns) in ((8, 24, 16384, 16384, 16), (8, 1, 16384, 4096, 32), (8, 64, 4096, 1024, 32), (8, 64, 4096, 1024, 16), (8, 128, 1024, 512, 32)):
     g = torch.Generator(device=dev).manual_seed(0)
     idx = torch.randint(0, N, (B, M, ns), generator=g, device=dev, dtype=torch.int32)
     idx[:, :, ns // 2:] = idx[:, :, :1]           # half-empty balls: repeats of the first hit
