@@ -288,9 +288,46 @@ extern "C" int sps_index_add_deterministic(int b, int c, int n, int cols, const 
 // ---- max over the samples of a group, with its gradient -------------------------------------------------------------------
 // F.max_pool2d(x, kernel_size=[1, nsample]) of the SA modules (pointnet2_modules.py:441-444) on a contiguous
 // (rows = B*C*M, nsample) view: torch's generic NCHW pooling kernels took 2.2 + 0.7 ms of a 23 ms training step at the
-// IA-SSD shapes.  Same values and the same gradient routing: the FIRST maximum of a row wins (strict '>', a NaN wins and
-// propagates), as in torch's max_pool2d kernels.
+// IA-SSD shapes.  Same values and the same gradient routing: the FIRST maximum of a row wins (strict '>'); a NaN wins and
+// propagates, and of several NaNs the LAST one keeps the index, as in torch's max_pool2d kernels.
 namespace sps {
+
+// does (b, bi) replace (a, ai) in the serial scan's outcome?  A NaN beats numbers and an earlier NaN (torch's max_pool2d tests
+// `val > max || isnan(val)`, so the LAST NaN keeps the index); among numbers the larger value, then the smaller index
+__device__ __forceinline__ bool pool_takes(float b, int bi, float a, int ai) {
+    const bool an = a != a, bn = b != b;
+    if (an || bn) return bn && (!an || bi > ai);
+    return b > a || (b == a && bi < ai);
+}
+
+// G = nsample / 4 lanes share a row (16 bytes each: the wave reads 1 KiB contiguous), then a G-lane butterfly on
+// (value, index) whose order is total, so every lane ends with the serial scan's answer
+template <int G>
+__global__ __launch_bounds__(256) void pool_max_fwd_coop_kernel(long long rows, const float *__restrict__ x,
+                                                                float *__restrict__ out, unsigned char *__restrict__ arg) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long r = e / G;
+    const int sub = (int)(e - r * G);
+    const bool live = r < rows;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) v = *reinterpret_cast<const float4 *>(x + e * 4);
+    const float q[4] = {v.x, v.y, v.z, v.w};
+    float best = q[0];
+    int bi = sub * 4;
+#pragma unroll
+    for (int u = 1; u < 4; ++u)
+        if (q[u] > best || q[u] != q[u]) { best = q[u]; bi = sub * 4 + u; }
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1) {
+        const float ob = __shfl_xor(best, off);
+        const int oi = __shfl_xor(bi, off);
+        if (pool_takes(ob, oi, best, bi)) { best = ob; bi = oi; }
+    }
+    if (live && sub == 0) {
+        out[r] = best;
+        arg[r] = (unsigned char)bi;
+    }
+}
 
 __global__ __launch_bounds__(256) void pool_max_fwd_kernel(long long rows, int ns, const float *__restrict__ x,
                                                            float *__restrict__ out, unsigned char *__restrict__ arg) {
@@ -299,22 +336,24 @@ __global__ __launch_bounds__(256) void pool_max_fwd_kernel(long long rows, int n
     const float *p = x + r * ns;
     float best = p[0];
     int bi = 0;
-    if ((ns & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
-        for (int s = 0; s < ns; s += 4) {
-            const float4 v = *reinterpret_cast<const float4 *>(p + s);
-            const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (e[u] > best || (e[u] != e[u] && best == best)) { best = e[u]; bi = s + u; }
-        }
-    } else {
-        for (int s = 1; s < ns; ++s) {
-            const float e = p[s];
-            if (e > best || (e != e && best == best)) { best = e; bi = s; }
-        }
+    for (int s = 1; s < ns; ++s) {
+        const float e = p[s];
+        if (e > best || e != e) { best = e; bi = s; }
     }
     out[r] = best;
     arg[r] = (unsigned char)bi;
+}
+
+// one float4 of grad_in per thread when nsample % 4 == 0
+__global__ __launch_bounds__(256) void pool_max_bwd4_kernel(long long total4, int ns4, const float *__restrict__ grad_out,
+                                                            const unsigned char *__restrict__ arg, float *__restrict__ grad_in) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total4) return;
+    const long long r = e / ns4;
+    const int s = (int)(e - r * ns4) * 4;
+    const int a = (int)arg[r] - s;
+    const float g = ((unsigned)a < 4u) ? grad_out[r] : 0.f;
+    *reinterpret_cast<float4 *>(grad_in + e * 4) = make_float4(a == 0 ? g : 0.f, a == 1 ? g : 0.f, a == 2 ? g : 0.f, a == 3 ? g : 0.f);
 }
 
 __global__ __launch_bounds__(256) void pool_max_bwd_kernel(long long total, int ns, const float *__restrict__ grad_out,
@@ -333,6 +372,16 @@ extern "C" int sps_pool_max_fwd(long long rows, int nsample, const float *x, flo
     if (rows < 0 || nsample <= 0 || nsample > 255) return fail(SPS_ERR_INVALID, "pool_max: bad shape rows=%lld nsample=%d", rows, nsample);
     if (rows == 0) return SPS_OK;
     if (!x || !out || !arg) return fail(SPS_ERR_INVALID, "pool_max: null pointer");
+    const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (aligned && (nsample == 16 || nsample == 32 || nsample == 64)) {
+        const int lanes = nsample / 4;
+        const long long gc = (rows * lanes + 255) / 256;
+        if (gc > 0x7fffffffLL) return fail(SPS_ERR_INVALID, "pool_max: too many rows");
+        if (lanes == 4) hipLaunchKernelGGL(pool_max_fwd_coop_kernel<4>, dim3((unsigned)gc), dim3(256), 0, as_stream(stream), rows, x, out, arg);
+        else if (lanes == 8) hipLaunchKernelGGL(pool_max_fwd_coop_kernel<8>, dim3((unsigned)gc), dim3(256), 0, as_stream(stream), rows, x, out, arg);
+        else hipLaunchKernelGGL(pool_max_fwd_coop_kernel<16>, dim3((unsigned)gc), dim3(256), 0, as_stream(stream), rows, x, out, arg);
+        return check_launch("pool_max_fwd_coop_kernel");
+    }
     const long long g = (rows + 255) / 256;
     if (g > 0x7fffffffLL) return fail(SPS_ERR_INVALID, "pool_max: too many rows");
     hipLaunchKernelGGL(pool_max_fwd_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), rows, nsample, x, out, arg);
@@ -345,6 +394,12 @@ extern "C" int sps_pool_max_bwd(long long rows, int nsample, const float *grad_o
     if (rows < 0 || nsample <= 0 || nsample > 255) return fail(SPS_ERR_INVALID, "pool_max_grad: bad shape rows=%lld nsample=%d", rows, nsample);
     if (rows == 0) return SPS_OK;
     if (!grad_out || !arg || !grad_in) return fail(SPS_ERR_INVALID, "pool_max_grad: null pointer");
+    if ((nsample & 3) == 0 && (reinterpret_cast<uintptr_t>(grad_in) & 15) == 0) {
+        const long long total4 = rows * (nsample / 4), g4 = (total4 + 255) / 256;
+        if (g4 > 0x7fffffffLL) return fail(SPS_ERR_INVALID, "pool_max_grad: too many elements");
+        hipLaunchKernelGGL(pool_max_bwd4_kernel, dim3((unsigned)g4), dim3(256), 0, as_stream(stream), total4, nsample / 4, grad_out, arg, grad_in);
+        return check_launch("pool_max_bwd4_kernel");
+    }
     const long long total = rows * nsample, g = (total + 255) / 256;
     if (g > 0x7fffffffLL) return fail(SPS_ERR_INVALID, "pool_max_grad: too many elements");
     hipLaunchKernelGGL(pool_max_bwd_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), total, nsample, grad_out, arg, grad_in);

@@ -1297,12 +1297,15 @@ def test_pool_max_matches_torch_max_pool2d(ext, dev):
     zeros) and NaNs: same values, same gradient routing."""
     from spsnet_amd import pointnet2_modules as M
     g = torch.Generator(device=dev).manual_seed(2)
-    for shape in ((2, 5, 33, 16), (1, 3, 7, 1), (2, 4, 20, 32), (1, 2, 9, 7)):
+    for shape in ((2, 5, 33, 16), (1, 3, 7, 1), (2, 4, 20, 32), (1, 2, 9, 7), (1, 2, 5, 64), (3, 64, 700, 16)):
         x = torch.randn(shape, generator=g, device=dev)
         x = torch.relu(x)                                  # masses of equal zeros
         x[..., shape[-1] // 2:] = x[..., :1]               # repeated first hit
         if shape[-1] > 2:
             x[0, 0, 0, 1] = float("nan")
+            x[-1, -1, -1, shape[-1] - 1] = float("nan")    # a NaN in the last lane's share
+            x[-1, -1, -2, shape[-1] // 3] = float("nan")   # two NaNs in one row: the first one is the arg-max
+            x[-1, -1, -2, shape[-1] - 2] = float("nan")
         a = x.clone().requires_grad_(True)
         b = x.clone().requires_grad_(True)
         ya = M._pool_over_samples(a, 'max_pool')
