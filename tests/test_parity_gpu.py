@@ -1568,3 +1568,45 @@ def test_conv1x1_training_kernels(ext, dev, B, ci, co, M, ns):
     for p, q, tol in zip(got, (yb.detach(), b.grad, conv.weight.grad), (1e-4, 1e-4, 2e-4)):
         assert p.shape == q.shape
         assert float((p - q).abs().max()) <= tol * max(1.0, float(q.abs().max()))
+
+
+def test_stack_ops_agree_with_pinned_batch_ops(ext, dev, G):
+    """Indirect pin for the stacked ops (whose oracle restatement has no reference fixture to check against): on scenes
+    of EQUAL size the stacked ball query, grouping, FPS, three_nn and three_interpolate are the same functions as the
+    batch-form ops, and those are pinned by the reference-generated goldens.  Bit-exact indices, equal features."""
+    from spsnet_amd import pointnet2_utils as BU
+    from spsnet_amd.pointnet2_stack import pointnet2_utils as SU
+    g = torch.Generator(device=dev).manual_seed(41)
+    B, N, M, C, ns, r = 3, 1500, 200, 7, 16, 0.45
+    xyz = torch.rand((B, N, 3), generator=g, device=dev) * 4.0
+    feats = torch.randn((B, C, N), generator=g, device=dev)
+    ncnt = torch.full((B,), N, dtype=torch.int32, device=dev)
+    mcnt = torch.full((B,), M, dtype=torch.int32, device=dev)
+    # farthest point sampling: global rows of the stacked form vs per-scene indices of the batch form
+    fb = BU.furthest_point_sample(xyz, M)
+    fs = SU.stack_farthest_point_sample(xyz.view(-1, 3), ncnt, M)
+    off = (torch.arange(B, device=dev, dtype=torch.int32) * N)[:, None]
+    assert torch.equal(fs.view(B, M), fb + off)
+    new_xyz = torch.gather(xyz, 1, fb.long()[..., None].expand(-1, -1, 3)).contiguous()
+    new_xyz[:, -3:] += 50.0                                      # a few empty balls
+    # ball query (+ the empty-ball convention: all-zero rows on both sides)
+    ib = BU.ball_query(r, ns, xyz, new_xyz)
+    is_, empty = SU.ball_query(r, ns, xyz.view(-1, 3), ncnt, new_xyz.view(-1, 3), mcnt)
+    assert torch.equal(is_.view(B, M, ns), ib)
+    assert bool(empty.view(B, M)[:, -3:].all()) and not bool(empty.view(B, M)[:, :-3].any())
+    # grouping: (M_total, C, ns) stacked vs (B, C, M, ns) batch; empty balls read point 0 of their scene on both sides
+    gb = BU.grouping_operation(feats, ib)
+    gs = SU.grouping_operation(feats.permute(0, 2, 1).reshape(-1, C).contiguous(), ncnt, is_, mcnt)
+    assert torch.equal(gs.view(B, M, C, ns).permute(0, 2, 1, 3), gb)
+    # three_nn / three_interpolate: unknown = all points, known = the sampled ones
+    known = torch.gather(xyz, 1, fb.long()[..., None].expand(-1, -1, 3)).contiguous()
+    db, tb = BU.three_nn(xyz, known)
+    ds, ts = SU.three_nn(xyz.view(-1, 3), ncnt, known.view(-1, 3), mcnt)
+    assert torch.equal(ts.view(B, N, 3), tb + (torch.arange(B, device=dev, dtype=torch.int32) * M)[:, None, None])
+    assert torch.equal(ds.view(B, N, 3), db)
+    w = 1.0 / (db + 1e-8)
+    w = w / w.sum(dim=2, keepdim=True)
+    kf = torch.randn((B, C, M), generator=g, device=dev)
+    yb = BU.three_interpolate(kf, tb, w)                          # (B, C, N)
+    ys = SU.three_interpolate(kf.permute(0, 2, 1).reshape(-1, C).contiguous(), ts, w.view(-1, 3).contiguous())
+    np.testing.assert_allclose(ys.view(B, N, C).permute(0, 2, 1).cpu().numpy(), yb.cpu().numpy(), rtol=0, atol=1e-6)
