@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
             for (int nt = 0; nt < NT; ++nt) {
                 const long long e = col0 + nt * 16 + c;
                 bj[nt] = e / NS;
-                bb[nt] = (int)(bj[nt] / a.m);
+                bb[nt] = ub;  // a unit never straddles scenes
                 src[nt] = a.idx[e];
             }
             // ---------------- layer 1: k-steps over the gathered channels (runtime count) ----------------
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(pooled4[r], 0.f);
                     if (c == 0) {
                         const long long cen = bj0 + cc;
-                        const int b = (int)(cen / a.m), j = (int)(cen - (long long)b * a.m);
+                        const int b = ub, j = (int)(cen - (long long)ub * a.m);  // no 64-bit division: the unit lies inside scene ub
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int row = 16 * mt + 4 * q + r;

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
             for (int nt = 0; nt < NT; ++nt) {
                 const long long e = col0 + nt * 16 + c;
                 bj[nt] = e / NS;
-                bb[nt] = (int)(bj[nt] / a.m);
+                bb[nt] = ub;  // a unit never straddles scenes
                 src[nt] = a.idx[e];
             }
             // ---------------- layer 1: k-steps of 32 gathered channels ----------------
@@ -143,6 +143,9 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
             }
             auto gather4 = [&](int k16, int nt) -> f32x4 {
                 f32x4 v;
+                // a block of padding only (its weights are zero): no loads, no address arithmetic -- the narrow scales
+                // (3 + 1 grouped channels) are VALU-bound and half of their gather was this
+                if (16 * k16 >= 3 + a.c_feat) return (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (a.feat_pm) {
                     // point-major features (B, N, C), C % 4 == 0, grouped channel order [features, xyz, pad]: a lane's
                     // four channels are one 16-byte load, the four q-lanes of a column read 64 contiguous bytes
@@ -189,7 +192,12 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     split4<0, false>(xcur[0][nt], xhi[nt], xlo[nt], mx);
-                    split4<4, false>(xcur[1][nt], xhi[nt], xlo[nt], mx);
+                    if (16 * (2 * ks + 1) >= 3 + a.c_feat) {  // padding block (zeros): nothing to split
+#pragma unroll
+                        for (int r = 4; r < 8; ++r) { xhi[nt][r] = (_Float16)0.f; xlo[nt][r] = (_Float16)0.f; }
+                    } else {
+                        split4<4, false>(xcur[1][nt], xhi[nt], xlo[nt], mx);
+                    }
                 }
 #pragma unroll
                 for (int t = 0; t < T1; ++t) {
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(pooled4[r], 0.f);
                     if (c == 0) {
                         const long long cen = bj0 + cc;
-                        const int b = (int)(cen / a.m), j = (int)(cen - (long long)b * a.m);
+                        const int b = ub, j = (int)(cen - (long long)ub * a.m);  // no 64-bit division: the unit lies inside scene ub
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int row = 16 * mt + 4 * q + r;

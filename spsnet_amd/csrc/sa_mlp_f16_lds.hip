@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa
             for (int nt = 0; nt < NT; ++nt) {
                 const long long e = col0 + nt * 16 + c;
                 bj[nt] = e / NS;
-                bb[nt] = (int)(bj[nt] / a.m);
+                bb[nt] = ub;  // a unit never straddles scenes
                 src[nt] = a.idx[e];
             }
             // ---------------- layer 1: k-steps of 32 gathered channels, stream order [k32][tile] ----------------
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa
             for (int e = lane; e < CPP * a.c3_real; e += 64) {
                 const int cc = e / a.c3_real, row = e - cc * a.c3_real;
                 const long long cen = bj0 + cc;
-                const int b = (int)(cen / a.m), j = (int)(cen - (long long)b * a.m);
+                const int b = ub, j = (int)(cen - (long long)ub * a.m);  // no 64-bit division: the unit lies inside scene ub
                 float v = my_stage[(size_t)cc * C3 + row];
 #pragma unroll
                 for (int o = 1; o < SPLIT; ++o) v = fmaxf(v, my_stage[(size_t)(o * CPP + cc) * C3 + row]);
