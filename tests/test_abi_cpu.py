@@ -127,3 +127,17 @@ def test_fill_parameters_is_deterministic_and_name_keyed():
     assert float(a[1].running_var.min()) >= 0.5
     scenes.fill_parameters(b, 4)
     assert not torch.equal(a[0].weight, b[0].weight)
+
+
+def test_equal_counts_check_mirrors_the_reference_assert():
+    """backbones.equal_counts_check: the reference's `assert xyz_batch_cnt.min() == xyz_batch_cnt.max()`
+    (IASSD_backbone.py:109-113) as a deferred verdict."""
+    import pytest
+    import torch
+    from spsnet_amd.backbones import equal_counts_check
+    assert equal_counts_check(torch.tensor([0., 0., 1., 1., 2., 2.]), 3)() is True
+    assert equal_counts_check(torch.tensor([1., 0., 1., 0.]), 2)() is True          # equal counts, any order
+    with pytest.raises(AssertionError):
+        equal_counts_check(torch.tensor([0., 0., 0., 1.]), 2)()
+    with pytest.raises(AssertionError):
+        equal_counts_check(torch.tensor([0., 0., 1., 1.]), 3)()                     # an empty scene

@@ -1610,3 +1610,20 @@ def test_stack_ops_agree_with_pinned_batch_ops(ext, dev, G):
     yb = BU.three_interpolate(kf, tb, w)                          # (B, C, N)
     ys = SU.three_interpolate(kf.permute(0, 2, 1).reshape(-1, C).contiguous(), ts, w.view(-1, 3).contiguous())
     np.testing.assert_allclose(ys.view(B, N, C).permute(0, 2, 1).cpu().numpy(), yb.cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_backbone_rejects_scenes_of_unequal_size(ext, dev):
+    """The deferred equal-counts verdict (backbones.equal_counts_check) raises on the GPU path as the reference's
+    assert does, and passes silently for well-formed batches (covered by the golden tests)."""
+    from spsnet_amd import backbones, scenes
+    net = backbones.IASSD_Backbone(backbones.scaled_cfg(backbones.IASSD_KITTI_CFG, [1024, 256, 128, 64, -1, 64]), num_class=3, input_channels=4)
+    scenes.fill_parameters(net, 3)
+    net = net.to(dev).eval()
+    B, N = 2, 2048
+    g = torch.Generator(device=dev).manual_seed(1)
+    pts = torch.rand((B * N, 4), generator=g, device=dev) * 10.0
+    bidx = torch.arange(B, device=dev).repeat_interleave(N).float()
+    bidx[N - 1] = 1.0                                             # scene 0 has N-1 points, scene 1 has N+1
+    with torch.no_grad(), pytest.raises(AssertionError):
+        net({'batch_size': B, 'points': torch.cat([bidx[:, None], pts], dim=1)})
+    torch.cuda.synchronize()
