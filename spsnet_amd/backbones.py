@@ -29,9 +29,9 @@ def equal_counts_check(batch_idx, batch_size):
     """The reference's `assert xyz_batch_cnt.min() == xyz_batch_cnt.max()` (IASSD_backbone.py:109-113,
     stability_generate/model.py:135-139) without stalling the queue: the per-scene counts are computed asynchronously and
     the returned callable raises AssertionError exactly as the reference would.  On a GPU the callable reads the verdict
-    on a side stream that waits only for the count kernels, so the caller can enqueue its first layer (layer 0's FPS:
-    1.8 ms) BEFORE blocking -- the reference's B `.sum()` calls + assert (and the bincount this replaced: four
-    device-to-host round trips) left the GPU idle for ~0.25 ms per forward at 8 x 16 384."""
+    on a side stream that waits only for the count kernels, so the caller can enqueue its layers BEFORE blocking -- the
+    reference's B `.sum()` calls + assert (and the bincount this replaced: four device-to-host round trips) left the GPU
+    idle for ~0.25 ms per forward at 8 x 16 384."""
     scenes = torch.arange(batch_size, device=batch_idx.device, dtype=batch_idx.dtype)
     counts = (batch_idx.view(1, -1) == scenes.view(-1, 1)).sum(dim=1)
     ok = counts.min() == counts.max()
@@ -181,8 +181,8 @@ class _PointBackbone(nn.Module):
         batch_idx, xyz, features = self.break_up_pc(points)
         stds = batch_dict.get('stds', None) if self._surface else None
 
-        # every scene must hold the same number of points (reference :109-113); on the GPU the verdict is read after
-        # layer 0's FPS is in the queue, on a stream of its own (equal_counts_check)
+        # every scene must hold the same number of points (reference :109-113); on the GPU the verdict is read once the
+        # whole forward is in the queue, on a stream of its own (equal_counts_check)
         counts_ok = equal_counts_check(batch_idx, batch_size)
         xyz = xyz.view(batch_size, -1, 3)
         features = (features.view(batch_size, -1, features.shape[-1]).permute(0, 2, 1).contiguous()
@@ -234,8 +234,6 @@ class _PointBackbone(nn.Module):
                 li_xyz, li_features, li_cls_pred, sampled_idx_list, stds = self._sa_layer(
                     i, xyz_input, feature_input, li_cls_pred, ctr_xyz, stds, fast, hook)
                 sample_list.append(sampled_idx_list)
-                if i == 0:
-                    counts_ok = counts_ok()
                 if self._surface and hasattr(self, 'SF_extract') and i <= 4:
                     if fast:
                         pending_gathers.append(sampled_idx_list)
@@ -261,8 +259,7 @@ class _PointBackbone(nn.Module):
             else:
                 sa_ins_preds.append([])
 
-        if callable(counts_ok):
-            counts_ok()
+        counts_ok()   # everything is in the queue: blocking here starves nothing
         ctr_batch_idx = batch_idx.view(batch_size, -1)[:, :li_xyz.shape[1]].contiguous().view(-1)
         col = ctr_batch_idx[:, None].float()
         batch_dict['ctr_offsets'] = torch.cat((col, ctr_offsets.contiguous().view(-1, 3)), dim=1)

@@ -68,7 +68,7 @@ class Surface_PW_feature(nn.Module):
         batch_size = batch_dict['batch_size']
         points = batch_dict['points']
         batch_idx, xyz, features = self.break_up_pc(points)
-        counts_ok = equal_counts_check(batch_idx, batch_size)   # verdict read once the first layer is in the queue
+        counts_ok = equal_counts_check(batch_idx, batch_size)   # verdict read once the layers are in the queue
         xyz = xyz.view(batch_size, -1, 3)
         features = (features.view(batch_size, -1, features.shape[-1]).permute(0, 2, 1).contiguous()
                     if features is not None else None)
@@ -79,13 +79,12 @@ class Surface_PW_feature(nn.Module):
             feature_input = encoder_features[self.layer_inputs[i]]
             ctr_xyz = encoder_xyz[self.ctr_idx_list[i]] if self.ctr_idx_list[i] != -1 else None
             li_xyz, li_features, _ = self.SA_modules[i](xyz_input, feature_input, None, ctr_xyz=ctr_xyz)
-            if i == 0:
-                counts_ok()
             encoder_xyz.append(li_xyz)
             li_batch_idx = batch_idx.view(batch_size, -1)[:, :li_xyz.shape[1]]
             encoder_coords.append(torch.cat([li_batch_idx[..., None].float(), li_xyz.view(batch_size, -1, 3)], dim=-1))
             encoder_features.append(li_features)
             sa_ins_preds.append([])
+        counts_ok()
         batch_dict['encoder_xyz'] = encoder_xyz
         batch_dict['encoder_coords'] = encoder_coords
         batch_dict['sa_ins_preds'] = sa_ins_preds

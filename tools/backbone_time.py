@@ -30,4 +30,17 @@ for tag, cls, cfg in (("IASSD_Backbone", BB.IASSD_Backbone, BB.IASSD_KITTI_CFG),
             net(batch())
         torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / reps
-    print(f"{tag:16s} {B}x{N}: {ms:7.3f} ms per forward  ({B * N / ms / 1e3:.1f} M points/s)", flush=True)
+    # host side alone: how long the Python call takes to enqueue one forward on an idle GPU (includes the one blocking
+    # read of the equal-size verdict), and the latency of a single forward
+    host = lat = 0.0
+    with torch.no_grad():
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            net(batch())
+            t2 = time.perf_counter()
+            torch.cuda.synchronize()
+            host += t2 - t1
+            lat += time.perf_counter() - t1
+    print(f"{tag:16s} {B}x{N}: {ms:7.3f} ms per forward  ({B * N / ms / 1e3:.1f} M points/s); host enqueue "
+          f"{1e3 * host / reps:.3f} ms, single-forward latency {1e3 * lat / reps:.3f} ms", flush=True)
