@@ -117,14 +117,33 @@ def _can_prefetch(layer, nxt):
 # long way to go, small ones at the end (what is left to do after the last pick is the last chunk's work; a chunk
 # costs ~70 us however small it is -- one wave scans the whole cloud per centroid -- so finer tails only add launches)
 _CHUNK_ENDS_16 = (4, 8, 12, 14, 15, 16)
-_TIMEOUT_FLAGS = []   # device flags of the bounded waits issued so far (see check_timeouts)
+_TIMEOUT_FLAGS = []   # [device flag of a pass's bounded waits, pinned host copy, event behind that copy] (see check_timeouts)
+_PINNED_POOL = []     # pinned one-int host tensors not in use
 
 
 def check_timeouts():
     """True if any device-side progress wait gave up (synchronises; for tests / debugging)."""
-    bad = any(int(f.item()) != 0 for f in _TIMEOUT_FLAGS)
+    bad = any(int(f.item()) != 0 for f, _, _ in _TIMEOUT_FLAGS)
+    for _, host, _ in _TIMEOUT_FLAGS:
+        if host is not None:
+            _PINNED_POOL.append(host)
     _TIMEOUT_FLAGS.clear()
     return bad
+
+
+def _retire_timeout_flags():
+    """Look at the flags of passes that have finished: a bounded wait that gave up means a consumer ran on samples that had
+    not been written -- never let that pass silently.  Each pass copies its flag to pinned host memory behind its last
+    chunk (side stream, non-blocking); here only copies whose event has completed are read, so nothing is ever waited
+    for.  (A plain `.item()` on the main stream blocked the host until the previous forward had drained with the next FPS
+    not yet enqueued; a read through a fresh stream made the caching allocator hipMalloc, which is worse.)"""
+    while _TIMEOUT_FLAGS and _TIMEOUT_FLAGS[0][2] is not None and _TIMEOUT_FLAGS[0][2].query():
+        _, host, _ = _TIMEOUT_FLAGS.pop(0)
+        bad = int(host[0]) != 0
+        _PINNED_POOL.append(host)
+        if bad:
+            raise RuntimeError("spsnet_amd.sa_stack: a device-side wait on FPS progress timed out in an earlier pass "
+                               "(results of that pass are invalid); use run_sa_layers(..., stream_first_layer=False)")
 
 
 def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=None):
@@ -167,14 +186,9 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
     idx_b = torch.empty((B, M, gb.nsample), dtype=torch.int32, device=dev)
     out = (torch.zeros if max(ga.nsample, gb.nsample) > 32 else torch.empty)(
         (B, sum(p.c3_real for p in plan), M), dtype=torch.float32, device=dev)
-    _TIMEOUT_FLAGS.append(timed_out)
-    if len(_TIMEOUT_FLAGS) > 8:
-        # the flags of passes issued long ago: reading them costs nothing by now, and a bounded wait that gave up means a
-        # consumer ran on samples that had not been written -- never let that pass silently
-        old, _TIMEOUT_FLAGS[:4] = _TIMEOUT_FLAGS[:4], []
-        if any(int(f.item()) != 0 for f in old):
-            raise RuntimeError("spsnet_amd.sa_stack: a device-side wait on FPS progress timed out in an earlier pass "
-                               "(results of that pass are invalid); use run_sa_layers(..., stream_first_layer=False)")
+    _retire_timeout_flags()
+    flag_entry = [timed_out, None, None]
+    _TIMEOUT_FLAGS.append(flag_entry)
 
     start = torch.cuda.Event()
     start.record(main)
@@ -216,6 +230,12 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
                 tail.run(j0, chunk)
         done = torch.cuda.Event()
         done.record(side)
+        # behind `done` (which is all the main stream waits for): the flag's copy to pinned host memory
+        host_flag = _PINNED_POOL.pop() if _PINNED_POOL else torch.zeros((1,), dtype=torch.int32).pin_memory()
+        host_flag.copy_(timed_out, non_blocking=True)
+        copied = torch.cuda.Event()
+        copied.record(side)
+        flag_entry[1], flag_entry[2] = host_flag, copied
     main.wait_event(xyz_ready)                           # all centroids exist: the next layer's FPS check can finish
     if verify is not None:
         third = _side_stream(dev)                        # beside the last chunk's ball query, not behind it
