@@ -180,8 +180,8 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
 
     idx = torch.empty((B, M), dtype=torch.int32, device=dev)
     temp = torch.full((B, N), 1e10, dtype=torch.float32, device=dev)
-    progress = torch.zeros((B,), dtype=torch.int32, device=dev)  # zeroed on `main` BEFORE the consumer is released
-    timed_out = torch.zeros((1,), dtype=torch.int32, device=dev)
+    zeros = torch.zeros((B + 1,), dtype=torch.int32, device=dev)  # one fill, on `main` BEFORE the consumer is released
+    progress, timed_out = zeros[:B], zeros[B:]
     idx_a = torch.empty((B, M, ga.nsample), dtype=torch.int32, device=dev)
     idx_b = torch.empty((B, M, gb.nsample), dtype=torch.int32, device=dev)
     out = (torch.zeros if max(ga.nsample, gb.nsample) > 32 else torch.empty)(

@@ -1,5 +1,5 @@
 """Time a training step (forward + backward) of IASSD_Backbone / PAGNet_Backbone at the KITTI configuration.
-usage: python tools/backbone_train_time.py [B] [N] [reps]"""
+usage: python tools/backbone_train_time.py [B] [N] [reps] [IASSD|PAGNet]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,13 +9,16 @@ from spsnet_amd import backbones as BB, scenes, surface_feature as SF
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+only = sys.argv[4] if len(sys.argv) > 4 else ""
 dev = torch.device("cuda:0")
 xyz, feats = scenes.make_batch("kitti-lidar-v1", B, N, seed0=1)
 bidx = np.repeat(np.arange(B, dtype=np.float32), N)[:, None]
 points = torch.from_numpy(np.concatenate([bidx, xyz.reshape(-1, 3), feats.transpose(0, 2, 1).reshape(-1, 1)], 1).astype(np.float32)).to(dev)
 stds = torch.from_numpy(np.random.default_rng(0).uniform(0, 40, (B, N)).astype(np.float32)).to(dev)
 for tag, cls, cfg in (("IASSD_Backbone", BB.IASSD_Backbone, BB.IASSD_KITTI_CFG), ("PAGNet_Backbone", BB.PAGNet_Backbone, BB.SPSNET_KITTI_CFG)):
-    for fused_fe in ((True, False) if tag.startswith("PAG") else (True,)):
+    if only and not tag.startswith(only):
+        continue
+    for fused_fe in ((True, False) if tag.startswith("PAG") and not only else (True,)):
         SF.FUSED_TRAINING = fused_fe
         net = scenes.fill_parameters(cls(cfg, num_class=3, input_channels=4), 5).to(dev).train()
         def step():
@@ -38,6 +41,13 @@ for tag, cls, cfg in (("IASSD_Backbone", BB.IASSD_Backbone, BB.IASSD_KITTI_CFG),
             step()
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / reps
+        host = 0.0   # host side alone: the step's Python + autograd-engine time on an idle GPU
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step()
+            host += time.perf_counter() - t1
+        torch.cuda.synchronize()
         note = "" if tag.startswith("IASSD") else (" (fused surface-feature training kernels)" if fused_fe else " (surface features op by op)")
-        print(f"{tag:16s} training step {B}x{N}: {ms:7.2f} ms{note}", flush=True)
+        print(f"{tag:16s} training step {B}x{N}: {ms:7.2f} ms, host enqueue {1e3 * host / reps:.2f} ms{note}", flush=True)
 SF.FUSED_TRAINING = True
