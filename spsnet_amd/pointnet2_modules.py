@@ -75,15 +75,28 @@ class _BatchNormReLUTrain(torch.autograd.Function):
         return dx, dweight, dbias, None
 
 
+# 1x1 convolutions whose narrower side has at least this many channels are plain GEMMs big enough for the BLAS library
+# (torch.matmul / bmm -> hipBLASLt, true fp32): measured on IASSD_Backbone's training step, 8 x 16 384, library from
+# 512 / 256 / 128 / 64 / 32 / 16 channels up: 16.4 / 15.6 / 15.3 / 15.0 / 15.2 / 15.3 ms against 17.25 ms with
+# conv1x1_train.hip everywhere (its wide-layer forms re-read their operands per 64-row block).  Below the threshold (the
+# 4..64-channel layers of SA layers 0-1, where the library was 2x slower than MIOpen) conv1x1_train.hip stays.
+_BLAS_MIN = 64
+_BLAS_MIN_WG = 64
+
+
 class _Conv1x1Train(torch.autograd.Function):
-    """Conv2d(kernel 1, no bias) on (B, C, M, ns) with gradients: csrc/conv1x1_train.hip (forward, data and weight
-    gradient on fp32 MFMA, channel-major throughout) instead of MIOpen's NHWC implicit-GEMM kernels and their transposes."""
+    """Conv2d(kernel 1, no bias) on (B, C, M, ns) with gradients, channel-major throughout: csrc/conv1x1_train.hip
+    (forward, data and weight gradient on fp32 MFMA) for the narrow layers, batched library GEMMs on the same layout for
+    the wide ones -- instead of MIOpen's NHWC implicit-GEMM kernels and their transposes."""
 
     @staticmethod
     def forward(ctx, x, weight):
         x = x.contiguous()
         w2 = weight.detach().reshape(weight.shape[0], weight.shape[1])
         ctx.save_for_backward(x, weight)
+        if min(w2.shape) >= _BLAS_MIN:
+            B, C, M, S = x.shape
+            return torch.matmul(w2, x.view(B, C, M * S)).view(B, w2.shape[0], M, S)
         return _ext.conv1x1_apply(x, w2, False)
 
     @staticmethod
@@ -91,8 +104,18 @@ class _Conv1x1Train(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
         w2 = weight.detach().reshape(weight.shape[0], weight.shape[1])
-        dx = _ext.conv1x1_apply(dy, w2, True) if ctx.needs_input_grad[0] else None
-        dw = _ext.conv1x1_wgrad(x, dy).view_as(weight) if ctx.needs_input_grad[1] else None
+        B, C, M, S = x.shape
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if min(w2.shape) >= _BLAS_MIN:
+                dx = torch.matmul(w2.t(), dy.view(B, w2.shape[0], M * S)).view(B, C, M, S)
+            else:
+                dx = _ext.conv1x1_apply(dy, w2, True)
+        if ctx.needs_input_grad[1]:
+            if min(w2.shape) >= _BLAS_MIN_WG:
+                dw = torch.bmm(dy.view(B, w2.shape[0], M * S), x.view(B, C, M * S).transpose(1, 2)).sum(dim=0).view_as(weight)
+            else:
+                dw = _ext.conv1x1_wgrad(x, dy).view_as(weight)
         return dx, dw
 
 

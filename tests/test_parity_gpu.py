@@ -1627,3 +1627,22 @@ def test_backbone_rejects_scenes_of_unequal_size(ext, dev):
     with torch.no_grad(), pytest.raises(AssertionError):
         net({'batch_size': B, 'points': torch.cat([bidx[:, None], pts], dim=1)})
     torch.cuda.synchronize()
+
+
+def test_conv1x1_train_wide_layers_match_conv2d(ext, dev):
+    """_Conv1x1Train on both of its routes (conv1x1_train.hip below pointnet2_modules._BLAS_MIN channels, batched library
+    GEMM from there up) against nn.functional.conv2d: output, input gradient, weight gradient."""
+    from spsnet_amd import pointnet2_modules as M
+    g = torch.Generator(device=dev).manual_seed(12)
+    for (B, ci, co, m, ns) in ((2, 131, 128, 40, 16), (3, 64, 96, 24, 32), (2, 40, 200, 16, 16), (1, 256, 64, 8, 16)):
+        x = torch.randn((B, ci, m, ns), generator=g, device=dev)
+        w = torch.randn((co, ci, 1, 1), generator=g, device=dev) / ci ** 0.5
+        go = torch.randn((B, co, m, ns), generator=g, device=dev)
+        xa, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        xb, wb = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        ya = M._Conv1x1Train.apply(xa, wa)
+        yb = torch.nn.functional.conv2d(xb.double(), wb.double())
+        ya.backward(go); yb.backward(go.double())
+        for got, ref in ((ya, yb), (xa.grad, xb.grad), (wa.grad, wb.grad)):
+            scale = float(ref.abs().max())
+            assert float((got.double() - ref).abs().max()) <= 2e-6 * scale + 1e-6
