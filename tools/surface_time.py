@@ -16,6 +16,7 @@ for mode in ("dynamic", "static"):
     outs = {}
     for label, grad in (("fused", False), ("op_by_op", True)):
         ctx = torch.enable_grad() if grad else torch.no_grad()
+        SF.FUSED_TRAINING = not grad          # grad mode with the fused training kernels off = the reference's op sequence
         with ctx:
             for _ in range(5):
                 out = net(x)
@@ -31,3 +32,4 @@ for mode in ("dynamic", "static"):
     diff = (outs["fused"] - outs["op_by_op"]).abs().amax(dim=-1) / scale
     print(f"{mode:8s} max |fused - op_by_op| / max |op_by_op| = {diff.max().item():.2e}; points off by more than 1e-4: "
           f"{(diff > 1e-4).float().mean().item():.2e} of {diff.numel()}", flush=True)
+SF.FUSED_TRAINING = True
