@@ -567,15 +567,9 @@ extern "C" int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcoun
     typedef void (*dual_fn)(int, int, int, float, float, int, int, const float *, const float *, int *, int *, const int *, int, int);
     const dual_fn fn = seg_len <= 65536 ? ball_query_dual_kernel<unsigned short> : ball_query_dual_kernel<int>;
     if (lds_bytes(S) > 64 * 1024) {
-        static const void *raised[4] = {nullptr, nullptr, nullptr, nullptr};
-        bool have = false;
-        for (const void *r : raised) have |= r == (const void *)fn;
-        if (!have) {
-            if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-                return fail(SPS_ERR_LAUNCH, "ball_query_full2: cannot raise the dynamic LDS limit");
-            for (const void *&r : raised)
-                if (!r) { r = (const void *)fn; break; }
-        }
+        static LdsLimitOnce raised[2];
+        const int rc = raise_lds_limit((const void *)fn, 150 * 1024, raised[seg_len <= 65536 ? 0 : 1], "ball_query_full2");
+        if (rc != SPS_OK) return rc;
     }
     hipLaunchKernelGGL(fn, dim3(groups, b), dim3(BQ_LANES * S), lds_bytes(S), as_stream(stream), n, m, seg_len,
                        radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, perm, j0,

@@ -581,12 +581,11 @@ static int bqg_run(int R, bool dilated, int b, int n, int m, float ra, float rb,
     if (lds > 150 * 1024) return -1;  // caller falls back to the scan kernels
     const void *fn = R == 2 ? (const void *)bqg_query_kernel<false, 2>
                             : (dilated ? (const void *)bqg_query_kernel<true, 1> : (const void *)bqg_query_kernel<false, 1>);
-    static bool raised[3] = {false, false, false};
+    static LdsLimitOnce raised[3];
     const int which = R == 2 ? 2 : (dilated ? 1 : 0);
-    if (lds > 64 * 1024 && !raised[which]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-            return fail(SPS_ERR_LAUNCH, "ball_query_grid: cannot raise the dynamic LDS limit");
-        raised[which] = true;
+    if (lds > 64 * 1024) {
+        const int rc = raise_lds_limit(fn, 150 * 1024, raised[which], "ball_query_grid");
+        if (rc != SPS_OK) return rc;
     }
     const int big = n > m ? n : m;
     const float rbox = (R == 2 && rb > ra) ? rb : ra;

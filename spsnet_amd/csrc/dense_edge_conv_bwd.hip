@@ -364,19 +364,19 @@ extern "C" int sps_dense_edge_conv_bwd(int b, int n, int d, int k, int growth, i
     const int blocks = sps_dense_edge_conv_bwd_blocks();
     hipStream_t st = as_stream(stream);
     if (b == 0 || n == 0) {
-        hipMemsetAsync(grad_tiles, 0, sizeof(float) * tiles * 256, st);
+        if (hipMemsetAsync(grad_tiles, 0, sizeof(float) * tiles * 256, st) != hipSuccess)
+            return fail(SPS_ERR_LAUNCH, "dense_edge_conv_bwd: memset failed");
         return SPS_OK;
     }
     DbArgs a;
     a.n = n; a.units = (long long)b * n; a.x = x; a.idx = idx; a.g = grad_out; a.wf = w_fwd; a.wt = w_transposed;
     a.b1 = b1; a.b2 = b2; a.b3 = b3; a.dxc = dx_centre; a.dxn = dx_neighbour; a.partial = partial;
     const size_t lds = sizeof(float) * ((size_t)DB_WT * 64 + (size_t)DB_WAVES * DB_LDS_WAVE);
-    static bool raised[2] = {false, false};
+    static LdsLimitOnce raised[2];
     const void *fn = relative_only ? (const void *)dense_edge_conv_bwd_kernel<true> : (const void *)dense_edge_conv_bwd_kernel<false>;
-    if (lds > 64 * 1024 && !raised[relative_only ? 1 : 0]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) != hipSuccess)
-            return fail(SPS_ERR_LAUNCH, "dense_edge_conv_bwd: cannot raise the dynamic LDS limit");
-        raised[relative_only ? 1 : 0] = true;
+    if (lds > 64 * 1024) {
+        const int rc = raise_lds_limit(fn, 100 * 1024, raised[relative_only ? 1 : 0], "dense_edge_conv_bwd");
+        if (rc != SPS_OK) return rc;
     }
     if (relative_only) hipLaunchKernelGGL(dense_edge_conv_bwd_kernel<true>, dim3(blocks), dim3(64 * DB_WAVES), lds, st, a);
     else hipLaunchKernelGGL(dense_edge_conv_bwd_kernel<false>, dim3(blocks), dim3(64 * DB_WAVES), lds, st, a);
@@ -395,7 +395,8 @@ extern "C" int sps_linear_rows_bwd(long long rows, int cin, int cout, const floa
     hipStream_t st = as_stream(stream);
     const int count = LB_COUT * cin + LB_COUT, blocks = sps_linear_rows_bwd_blocks();
     if (rows == 0) {
-        hipMemsetAsync(grad_w_b, 0, sizeof(float) * count, st);
+        if (hipMemsetAsync(grad_w_b, 0, sizeof(float) * count, st) != hipSuccess)
+            return fail(SPS_ERR_LAUNCH, "linear_rows_bwd: memset failed");
         return SPS_OK;
     }
     hipLaunchKernelGGL(linear_rows24_bwd_kernel, dim3(blocks), dim3(256), 0, st, rows, cin, x, y, dy, w, relu, dx, partial);

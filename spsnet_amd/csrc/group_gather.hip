@@ -104,11 +104,10 @@ static int launch_group(bool grad, const char *what, int b, int c, int n, int np
     if (b > 65535 || divup(c, GG_CCHUNK) > 65535) return fail(SPS_ERR_INVALID, "%s: grid too large", what);
     if (grad && cols >= 1024 && (size_t)n * 4 <= 150 * 1024 && c <= 65535 && (long long)b * c >= 64) {
         const size_t lds = (size_t)n * 4;
-        static bool raised = false;
-        if (lds > 64 * 1024 && !raised) {
-            if (hipFuncSetAttribute((const void *)group_grad_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-                return fail(SPS_ERR_LAUNCH, "%s: cannot raise the dynamic LDS limit", what);
-            raised = true;
+        static LdsLimitOnce raised;
+        if (lds > 64 * 1024) {
+            const int rc = raise_lds_limit((const void *)group_grad_lds_kernel, 150 * 1024, raised, what);
+            if (rc != SPS_OK) return rc;
         }
         hipLaunchKernelGGL(group_grad_lds_kernel, dim3(c, b), dim3(GGL_THREADS), lds, st, c, n, cols, src, idx, dst);
         return check_launch(what);

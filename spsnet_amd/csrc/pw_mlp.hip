@@ -137,11 +137,10 @@ extern "C" int sps_pointwise_mlp_range(int b, int m, int j0, int jcount, int cin
     const int wide = (deep && c2 > cin) ? c2 : cin;
     const size_t lds = sizeof(float) * (size_t)PW_PAD * ((size_t)wide + c1);
     if (lds > 150 * 1024) return fail(SPS_ERR_INVALID, "pointwise_mlp: widths (%d, %d, %d) need more LDS than a workgroup has", cin, c1, c2);
-    static bool raised = false;
-    if (lds > 64 * 1024 && !raised) {
-        if (hipFuncSetAttribute((const void *)pw_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-            return fail(SPS_ERR_LAUNCH, "pointwise_mlp: cannot raise the dynamic LDS limit");
-        raised = true;
+    static LdsLimitOnce raised;
+    if (lds > 64 * 1024) {
+        const int rc = raise_lds_limit((const void *)pw_mlp_kernel, 150 * 1024, raised, "pointwise_mlp");
+        if (rc != SPS_OK) return rc;
     }
     // one wave per output tile of the widest layer (4..16): the tiles of a layer are independent, a tile is a serial
     // chain of MFMAs fed by L2-latency weight loads, so waves are what hides that latency

@@ -336,13 +336,10 @@ static int launch_f16_variant(const SaMlpArgs &a, hipStream_t st) {
     // launch is big enough to amortise the copy
     const size_t wbytes = (size_t)FRAG * ((size_t)(C1 / 16) * k.ks1 + (size_t)(C2 / 16) * (C1 / 32) + (size_t)(a.c3 / 16) * (C2 / 32));
     if (C1 >= 64 && wbytes <= 128 * 1024 && k.units >= 2048) {  // (the 32-wide scale is faster streaming: measured)
-        static bool raised = false;
-        if (!raised) {
-            if (hipFuncSetAttribute((const void *)sa_group_mlp_f16_kernel<C1, C2, NT, NS, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
-                return fail(SPS_ERR_LAUNCH, "sa_group_mlp(f16): cannot raise the dynamic LDS limit");
-            raised = true;
-        }
+        static LdsLimitOnce raised;  // one per instantiation
+        const int rc = raise_lds_limit((const void *)sa_group_mlp_f16_kernel<C1, C2, NT, NS, true>, 128 * 1024, raised,
+                                       "sa_group_mlp(f16)");
+        if (rc != SPS_OK) return rc;
         int blocks = divup(k.units, 8);
         if (blocks > 256) blocks = 256;
         hipLaunchKernelGGL((sa_group_mlp_f16_kernel<C1, C2, NT, NS, true>), dim3(blocks), dim3(512), wbytes, st, k);

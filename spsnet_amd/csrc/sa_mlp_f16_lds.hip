@@ -371,12 +371,11 @@ static int launch_lds_variant(const SaMlpArgs &a, hipStream_t st) {
     const int groups = divup(k.units, WAVES);
     int blocks = groups < 256 * 2 ? groups : 256 * 2;
     const size_t lds = (size_t)RING * CHUNK_BYTES + sizeof(float) * ((size_t)C1 + C2 + C3 + (size_t)WAVES * (UNIT >= NS ? UNIT / NS : 1) * C3);
-    static bool raised = false;
-    if (lds > 64 * 1024 && !raised) {
-        if (hipFuncSetAttribute((const void *)sa_group_mlp_f16_lds_kernel<C1, C2, C3, NT, NS, WAVES>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-            return fail(SPS_ERR_LAUNCH, "sa_group_mlp(f16/lds): cannot raise the dynamic LDS limit");
-        raised = true;
+    static LdsLimitOnce raised;  // one per instantiation
+    if (lds > 64 * 1024) {
+        const int rc = raise_lds_limit((const void *)sa_group_mlp_f16_lds_kernel<C1, C2, C3, NT, NS, WAVES>, 150 * 1024, raised,
+                                       "sa_group_mlp(f16/lds)");
+        if (rc != SPS_OK) return rc;
     }
     hipLaunchKernelGGL((sa_group_mlp_f16_lds_kernel<C1, C2, C3, NT, NS, WAVES>), dim3(blocks), dim3(64 * WAVES), lds, st, k);
     return check_launch("sa_group_mlp_f16_lds_kernel");

@@ -93,13 +93,9 @@ extern "C" int sps_score_topk(int b, int n, int c, int k, const float *cls, cons
     threads = threads < 64 ? 64 : (threads > 1024 ? 1024 : threads);
     const size_t lds = (size_t)np2 * sizeof(unsigned long long);
     if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            const hipError_t e = hipFuncSetAttribute((const void *)score_topk_kernel,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return fail(SPS_ERR_LAUNCH, "score_topk: cannot raise LDS limit: %s", hipGetErrorString(e));
-            raised = true;
-        }
+        static LdsLimitOnce raised;
+        const int rc = raise_lds_limit((const void *)score_topk_kernel, 160 * 1024, raised, "score_topk");
+        if (rc != SPS_OK) return rc;
     }
     hipLaunchKernelGGL(score_topk_kernel, dim3(b), dim3(threads), lds, as_stream(stream), n, c, k, np2, cls, stds,
                        idx, score_out);
