@@ -44,7 +44,8 @@ int sps_opt_n_threads(int work_size);
 int sps_set_fps_mode(int mode);
 
 /* DIAGNOSTIC ONLY: s_memtime-instrumented build of the pruned FPS kernel (never on the product path).
- * dbg (B, 8 waves, 8) u64 receives per-wave cycle sums of the loop segments. */
+ * dbg (B, 8 waves, 12) u64 receives per-wave cycle sums of the loop segments, touched-bucket / tie-path counts and why the
+ * accepted prefix of a round ended (lowered, hidden, nothing rejected; picks). */
 int sps_debug_fps_profile(int b, int n, int m, const float *dataset, float *temp, int *idxs,
                           unsigned long long *dbg, sps_stream_t stream);
 

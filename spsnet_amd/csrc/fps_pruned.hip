@@ -269,7 +269,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
     int j = 1;  // picks made so far
     int round = 0;
 
-    unsigned long long tseg[6] = {0, 0, 0, 0, 0, 0}, ntouch = 0;
+    unsigned long long tseg[6] = {0, 0, 0, 0, 0, 0}, ntouch = 0, why[4] = {0, 0, 0, 0};
     nslow = 0;
     auto stamp = [&]() -> unsigned long long {
         if constexpr (PROF) {
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
         const float jx = __int_as_float(sh.soa[buf][2][rj]), jy = __int_as_float(sh.soa[buf][3][rj]);
         const float jz = __int_as_float(sh.soa[buf][4][rj]);
         const float jt = __int_as_float(jd);
-        int nbef = 0, nbad = 0;
+        int nbef = 0, nbad = 0, nlow = 0;  // nlow (PROF): earlier records that lower this one's distance
         auto pair = [&](int idist, int iklo, int ixb, int iyb, int izb, int ibound) {
             const bool before = (idist > jd) | ((idist == jd) & ((unsigned)iklo > (unsigned)jk));  // no short circuit: no branches
             // as the update would compute it: point j, centre i
@@ -396,6 +396,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
             const bool hidden = !(jt > __int_as_float(ibound));
             nbef += before ? 1 : 0;
             nbad += (before & (lowered | hidden)) ? 1 : 0;
+            if constexpr (PROF) nlow += (before & lowered) ? 1 : 0;
         };
         pair(id.x, ik.x, ixv.x, iyv.x, izv.x, ibv.x);
         pair(id.y, ik.y, ixv.y, iyv.y, izv.y, ibv.y);
@@ -409,6 +410,18 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
         const int pos = cnt & 0xFF;
         const int firstbad = -wave_max_i32_id((cnt >> 8) ? -pos : -2 * PF_WAVES);
         int L = firstbad < m - j ? firstbad : m - j;
+        if constexpr (PROF) {
+            // why did the accepted prefix end?  the first rejected record was lowered by an earlier one (a), only hidden
+            // behind an unpublished point (b), or nothing was rejected (all 2 * PF_WAVES records taken / end of the run)
+            const unsigned long long stop = __ballot(rb4 == 0 && pos == firstbad && ((cnt >> 8) & 0xFF));
+            const unsigned long long low = __ballot(nlow > 0) & 0x1111111111111111ull;
+            unsigned long long lowrec = low | ((__ballot(nlow > 0) >> 1) & 0x1111111111111111ull) |
+                                        ((__ballot(nlow > 0) >> 2) & 0x1111111111111111ull) | ((__ballot(nlow > 0) >> 3) & 0x1111111111111111ull);
+            if (!stop) why[2] += 1;
+            else if (stop & lowrec) why[0] += 1;
+            else why[1] += 1;
+            why[3] += (unsigned long long)L;
+        }
         const bool taken = rb4 == 0 && pos < L;
         if (tid < 64 && taken) {
             const unsigned rank = 0x0FFFFFFFu - ((unsigned)jk >> 4);
@@ -435,9 +448,10 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
     }
     if constexpr (PROF) {
         if (lane == 0 && dbg) {
-            unsigned long long *o = dbg + ((size_t)scene * PF_WAVES + wave) * 8;
+            unsigned long long *o = dbg + ((size_t)scene * PF_WAVES + wave) * 12;
             for (int i = 0; i < 6; ++i) o[i] = tseg[i];
             o[6] = ntouch; o[7] = nslow;
+            for (int i = 0; i < 4; ++i) o[8 + i] = why[i];
         }
     }
 
