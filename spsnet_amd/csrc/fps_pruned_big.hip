@@ -232,7 +232,9 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_big_kernel(int n, int m
     float ax = xyz[0], ay = xyz[1], az = xyz[2];
     unsigned long long pend = m > 1 ? 1ull : 0ull;
     int j = 1, round = 0;
+    const bool younger = wave >= PF_WAVES / 2;  // priority alternates by phase between the two waves of a SIMD (fps_pruned.hip)
     for (;;) {
+        if (younger) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         while (pend) {
             const int rr = __builtin_ctzll(pend);
             pend &= pend - 1;
@@ -332,6 +334,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_big_kernel(int n, int m
         const int buf = round & 1;
         if (lane < 12) sh.soa[buf][lane >> 1][2 * wave + (lane & 1)] = crec;
         __syncthreads();
+        if (younger) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
         const int rj = lane >> 2, rb4 = lane & 3;
         const int4 id = *(const int4 *)&sh.soa[buf][0][rb4 * 4], ik = *(const int4 *)&sh.soa[buf][1][rb4 * 4];
         const int4 ixv = *(const int4 *)&sh.soa[buf][2][rb4 * 4], iyv = *(const int4 *)&sh.soa[buf][3][rb4 * 4];
