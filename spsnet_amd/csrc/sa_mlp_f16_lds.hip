@@ -388,7 +388,7 @@ int launch_sa_mlp_f16_lds(const SaMlpArgs &a, int c1, int c2, int nsample, hipSt
     SPS_MLPL_CASE(64, 64, 128, 2, 16, 4)
     SPS_MLPL_CASE(64, 96, 128, 2, 32, 4)
     SPS_MLPL_CASE(128, 128, 256, 1, 16, 4)
-    SPS_MLPL_CASE(128, 256, 256, 1, 32, 4)
+    SPS_MLPL_CASE(128, 256, 256, 1, 32, 4)   // (NT = 2 here and one line up: 512 registers + spills, 2.30 -> 2.35 ms per pass)
     SPS_MLPL_CASE(256, 256, 512, 1, 16, 4)   // IA-SSD layer 5 [259,256,256,512]: 4 waves = 512 registers each
     SPS_MLPL_CASE(256, 512, 1024, 1, 32, 4)  // IA-SSD layer 5 [259,256,512,1024]
     SPS_MLPL_CASE(128, 128, 256, 1, 64, 8)   // nsample 64: a centroid spans four waves
