@@ -50,6 +50,11 @@ def _i(a):
     return a, a.ctypes.data_as(_I)
 
 
+def set_threads(n):
+    """OpenMP threads used by the following oracle calls (bench.py: all-cores and single-thread CPU rows)."""
+    lib().orc_set_threads(int(n))
+
+
 def opt_n_threads(n):
     return int(lib().orc_opt_n_threads(int(n)))
 

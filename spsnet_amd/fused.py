@@ -222,6 +222,14 @@ def point_major_twin(features):
     return t
 
 
+def attach_point_major_twin(features):
+    """Give a (B, C, N) feature tensor that did not come from pointwise_tail its (B, N, C) twin, so that the next SA
+    layer's grouped MLP takes the point-major gather path it takes inside a stack; returns `features`."""
+    if features is not None and features.dim() == 3 and features.shape[1] % 4 == 0:
+        features._sps_nc = features.transpose(1, 2).contiguous()
+    return features
+
+
 def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=0, jcount=None):
     """One launch: gather the nsample neighbours in `idx` (B,M,ns), run the packed 3-layer MLP, max-pool,
     and write channels [channel_offset, channel_offset + c3_real) of out (B, Ctot, M); optionally only for the

@@ -294,3 +294,29 @@ def run_sa_layers(layers, xyz, features, stds=None, overlap=True, stream_first_l
             layer._on_new_xyz = None
         outs.append((xyz, features, cls_pred, idx))
     return outs
+
+
+def pipelined_bench(step, steps, dev, in_flight=2):
+    """Time `steps` complete, independent passes issued round-robin on `in_flight` HIP streams (bench.py's informational
+    `pipelined` object; `value` stays the strictly sequential figure) -> dict with elapsed_s."""
+    import time
+    streams = [torch.cuda.Stream(device=dev) for _ in range(in_flight)]
+    for s_ in streams:
+        s_.wait_stream(torch.cuda.current_stream(dev))
+    keep = []
+    for i in range(2 * in_flight):            # warm every stream's side streams / caches
+        with torch.cuda.stream(streams[i % in_flight]):
+            keep.append(step())
+    torch.cuda.synchronize()
+    keep.clear()
+    t1 = time.perf_counter()
+    for i in range(steps):
+        with torch.cuda.stream(streams[i % in_flight]):
+            keep.append(step())
+            if len(keep) > 2 * in_flight:
+                keep.pop(0)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t1
+    return {"batches_in_flight": in_flight, "unit": "points/s", "ms_per_step": 1e3 * el / steps, "elapsed_s": el,
+            "note": "same complete, independent passes issued round-robin on several HIP streams; informational, "
+                    "`value` above is the strictly sequential figure"}

@@ -57,3 +57,24 @@ def gather(ext, pts, idx):
     out = torch.empty((B, C, M), dtype=torch.float32, device=DEV)
     assert ext.gather_points_wrapper(B, C, N, M, t(pts), t(idx), out) == 1
     return n(out)
+
+
+def compare_matched_rows(got_idx, want_idx, triples):
+    """Two score-sampled layers whose picks agree up to near-ties: match rows by sampled index and compare each
+    (got, want, rel_tol, axis) tensor on the intersection (`axis` = the axis that runs over the M picks; tol 0 = exact).
+    -> mean fraction of picks shared."""
+    B = got_idx.shape[0]
+    shared = []
+    for b in range(B):
+        common, gpos, wpos = np.intersect1d(got_idx[b], want_idx[b], return_indices=True)
+        shared.append(len(common) / want_idx.shape[1])
+        for got, want, tol, axis in triples:
+            g = np.take(got[b], gpos, axis=axis - 1)
+            w = np.take(want[b], wpos, axis=axis - 1)
+            if tol == 0.0:
+                np.testing.assert_array_equal(g, w)
+            else:
+                scale = max(1.0, float(np.abs(want[b]).max()))
+                err = float(np.abs(g - w).max()) if g.size else 0.0
+                assert err <= tol * scale, f"scene {b}: matched rows differ by {err} (scale {scale})"
+    return float(np.mean(shared))

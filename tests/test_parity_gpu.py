@@ -557,10 +557,24 @@ def test_full_size_stack_against_cpu_oracle(ext, G, dev):
         ref = want[k][1]
         assert float(np.abs(G.n(got[k][1]) - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
     np.testing.assert_allclose(G.n(got[1][2]), want[1][2], rtol=1e-4, atol=1e-4)
-    # layer 2 samples by score: same set up to near-ties of the scores (which carry the 1e-4 feature tolerance)
-    gi, wi = G.n(got[2][3]), want[2][3]
-    overlap = np.mean([len(np.intersect1d(gi[b], wi[b])) / wi.shape[1] for b in range(gi.shape[0])])
+    # layer 2 samples by score: same set up to near-ties of the scores (which carry the 1e-4 feature tolerance); rows are
+    # matched by sampled index and compared on the intersection
+    from tests.gpu_util import compare_matched_rows
+    overlap = compare_matched_rows(G.n(got[2][3]), want[2][3], [(G.n(got[2][0]), want[2][0], 0.0, 1),
+                                                               (G.n(got[2][1]), want[2][1], 1e-4, 2),
+                                                               (G.n(got[2][2]), want[2][2], 1e-4, 1)])
     assert overlap >= 0.99
+    # ... and layer 2 alone at full size on the ORACLE's layer-1 outputs (identical inputs on both sides): indices
+    # bit-exact, every feature / class-score row within 1e-4 -- the 128-wide shared-stream kernel at M = 512, N = 1024
+    x1, f1, c1 = G.t(want[1][0]), fused.attach_point_major_twin(G.t(want[1][1])), G.t(want[1][2])
+    with torch.no_grad():
+        nx, nf, nc, ni, _ = layers[2](x1, f1, c1)
+    np.testing.assert_array_equal(G.n(ni), want[2][3])
+    np.testing.assert_array_equal(G.n(nx), want[2][0])
+    ref = want[2][1]
+    assert float(np.abs(G.n(nf) - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(G.n(nc), want[2][2], rtol=1e-4, atol=1e-4)
+    assert not fused.check_overflow()
 
 
 # ------------------------------------------------------------------ pruned vs brute-force FPS kernels
@@ -1646,3 +1660,15 @@ def test_conv1x1_train_wide_layers_match_conv2d(ext, dev):
         for got, ref in ((ya, yb), (xa.grad, xb.grad), (wa.grad, wb.grad)):
             scale = float(ref.abs().max())
             assert float((got.double() - ref).abs().max()) <= 2e-6 * scale + 1e-6
+
+
+# ------------------------------------------------------------------ pointnet2_stack modules vs reference-generated fixtures
+def test_stack_modules_match_reference_fixtures(dev):
+    """tests/golden/stackmod_*.npz (the REFERENCE's pointnet2_stack Python run over the C oracle, oracle/gen_golden_stack.py)
+    replayed through the build's stack modules on the HIP extension: indices / groupings bit-exact, module outputs and
+    input gradients 1e-5, state_dict names by strict load.  Pins everything above the extension boundary; the kernels'
+    arithmetic stays pinned by the oracle only."""
+    from tests import stack_replay as R
+    R.replay_sa_fp(dev)
+    R.replay_vector_pool(dev)
+    R.replay_voxel_sa(dev)
