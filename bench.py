@@ -190,7 +190,7 @@ def pmc_mfma_busy(widths, nsample, precision):
     data, where = _profile_json("pmc_mfma.json")
     if not data:
         return None, None
-    key = f"{precision}:{widths[1]},{widths[2]},{widths[3]},ns{nsample}"
+    key = f"{precision}:{widths[1]},{widths[2]},ns{nsample}"
     rec = data.get(key)
     if not rec:
         return None, None

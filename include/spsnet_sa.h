@@ -49,6 +49,16 @@ int sps_set_fps_mode(int mode);
 int sps_debug_fps_profile(int b, int n, int m, const float *dataset, float *temp, int *idxs,
                           unsigned long long *dbg, sps_stream_t stream);
 
+/* DIAGNOSTIC ONLY: one {XCC_ID, HW_ID} register pair per workgroup -> out (blocks, 2) u32; tools/cumask_probe.py uses it to
+ * print which physical compute units a CU-masked stream reaches. */
+int sps_debug_where(int blocks, int threads, int spin, unsigned *out, sps_stream_t stream);
+/* Stream plumbing for the CU-fenced schedule (no counterpart in the reference, which launches everything on the legacy
+ * default stream): a HIP stream restricted to the compute units set in mask[0 .. words) (hipExtStreamCreateWithCUMask);
+ * the caller owns it.  A pass's FPS chain occupies one CU per scene for most of the pass; on a stream of its own CUs a
+ * second pass's whole-chip kernels no longer land on those CUs. */
+int sps_stream_create_cu_mask(int words, const unsigned *mask, sps_stream_t *stream);
+int sps_stream_destroy(sps_stream_t stream);
+
 /* ---- the 11 functions of pointnet2_batch_cuda (src/pointnet2_api.cpp:10-26) ---------- */
 
 /* farthest_point_sampling_kernel_launcher, sampling_gpu.cu:211-253 / sampling_gpu.h:24-25.

@@ -21,6 +21,9 @@ _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 # name -> argument types (every entry point returns int status unless noted)
 _PROTOS = {
     "sps_set_fps_mode": [_i],
+    "sps_debug_where": [_i, _i, _i, _vp, _vp],
+    "sps_stream_create_cu_mask": [_i, _vp, _vp],
+    "sps_stream_destroy": [_vp],
     "sps_fps_ordered_prefix": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_fps_ordered_prefix_begin": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_fps_ordered_prefix_finish": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
