@@ -329,7 +329,7 @@ extern "C" int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int 
         return fail(SPS_ERR_INVALID, "sa_group_mlp: point-major features need a split-fp16 mode and c_feat %% 4 == 0 (got %d)", c_feat);
     hipStream_t st = as_stream(stream);
     if (arith == 2) return launch_sa_mlp_f16_lds(a, c1, c2, nsample, st);
-    if (arith) return launch_sa_mlp_f16(a, c1, c2, nsample, st);
+    if (arith) return launch_sa_mlp_f16(a, c1, c2, nsample, st, arith == 3);   // 3: `features` holds halves (fp16 in HBM)
 #define SPS_MLP_CASE(C1, C2, NT, NS) \
     if (c1 == C1 && c2 == C2 && nsample == NS) return launch_variant<C1, C2, NT, NS>(a, st);
     SPS_MLP_CASE(16, 16, 2, 16)    // IA-SSD L0 r=0.2 [4,16,16,32]

@@ -16,6 +16,7 @@ struct SaMlpArgs {
     const float *w1, *b1, *w2, *b2, *w3, *b3;
     float *out;
     int feat_pm;                   // 1: `feat` is point-major (B, N, c_feat) and layer 1's channel order is [features, xyz]
+                                   // (mode 3, pure fp16: `feat` points at halves)
     int *overflow;                 // split-fp16 kernel: set to 1 if an operand exceeded the exactly splittable range
 };
 
@@ -43,7 +44,7 @@ __device__ __forceinline__ sps_f32x4 row_allmax4(sps_f32x4 v) {
 
 extern int g_mlp_f16;
 // sa_mlp_f16.hip: split-fp16 variant; same argument block (units = scenes, ups = centroids per scene on entry)
-int launch_sa_mlp_f16(const SaMlpArgs &a, int c1, int c2, int nsample, hipStream_t st);
+int launch_sa_mlp_f16(const SaMlpArgs &a, int c1, int c2, int nsample, hipStream_t st, bool pure = false);
 // sa_mlp_f16_lds.hip: the same arithmetic with the weight stream shared through LDS (a.w1 = concatenated stream)
 int launch_sa_mlp_f16_lds(const SaMlpArgs &a, int c1, int c2, int nsample, hipStream_t st);
 

@@ -28,7 +28,7 @@ __device__ __forceinline__ f32x4 mfma32h(h8 a, h8 b, f32x4 c) { return __builtin
 // first (RELU: to [0, 65504], which is the layer's ReLU as well), so hi is finite and lo = fp16(c - hi) is tiny: no
 // inf/NaN can arise.  |x| <= 65504 splits exactly to 22 bits; `mx` tracks the largest magnitude seen so that the
 // launch can report operands beyond that (fused.check_overflow) -- never silent.
-template <int OFF, bool RELU>
+template <int OFF, bool RELU, bool PURE = false>
 __device__ __forceinline__ void split4(const f32x4 v, h8 &hi, h8 &lo, float &mx) {
     mx = __builtin_amdgcn_fmed3f(mx, INFINITY, fmaxf(fabsf(v[0]), fabsf(v[1])));  // max3(mx, |v0|, |v1|) for mx >= 0
     mx = __builtin_amdgcn_fmed3f(mx, INFINITY, fmaxf(fabsf(v[2]), fabsf(v[3])));
@@ -37,23 +37,26 @@ __device__ __forceinline__ void split4(const f32x4 v, h8 &hi, h8 &lo, float &mx)
         const float c = __builtin_amdgcn_fmed3f(v[r], RELU ? 0.f : -65504.f, 65504.f);
         const _Float16 h = (_Float16)c;
         hi[OFF + r] = h;
-        lo[OFF + r] = (_Float16)(c - (float)h);
+        if constexpr (!PURE) lo[OFF + r] = (_Float16)(c - (float)h);  // PURE (fp16 features): operands ARE halves, no lo part
     }
 }
 
-// a fragment = (16-row tile, 32-channel step): 2 KiB = [lane][hi x8] then [lane][lo x8]
+// a fragment = (16-row tile, 32-channel step): split mode 2 KiB = [lane][hi x8] then [lane][lo x8]; pure-fp16 mode 1 KiB =
+// [lane][8 halves] (the weights themselves are rounded to fp16 by the host, fused._pack_h16)
 struct WFrag { h8 hi, lo; };
-constexpr int FRAG = 2048;
+template <bool PURE> constexpr int frag_bytes() { return PURE ? 1024 : 2048; }
+template <bool PURE>
 __device__ __forceinline__ WFrag wload_h(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     union { i32x4 i; h8 h; } a, b;
     a.i = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    if constexpr (PURE) return WFrag{a.h, a.h};
     b.i = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff + 1024, 0);
     return WFrag{a.h, b.h};
 }
 // Weight source of a layer: a buffer resource (fragments streamed from L2 by every wave) or, when all three layers fit
 // (WLDS: the 64-wide scales, <= 96 KiB), a copy in LDS made once per workgroup -- the L1 scales moved 805 MB of
 // weights per launch through L2 (8.4 TB/s: that bandwidth, not the matrix cores, bounded them).
-template <bool WLDS>
+template <bool WLDS, bool PURE>
 struct WSrc {
     __amdgpu_buffer_rsrc_t rs;
     unsigned lds;  // byte address of the layer's first fragment in LDS
@@ -62,28 +65,36 @@ struct WSrc {
             typedef const __attribute__((address_space(3))) i32x4 lds_v;
             lds_v *p = (lds_v *)(size_t)(lds + (unsigned)soff + (unsigned)lane16);
             union { i32x4 i; h8 h; } a, b;
-            a.i = p[0]; b.i = p[64];
+            a.i = p[0];
+            if constexpr (PURE) return WFrag{a.h, a.h};
+            b.i = p[64];
             return WFrag{a.h, b.h};
         } else {
-            return wload_h(rs, lane16, soff);
+            return wload_h<PURE>(rs, lane16, soff);
         }
     }
 };
 
-template <int NT>
+template <int NT, bool PURE = false>
 __device__ __forceinline__ void mac3(const WFrag &w, const h8 (&xh)[NT], const h8 (&xl)[NT], f32x4 (&acc)[NT]) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32h(w.hi, xh[nt], acc[nt]);
+    if constexpr (!PURE) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32h(w.hi, xl[nt], acc[nt]);
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32h(w.hi, xl[nt], acc[nt]);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32h(w.lo, xh[nt], acc[nt]);
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32h(w.lo, xh[nt], acc[nt]);
+    }
 }
 
 
 // a.ks1 = layer-1 k-steps of 32 grouped channels = ceil((3 + c_feat) / 32)
-template <int C1, int C2, int NT, int NS, bool WLDS>
+// PURE: the feature tensor holds halves (fp16 features in HBM, BASELINE configs[4]) and every operand is ONE half -- one MFMA
+// per product block instead of three; coordinates are still differenced in fp32 and rounded once.
+template <int C1, int C2, int NT, int NS, bool WLDS, bool PURE>
 __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
+    constexpr int FRAG = frag_bytes<PURE>();
+    const _Float16 *feat_h = reinterpret_cast<const _Float16 *>(a.feat);
     constexpr int T1 = C1 / 16, T2 = C2 / 16;
     constexpr int S1 = T1 / 2, S2 = T2 / 2;  // k32-steps over the previous layer's channels
     constexpr int UNIT = 16 * NT;
@@ -96,7 +107,7 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
 
-    WSrc<WLDS> ws1, ws2, ws3;
+    WSrc<WLDS, PURE> ws1, ws2, ws3;
     {
         const int MT3 = a.c3 / 16;
         const unsigned n1 = (unsigned)(T1 * a.ks1 * FRAG), n2 = (unsigned)(T2 * S1 * FRAG), n3 = (unsigned)(MT3 * S2 * FRAG);
@@ -151,7 +162,12 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
                     // four channels are one 16-byte load, the four q-lanes of a column read 64 contiguous bytes
                     const int ch0 = 16 * k16 + 4 * q;
                     if (ch0 < a.c_feat) {
-                        v = *reinterpret_cast<const f32x4 *>(a.feat + ((size_t)bb[nt] * a.n + src[nt]) * a.c_feat + ch0);
+                        if constexpr (PURE) {
+                            const h4 hv = *reinterpret_cast<const h4 *>(feat_h + ((size_t)bb[nt] * a.n + src[nt]) * a.c_feat + ch0);
+                            v = (f32x4){(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                        } else {
+                            v = *reinterpret_cast<const f32x4 *>(a.feat + ((size_t)bb[nt] * a.n + src[nt]) * a.c_feat + ch0);
+                        }
                     } else {
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) {
@@ -172,7 +188,8 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
                     } else {
                         int cf = ch - 3;
                         cf = cf < a.c_feat ? cf : a.c_feat - 1;  // padded channel: finite data times a zero weight
-                        x = a.feat[((size_t)bb[nt] * a.c_feat + cf) * a.n + src[nt]];
+                        const size_t at = ((size_t)bb[nt] * a.c_feat + cf) * a.n + src[nt];
+                        x = PURE ? (float)feat_h[at] : a.feat[at];
                     }
                     v[jj] = x;
                 }
@@ -191,18 +208,18 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
                 h8 xhi[NT], xlo[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    split4<0, false>(xcur[0][nt], xhi[nt], xlo[nt], mx);
+                    split4<0, false, PURE>(xcur[0][nt], xhi[nt], xlo[nt], mx);
                     if (16 * (2 * ks + 1) >= 3 + a.c_feat) {  // padding block (zeros): nothing to split
 #pragma unroll
                         for (int r = 4; r < 8; ++r) { xhi[nt][r] = (_Float16)0.f; xlo[nt][r] = (_Float16)0.f; }
                     } else {
-                        split4<4, false>(xcur[1][nt], xhi[nt], xlo[nt], mx);
+                        split4<4, false, PURE>(xcur[1][nt], xhi[nt], xlo[nt], mx);
                     }
                 }
 #pragma unroll
                 for (int t = 0; t < T1; ++t) {
                     const WFrag w = ws1.load(lane * 16, (t * a.ks1 + ks) * FRAG);
-                    mac3<NT>(w, xhi, xlo, acc1[t]);
+                    mac3<NT, PURE>(w, xhi, xlo, acc1[t]);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) { xcur[0][nt] = xnext[0][nt]; xcur[1][nt] = xnext[1][nt]; }
@@ -212,8 +229,8 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
             for (int t = 0; t < T1; ++t)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    if (t % 2 == 0) split4<0, true>(acc1[t][nt], h1hi[t / 2][nt], h1lo[t / 2][nt], mx);
-                    else split4<4, true>(acc1[t][nt], h1hi[t / 2][nt], h1lo[t / 2][nt], mx);
+                    if (t % 2 == 0) split4<0, true, PURE>(acc1[t][nt], h1hi[t / 2][nt], h1lo[t / 2][nt], mx);
+                    else split4<4, true, PURE>(acc1[t][nt], h1hi[t / 2][nt], h1lo[t / 2][nt], mx);
                 }
 
             // ---------------- layer 2 ----------------
@@ -239,12 +256,12 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
                         for (int nt = 0; nt < NT; ++nt) acc[nt] = bias;
                     }
 #pragma unroll
-                    for (int u = 0; u < KCH; ++u) mac3<NT>(w[g & 1][u], h1hi[ch * KCH + u], h1lo[ch * KCH + u], acc);
+                    for (int u = 0; u < KCH; ++u) mac3<NT, PURE>(w[g & 1][u], h1hi[ch * KCH + u], h1lo[ch * KCH + u], acc);
                     if (ch == NCH - 1) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            if (mt % 2 == 0) split4<0, true>(acc[nt], h2hi[mt / 2][nt], h2lo[mt / 2][nt], mx);
-                            else split4<4, true>(acc[nt], h2hi[mt / 2][nt], h2lo[mt / 2][nt], mx);
+                            if (mt % 2 == 0) split4<0, true, PURE>(acc[nt], h2hi[mt / 2][nt], h2lo[mt / 2][nt], mx);
+                            else split4<4, true, PURE>(acc[nt], h2hi[mt / 2][nt], h2lo[mt / 2][nt], mx);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -282,7 +299,7 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int u = 0; u < KCH; ++u) mac3<NT>(w[ch & 1][u], h2hi[ch * KCH + u], h2lo[ch * KCH + u], acc);
+                    for (int u = 0; u < KCH; ++u) mac3<NT, PURE>(w[ch & 1][u], h2hi[ch * KCH + u], h2lo[ch * KCH + u], acc);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 f32x4 best[CPP];
@@ -322,9 +339,10 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
     if (mx > 65504.f && a.overflow) *a.overflow = 1;
 }
 
-template <int C1, int C2, int NT, int NS>
+template <int C1, int C2, int NT, int NS, bool PURE>
 static int launch_f16_variant(const SaMlpArgs &a, hipStream_t st) {
     constexpr int UNIT = 16 * NT;
+    constexpr int FRAG = frag_bytes<PURE>();
     SaMlpArgs k = a;
     const long long cols_scene = (long long)a.ups * NS;
     if (cols_scene % UNIT != 0)
@@ -337,23 +355,25 @@ static int launch_f16_variant(const SaMlpArgs &a, hipStream_t st) {
     const size_t wbytes = (size_t)FRAG * ((size_t)(C1 / 16) * k.ks1 + (size_t)(C2 / 16) * (C1 / 32) + (size_t)(a.c3 / 16) * (C2 / 32));
     if (C1 >= 64 && wbytes <= 128 * 1024 && k.units >= 2048) {  // (the 32-wide scale is faster streaming: measured)
         static LdsLimitOnce raised;  // one per instantiation
-        const int rc = raise_lds_limit((const void *)sa_group_mlp_f16_kernel<C1, C2, NT, NS, true>, 128 * 1024, raised,
+        const int rc = raise_lds_limit((const void *)sa_group_mlp_f16_kernel<C1, C2, NT, NS, true, PURE>, 128 * 1024, raised,
                                        "sa_group_mlp(f16)");
         if (rc != SPS_OK) return rc;
         int blocks = divup(k.units, 8);
         if (blocks > 256) blocks = 256;
-        hipLaunchKernelGGL((sa_group_mlp_f16_kernel<C1, C2, NT, NS, true>), dim3(blocks), dim3(512), wbytes, st, k);
+        hipLaunchKernelGGL((sa_group_mlp_f16_kernel<C1, C2, NT, NS, true, PURE>), dim3(blocks), dim3(512), wbytes, st, k);
         return check_launch("sa_group_mlp_f16_kernel<lds weights>");
     }
     int blocks = divup(k.units, 4);
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL((sa_group_mlp_f16_kernel<C1, C2, NT, NS, false>), dim3(blocks), dim3(256), 0, st, k);
+    hipLaunchKernelGGL((sa_group_mlp_f16_kernel<C1, C2, NT, NS, false, PURE>), dim3(blocks), dim3(256), 0, st, k);
     return check_launch("sa_group_mlp_f16_kernel");
 }
 
-int launch_sa_mlp_f16(const SaMlpArgs &a, int c1, int c2, int nsample, hipStream_t st) {
-#define SPS_MLPH_CASE(C1, C2, NT, NS) \
-    if (c1 == C1 && c2 == C2 && nsample == NS) return launch_f16_variant<C1, C2, NT, NS>(a, st);
+// pure = the feature tensor and every MFMA operand are fp16 (mode 3 of sps_sa_group_mlp_ex); otherwise split-fp16 (mode 1)
+int launch_sa_mlp_f16(const SaMlpArgs &a, int c1, int c2, int nsample, hipStream_t st, bool pure) {
+#define SPS_MLPH_CASE(C1, C2, NT, NS)                                                                \
+    if (c1 == C1 && c2 == C2 && nsample == NS)                                                       \
+        return pure ? launch_f16_variant<C1, C2, NT, NS, true>(a, st) : launch_f16_variant<C1, C2, NT, NS, false>(a, st);
     SPS_MLPH_CASE(32, 32, 2, 32)
     SPS_MLPH_CASE(64, 64, 2, 16)
     SPS_MLPH_CASE(64, 96, 2, 32)
