@@ -220,7 +220,9 @@ int sps_sa_group_mlp_range(int b, int n, int m, int j0, int jcount, int c_feat, 
 
 /* sps_sa_group_mlp_range with the arithmetic chosen per call (split_fp16 = 0: fp32 MFMA; 1: split-fp16, per-layer
  * fragment arrays; 2: split-fp16 with ONE concatenated fragment stream in w1 that a workgroup's waves share through
- * LDS -- first hidden width a multiple of 64; w2 / w3 are ignored; weights packed accordingly by the caller; + 4:
+ * LDS -- first hidden width a multiple of 64; w2 / w3 are ignored; 3: pure fp16 -- `features` points at HALVES
+ * (fp16 features in HBM, BASELINE configs[4]), weights are fp16 fragments of 1 KiB, one MFMA per product block, fp32
+ * accumulate, hidden widths multiples of 32; weights packed accordingly by the caller; + 4:
  * `features` is point-major (b, n, c_feat), c_feat % 4 == 0, and layer 1's input channels are ordered
  * [features, xyz] instead of [xyz, features] -- a neighbour's channels are then contiguous 16-byte loads) and,
  * for the split-fp16 kernel, a device flag that is set to 1 if an operand left the exactly splittable range
@@ -244,6 +246,11 @@ int sps_pointwise_mlp(int b, int m, int cin, int c1, int c2, int classes, const 
 int sps_pointwise_mlp_range(int b, int m, int j0, int jcount, int cin, int c1, int c2, int classes, const float *x,
                             const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                             const float *b3, float *y1, float *y1_point_major, float *y3, sps_stream_t stream);
+/* The same with flags: 1 = y1 / y1_point_major are fp16 buffers (features stored as halves in HBM: BASELINE configs[4];
+ * the arithmetic stays fp32 and the class scores are computed from the rounded features), 2 = x is point-major (B, M, cin). */
+int sps_pointwise_mlp_ex(int b, int m, int j0, int jcount, int cin, int c1, int c2, int c3_real, const float *x,
+                         const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                         const float *b3, void *y1, void *y1_point_major, float *y3, int flags, sps_stream_t stream);
 
 /* farthest_point_sampling_kernel_launcher (sampling_gpu.cu:93-253) with an optional device workspace of
  * b * sps_fps_workspace_floats(n) floats (0 for sizes that need none).  With it, scenes of 16 385 .. 262 144 points

@@ -53,6 +53,7 @@ _PROTOS = {
     "sps_sa_group_mlp_supported_stream": [_i, _i, _i, _i],
     "sps_fps_with_workspace": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_pointwise_mlp_range": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_pointwise_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "sps_pointwise_mlp": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_ball_query_grid": [_i, _i, _i, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_ball_query_grid2": [_i, _i, _i, _f, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -26,6 +26,8 @@ struct PwArgs {
     int m, j0, cin, c1, c2, c3, c3_real;  // j0: first point of the launch (a multiple of 16)
     const float *x, *w1, *b1, *w2, *b2, *w3, *b3;
     float *y1, *y1t, *y3;
+    int out_h16;   // y1 / y1t are written as halves (fp16 features in HBM, BASELINE configs[4]); arithmetic stays fp32
+    int x_pm;      // x is point-major (B, M, cin) instead of (B, cin, M)
 };
 
 __device__ __forceinline__ f32x4 pw_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -62,8 +64,14 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void pw_mlp_kernel(PwArgs a) {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     const int scene = blockIdx.y, m0 = a.j0 + blockIdx.x * 16;
 
-    // ---- stage the 16 input columns: cin rows of 64 bytes, coalesced ----
-    {
+    // ---- stage the 16 input columns: cin rows of 64 bytes (or, point-major, 16 rows of cin floats), coalesced ----
+    if (a.x_pm) {
+        const float *xs = a.x + ((size_t)scene * a.m + m0) * a.cin;
+        for (int e = threadIdx.x; e < a.cin * 16; e += blockDim.x) {
+            const int col = e / a.cin, ch = e - col * a.cin;
+            xt[ch * PW_PAD + col] = xs[e];
+        }
+    } else {
         const float *xs = a.x + (size_t)scene * a.cin * a.m + m0;
         for (int e = threadIdx.x; e < a.cin * 16; e += blockDim.x) {
             const int ch = e >> 4, col = e & 15;
@@ -81,11 +89,29 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void pw_mlp_kernel(PwArgs a) {
             for (int r = 0; r < 4; ++r) {
                 acc[r] = fmaxf(acc[r], 0.f);
                 const int row = 16 * t + 4 * q + r;
-                a.y1[((size_t)scene * a.c1 + row) * a.m + m0 + c] = acc[r];
+                const size_t at = ((size_t)scene * a.c1 + row) * a.m + m0 + c;
+                if (a.out_h16) {
+                    // features live in HBM as halves; the head below keeps reading what was STORED (the rounded value), so
+                    // that the class scores are a function of the returned features
+                    const _Float16 hv = (_Float16)acc[r];
+                    reinterpret_cast<_Float16 *>(a.y1)[at] = hv;
+                    acc[r] = (float)hv;
+                } else {
+                    a.y1[at] = acc[r];
+                }
                 act1[row * PW_PAD + c] = acc[r];
             }
-            // point-major twin (B, M, C1) for the next layer's grouped-MLP gathers: 16 bytes per lane, 64 per column
-            if (a.y1t) *reinterpret_cast<f32x4 *>(a.y1t + ((size_t)scene * a.m + m0 + c) * a.c1 + 16 * t + 4 * q) = acc;
+            // point-major twin (B, M, C1) for the next layer's grouped-MLP gathers: 16 (8) bytes per lane, 64 (32) per column
+            if (a.y1t) {
+                const size_t at = ((size_t)scene * a.m + m0 + c) * a.c1 + 16 * t + 4 * q;
+                if (a.out_h16) {
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<h4 *>(reinterpret_cast<_Float16 *>(a.y1t) + at) =
+                        (h4){(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};
+                } else {
+                    *reinterpret_cast<f32x4 *>(a.y1t + at) = acc;
+                }
+            }
         }
     }
     if (!a.w2) return;
@@ -118,6 +144,15 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void pw_mlp_kernel(PwArgs a) {
 extern "C" int sps_pointwise_mlp_range(int b, int m, int j0, int jcount, int cin, int c1, int c2, int c3_real, const float *x,
                                        const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                                        const float *b3, float *y1, float *y1_point_major, float *y3, sps_stream_t stream) {
+    return sps_pointwise_mlp_ex(b, m, j0, jcount, cin, c1, c2, c3_real, x, w1, b1, w2, b2, w3, b3, y1, y1_point_major, y3, 0,
+                                stream);
+}
+
+// flags: 1 = y1 / y1_point_major are fp16 buffers (halves), 2 = x is point-major (B, M, cin)
+extern "C" int sps_pointwise_mlp_ex(int b, int m, int j0, int jcount, int cin, int c1, int c2, int c3_real, const float *x,
+                                    const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                                    const float *b3, void *y1, void *y1_point_major, float *y3, int flags,
+                                    sps_stream_t stream) {
     using namespace sps;
     if (b < 0 || m < 0 || cin <= 0 || c1 <= 0) return fail(SPS_ERR_INVALID, "pointwise_mlp: bad shape b=%d m=%d cin=%d c1=%d", b, m, cin, c1);
     if (j0 < 0 || jcount < 0 || j0 + jcount > m || j0 % 16 || jcount % 16)
@@ -133,7 +168,8 @@ extern "C" int sps_pointwise_mlp_range(int b, int m, int j0, int jcount, int cin
     if (b > 65535) return fail(SPS_ERR_INVALID, "pointwise_mlp: batch %d exceeds the grid limit", b);
     PwArgs a;
     a.m = m; a.j0 = j0; a.cin = cin; a.c1 = c1; a.c2 = deep ? c2 : 0; a.c3 = 16; a.c3_real = deep ? c3_real : 0;
-    a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = deep ? w2 : nullptr; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.y1 = y1; a.y1t = y1_point_major; a.y3 = y3;
+    a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = deep ? w2 : nullptr; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.y1 = (float *)y1; a.y1t = (float *)y1_point_major; a.y3 = y3;
+    a.out_h16 = flags & 1; a.x_pm = (flags >> 1) & 1;
     const int wide = (deep && c2 > cin) ? c2 : cin;
     const size_t lds = sizeof(float) * (size_t)PW_PAD * ((size_t)wide + c1);
     if (lds > 150 * 1024) return fail(SPS_ERR_INVALID, "pointwise_mlp: widths (%d, %d, %d) need more LDS than a workgroup has", cin, c1, c2);

@@ -75,6 +75,20 @@ def _pack_f16(w, cout_pad, cin_pad):
     return _frags_k32(w, cout_pad, cin_pad).reshape(-1)
 
 
+def _pack_h16(w, cout_pad, cin_pad):
+    """[tile][k32] fragments of the pure-fp16 mode of csrc/sa_mlp_f16.hip (1 KiB each): the weights rounded to fp16 once,
+    same k-slot order as _frags_k32."""
+    cout, cin_ = w.shape
+    wp = w.new_zeros(cout_pad, cin_pad)
+    wp[:cout, :cin_] = w
+    f = wp.view(cout_pad // 16, 16, cin_pad // 32, 2, 4, 4).permute(0, 2, 4, 1, 3, 5)
+    return f.reshape(cout_pad // 16, cin_pad // 32, 64, 8).half().contiguous().view(torch.int16).reshape(-1)
+
+
+def _pad32(c):
+    return (c + 31) // 32 * 32
+
+
 def _pack_stream(w1, w2, w3, c1, c2, c3, cin):
     """The three layers' split-fp16 fragments as ONE stream in the order csrc/sa_mlp_f16_lds.hip consumes them:
     layer 1 as [k32][tile]; then, for every k32-step s of layer 3, the layer-2 tiles 2s and 2s+1 as [tile][k32]
@@ -102,7 +116,7 @@ def _pad_bias(b, cpad):
 
 
 class PackedScale:
-    __slots__ = ("c1", "c2", "c3", "c3_real", "cin", "w1", "b1", "w2", "b2", "w3", "b3", "key", "split", "point_major")
+    __slots__ = ("c1", "c2", "c3", "c3_real", "cin", "w1", "b1", "w2", "b2", "w3", "b3", "key", "split", "point_major", "half")
 
 
 def _stack_layers(mlp):
@@ -165,25 +179,28 @@ def check_overflow():
     return bad
 
 
-def pack_scale(mlp, nsample, point_major=False):
+def pack_scale(mlp, nsample, point_major=False, half=False):
     """-> PackedScale (cached on the module) or None when the fused kernel has no variant for this scale.
     point_major: layer 1's input channels ordered [features, xyz] for gathers from a (B, N, C) feature tensor
-    (only used, and only honoured, by the split-fp16 kernels with C % 4 == 0)."""
+    (only used, and only honoured, by the fp16 kernels with C % 4 == 0).
+    half: the feature tensors are fp16 (BASELINE configs[4]): weights rounded to fp16, one MFMA per product block
+    (mode 3 of sps_sa_group_mlp_ex), hidden widths padded to multiples of 32 with zero rows."""
     pairs = _stack_layers(mlp)
     if pairs is None:
         return None
     (c1m, _), (c2m, _), (c3m, _) = pairs
-    c1, c2, c3 = _pad16(c1m.out_channels), _pad16(c2m.out_channels), _pad16(c3m.out_channels)
-    stream_only = bool(_L.sps_sa_group_mlp_supported_stream(c1, c2, c3, nsample))
+    pad = _pad32 if half else _pad16
+    c1, c2, c3 = pad(c1m.out_channels), pad(c2m.out_channels), _pad16(c3m.out_channels)
+    stream_only = bool(_L.sps_sa_group_mlp_supported_stream(c1, c2, c3, nsample)) and not half
     if stream_only and not (PRECISION == "fp16x2" and SHARE_WEIGHTS):
         return None
     if not stream_only and not _L.sps_sa_group_mlp_supported(c1, c2, nsample):
         return None
     device = c1m.weight.device
     c_feat = c1m.in_channels - 3
-    point_major = bool(point_major and PRECISION == "fp16x2" and c1 >= 32 and c_feat >= 4 and c_feat % 4 == 0)
-    key = _version_key(pairs, device) + (PRECISION, SHARE_WEIGHTS, point_major)
-    slot = "_sps_packed_pm" if point_major else "_sps_packed"
+    point_major = bool(point_major and (half or PRECISION == "fp16x2") and c1 >= 32 and c_feat >= 4 and c_feat % 4 == 0)
+    key = _version_key(pairs, device) + (PRECISION, SHARE_WEIGHTS, point_major, half)
+    slot = ("_sps_packed_pm" if point_major else "_sps_packed") + ("_h" if half else "")
     cached = getattr(mlp, slot, None)
     if cached is not None and cached.key == key:
         return cached
@@ -192,13 +209,17 @@ def pack_scale(mlp, nsample, point_major=False):
         if point_major:
             w1 = torch.cat([w1[:, 3:], w1[:, :3]], dim=1)  # grouped channels as [features, xyz]
         p = PackedScale()
-        p.point_major = point_major
+        p.point_major, p.half = point_major, bool(half)
         p.c1, p.c2, p.c3, p.c3_real, p.cin = c1, c2, c3, c3m.out_channels, c1m.in_channels
         p.split = 0
-        if PRECISION == "fp16x2" and c1 >= 32:
+        if half:
+            p.split = 3
+        elif PRECISION == "fp16x2" and c1 >= 32:
             p.split = 2 if (SHARE_WEIGHTS and _lds_stream_ok(c1, c2, c3)) else 1
         cin_pad = (c1m.in_channels + 31) // 32 * 32
-        if p.split == 2:
+        if p.split == 3:
+            p.w1, p.w2, p.w3 = _pack_h16(w1, c1, cin_pad), _pack_h16(w2, c2, c1), _pack_h16(w3, c3, c2)
+        elif p.split == 2:
             p.w1 = _pack_stream(w1, w2, w3, c1, c2, c3, c1m.in_channels)
             p.w2 = p.w3 = p.w1
         elif p.split:
@@ -217,7 +238,7 @@ def point_major_twin(features):
     if t is None or features is None:
         return None
     B, C, N = features.shape
-    if t.shape != (B, N, C) or t.device != features.device or not t.is_contiguous() or C % 4:
+    if t.shape != (B, N, C) or t.device != features.device or t.dtype != features.dtype or not t.is_contiguous() or C % 4:
         return None
     return t
 
@@ -247,6 +268,8 @@ def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=
         mode |= 4
     if 3 + c_feat != packed.cin:
         raise ValueError(f"grouped input has {3 + c_feat} channels, the MLP expects {packed.cin}")
+    if features is not None and (features.dtype == torch.float16) != bool(packed.half):
+        raise ValueError(f"feature tensor is {features.dtype}, but the scale was packed for {'fp16' if packed.half else 'fp32'}")
     stream = torch.cuda.current_stream(xyz.device).cuda_stream
     _lib.check(_L.sps_sa_group_mlp_ex(
         B, N, M, j0, jcount, c_feat, ns, xyz.data_ptr(), new_xyz.data_ptr(), 0 if features is None else features.data_ptr(),
@@ -296,12 +319,14 @@ class TailRunner:
     """The aggregation stack (+ confidence head) of an SA layer on `pooled` (B, C, M), launched for the whole layer or
     range by range (`run(j0, jcount)`, on torch's current stream); `result()` -> (new_features (B, Cagg, M), cls | None)."""
 
-    def __init__(self, packed, pooled, with_head):
+    def __init__(self, packed, pooled, with_head, half_out=False):
         B, _, M = pooled.shape
         dev = pooled.device
         self.packed, self.x, self.B, self.M = packed, pooled, B, M
-        self.y1 = torch.empty((B, packed.c1, M), dtype=torch.float32, device=dev)
-        self.y1t = torch.empty((B, M, packed.c1), dtype=torch.float32, device=dev)  # point-major twin for the next SA layer
+        self.half_out = bool(half_out)   # features leave as fp16 (BASELINE configs[4]); the class scores stay fp32
+        ftype = torch.float16 if half_out else torch.float32
+        self.y1 = torch.empty((B, packed.c1, M), dtype=ftype, device=dev)
+        self.y1t = torch.empty((B, M, packed.c1), dtype=ftype, device=dev)  # point-major twin for the next SA layer
         self.y3 = torch.empty((B, M, packed.classes), dtype=torch.float32, device=dev) if with_head else None
 
     def tensors(self):
@@ -310,17 +335,18 @@ class TailRunner:
     def run(self, j0=0, jcount=None):
         p = self.packed
         ptr = lambda t: 0 if t is None else t.data_ptr()
-        _lib.check(_L.sps_pointwise_mlp_range(self.B, self.M, j0, self.M - j0 if jcount is None else jcount, p.cin, p.c1, p.c2,
-                                              p.classes, self.x.data_ptr(), ptr(p.w1), ptr(p.b1), ptr(p.w2), ptr(p.b2),
-                                              ptr(p.w3), ptr(p.b3), self.y1.data_ptr(), self.y1t.data_ptr(), ptr(self.y3),
-                                              torch.cuda.current_stream(self.x.device).cuda_stream), "pointwise_mlp")
+        _lib.check(_L.sps_pointwise_mlp_ex(self.B, self.M, j0, self.M - j0 if jcount is None else jcount, p.cin, p.c1, p.c2,
+                                           p.classes, self.x.data_ptr(), ptr(p.w1), ptr(p.b1), ptr(p.w2), ptr(p.b2),
+                                           ptr(p.w3), ptr(p.b3), self.y1.data_ptr(), self.y1t.data_ptr(), ptr(self.y3),
+                                           1 if self.half_out else 0,
+                                           torch.cuda.current_stream(self.x.device).cuda_stream), "pointwise_mlp")
 
     def result(self):
         self.y1._sps_nc = self.y1t
         return self.y1, self.y3
 
 
-def tail_runner(agg, head, pooled):
+def tail_runner(agg, head, pooled, half_out=False):
     """-> TailRunner, or None when the fused path does not apply (training, gradients wanted, widths that are not
     multiples of 16, more than 16 classes, ...).  `pooled` must be contiguous and may still be being filled."""
     if agg is None or agg.training or (head is not None and head.training) or not pooled.is_cuda or pooled.dtype != torch.float32:
@@ -363,13 +389,13 @@ def tail_runner(agg, head, pooled):
                 b3 = c_out.bias.detach().float() if c_out.bias is not None else w3.new_zeros(classes)
                 packed.w3, packed.b3 = _pack_pw(w3, 16), _pad_bias(b3, 16)
         object.__setattr__(agg, "_sps_tail", packed)
-    return TailRunner(packed, pooled, head is not None)
+    return TailRunner(packed, pooled, head is not None, half_out)
 
 
-def pointwise_tail(agg, head, pooled):
+def pointwise_tail(agg, head, pooled, half_out=False):
     """Aggregation stack (+ confidence head) of an SA layer on `pooled` (B, C, M) as one kernel ->
     (new_features (B, Cagg, M), cls (B, M, K) | None), or None when the fused path does not apply."""
-    runner = tail_runner(agg, head, pooled.contiguous())
+    runner = tail_runner(agg, head, pooled.contiguous(), half_out)
     if runner is None:
         return None
     runner.run()

@@ -194,7 +194,8 @@ class _PointnetSAModuleBase(nn.Module):
                 return None
             if (xyz.shape[0] * new_xyz.shape[1] * grouper.nsample) % 32 != 0:
                 return None
-            packed = _fused.pack_scale(mlp, grouper.nsample, point_major=_fused.point_major_twin(features) is not None)
+            packed = _fused.pack_scale(mlp, grouper.nsample, point_major=_fused.point_major_twin(features) is not None,
+                                       half=features is not None and features.dtype == torch.float16)
             if packed is None:
                 return None
             plan.append(packed)
@@ -219,6 +220,9 @@ class _PointnetSAModuleBase(nn.Module):
                 _fused.group_mlp_pool(xyz_c, new_c, feats_c, idx, packed, out, offset)
                 offset += packed.c3_real
             return out
+        if features is not None and features.dtype == torch.float16:
+            raise NotImplementedError("fp16 feature tensors are served by the fused inference path only (eval mode, no "
+                                      "gradients, max pooling, IA-SSD layer widths); cast to float32 for anything else")
         scales = []
         for grouper, mlp in zip(self.groupers, self.mlps):
             grouped = grouper(xyz, new_xyz, features)      # (B, C, M, ns)
@@ -473,22 +477,28 @@ class _SamplingSAModule(_PointnetSAModuleBase):
             hook(new_xyz)
         return sampled_idx, new_xyz, stds
 
-    def _tail(self, pooled):
+    def _tail(self, pooled, half_out=False):
         """Aggregation stack and confidence head (reference :449-455) -> (new_features, cls (B,M,K) | None).  In
-        inference both run as ONE kernel (csrc/pw_mlp.hip, BatchNorm folded, exact fp32) when their shapes allow."""
+        inference both run as ONE kernel (csrc/pw_mlp.hip, BatchNorm folded, exact fp32) when their shapes allow.
+        half_out: the layer's input features were fp16, so its output features are stored as fp16 too."""
         head = getattr(self, "confidence_layers", None)
         if self.aggregation_layer is not None:
-            done = _fused.pointwise_tail(self.aggregation_layer, head, pooled)
+            done = _fused.pointwise_tail(self.aggregation_layer, head, pooled, half_out)
             if done is not None:
                 return done
+            if half_out:
+                raise NotImplementedError("fp16 feature tensors need the fused aggregation kernel (widths multiples of 16)")
             pooled = self.aggregation_layer(pooled)
+        elif half_out:
+            pooled = pooled.half()
         cls = head(pooled).transpose(1, 2) if head is not None else None
         return pooled, cls
 
     def _abstract(self, xyz, new_xyz, features, sampled_idx):
         """-> (new_features, cls | None)"""
         if len(self.groupers) > 0:
-            return self._tail(self._group_mlp_pool(xyz, new_xyz, features))
+            return self._tail(self._group_mlp_pool(xyz, new_xyz, features),
+                              features is not None and features.dtype == torch.float16)
         new_features = pointnet2_utils.gather_operation(features, sampled_idx).contiguous()
         head = getattr(self, "confidence_layers", None)
         return new_features, (head(new_features).transpose(1, 2) if head is not None else None)

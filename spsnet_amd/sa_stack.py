@@ -190,14 +190,19 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
     flag_entry = [timed_out, None, None]
     _TIMEOUT_FLAGS.append(flag_entry)
 
+    # the aggregation / confidence tail runs chunk by chunk behind the grouped MLPs (its 16-point tiles are independent),
+    # so that only the last chunk's share of it is left when FPS ends.  Its runner is built HERE, before the producer is
+    # launched: on the first call of a module it folds and packs the weights with torch ops on the main stream, and the
+    # consumer stream below is ordered after `start` only -- packed behind the FPS kernel, the weights reached the early
+    # chunks too late (the first pass of freshly built modules returned wrong features for all chunks but the last).
+    half = features.dtype == torch.float16
+    tail = _fused.tail_runner(layer.aggregation_layer, getattr(layer, "confidence_layers", None), out, half)
+    _fused._overflow_flag(dev)                           # (created on first use: also before `start`)
     start = torch.cuda.Event()
     start.record(main)
     _ext.fps_publish(xyz, temp, idx, progress)          # producer, on the main stream
     if after_producer is not None:
         after_producer()
-    # the aggregation / confidence tail runs chunk by chunk behind the grouped MLPs (its 16-point tiles are independent),
-    # so that only the last chunk's share of it is left when FPS ends
-    tail = _fused.tail_runner(layer.aggregation_layer, getattr(layer, "confidence_layers", None), out)
     for t in (xyz, features, idx, progress, timed_out, new_xyz, idx_a, idx_b, out) + (tail.tensors() if tail else ()):
         t.record_stream(side)
     ends = [M * e // 16 for e in _CHUNK_ENDS_16]
@@ -250,7 +255,7 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
     elif nxt is not None and _can_prefetch(layer, nxt):
         _prefetch_dfps(nxt, new_xyz, True)
     main.wait_event(done)
-    new_features, cls = tail.result() if tail is not None else layer._tail(out)
+    new_features, cls = tail.result() if tail is not None else layer._tail(out, half)
     if stds is not None:  # the layer's sampler thins the stability scores with its picks (reference :307-310)
         stds = pointnet2_utils.gather_operation(stds.view(B, 1, -1).contiguous(), idx).squeeze()
     return new_xyz, new_features, cls, idx, stds
