@@ -71,6 +71,10 @@ def parse():
     ap.add_argument("--pipelined", action="store_true",
                     help="also time the same passes with two batches in flight (informational object)")
     ap.add_argument("--no-pipelined", action="store_true", help=argparse.SUPPRESS)  # accepted for older command lines
+    ap.add_argument("--no-cu-fence", action="store_true", help="pipelined leg without the CU partition")
+    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight in the pipelined leg")
+    ap.add_argument("--cu-fence", action="store_true",
+                    help="also in the sequential steps: layer-0 FPS on compute units of its own (CuFence)")
     ap.add_argument("--cpu-scenes", type=int, default=8, help="scenes in the bounded CPU-baseline sample")
     args = ap.parse_args()
     if args.config == 5:
@@ -137,31 +141,32 @@ class MlpProbe:
         self.best = None
         fused.group_mlp_pool = self
 
-    def __call__(self, xyz, new_xyz, features, idx, packed, out, channel_offset, j0=0, jcount=None):
+    def __call__(self, xyz, new_xyz, features, idx, packed, out, channel_offset, j0=0, jcount=None, **kw):
         B, M, ns = idx.shape
         cols = B * (M if jcount is None else jcount) * ns
         flop = 2.0 * cols * (packed.cin * packed.c1 + packed.c1 * packed.c2 + packed.c2 * packed.c3_real)
         if self.best is None or flop > self.best[0]:
-            self.best = (flop, (xyz, new_xyz, features, idx, packed, out, channel_offset, j0, jcount))
-        return self.orig(xyz, new_xyz, features, idx, packed, out, channel_offset, j0, jcount)
+            self.best = (flop, (xyz, new_xyz, features, idx, packed, out, channel_offset, j0, jcount), kw)
+        return self.orig(xyz, new_xyz, features, idx, packed, out, channel_offset, j0, jcount, **kw)
 
     def measure(self, reps=20):
         if self.best is None:
             return None
-        flop, call = self.best
+        flop, call, kw = self.best
         for _ in range(3):
-            self.orig(*call)
+            self.orig(*call, **kw)
         pairs = []
         for _ in range(reps):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            self.orig(*call)
+            self.orig(*call, **kw)
             e.record()
             pairs.append((s, e))
         torch.cuda.synchronize()
         ms = [s.elapsed_time(e) for s, e in pairs]
         packed, idx = call[4], call[3]
         return {"flop": flop, "ms": float(np.median(ms)), "widths": (packed.cin, packed.c1, packed.c2, packed.c3_real),
+                "packed_columns": kw.get("columns") is not None,
                 "nsample": int(idx.shape[2]), "columns": int(flop / (2.0 * (packed.cin * packed.c1 + packed.c1 * packed.c2
                                                                            + packed.c2 * packed.c3_real)))}
 
@@ -288,6 +293,13 @@ def main():
         stds = torch.from_numpy(np.random.default_rng(99 + rank).uniform(0, 40, (args.batch, args.points))
                                 .astype(np.float32)).to(dev)
 
+    if args.cu_fence:
+        # CU-masked streams are blocking streams: they synchronise with the legacy default stream, so the steps must be
+        # issued on a stream of their own for the fenced FPS to run beside anything
+        own = torch.cuda.Stream(device=dev)
+        own.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(own)
+        sa_stack.enable_cu_fence(dev, scenes=args.batch)
     probe = FpsProbe(ext, args.points)
     mlp_probe = MlpProbe(fused)
 
@@ -365,9 +377,13 @@ def main():
     # streams -- layer-0 FPS keeps one CU per scene busy for most of a pass, so a second pass fits beside it.
     pipelined = None
     if world == 1 and args.pipelined and not args.no_pipelined:
-        pipelined = sa_stack.pipelined_bench(step, args.steps, dev) if hasattr(sa_stack, "pipelined_bench") else None
-        if pipelined is not None:
-            pipelined["value"] = args.batch * args.points * args.steps / pipelined.pop("elapsed_s")
+        pipelined = sa_stack.pipelined_bench(step, args.steps, dev, in_flight=args.in_flight, scenes=args.batch,
+                                             fenced=not args.no_cu_fence)
+        pipelined["value"] = args.batch * args.points * args.steps / pipelined.pop("elapsed_s")
+        same, where = same_outputs(pipelined.pop("last_outputs"), outs)
+        if not same or sa_stack.check_timeouts():
+            raise SystemExit(f"bench.py: the pipelined leg's outputs differ from the sequential steps' ({where})")
+        pipelined["validated"] = "last pass bit-identical to the sequential steps' outputs, no progress-wait timeout"
 
     if rank == 0:
         total_points = world * args.batch * args.points * args.steps
@@ -421,7 +437,7 @@ def main():
                 "bound": "mfma", "kernel": f"grouped MLP {mlp['widths'][0]}->{mlp['widths'][1]}->{mlp['widths'][2]}->"
                                            f"{mlp['widths'][3]}, nsample {mlp['nsample']}, {mlp['columns']} columns",
                 "achieved": ach_tf, "peak": peak, "unit": "TFLOP/s", "frac": ach_tf / peak, "launch_ms": mlp["ms"],
-                "flop": mlp["flop"],
+                "flop": mlp["flop"], "packed_columns": mlp["packed_columns"],
                 "mfma_busy_frac": None if busy is None else busy.get("mfma_busy_frac"),
                 "mfma_busy_source": src,
                 "note": "achieved = ALGORITHMIC flop 2*columns*sum(Cin*Cout) of the launch (padded duplicate columns "

@@ -233,6 +233,24 @@ int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int c_feat, int
                         const float *w3, const float *b3, float *out, int out_c_total, int out_c_off,
                         int split_fp16, int *overflow_flag, sps_stream_t stream);
 
+/* ---- packed columns: only the distinct neighbours of a ball go through the grouped MLP -------------------------------
+ * A ball-query row repeats its first hit in the slots it could not fill (ball_query_gpu.cu:35-42) and max-pooling is
+ * idempotent, so the repeated columns need not be computed: same pooled features bit for bit.  sps_pack_columns turns
+ * idx (b, m, nsample), centroids [j0, j0 + jcount) of every scene, into a stream of 16-column tiles (cols = point index,
+ * meta = centroid / scene / slot size per column, *ntiles = tiles written; the caller zeroes *ntiles and provides
+ * tile_cap >= sps_pack_columns_capacity(b, jcount, nsample) tiles of 16 ints each).  nsample <= 64, m < 2^20, b <= 256. */
+long long sps_pack_columns_capacity(int b, int jcount, int nsample);
+int sps_pack_columns(int b, int m, int j0, int jcount, int nsample, const int *idx, int *cols, unsigned *meta, int *ntiles,
+                     long long tile_cap, sps_stream_t stream);
+/* sps_sa_group_mlp_ex over either idx + range or (cols != NULL) a packed column stream; split_fp16 + 8: `out` is
+ * point-major (b, m, out_c_total).  With packed columns and nsample 64 `out` must be zero-filled as before. */
+int sps_sa_group_mlp_packed(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,
+                            const float *new_xyz, const float *features, const int *idx, const int *cols,
+                            const unsigned *meta, const int *ntiles, long long tile_cap, int c1, int c2, int c3,
+                            int c3_real, const float *w1, const float *b1, const float *w2, const float *b2,
+                            const float *w3, const float *b3, float *out, int out_c_total, int out_c_off,
+                            int split_fp16, int *overflow_flag, sps_stream_t stream);
+
 /* Aggregation stack (+ confidence head) of an SA layer as one kernel -- replaces, for inference with BatchNorm folded,
  * Conv1d+BN+ReLU (pointnet2_modules.py:213-228, 449-450) and Conv1d+BN+ReLU, Conv1d(bias) (:230-245, 454-455).
  * x (b, cin, m) -> y1 (b, c1, m) = relu(W1 x + b1); if w2 != NULL also y3 (b, m, classes) = W3 relu(W2 y1 + b2) + b3.

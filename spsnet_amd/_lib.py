@@ -84,6 +84,9 @@ _PROTOS = {
     "sps_linear_rows": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "sps_sa_group_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                             _vp, _vp, _i, _i, _i, _vp, _vp],
+    "sps_pack_columns": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _vp],
+    "sps_sa_group_mlp_packed": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _i,
+                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "sps_fps_publish": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_wait_progress": [_vp, _i, _i, _vp, _vp],
     "sps_gather_xyz_range": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
@@ -92,7 +95,8 @@ _PROTOS = {
                                _vp, _vp, _i, _i, _vp],
 }
 EXPORTS = ["sps_abi_version", "sps_last_error", "sps_opt_n_threads", "sps_fps_workspace_floats",
-           "sps_index_add_workspace_ints", "sps_ball_query_grid_workspace_ints", "sps_bn_train_workspace_doubles", "sps_conv1x1_wgrad_workspace_floats"] + list(_PROTOS)
+           "sps_index_add_workspace_ints", "sps_ball_query_grid_workspace_ints", "sps_bn_train_workspace_doubles", "sps_conv1x1_wgrad_workspace_floats",
+           "sps_pack_columns_capacity"] + list(_PROTOS)
 
 _lib = None
 
@@ -127,6 +131,8 @@ def load():
     lib.sps_conv1x1_wgrad_workspace_floats.argtypes = [_i, _i, _i, ctypes.c_longlong]
     lib.sps_conv1x1_wgrad_workspace_floats.restype = ctypes.c_longlong
     lib.sps_index_add_workspace_ints.argtypes = [_i, _i, _i]
+    lib.sps_pack_columns_capacity.argtypes = [_i, _i, _i]
+    lib.sps_pack_columns_capacity.restype = ctypes.c_longlong
     for name, args in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = _i

@@ -1,0 +1,119 @@
+// pack_columns.hip -- drop the padded columns of a ball query before the grouped MLP.
+//
+// A ball-query row holds the first `nsample` hits in index order and REPEATS the first hit in the slots it could not fill
+// (ball_query_gpu.cu:35-42); the reference then runs the shared MLP over all nsample columns and max-pools
+// (pointnet2_modules.py:429-447).  A repeated column reproduces the first column's activations bit for bit, and max is
+// idempotent, so only the distinct columns of a ball have to be computed.  On KITTI-shaped scenes a ball of the 16-sample
+// scales holds 3-6 distinct neighbours and 20-40 % of the 32-sample balls hold <= 16.
+//
+// This kernel turns idx (B, M, nsample) into a stream of 16-column MFMA tiles:
+//   * a centroid with cnt distinct columns gets a SLOT of 2^ceil(log2 cnt) columns, filled with its cnt columns and then
+//     with repeats of its first column (exactly what the reference's padding does, only less of it);
+//   * inside a window of 64 consecutive centroids the slots are laid out by decreasing size, so every slot is aligned to
+//     its own size: the max over a slot is then a PREFIX of the xor butterfly the kernels already use for pooling
+//     (steps 1, 2, 4, 8 with the lanes of smaller slots masked off) -- no segmented scan, no atomics;
+//   * slots of 32 (64) columns are whole pairs (quads) of tiles; a window's tail is padded to a multiple of 4 tiles with
+//     unused lanes (their columns repeat a valid point and are never written).
+// Every column carries a meta word: centroid j within its scene [19:0], scene [27:20], log2(slot) [30:28], unused [31].
+// Windows reserve their tiles with one atomic add, so the tile order across windows is arbitrary; results do not depend
+// on it (a column's activations do not depend on its neighbours in the tile).
+#include "sps_common.h"
+
+namespace sps {
+
+constexpr int PACK_WINDOW = 64;
+
+__global__ __launch_bounds__(256) void pack_columns_kernel(int m, int ns, int j0, int jcount, const int *__restrict__ idx,
+                                                           int *__restrict__ cols, unsigned *__restrict__ meta,
+                                                           int *__restrict__ ntiles, int tile_cap) {
+    extern __shared__ int s_idx[];   // [PACK_WINDOW][ns]
+    __shared__ int s_cnt[PACK_WINDOW], s_lg[PACK_WINDOW], s_pos[PACK_WINDOW];
+    __shared__ int s_total, s_base;
+    const int windows = (jcount + PACK_WINDOW - 1) / PACK_WINDOW;
+    const int scene = blockIdx.x / windows, w = blockIdx.x - scene * windows;
+    const int jw = j0 + w * PACK_WINDOW;                               // first centroid of the window
+    const int nw = min(PACK_WINDOW, j0 + jcount - jw);                 // centroids in it
+    const int t = threadIdx.x;
+    const int *rows = idx + ((size_t)scene * m + jw) * ns;
+    for (int e = t; e < nw * ns; e += blockDim.x) s_idx[e] = rows[e];
+    __syncthreads();
+    if (t < 64) {                                                      // wave 0: one lane per centroid of the window
+        int cnt = 0, lg = -1;
+        if (t < nw) {
+            const int *r = s_idx + t * ns;
+            const int first = r[0];
+            cnt = 1;
+            for (int s = ns - 1; s >= 1; --s)
+                if (r[s] != first) { cnt = s + 1; break; }              // real entries form a prefix; the rest repeats r[0]
+            lg = cnt <= 1 ? 0 : 32 - __builtin_clz(cnt - 1);
+        }
+        // slots by decreasing size: rank inside the class from a ballot, class bases from the class sizes
+        int pos = 0, running = 0;
+#pragma unroll
+        for (int cls = 6; cls >= 0; --cls) {
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(lg == cls);
+            if (lg == cls) pos = running + (__builtin_popcountll(mask & ((1ull << t) - 1ull)) << cls);
+            running += __builtin_popcountll(mask) << cls;
+        }
+        s_cnt[t] = cnt; s_lg[t] = lg; s_pos[t] = pos;
+        if (t == 0) {
+            const int tiles = ((running + 15) / 16 + 3) & ~3;
+            s_total = running;
+            s_base = atomicAdd(ntiles, tiles);
+        }
+    }
+    __syncthreads();
+    const int base_tile = s_base;
+    const int total = s_total;
+    const int tiles = ((total + 15) / 16 + 3) & ~3;
+    if (base_tile + tiles > tile_cap) return;                          // cannot happen with the documented capacity
+    int *oc = cols + (size_t)base_tile * 16;
+    unsigned *om = meta + (size_t)base_tile * 16;
+    {
+        const int cen = t & 63, part = t >> 6;                          // four threads share a slot
+        if (cen < nw) {
+            const int cnt = s_cnt[cen], lg = s_lg[cen], pos = s_pos[cen];
+            const unsigned word = (unsigned)(jw + cen) | ((unsigned)scene << 20) | ((unsigned)lg << 28);
+            const int *r = s_idx + cen * ns;
+            for (int s = part; s < (1 << lg); s += 4) {
+                oc[pos + s] = r[s < cnt ? s : 0];
+                om[pos + s] = word;
+            }
+        }
+    }
+    const unsigned idle = (unsigned)jw | ((unsigned)scene << 20) | 0x80000000u;
+    for (int e = total + t; e < tiles * 16; e += blockDim.x) {         // the window's tail: valid addresses, never written
+        oc[e] = s_idx[0];
+        om[e] = idle;
+    }
+}
+
+}  // namespace sps
+
+// Tiles needed in the worst case (no padded column anywhere) for b scenes x jcount centroids x nsample columns.
+extern "C" long long sps_pack_columns_capacity(int b, int jcount, int nsample) {
+    if (b <= 0 || jcount <= 0 || nsample <= 0) return 0;
+    const long long windows = (jcount + sps::PACK_WINDOW - 1) / sps::PACK_WINDOW;
+    int slot = 1;
+    while (slot < nsample) slot <<= 1;
+    const long long per_window = ((long long)sps::PACK_WINDOW * slot / 16 + 3) & ~3LL;
+    return (long long)b * windows * per_window;
+}
+
+// idx (b, m, nsample) rows of centroids [j0, j0 + jcount) of every scene -> cols / meta (tile_cap x 16 each) and the number
+// of tiles written (*ntiles, a multiple of 4; the caller zeroes it).  nsample <= 64, m < 2^20, b <= 256.
+extern "C" int sps_pack_columns(int b, int m, int j0, int jcount, int nsample, const int *idx, int *cols, unsigned *meta,
+                                int *ntiles, long long tile_cap, sps_stream_t stream) {
+    using namespace sps;
+    if (b < 0 || m <= 0 || j0 < 0 || jcount < 0 || j0 + jcount > m || nsample <= 0 || nsample > 64 || m >= (1 << 20) || b > 256)
+        return fail(SPS_ERR_INVALID, "pack_columns: bad shape (b=%d m=%d range [%d, +%d) nsample=%d)", b, m, j0, jcount, nsample);
+    if (b == 0 || jcount == 0) return SPS_OK;
+    if (!idx || !cols || !meta || !ntiles) return fail(SPS_ERR_INVALID, "pack_columns: null pointer");
+    if (tile_cap < sps_pack_columns_capacity(b, jcount, nsample) || tile_cap > 0x7FFFFFF)
+        return fail(SPS_ERR_INVALID, "pack_columns: tile capacity %lld, need %lld", tile_cap,
+                    sps_pack_columns_capacity(b, jcount, nsample));
+    const int windows = (jcount + PACK_WINDOW - 1) / PACK_WINDOW;
+    hipLaunchKernelGGL(pack_columns_kernel, dim3(b * windows), dim3(256), (size_t)PACK_WINDOW * nsample * sizeof(int),
+                       as_stream(stream), m, nsample, j0, jcount, idx, cols, meta, ntiles, (int)tile_cap);
+    return check_launch("pack_columns_kernel");
+}

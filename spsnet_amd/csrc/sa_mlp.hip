@@ -51,7 +51,7 @@ __device__ __forceinline__ f32x4 wload4(__amdgpu_buffer_rsrc_t r, int voff, int 
 
 // C1, C2: padded widths of layers 1 and 2 (multiples of 16).  NT: 16-column tiles per MFMA pass.
 // NS: nsample (16, 32 or 64), with 16*NT >= NS: a unit is 16*NT columns = 16*NT/NS whole centroids.
-template <int C1, int C2, int NT, int NS>
+template <int C1, int C2, int NT, int NS, bool PACKED>
 __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
     constexpr int T1 = C1 / 16, T2 = C2 / 16;
     constexpr int COLS = 16 * NT;
@@ -65,22 +65,29 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
 
-    for (int unit = wave; unit < a.units; unit += nwaves) {
+    constexpr bool packed = PACKED;   // a separate instantiation: the padded form keeps its register budget
+    const int nunits = packed ? (*a.ntiles) / NT : a.units;   // packed: as many units as pack_columns produced tiles for
+    for (int unit = wave; unit < nunits; unit += nwaves) {
         // first flattened (b, j, s) column of the unit: scene = unit / ups, centroids from j0 on
-        const int ub = unit / a.ups;
+        const int ub = packed ? 0 : unit / a.ups;
         const long long col0 = ((long long)ub * a.m + a.j0) * NS + (long long)(unit - ub * a.ups) * UNIT;
         f32x4 h2[T2][NT];
+        PackedUnit<NT> pu;
         {
             // column owned by this lane in tile nt
             int src[NT];
             long long bj[NT];
             int bb[NT];
+            if constexpr (packed) {
+                load_packed_unit<NT>(a, unit, c, src, bj, bb, pu);
+            } else {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const long long e = col0 + nt * 16 + c;
-                bj[nt] = e / NS;
-                bb[nt] = ub;  // a unit never straddles scenes
-                src[nt] = a.idx[e];
+                for (int nt = 0; nt < NT; ++nt) {
+                    const long long e = col0 + nt * 16 + c;
+                    bj[nt] = e / NS;
+                    bb[nt] = ub;  // a unit never straddles scenes
+                    src[nt] = a.idx[e];
+                }
             }
             // ---------------- layer 1: k-steps over the gathered channels (runtime count) ----------------
             f32x4 h1[T1][NT];
@@ -213,6 +220,10 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if constexpr (packed) {
+                    pool_write_packed<NT>(a, acc, pu, mt, q, c);
+                    continue;
+                }
                 f32x4 best[CPP];
 #pragma unroll
                 for (int cc = 0; cc < CPP; ++cc) best[cc] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -231,14 +242,14 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
                     if (c == 0) {
                         const long long cen = bj0 + cc;
                         const int b = ub, j = (int)(cen - (long long)ub * a.m);  // no 64-bit division: the unit lies inside scene ub
+                        // PART = a slice of the centroid's samples: combine with the other slices.  Pooled values are
+                        // >= 0 after the ReLU, so their bit patterns order like ints and the caller's zero fill is the
+                        // identity (sps_sa_group_mlp_ex requires a zeroed `out` for nsample 64)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int row = 16 * mt + 4 * q + r;
                             if (row < a.c3_real) {
                                 float *dst = a.out + ((size_t)b * a.out_c_total + a.out_c_off + row) * a.m + j;
-                                // a slice of the centroid's samples: combine with the other slices.  Pooled values are
-                                // >= 0 after the ReLU, so their bit patterns order like ints and the caller's zero
-                                // fill is the identity (sps_sa_group_mlp_ex requires a zeroed `out` for nsample 64)
                                 if constexpr (PART) atomicMax(reinterpret_cast<int *>(dst), __float_as_int(v[r]));
                                 else *dst = v[r];
                             }
@@ -254,16 +265,22 @@ template <int C1, int C2, int NT, int NS>
 static int launch_variant(const SaMlpArgs &a, hipStream_t st) {
     constexpr int UNIT = 16 * NT;
     SaMlpArgs k = a;
-    const long long cols_scene = (long long)a.ups * NS;  // caller passes centroids per scene in `ups`, scenes in `units`
-    if (cols_scene % UNIT != 0)
-        return fail(SPS_ERR_INVALID, "sa_group_mlp: centroids*nsample per scene (%lld) not a multiple of %d", cols_scene, UNIT);
-    k.ups = (int)(cols_scene / UNIT);
-    k.units = a.units * k.ups;
+    if (a.cols) {                      // packed columns: `units` = tile capacity on entry; the kernel reads the real count
+        k.ups = 1;
+        k.units = a.units / NT;
+    } else {
+        const long long cols_scene = (long long)a.ups * NS;  // caller passes centroids per scene in `ups`, scenes in `units`
+        if (cols_scene % UNIT != 0)
+            return fail(SPS_ERR_INVALID, "sa_group_mlp: centroids*nsample per scene (%lld) not a multiple of %d", cols_scene, UNIT);
+        k.ups = (int)(cols_scene / UNIT);
+        k.units = a.units * k.ups;
+    }
     const int waves_per_block = 4;
     int blocks = divup(k.units, waves_per_block);
     const int max_blocks = 256 * 8;
     if (blocks > max_blocks) blocks = max_blocks;
-    hipLaunchKernelGGL((sa_group_mlp_kernel<C1, C2, NT, NS>), dim3(blocks), dim3(64 * waves_per_block), 0, st, k);
+    if (a.cols) hipLaunchKernelGGL((sa_group_mlp_kernel<C1, C2, NT, NS, true>), dim3(blocks), dim3(64 * waves_per_block), 0, st, k);
+    else hipLaunchKernelGGL((sa_group_mlp_kernel<C1, C2, NT, NS, false>), dim3(blocks), dim3(64 * waves_per_block), 0, st, k);
     return check_launch("sa_group_mlp_kernel");
 }
 
@@ -304,20 +321,44 @@ extern "C" int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int 
                                    int c3, int c3_real, const float *w1, const float *b1, const float *w2,
                                    const float *b2, const float *w3, const float *b3, float *out, int out_c_total,
                                    int out_c_off, int split_fp16, int *overflow_flag, sps_stream_t stream) {
+    return sps_sa_group_mlp_packed(b, n, m, j0, jcount, c_feat, nsample, xyz, new_xyz, features, idx, nullptr, nullptr, nullptr,
+                                   0, c1, c2, c3, c3_real, w1, b1, w2, b2, w3, b3, out, out_c_total, out_c_off, split_fp16,
+                                   overflow_flag, stream);
+}
+
+// The general entry point.  Either idx (b, m, nsample) and the centroid range [j0, j0 + jcount), or -- cols != NULL -- the
+// packed column stream of sps_pack_columns (cols / meta / *ntiles on the device, tile_cap = the capacity the pack call was
+// given; idx, j0 and jcount are then ignored).  mode = the split_fp16 word of sps_sa_group_mlp_ex, + 8: `out` is point-major
+// (b, m, out_c_total) instead of (b, out_c_total, m).  Packed columns are served by modes 0, 1 and 3.
+extern "C" int sps_sa_group_mlp_packed(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,
+                                       const float *new_xyz, const float *features, const int *idx, const int *cols,
+                                       const unsigned *meta, const int *ntiles, long long tile_cap, int c1, int c2, int c3,
+                                       int c3_real, const float *w1, const float *b1, const float *w2, const float *b2,
+                                       const float *w3, const float *b3, float *out, int out_c_total, int out_c_off,
+                                       int split_fp16, int *overflow_flag, sps_stream_t stream) {
     using namespace sps;
     if (b < 0 || n <= 0 || m < 0 || c_feat < 0 || nsample <= 0 || c3 <= 0 || (c3 % 16) || c3_real > c3 ||
         out_c_off < 0 || out_c_off + c3_real > out_c_total || j0 < 0 || jcount < 0 || j0 + jcount > m)
         return fail(SPS_ERR_INVALID, "sa_group_mlp: bad shape");
-    if (b == 0 || jcount == 0) return SPS_OK;
-    if (!xyz || !new_xyz || !idx || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !out || (c_feat > 0 && !features))
+    if (b == 0 || (jcount == 0 && !cols)) return SPS_OK;
+    if (!xyz || !new_xyz || (!idx && !cols) || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !out || (c_feat > 0 && !features))
         return fail(SPS_ERR_INVALID, "sa_group_mlp: null pointer");
-    const long long cols = (long long)b * m * nsample;
-    if (cols > 0x7FFFFFFFLL) return fail(SPS_ERR_INVALID, "sa_group_mlp: too many grouped points");
+    if (cols && (!meta || !ntiles || tile_cap <= 0 || tile_cap > 0x7FFFFFF || (tile_cap & 3) || m >= (1 << 20) || b > 256))
+        return fail(SPS_ERR_INVALID, "sa_group_mlp: packed columns need meta, ntiles, a tile capacity that is a multiple of 4, "
+                                     "m < 2^20 and b <= 256");
+    if ((split_fp16 & 8) && !cols && (split_fp16 & 3) != 2)
+        return fail(SPS_ERR_INVALID, "sa_group_mlp: a point-major `out` is served by the packed-column and shared-stream kernels");
+    if (cols && (split_fp16 & 3) == 2)
+        return fail(SPS_ERR_INVALID, "sa_group_mlp: the shared-stream kernel (mode 2) does not take packed columns");
+    const long long cols_total = (long long)b * m * nsample;
+    if (cols_total > 0x7FFFFFFFLL) return fail(SPS_ERR_INVALID, "sa_group_mlp: too many grouped points");
     SaMlpArgs a;
     a.n = n; a.m = m; a.c_feat = c_feat;
-    a.units = b;       // scenes (launch_variant turns this into the total unit count)
+    a.units = cols ? (int)tile_cap : b;   // scenes (launch_variant turns this into the total unit count) / tile capacity
     a.ups = jcount;    // centroids per scene in the range (launch_variant turns this into units per scene)
     a.j0 = j0;
+    a.cols = cols; a.meta = meta; a.ntiles = ntiles;
+    a.out_pm = (split_fp16 & 8) ? 1 : 0;
     a.ks1 = (3 + c_feat + 3) / 4;
     a.c3 = c3; a.c3_real = c3_real; a.out_c_total = out_c_total; a.out_c_off = out_c_off;
     a.xyz = xyz; a.new_xyz = new_xyz; a.feat = features; a.idx = idx;

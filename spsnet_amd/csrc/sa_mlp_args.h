@@ -18,6 +18,12 @@ struct SaMlpArgs {
     int feat_pm;                   // 1: `feat` is point-major (B, N, c_feat) and layer 1's channel order is [features, xyz]
                                    // (mode 3, pure fp16: `feat` points at halves)
     int *overflow;                 // split-fp16 kernel: set to 1 if an operand exceeded the exactly splittable range
+    // Packed columns (pack_columns.hip): when `cols` is set, `idx` / j0 / ups are ignored, a unit is UNIT consecutive
+    // entries of cols / meta and the number of units is *ntiles / (UNIT / 16), read on the device.
+    const int *cols;
+    const unsigned *meta;
+    const int *ntiles;
+    int out_pm;                    // 1: `out` is point-major (B, M, out_c_total): a centroid's pooled rows are contiguous
 };
 
 
@@ -40,7 +46,114 @@ __device__ __forceinline__ sps_f32x4 row_allmax4(sps_f32x4 v) {
 #undef SPS_DPP_MAX4
     return (sps_f32x4){a, b, c, d};
 }
-#endif
+
+// ---- packed-column epilogue shared by the per-wave kernels (sa_mlp.hip, sa_mlp_f16.hip) ------------------------------------
+// meta word of a column: centroid j within its scene [19:0], scene [27:20], log2(slot) [30:28], unused [31].  A unit keeps
+// only these words (one VGPR per tile) across the three layers; everything else is decoded where it is used.
+template <int NT>
+struct PackedUnit {
+    unsigned w[NT];
+};
+
+template <int NT>
+__device__ __forceinline__ void load_packed_unit(const SaMlpArgs &a, int unit, int c, int (&src)[NT], long long (&bj)[NT],
+                                                 int (&bb)[NT], PackedUnit<NT> &pu) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const size_t e = (size_t)unit * (16 * NT) + nt * 16 + c;
+        src[nt] = a.cols[e];
+        pu.w[nt] = a.meta[e];
+        // a unit never straddles windows (pack_columns pads a window to whole groups of four tiles), hence never scenes:
+        // the scene stays wave-uniform, and with it the gathers' address arithmetic stays on the scalar unit
+        bb[nt] = __builtin_amdgcn_readfirstlane((int)((pu.w[nt] >> 20) & 0xFFu));
+        bj[nt] = (long long)bb[nt] * a.m + (int)(pu.w[nt] & 0xFFFFFu);
+    }
+}
+
+// row_allmax4 restricted to each lane's slot of 2^lg columns: step s of the xor butterfly runs only in the lanes with
+// lg > s (EXEC masked; the mask comes from one v_cmp per step); their partners lie in the same aligned slot, hence are
+// enabled too.  Afterwards every lane of a slot holds the slot's maximum.
+__device__ __forceinline__ sps_f32x4 slot_allmax4(sps_f32x4 v, unsigned lg) {
+    float a = v[0], b = v[1], c = v[2], d = v[3];
+    unsigned long long saved, mask;
+#define SPS_DPP_MAX4(CTRL)                                                    \
+    "v_max_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n"           \
+    "v_max_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n"           \
+    "v_max_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n"           \
+    "v_max_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n"
+#define SPS_SLOT_STEP(S, CTRL)                                                \
+    "v_cmp_lt_u32_e64 %5, " S ", %6\n"                                        \
+    "s_and_saveexec_b64 %4, %5\n"                                             \
+    "s_nop 4\n" SPS_DPP_MAX4(CTRL)                                            \
+    "s_mov_b64 exec, %4\n"
+    asm volatile(SPS_SLOT_STEP("0", "quad_perm:[1,0,3,2]") SPS_SLOT_STEP("1", "quad_perm:[2,3,0,1]")
+                 SPS_SLOT_STEP("2", "row_half_mirror") SPS_SLOT_STEP("3", "row_mirror")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&s"(saved), "=&s"(mask)
+                 : "v"(lg)
+                 : "scc");
+#undef SPS_SLOT_STEP
+#undef SPS_DPP_MAX4
+    return (sps_f32x4){a, b, c, d};
+}
+
+// rows 16 mt + 4 q .. + 3 of centroid (b, j): plain stores, or an atomic max of the (non-negative) values onto zeros
+// PM: the instantiation honours a point-major `out` (the packed kernels; the padded per-wave kernels keep the reference
+// layout only, and with it their register budget)
+template <bool PM>
+__device__ __forceinline__ void store_pooled_rows(const SaMlpArgs &a, int b, int j, int mt, int q, const float (&v)[4], bool atomic) {
+    const int row0 = 16 * mt + 4 * q;
+    if (PM && a.out_pm) {
+        float *dst = a.out + ((size_t)b * a.m + j) * a.out_c_total + a.out_c_off + row0;
+        if (!atomic && row0 + 3 < a.c3_real && ((a.out_c_total | a.out_c_off) & 3) == 0) {
+            *reinterpret_cast<sps_f32x4 *>(dst) = (sps_f32x4){v[0], v[1], v[2], v[3]};
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (row0 + r < a.c3_real) {
+                if (atomic) atomicMax(reinterpret_cast<int *>(dst + r), __float_as_int(v[r]));
+                else dst[r] = v[r];
+            }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (row0 + r < a.c3_real) {
+            float *dst = a.out + ((size_t)b * a.out_c_total + a.out_c_off + row0 + r) * a.m + j;
+            if (atomic) atomicMax(reinterpret_cast<int *>(dst), __float_as_int(v[r]));
+            else *dst = v[r];
+        }
+}
+
+// Pool one 16-row output tile of a PACKED unit over each centroid's slot, ReLU, write.
+template <int NT>
+__device__ __forceinline__ void pool_write_packed(const SaMlpArgs &a, const sps_f32x4 (&acc)[NT], const PackedUnit<NT> &pu,
+                                                  int mt, int q, int c) {
+    const int lg0 = __builtin_amdgcn_readfirstlane((int)((pu.w[0] >> 28) & 7u));
+    const int scene = __builtin_amdgcn_readfirstlane((int)((pu.w[0] >> 20) & 0xFFu));
+    if (lg0 >= 5) {   // the whole unit is (part of) ONE centroid's slot of 32 or 64 columns
+        sps_f32x4 best = acc[0];
+#pragma unroll
+        for (int nt = 1; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) best[r] = fmaxf(best[r], acc[nt][r]);
+        const sps_f32x4 p = row_allmax4(best);
+        const float v[4] = {fmaxf(p[0], 0.f), fmaxf(p[1], 0.f), fmaxf(p[2], 0.f), fmaxf(p[3], 0.f)};
+        // 64 columns = two units: they meet through an atomic max on the zero-filled `out` (values >= 0 order like ints)
+        if (c == 0) store_pooled_rows<true>(a, scene, (int)(pu.w[0] & 0xFFFFFu), mt, q, v, lg0 >= 6);
+        return;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const unsigned w = pu.w[nt], lg = (w >> 28) & 7u;
+        const sps_f32x4 p = slot_allmax4(acc[nt], lg);
+        const float v[4] = {fmaxf(p[0], 0.f), fmaxf(p[1], 0.f), fmaxf(p[2], 0.f), fmaxf(p[3], 0.f)};
+        const bool writer = (w >> 31) == 0u && (c & ((1 << lg) - 1)) == 0;   // first lane of a slot, never an unused lane
+        if (writer) store_pooled_rows<true>(a, scene, (int)(w & 0xFFFFFu), mt, q, v, false);
+    }
+}
+
+#endif  // __HIPCC__
 
 extern int g_mlp_f16;
 // sa_mlp_f16.hip: split-fp16 variant; same argument block (units = scenes, ups = centroids per scene on entry)

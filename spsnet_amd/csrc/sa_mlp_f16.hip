@@ -91,7 +91,7 @@ __device__ __forceinline__ void mac3(const WFrag &w, const h8 (&xh)[NT], const h
 // a.ks1 = layer-1 k-steps of 32 grouped channels = ceil((3 + c_feat) / 32)
 // PURE: the feature tensor holds halves (fp16 features in HBM, BASELINE configs[4]) and every operand is ONE half -- one MFMA
 // per product block instead of three; coordinates are still differenced in fp32 and rounded once.
-template <int C1, int C2, int NT, int NS, bool WLDS, bool PURE>
+template <int C1, int C2, int NT, int NS, bool WLDS, bool PURE, bool PACKED>
 __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
     constexpr int FRAG = frag_bytes<PURE>();
     const _Float16 *feat_h = reinterpret_cast<const _Float16 *>(a.feat);
@@ -129,20 +129,27 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
         }
     }
     float mx = 0.f;  // largest operand magnitude this lane has split
-    for (int unit = wave; unit < a.units; unit += nwaves) {
-        const int ub = unit / a.ups;
+    constexpr bool packed = PACKED;   // a separate instantiation: the padded form keeps its register budget
+    const int nunits = packed ? (*a.ntiles) / NT : a.units;   // packed: as many units as pack_columns produced tiles for
+    for (int unit = wave; unit < nunits; unit += nwaves) {
+        const int ub = packed ? 0 : unit / a.ups;
         const long long col0 = ((long long)ub * a.m + a.j0) * NS + (long long)(unit - ub * a.ups) * UNIT;
         h8 h2hi[S2][NT], h2lo[S2][NT];
+        PackedUnit<NT> pu;
         {
             int src[NT];
             long long bj[NT];
             int bb[NT];
+            if constexpr (packed) {
+                load_packed_unit<NT>(a, unit, c, src, bj, bb, pu);
+            } else {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const long long e = col0 + nt * 16 + c;
-                bj[nt] = e / NS;
-                bb[nt] = ub;  // a unit never straddles scenes
-                src[nt] = a.idx[e];
+                for (int nt = 0; nt < NT; ++nt) {
+                    const long long e = col0 + nt * 16 + c;
+                    bj[nt] = e / NS;
+                    bb[nt] = ub;  // a unit never straddles scenes
+                    src[nt] = a.idx[e];
+                }
             }
             // ---------------- layer 1: k-steps of 32 gathered channels ----------------
             f32x4 acc1[T1][NT];
@@ -302,6 +309,10 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
                     for (int u = 0; u < KCH; ++u) mac3<NT, PURE>(w[ch & 1][u], h2hi[ch * KCH + u], h2lo[ch * KCH + u], acc);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if constexpr (packed) {
+                    pool_write_packed<NT>(a, acc, pu, mt, q, c);
+                    continue;
+                }
                 f32x4 best[CPP];
 #pragma unroll
                 for (int cc = 0; cc < CPP; ++cc) best[cc] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -320,13 +331,13 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
                     if (c == 0) {
                         const long long cen = bj0 + cc;
                         const int b = ub, j = (int)(cen - (long long)ub * a.m);  // no 64-bit division: the unit lies inside scene ub
+                        // PART = a slice of the centroid's samples: combine with the other slices (values >= 0 after the
+                        // ReLU order like ints; the caller zero-fills `out` for nsample 64)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int row = 16 * mt + 4 * q + r;
                             if (row < a.c3_real) {
                                 float *dst = a.out + ((size_t)b * a.out_c_total + a.out_c_off + row) * a.m + j;
-                                // a slice of the centroid's samples: combine with the other slices (values >= 0 after
-                                // the ReLU order like ints; the caller zero-fills `out` for nsample 64)
                                 if constexpr (PART) atomicMax(reinterpret_cast<int *>(dst), __float_as_int(v[r]));
                                 else *dst = v[r];
                             }
@@ -344,28 +355,42 @@ static int launch_f16_variant(const SaMlpArgs &a, hipStream_t st) {
     constexpr int UNIT = 16 * NT;
     constexpr int FRAG = frag_bytes<PURE>();
     SaMlpArgs k = a;
-    const long long cols_scene = (long long)a.ups * NS;
-    if (cols_scene % UNIT != 0)
-        return fail(SPS_ERR_INVALID, "sa_group_mlp(f16): centroids*nsample per scene (%lld) not a multiple of %d", cols_scene, UNIT);
-    k.ups = (int)(cols_scene / UNIT);
-    k.units = a.units * k.ups;
+    if (a.cols) {                      // packed columns: `units` = tile capacity on entry; the kernel reads the real count
+        k.ups = 1;
+        k.units = a.units / NT;
+    } else {
+        const long long cols_scene = (long long)a.ups * NS;
+        if (cols_scene % UNIT != 0)
+            return fail(SPS_ERR_INVALID, "sa_group_mlp(f16): centroids*nsample per scene (%lld) not a multiple of %d", cols_scene, UNIT);
+        k.ups = (int)(cols_scene / UNIT);
+        k.units = a.units * k.ups;
+    }
     k.ks1 = (3 + a.c_feat + 31) / 32;
     // all three layers' fragments in LDS when they fit beside nothing else (one workgroup of 8 waves per CU) and the
     // launch is big enough to amortise the copy
     const size_t wbytes = (size_t)FRAG * ((size_t)(C1 / 16) * k.ks1 + (size_t)(C2 / 16) * (C1 / 32) + (size_t)(a.c3 / 16) * (C2 / 32));
     if (C1 >= 64 && wbytes <= 128 * 1024 && k.units >= 2048) {  // (the 32-wide scale is faster streaming: measured)
-        static LdsLimitOnce raised;  // one per instantiation
-        const int rc = raise_lds_limit((const void *)sa_group_mlp_f16_kernel<C1, C2, NT, NS, true, PURE>, 128 * 1024, raised,
-                                       "sa_group_mlp(f16)");
-        if (rc != SPS_OK) return rc;
         int blocks = divup(k.units, 8);
         if (blocks > 256) blocks = 256;
-        hipLaunchKernelGGL((sa_group_mlp_f16_kernel<C1, C2, NT, NS, true, PURE>), dim3(blocks), dim3(512), wbytes, st, k);
+        if (a.cols) {
+            static LdsLimitOnce raised;  // one per instantiation
+            const int rc = raise_lds_limit((const void *)sa_group_mlp_f16_kernel<C1, C2, NT, NS, true, PURE, true>, 128 * 1024,
+                                           raised, "sa_group_mlp(f16)");
+            if (rc != SPS_OK) return rc;
+            hipLaunchKernelGGL((sa_group_mlp_f16_kernel<C1, C2, NT, NS, true, PURE, true>), dim3(blocks), dim3(512), wbytes, st, k);
+        } else {
+            static LdsLimitOnce raised;
+            const int rc = raise_lds_limit((const void *)sa_group_mlp_f16_kernel<C1, C2, NT, NS, true, PURE, false>, 128 * 1024,
+                                           raised, "sa_group_mlp(f16)");
+            if (rc != SPS_OK) return rc;
+            hipLaunchKernelGGL((sa_group_mlp_f16_kernel<C1, C2, NT, NS, true, PURE, false>), dim3(blocks), dim3(512), wbytes, st, k);
+        }
         return check_launch("sa_group_mlp_f16_kernel<lds weights>");
     }
     int blocks = divup(k.units, 4);
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL((sa_group_mlp_f16_kernel<C1, C2, NT, NS, false, PURE>), dim3(blocks), dim3(256), 0, st, k);
+    if (a.cols) hipLaunchKernelGGL((sa_group_mlp_f16_kernel<C1, C2, NT, NS, false, PURE, true>), dim3(blocks), dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((sa_group_mlp_f16_kernel<C1, C2, NT, NS, false, PURE, false>), dim3(blocks), dim3(256), 0, st, k);
     return check_launch("sa_group_mlp_f16_kernel");
 }
 

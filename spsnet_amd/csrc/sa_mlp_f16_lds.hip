@@ -344,7 +344,8 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa
                 float v = my_stage[(size_t)cc * C3 + row];
 #pragma unroll
                 for (int o = 1; o < SPLIT; ++o) v = fmaxf(v, my_stage[(size_t)(o * CPP + cc) * C3 + row]);
-                a.out[((size_t)b * a.out_c_total + a.out_c_off + row) * a.m + j] = v;
+                if (a.out_pm) a.out[((size_t)b * a.m + j) * a.out_c_total + a.out_c_off + row] = v;   // lanes <-> rows: contiguous
+                else a.out[((size_t)b * a.out_c_total + a.out_c_off + row) * a.m + j] = v;
             }
         }
         if constexpr (SPLIT > 1) {  // the partner's stage is read above: nobody may overwrite it before everybody is here

@@ -243,6 +243,64 @@ def point_major_twin(features):
     return t
 
 
+# Only the DISTINCT columns of a ball go through the grouped MLP (csrc/pack_columns.hip): a ball-query row repeats its first
+# hit in the slots it could not fill and max-pooling is idempotent, so the pooled features are the same bit for bit.  Applied
+# to whole-layer launches of at least this many columns (the pack kernel is one more launch); the shared-stream kernel
+# (mode 2) keeps the padded form.
+# PACK_COLUMNS: False (default) = never, True = launches of many wave rounds, "always" = wherever the kernels allow it.
+# OFF by default, because on MI355X it does not pay at IA-SSD's sizes (profiles/round2, 8 x 16 384 KITTI-shaped scenes,
+# un-profiled HIP-event times): a whole-layer launch of layers 1-2 is ONE to FOUR rounds of waves, so its time is set by
+# a unit's latency and the round count, not by the number of units -- 0.87 x the columns of the 131-128-256-256 scale are
+# still four rounds (0.318 ms padded, 0.321 ms packed, fp32), and the 6-10 us pack launch is on the critical path; the
+# generator's M = N layer (many rounds, but VALU-bound narrow widths) lost 0.87 -> 0.91 ms to the packed kernels' larger
+# register footprint.  Kept as a tested option (bit-identical results) for shapes with many rounds of wide units.
+PACK_COLUMNS = {"1": True, "2": "always"}.get(__import__("os").environ.get("SPS_PACK_COLUMNS", "0"), False)
+PACK_MIN_COLUMNS = 1 << 15
+PACK_BIG_COLUMNS = 1 << 20
+_COUNTERS = {}
+
+
+def _zero_counter(device):
+    """A zeroed int32 on the device without a fill launch per use: slices of a pre-zeroed buffer, refilled every 256 uses."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf, used = _COUNTERS.get(key, (None, 256))
+    if used >= 256:
+        buf, used = torch.zeros((256,), dtype=torch.int32, device=device), 0
+    _COUNTERS[key] = (buf, used + 1)
+    return buf[used:used + 1]
+
+
+class PackedColumns:
+    __slots__ = ("cols", "meta", "ntiles", "cap")
+
+
+def pack_columns(idx, j0=0, jcount=None):
+    """idx (B, M, nsample) int32 -> PackedColumns: the tile stream of csrc/pack_columns.hip for centroids [j0, j0 + jcount)
+    of every scene (one launch; the tile count stays on the device)."""
+    B, M, ns = idx.shape
+    jcount = M - j0 if jcount is None else jcount
+    p = PackedColumns()
+    p.cap = int(_L.sps_pack_columns_capacity(B, jcount, ns))
+    p.cols = torch.empty((p.cap * 16,), dtype=torch.int32, device=idx.device)
+    p.meta = torch.empty((p.cap * 16,), dtype=torch.int32, device=idx.device)
+    p.ntiles = _zero_counter(idx.device)
+    _lib.check(_L.sps_pack_columns(B, M, j0, jcount, ns, idx.data_ptr(), p.cols.data_ptr(), p.meta.data_ptr(),
+                                   p.ntiles.data_ptr(), p.cap, torch.cuda.current_stream(idx.device).cuda_stream), "pack_columns")
+    return p
+
+
+def want_packed(idx_shape, packed):
+    """Pack a launch over idx of this (B, M, nsample) shape?  Whole-layer launches of the per-wave kernels where dropping
+    the padded columns was measured to pay for the extra launch (see PACK_COLUMNS)."""
+    B, M, ns = idx_shape
+    cols = B * M * ns
+    if not PACK_COLUMNS or packed.split == 2 or ns > 64 or B > 256 or M >= (1 << 20) or cols < PACK_MIN_COLUMNS:
+        return False
+    if PACK_COLUMNS == "always":
+        return True
+    return cols >= PACK_BIG_COLUMNS or (packed.split == 0 and packed.c1 >= 128)
+
+
 def attach_point_major_twin(features):
     """Give a (B, C, N) feature tensor that did not come from pointwise_tail its (B, N, C) twin, so that the next SA
     layer's grouped MLP takes the point-major gather path it takes inside a stack; returns `features`."""
@@ -251,10 +309,13 @@ def attach_point_major_twin(features):
     return features
 
 
-def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=0, jcount=None):
+def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=0, jcount=None, columns=None,
+                   out_point_major=False):
     """One launch: gather the nsample neighbours in `idx` (B,M,ns), run the packed 3-layer MLP, max-pool,
-    and write channels [channel_offset, channel_offset + c3_real) of out (B, Ctot, M); optionally only for the
-    centroids [j0, j0+jcount) of every scene.  A scale packed with point_major reads the features' (B, N, C) twin."""
+    and write channels [channel_offset, channel_offset + c3_real) of out (B, Ctot, M) -- or (B, M, Ctot) with
+    out_point_major; optionally only for the centroids [j0, j0+jcount) of every scene.  A scale packed with point_major
+    reads the features' (B, N, C) twin.  columns: a PackedColumns of `idx` (pack_columns): only the distinct neighbours of
+    every ball are computed, same result."""
     B, N, _ = xyz.shape
     M, ns = idx.shape[1], idx.shape[2]
     jcount = M if jcount is None else jcount
@@ -266,16 +327,21 @@ def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=
             raise ValueError("scale packed for point-major features, but the feature tensor carries no (B, N, C) twin")
         features = twin
         mode |= 4
+    if out_point_major:
+        mode |= 8
     if 3 + c_feat != packed.cin:
         raise ValueError(f"grouped input has {3 + c_feat} channels, the MLP expects {packed.cin}")
     if features is not None and (features.dtype == torch.float16) != bool(packed.half):
         raise ValueError(f"feature tensor is {features.dtype}, but the scale was packed for {'fp16' if packed.half else 'fp32'}")
+    c_total = out.shape[2] if out_point_major else out.shape[1]
     stream = torch.cuda.current_stream(xyz.device).cuda_stream
-    _lib.check(_L.sps_sa_group_mlp_ex(
+    cp = (0, 0, 0, 0) if columns is None else (columns.cols.data_ptr(), columns.meta.data_ptr(), columns.ntiles.data_ptr(),
+                                               columns.cap)
+    _lib.check(_L.sps_sa_group_mlp_packed(
         B, N, M, j0, jcount, c_feat, ns, xyz.data_ptr(), new_xyz.data_ptr(), 0 if features is None else features.data_ptr(),
-        idx.data_ptr(), packed.c1, packed.c2, packed.c3, packed.c3_real, packed.w1.data_ptr(), packed.b1.data_ptr(),
-        packed.w2.data_ptr(), packed.b2.data_ptr(), packed.w3.data_ptr(), packed.b3.data_ptr(), out.data_ptr(),
-        out.shape[1], channel_offset, mode,
+        idx.data_ptr(), cp[0], cp[1], cp[2], cp[3], packed.c1, packed.c2, packed.c3, packed.c3_real, packed.w1.data_ptr(),
+        packed.b1.data_ptr(), packed.w2.data_ptr(), packed.b2.data_ptr(), packed.w3.data_ptr(), packed.b3.data_ptr(),
+        out.data_ptr(), c_total, channel_offset, mode,
         _overflow_flag(xyz.device).data_ptr() if packed.split else 0, stream), "sa_group_mlp")
 
 
@@ -319,8 +385,9 @@ class TailRunner:
     """The aggregation stack (+ confidence head) of an SA layer on `pooled` (B, C, M), launched for the whole layer or
     range by range (`run(j0, jcount)`, on torch's current stream); `result()` -> (new_features (B, Cagg, M), cls | None)."""
 
-    def __init__(self, packed, pooled, with_head, half_out=False):
-        B, _, M = pooled.shape
+    def __init__(self, packed, pooled, with_head, half_out=False, x_pm=False):
+        B, M = pooled.shape[0], (pooled.shape[1] if x_pm else pooled.shape[2])
+        self.x_pm = bool(x_pm)           # pooled is point-major (B, M, C): what the grouped-MLP kernels write contiguously
         dev = pooled.device
         self.packed, self.x, self.B, self.M = packed, pooled, B, M
         self.half_out = bool(half_out)   # features leave as fp16 (BASELINE configs[4]); the class scores stay fp32
@@ -338,7 +405,7 @@ class TailRunner:
         _lib.check(_L.sps_pointwise_mlp_ex(self.B, self.M, j0, self.M - j0 if jcount is None else jcount, p.cin, p.c1, p.c2,
                                            p.classes, self.x.data_ptr(), ptr(p.w1), ptr(p.b1), ptr(p.w2), ptr(p.b2),
                                            ptr(p.w3), ptr(p.b3), self.y1.data_ptr(), self.y1t.data_ptr(), ptr(self.y3),
-                                           1 if self.half_out else 0,
+                                           (1 if self.half_out else 0) | (2 if self.x_pm else 0),
                                            torch.cuda.current_stream(self.x.device).cuda_stream), "pointwise_mlp")
 
     def result(self):
@@ -346,7 +413,7 @@ class TailRunner:
         return self.y1, self.y3
 
 
-def tail_runner(agg, head, pooled, half_out=False):
+def tail_runner(agg, head, pooled, half_out=False, x_pm=False):
     """-> TailRunner, or None when the fused path does not apply (training, gradients wanted, widths that are not
     multiples of 16, more than 16 classes, ...).  `pooled` must be contiguous and may still be being filled."""
     if agg is None or agg.training or (head is not None and head.training) or not pooled.is_cuda or pooled.dtype != torch.float32:
@@ -357,7 +424,7 @@ def tail_runner(agg, head, pooled, half_out=False):
     if layers is None or not pooled.is_contiguous():
         return None
     (c_agg, bn_agg) = layers[0]
-    B, cin, M = pooled.shape
+    B, cin, M = (pooled.shape[0], pooled.shape[2], pooled.shape[1]) if x_pm else pooled.shape
     c1 = c_agg.out_channels
     if cin != c_agg.in_channels or cin % 16 or c1 % 16 or M % 16:
         return None
@@ -389,13 +456,13 @@ def tail_runner(agg, head, pooled, half_out=False):
                 b3 = c_out.bias.detach().float() if c_out.bias is not None else w3.new_zeros(classes)
                 packed.w3, packed.b3 = _pack_pw(w3, 16), _pad_bias(b3, 16)
         object.__setattr__(agg, "_sps_tail", packed)
-    return TailRunner(packed, pooled, head is not None, half_out)
+    return TailRunner(packed, pooled, head is not None, half_out, x_pm)
 
 
-def pointwise_tail(agg, head, pooled, half_out=False):
-    """Aggregation stack (+ confidence head) of an SA layer on `pooled` (B, C, M) as one kernel ->
+def pointwise_tail(agg, head, pooled, half_out=False, x_pm=False):
+    """Aggregation stack (+ confidence head) of an SA layer on `pooled` (B, C, M) -- (B, M, C) with x_pm -- as one kernel ->
     (new_features (B, Cagg, M), cls (B, M, K) | None), or None when the fused path does not apply."""
-    runner = tail_runner(agg, head, pooled.contiguous(), half_out)
+    runner = tail_runner(agg, head, pooled.contiguous(), half_out, x_pm)
     if runner is None:
         return None
     runner.run()

@@ -201,24 +201,33 @@ class _PointnetSAModuleBase(nn.Module):
             plan.append(packed)
         return plan
 
-    def _group_mlp_pool(self, xyz, new_xyz, features):
+    def _group_mlp_pool(self, xyz, new_xyz, features, point_major_ok=False):
+        """-> pooled features (B, sum C_out, M); with point_major_ok (the caller's aggregation kernel reads either layout)
+        the fused path may return them point-major, (B, M, sum C_out), tagged `_sps_point_major`: the grouped-MLP kernels
+        then write a centroid's pooled rows contiguously."""
         plan = self._fused_plan(xyz, new_xyz, features)
         if plan:
             xyz_c, new_c = xyz.contiguous(), new_xyz.contiguous()
             feats_c = features.contiguous() if features is not None else None
             # nsample 64: a centroid's samples span several kernel units, combined by an atomic max onto zeros
             alloc = torch.zeros if any(g.nsample > 32 for g in self.groupers) else torch.empty
-            out = alloc((xyz.shape[0], sum(p.c3_real for p in plan), new_xyz.shape[1]),
-                        dtype=torch.float32, device=xyz.device)
+            B, M, width = xyz.shape[0], new_xyz.shape[1], sum(p.c3_real for p in plan)
+            pack = [_fused.want_packed((B, M, g.nsample), p) for g, p in zip(self.groupers, plan)]
+            # a point-major `out` is written by the packed-column and the shared-stream kernels only
+            pm = bool(point_major_ok) and all(pk or p.split == 2 for pk, p in zip(pack, plan))
+            out = alloc((B, M, width) if pm else (B, width, M), dtype=torch.float32, device=xyz.device)
             offset = 0
             if len(plan) == 2:  # the usual two-scale layer: both ball queries share one scan
                 ga, gb = self.groupers
                 idxs = _ext.ball_query_full2(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz_c, new_c)
             else:
                 idxs = [_ext.ball_query_full(g.radius, g.nsample, xyz_c, new_c) for g in self.groupers]
-            for idx, packed in zip(idxs, plan):
-                _fused.group_mlp_pool(xyz_c, new_c, feats_c, idx, packed, out, offset)
+            for idx, packed, pk in zip(idxs, plan, pack):
+                columns = _fused.pack_columns(idx) if pk else None
+                _fused.group_mlp_pool(xyz_c, new_c, feats_c, idx, packed, out, offset, columns=columns, out_point_major=pm)
                 offset += packed.c3_real
+            if pm:
+                out._sps_point_major = True
             return out
         if features is not None and features.dtype == torch.float16:
             raise NotImplementedError("fp16 feature tensors are served by the fused inference path only (eval mode, no "
@@ -477,27 +486,45 @@ class _SamplingSAModule(_PointnetSAModuleBase):
             hook(new_xyz)
         return sampled_idx, new_xyz, stds
 
+    def _tail_reads_point_major(self, xyz, new_xyz):
+        """True if _tail will run the fused aggregation kernel (which reads pooled features in either layout)."""
+        agg = self.aggregation_layer
+        if agg is None or agg.training or not xyz.is_cuda:
+            return False
+        head = getattr(self, "confidence_layers", None)
+        if (head is not None and head.training) or new_xyz.shape[1] % 16:
+            return False
+        if torch.is_grad_enabled() and any(p.requires_grad for p in agg.parameters()):
+            return False
+        return _fused._tail_layers(agg, head) is not None
+
     def _tail(self, pooled, half_out=False):
         """Aggregation stack and confidence head (reference :449-455) -> (new_features, cls (B,M,K) | None).  In
         inference both run as ONE kernel (csrc/pw_mlp.hip, BatchNorm folded, exact fp32) when their shapes allow.
         half_out: the layer's input features were fp16, so its output features are stored as fp16 too."""
         head = getattr(self, "confidence_layers", None)
+        x_pm = bool(getattr(pooled, "_sps_point_major", False))
         if self.aggregation_layer is not None:
-            done = _fused.pointwise_tail(self.aggregation_layer, head, pooled, half_out)
+            done = _fused.pointwise_tail(self.aggregation_layer, head, pooled, half_out, x_pm)
             if done is not None:
                 return done
+            if x_pm:   # the fused kernel declined after all: back to the reference layout
+                pooled = pooled.transpose(1, 2).contiguous()
             if half_out:
                 raise NotImplementedError("fp16 feature tensors need the fused aggregation kernel (widths multiples of 16)")
             pooled = self.aggregation_layer(pooled)
-        elif half_out:
-            pooled = pooled.half()
+        else:
+            if x_pm:
+                pooled = pooled.transpose(1, 2).contiguous()
+            if half_out:
+                pooled = pooled.half()
         cls = head(pooled).transpose(1, 2) if head is not None else None
         return pooled, cls
 
     def _abstract(self, xyz, new_xyz, features, sampled_idx):
         """-> (new_features, cls | None)"""
         if len(self.groupers) > 0:
-            return self._tail(self._group_mlp_pool(xyz, new_xyz, features),
+            return self._tail(self._group_mlp_pool(xyz, new_xyz, features, self._tail_reads_point_major(xyz, new_xyz)),
                               features is not None and features.dtype == torch.float16)
         new_features = pointnet2_utils.gather_operation(features, sampled_idx).contiguous()
         head = getattr(self, "confidence_layers", None)

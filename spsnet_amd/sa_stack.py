@@ -69,15 +69,88 @@ def build_sa_layers(modules_pkg, cfg=IASSD_KITTI, input_channels=4, num_class=3,
     return layers.eval()
 
 
+CONSUMER_ON_MAIN = __import__("os").environ.get("SPS_CONSUMER_ON_MAIN", "1") != "0"
 _SIDE_STREAMS = {}
+_FENCES = {}          # (device index, main stream handle) -> CuFence
+
+
+class CuFence:
+    """Compute-unit partition for the passes issued on one main stream: the serial FPS chain of a pass gets compute units of
+    its own, every helper stream of the pass is kept off them.  FPS occupies one CU per scene for most of a pass and
+    whatever shares a CU with one of its workgroups slows that chain (two waves on a SIMD cost each other ~25 %); with two
+    passes in flight the second pass's whole-chip kernels otherwise land exactly there.
+
+    Mask numbering as measured on MI355X (tools/cumask_probe.py, profiles/round2/cumask_probe_gfx950.txt): bit i of a
+    hipExtStreamCreateWithCUMask mask is CU i // 8 of XCD i % 8, and an XCD WITHOUT any bit set is not restricted at all --
+    so every mask here carries bits for all eight XCDs.  Slot k of `slots` concurrent passes owns CU indices
+    [k c, (k + 1) c) of every XCD, c = ceil(scenes / 8) (workgroups are dealt round-robin over the XCDs: one FPS
+    workgroup per owned CU); helper streams get CU indices >= slots * c."""
+
+    XCDS, CUS_PER_XCD = 8, 32
+
+    def __init__(self, device, slot=0, slots=1, scenes=8):
+        from . import _lib
+        self.device = device
+        per = max(1, -(-scenes // self.XCDS))
+        if slots * per >= self.CUS_PER_XCD:
+            raise ValueError("no compute units left for the helper streams")
+        self.fps_bits = [cu * self.XCDS + x for cu in range(slot * per, (slot + 1) * per) for x in range(self.XCDS)]
+        self.rest_bits = [cu * self.XCDS + x for cu in range(slots * per, self.CUS_PER_XCD) for x in range(self.XCDS)]
+        self._lib, self._handles = _lib, []
+
+    def stream(self, bits):
+        import ctypes
+        words = self.XCDS * self.CUS_PER_XCD // 32
+        mask = (ctypes.c_uint * words)()
+        for b in bits:
+            mask[b // 32] |= 1 << (b % 32)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            self._lib.check(self._lib.load().sps_stream_create_cu_mask(words, ctypes.cast(mask, ctypes.c_void_p),
+                                                                       ctypes.byref(handle)), "stream_create_cu_mask")
+        self._handles.append(handle)      # owned for the life of the process (a handful of streams)
+        return torch.cuda.ExternalStream(handle.value, device=self.device)
+
+    def new_stream(self, tag):
+        return self.stream(self.fps_bits if tag == "fps" else self.rest_bits)
+
+
+def enable_cu_fence(device, main_stream=None, slot=0, slots=1, scenes=8):
+    """Fence the FPS chain of every streamed pass issued on `main_stream` (default: the device's current stream) onto its
+    own compute units; -> the CuFence (use .stream(.rest_bits) to make a main stream for slot k of a pipelined server)."""
+    device = torch.device(device)
+    main = torch.cuda.current_stream(device) if main_stream is None else main_stream
+    fence = CuFence(device, slot, slots, scenes)
+    _FENCES[(device.index, main.cuda_stream)] = fence
+    for key in [k for k in _SIDE_STREAMS if k[1] == device.index and k[2] == main.cuda_stream]:
+        del _SIDE_STREAMS[key]
+    return fence
+
+
+def disable_cu_fence(device, main_stream=None):
+    device = torch.device(device)
+    main = torch.cuda.current_stream(device) if main_stream is None else main_stream
+    _FENCES.pop((device.index, main.cuda_stream), None)
+    for key in [k for k in _SIDE_STREAMS if k[1] == device.index and k[2] == main.cuda_stream]:
+        del _SIDE_STREAMS[key]
+
+
+def _helper_stream(device, tag="side"):
+    """One helper stream per (device, current stream, role): concurrent passes on different streams do not share it.
+    With a CuFence registered for the current stream the helper streams are CU-masked; tag "fps" = the stream the FPS
+    producer runs on (None without a fence: the producer then stays on the main stream)."""
+    main = torch.cuda.current_stream(device)
+    fence = _FENCES.get((device.index, main.cuda_stream))
+    if tag == "fps" and fence is None:
+        return None
+    key = (device.type, device.index, main.cuda_stream, tag)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = fence.new_stream(tag) if fence is not None else torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
 
 
 def _side_stream(device):
-    """One helper stream per (device, current stream): concurrent passes on different streams do not share it."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _SIDE_STREAMS[key]
+    return _helper_stream(device, "side")
 
 
 def _prefetch_dfps(next_layer, new_xyz, fps_ordered=False):
@@ -173,10 +246,16 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
         return None
     ga, gb = layer.groupers
     main = torch.cuda.current_stream(dev)
-    key = (dev.type, dev.index, main.cuda_stream, "chunks")
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
-    side = _SIDE_STREAMS[key]
+    fps_stream = _helper_stream(dev, "fps")              # None unless a CuFence is registered for `main`
+    # Which of the two runs on the caller's stream?  The consumer (default): everything after the layer depends on ITS last
+    # kernel, so nothing downstream has to hop streams; the producer then gets a helper stream.  (The other way round the
+    # pass paid a cross-stream dependency between the last chunk and the next layer.)
+    if CONSUMER_ON_MAIN:
+        side = main
+        if fps_stream is None:
+            fps_stream = _helper_stream(dev, "producer")
+    else:
+        side = _helper_stream(dev, "chunks")
 
     idx = torch.empty((B, M), dtype=torch.int32, device=dev)
     temp = torch.full((B, N), 1e10, dtype=torch.float32, device=dev)
@@ -200,11 +279,22 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
     _fused._overflow_flag(dev)                           # (created on first use: also before `start`)
     start = torch.cuda.Event()
     start.record(main)
-    _ext.fps_publish(xyz, temp, idx, progress)          # producer, on the main stream
+    fps_done = None
+    if fps_stream is None:
+        _ext.fps_publish(xyz, temp, idx, progress)      # producer, on the main stream
+    else:                                                # ... or on compute units of its own (CuFence)
+        fps_stream.wait_event(start)
+        with torch.cuda.stream(fps_stream):
+            _ext.fps_publish(xyz, temp, idx, progress)
+            fps_done = torch.cuda.Event()
+            fps_done.record(fps_stream)
+        for t in (xyz, temp, idx, progress):
+            t.record_stream(fps_stream)
     if after_producer is not None:
         after_producer()
-    for t in (xyz, features, idx, progress, timed_out, new_xyz, idx_a, idx_b, out) + (tail.tensors() if tail else ()):
-        t.record_stream(side)
+    if side is not main:
+        for t in (xyz, features, idx, progress, timed_out, new_xyz, idx_a, idx_b, out) + (tail.tensors() if tail else ()):
+            t.record_stream(side)
     ends = [M * e // 16 for e in _CHUNK_ENDS_16]
     # the next layer's D-FPS over these centroids is the verified identity prefix (fps_verify.hip): its first pass
     # needs only the first npoint centroids and runs as soon as they exist, its second when the last one does
@@ -215,7 +305,8 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
         for t in verify.tensors():
             t.record_stream(main)
     with torch.cuda.stream(side):                        # consumer
-        side.wait_event(start)
+        if side is not main:
+            side.wait_event(start)
         for c, j1 in enumerate(ends):
             j0 = ends[c - 1] if c else 0
             chunk = j1 - j0
@@ -241,7 +332,10 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
         copied = torch.cuda.Event()
         copied.record(side)
         flag_entry[1], flag_entry[2] = host_flag, copied
-    main.wait_event(xyz_ready)                           # all centroids exist: the next layer's FPS check can finish
+    if fps_done is not None:
+        main.wait_event(fps_done)
+    if side is not main:
+        main.wait_event(xyz_ready)                       # all centroids exist: the next layer's FPS check can finish
     if verify is not None:
         third = _side_stream(dev)                        # beside the last chunk's ball query, not behind it
         with torch.cuda.stream(third):
@@ -254,7 +348,8 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
         nxt._presampled = (nidx, vdone, new_xyz)
     elif nxt is not None and _can_prefetch(layer, nxt):
         _prefetch_dfps(nxt, new_xyz, True)
-    main.wait_event(done)
+    if side is not main:
+        main.wait_event(done)
     new_features, cls = tail.result() if tail is not None else layer._tail(out, half)
     if stds is not None:  # the layer's sampler thins the stability scores with its picks (reference :307-310)
         stds = pointnet2_utils.gather_operation(stds.view(B, 1, -1).contiguous(), idx).squeeze()
@@ -301,15 +396,23 @@ def run_sa_layers(layers, xyz, features, stds=None, overlap=True, stream_first_l
     return outs
 
 
-def pipelined_bench(step, steps, dev, in_flight=2):
+def pipelined_bench(step, steps, dev, in_flight=2, scenes=8, fenced=True):
     """Time `steps` complete, independent passes issued round-robin on `in_flight` HIP streams (bench.py's informational
-    `pipelined` object; `value` stays the strictly sequential figure) -> dict with elapsed_s."""
+    `pipelined` object; `value` stays the strictly sequential figure) -> dict with elapsed_s.
+    fenced: every slot's FPS chain runs on compute units of its own and everything else of every slot is kept off them
+    (CuFence); unfenced, a second pass in flight is SLOWER per pass than one alone."""
     import time
-    streams = [torch.cuda.Stream(device=dev) for _ in range(in_flight)]
+    if fenced:
+        fences = [CuFence(dev, slot=k, slots=in_flight, scenes=scenes) for k in range(in_flight)]
+        streams = [f.stream(f.rest_bits) for f in fences]
+        for f, s_ in zip(fences, streams):
+            _FENCES[(dev.index, s_.cuda_stream)] = f
+    else:
+        streams = [torch.cuda.Stream(device=dev) for _ in range(in_flight)]
     for s_ in streams:
         s_.wait_stream(torch.cuda.current_stream(dev))
     keep = []
-    for i in range(2 * in_flight):            # warm every stream's side streams / caches
+    for i in range(2 * in_flight):            # warm every stream's helper streams / caches
         with torch.cuda.stream(streams[i % in_flight]):
             keep.append(step())
     torch.cuda.synchronize()
@@ -322,6 +425,11 @@ def pipelined_bench(step, steps, dev, in_flight=2):
                 keep.pop(0)
     torch.cuda.synchronize()
     el = time.perf_counter() - t1
-    return {"batches_in_flight": in_flight, "unit": "points/s", "ms_per_step": 1e3 * el / steps, "elapsed_s": el,
-            "note": "same complete, independent passes issued round-robin on several HIP streams; informational, "
-                    "`value` above is the strictly sequential figure"}
+    if fenced:
+        for s_ in streams:
+            _FENCES.pop((dev.index, s_.cuda_stream), None)
+    return {"batches_in_flight": in_flight, "cu_fenced": bool(fenced), "unit": "points/s", "ms_per_step": 1e3 * el / steps,
+            "elapsed_s": el, "last_outputs": keep[-1],
+            "note": "same complete, independent passes issued round-robin on several HIP streams" +
+                    (", each pass's FPS chain on compute units of its own (hipExtStreamCreateWithCUMask)" if fenced else "") +
+                    "; informational, `value` above is the strictly sequential figure"}

@@ -1768,3 +1768,154 @@ def test_config5_shape_end_to_end(ext, G, oracle, dev):
     new_xyz = want[0][0]
     for radius in (0.2, 0.8):
         np.testing.assert_array_equal(G.ball_query(ext, radius, 64, xyz, new_xyz), oracle.ball_query(radius, 64, xyz, new_xyz))
+
+
+# ------------------------------------------------------------------ packed columns (only a ball's distinct neighbours are computed)
+def _padded_rows(rng, B, M, ns, N):
+    """Ball-query-shaped rows: cnt sorted distinct indices, then repeats of the first (ball_query_gpu.cu:35-42); counts
+    cover every slot class, full rows and single-hit rows (= empty balls, which keep the caller's zeros)."""
+    idx = np.zeros((B, M, ns), np.int32)
+    for b in range(B):
+        for j in range(M):
+            cnt = int(rng.choice([1, 1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64])) if rng.random() < 0.7 else int(rng.integers(1, ns + 1))
+            cnt = min(cnt, ns)
+            row = np.sort(rng.choice(N, cnt, replace=False))
+            idx[b, j, :cnt] = row
+            idx[b, j, cnt:] = row[0]
+    return idx
+
+
+@pytest.mark.parametrize("B,M,ns,j0,jcount", [(2, 200, 16, 0, 200), (3, 130, 32, 0, 130), (1, 77, 64, 0, 77), (2, 256, 32, 64, 100),
+                                             (2, 64, 8, 0, 64)])
+def test_pack_columns_stream(dev, G, B, M, ns, j0, jcount):
+    """sps_pack_columns: every centroid of the range appears exactly once, in a slot of 2^ceil(log2 cnt) columns aligned to
+    its size that holds exactly its distinct neighbours (+ repeats of the first); tiles come in multiples of four; unused
+    lanes are marked."""
+    from spsnet_amd import fused
+    rng = np.random.default_rng(B * 1000 + M + ns)
+    idx = _padded_rows(rng, B, M, ns, 5000)
+    pc = fused.pack_columns(G.t(idx), j0, jcount)
+    ntiles = int(pc.ntiles.item())
+    assert ntiles % 4 == 0 and 0 < ntiles <= pc.cap
+    cols = G.n(pc.cols)[:ntiles * 16]
+    meta = G.n(pc.meta)[:ntiles * 16].view(np.uint32)
+    j, scene, lg, unused = meta & 0xFFFFF, (meta >> 20) & 0xFF, (meta >> 28) & 7, meta >> 31
+    seen = set()
+    e = 0
+    while e < ntiles * 16:
+        if unused[e]:
+            e += 1
+            continue
+        size = 1 << int(lg[e])
+        assert e % size == 0, "slot not aligned to its size"
+        assert (j[e:e + size] == j[e]).all() and (scene[e:e + size] == scene[e]).all() and not unused[e:e + size].any()
+        key = (int(scene[e]), int(j[e]))
+        assert key not in seen and j0 <= key[1] < j0 + jcount
+        seen.add(key)
+        row = idx[key[0], key[1]]
+        cnt = len(np.unique(row))
+        assert size == 1 << int(np.ceil(np.log2(cnt))) if cnt > 1 else size == 1
+        np.testing.assert_array_equal(np.unique(cols[e:e + size]), np.unique(row))
+        assert cols[e] == row[0]
+        e += size
+    assert len(seen) == B * jcount
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp16x2", "half"])
+@pytest.mark.parametrize("c_feat,widths,ns", [(1, [16, 16, 32], 16), (1, [32, 32, 64], 32), (64, [64, 64, 128], 16),
+                                              (64, [64, 96, 128], 32), (128, [128, 128, 256], 16), (128, [128, 256, 256], 32),
+                                              (64, [64, 96, 128], 64), (1, [32, 32, 64], 64)])
+def test_packed_group_mlp_is_bit_identical(G, dev, mode, c_feat, widths, ns):
+    """The grouped MLP over packed columns against the same kernel over all nsample columns: pooled features identical bit
+    for bit (a repeated column reproduces the first column's activations, max is idempotent), in both output layouts, for
+    the fp32, split-fp16 (per-wave kernel) and fp16-feature arithmetic."""
+    from spsnet_amd import fused, pointnet2_modules as M
+    if mode == "fp32" and widths[0] >= 128 and ns == 64:
+        pytest.skip("no fp32 variant")
+    rng = np.random.default_rng(ns * 7 + c_feat)
+    B, N, Mc = 2, 3000, 192
+    old, old_share = fused.set_precision("fp32" if mode == "fp32" else "fp16x2"), fused.SHARE_WEIGHTS
+    fused.SHARE_WEIGHTS = False      # the per-wave split-fp16 kernel (the shared-stream kernel keeps the padded form)
+    try:
+        torch.manual_seed(ns + c_feat)
+        mlp = M._conv_bn_relu_stack([c_feat + 3] + list(widths), torch.nn.Conv2d, torch.nn.BatchNorm2d).to(dev).eval()
+        gen = torch.Generator().manual_seed(3)
+        for m_ in mlp.modules():
+            if isinstance(m_, torch.nn.BatchNorm2d):
+                with torch.no_grad():
+                    m_.running_mean.copy_(torch.randn(m_.num_features, generator=gen) * 0.2)
+                    m_.running_var.copy_(torch.rand(m_.num_features, generator=gen) + 0.5)
+        xyz = G.t(cloud(rng, B, N))
+        new_xyz = xyz[:, :Mc].contiguous()
+        feats = G.t(rng.normal(size=(B, c_feat, N)).astype(np.float32))
+        if mode == "half":
+            feats = feats.half()
+        idx = G.t(_padded_rows(rng, B, Mc, ns, N))
+        packed = fused.pack_scale(mlp, ns, half=mode == "half")
+        assert packed is not None and packed.split == {"fp32": 0, "fp16x2": (1 if widths[0] >= 32 else 0), "half": 3}[mode]
+        alloc = torch.zeros if ns > 32 else torch.empty
+        c3 = widths[-1]
+        ref = alloc((B, c3, Mc), dtype=torch.float32, device=dev)
+        fused.group_mlp_pool(xyz, new_xyz, feats, idx, packed, ref, 0)
+        columns = fused.pack_columns(idx)
+        got = alloc((B, c3, Mc), dtype=torch.float32, device=dev)
+        fused.group_mlp_pool(xyz, new_xyz, feats, idx, packed, got, 0, columns=columns)
+        got_pm = alloc((B, Mc, c3), dtype=torch.float32, device=dev)
+        fused.group_mlp_pool(xyz, new_xyz, feats, idx, packed, got_pm, 0, columns=columns, out_point_major=True)
+        ref_pm = alloc((B, Mc, c3), dtype=torch.float32, device=dev)
+        fused.group_mlp_pool(xyz, new_xyz, feats, idx, packed, ref_pm, 0, out_point_major=True)
+        torch.cuda.synchronize()
+        assert float(ref.abs().max()) > 0
+        assert torch.equal(got, ref)
+        assert torch.equal(ref_pm.transpose(1, 2), ref) and torch.equal(got_pm, ref_pm)
+        assert int(columns.ntiles.item()) * 16 < B * Mc * ns      # and fewer columns were computed
+    finally:
+        fused.set_precision(old)
+        fused.SHARE_WEIGHTS = old_share
+
+
+def test_shared_stream_kernel_point_major_output(G, dev):
+    """sa_mlp_f16_lds.hip with a point-major `out` (lanes <-> rows: contiguous stores) against its channel-major form."""
+    from spsnet_amd import fused, pointnet2_modules as M
+    rng = np.random.default_rng(5)
+    B, N, Mc, ns, c_feat, widths = 2, 2048, 256, 32, 128, [128, 256, 256]
+    old = fused.set_precision("fp16x2")
+    try:
+        torch.manual_seed(1)
+        mlp = M._conv_bn_relu_stack([c_feat + 3] + widths, torch.nn.Conv2d, torch.nn.BatchNorm2d).to(dev).eval()
+        xyz = G.t(cloud(rng, B, N))
+        new_xyz = xyz[:, :Mc].contiguous()
+        feats = G.t(rng.normal(size=(B, c_feat, N)).astype(np.float32))
+        idx = G.t(_padded_rows(rng, B, Mc, ns, N))
+        packed = fused.pack_scale(mlp, ns)
+        assert packed.split == 2
+        ref = torch.empty((B, widths[-1], Mc), dtype=torch.float32, device=dev)
+        fused.group_mlp_pool(xyz, new_xyz, feats, idx, packed, ref, 0)
+        pm = torch.empty((B, Mc, widths[-1]), dtype=torch.float32, device=dev)
+        fused.group_mlp_pool(xyz, new_xyz, feats, idx, packed, pm, 0, out_point_major=True)
+        assert torch.equal(pm.transpose(1, 2), ref)
+    finally:
+        fused.set_precision(old)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x2"])
+def test_stack_with_and_without_packed_columns(G, dev, precision):
+    """The whole SA stack with PACK_COLUMNS on and off: every output of every layer bit-identical."""
+    from spsnet_amd import fused, pointnet2_modules as M, sa_stack, scenes
+    layers = sa_stack.build_sa_layers(M, sa_stack.IASSD_KITTI, seed=4).to(dev)
+    xyz, feats = scenes.make_batch("kitti-lidar-v1", 2, 16384, seed0=91, dup_fraction=0.01)
+    x, f = G.t(xyz), G.t(feats)
+    old, old_pack = fused.set_precision(precision), fused.PACK_COLUMNS
+    try:
+        with torch.no_grad():
+            fused.PACK_COLUMNS = False
+            a = sa_stack.run_sa_layers(layers, x, f)
+            fused.PACK_COLUMNS = "always"
+            b = sa_stack.run_sa_layers(layers, x, f)
+            c = sa_stack.run_sa_layers(layers, x, f, overlap=False, stream_first_layer=False)
+        for la, lb, lc in zip(a, b, c):
+            for ta, tb, tc in zip(la, lb, lc):
+                assert (ta is None and tb is None) or (torch.equal(ta, tb) and torch.equal(ta, tc))
+    finally:
+        fused.set_precision(old)
+        fused.PACK_COLUMNS = old_pack
