@@ -133,7 +133,7 @@ int sps_fps_ordered_prefix(int b, int n, int m, const float *xyz, float *temp, i
 int sps_fps_ordered_prefix_begin(int b, int n, int m, const float *xyz, const float *temp, float *work_T, int *flags,
                                  sps_stream_t stream);
 int sps_fps_ordered_prefix_finish(int b, int n, int m, const float *xyz, float *temp, int *idxs, const float *work_T,
-                                  float *work_temp, int *flags, sps_stream_t stream);
+                                  float *work_temp, int *flags, const int *force_redo, sps_stream_t stream);
 
 /* ---- fused entry points for the SA module layer (pointnet2_modules.py) ----------------- */
 
@@ -203,15 +203,27 @@ int sps_set_mlp_precision(int mode);
  * releasing any consumer stream).
  * sps_wait_progress: enqueue a bounded spin on `stream` until every scene has published `need` samples.
  * The *_range variants restrict the centroid loop of every scene to [j0, j0+jcount) (jcount a multiple of 64
- * for the ball query / MLP); buffers keep their full (B, M, ...) shapes. */
+ * for the ball query / MLP); buffers keep their full (B, M, ...) shapes.
+ * Correct-or-redo: a bounded wait that gives up sets *timed_out and its consumers run on samples that were never written
+ * (harmless: indices are clamped into the cloud).  The range kernels, sps_sa_group_mlp_packed and sps_pointwise_mlp_ex take
+ * `run_if` (device i32, may be NULL): a launch with *run_if == 0 returns at once.  The caller re-issues the whole layer
+ * behind the producer with run_if = timed_out -- a few empty launches normally, the repair when a wait did give up --
+ * and hands force_redo = timed_out to sps_fps_ordered_prefix_finish, which then recomputes every scene.
+ * sps_debug_set_wait_spins: DIAGNOSTIC, the spin bound of sps_wait_progress (tests force the redo path with it). */
+unsigned sps_debug_set_wait_spins(unsigned spins);
+/* sps_wait_progress sets timed_out[0 .. b) (one flag per scene, all of them) when it gives up.
+ * sps_fps_redo_where: the ordinary FPS for the scenes with redo[scene] != 0 only (temp must be pre-filled with 1e10 for
+ * them); the other scenes keep idxs / temp untouched. */
+int sps_fps_redo_where(int b, int n, int m, const float *dataset, float *temp, int *idxs, const int *redo,
+                       sps_stream_t stream);
 int sps_fps_publish(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress,
                     sps_stream_t stream);
 int sps_wait_progress(const int *progress, int b, int need, int *timed_out, sps_stream_t stream);
 int sps_gather_xyz_range(int b, int n, int m, int j0, int jcount, const float *xyz, const int *idx, float *out,
-                         sps_stream_t stream);
+                         const int *run_if, sps_stream_t stream);
 int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcount, float radius_a, int nsample_a,
                                float radius_b, int nsample_b, const float *new_xyz, const float *xyz, int *idx_a,
-                               int *idx_b, int *perm_work, sps_stream_t stream);
+                               int *idx_b, int *perm_work, const int *run_if, sps_stream_t stream);
 int sps_sa_group_mlp_range(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,
                            const float *new_xyz, const float *features, const int *idx, int c1, int c2, int c3,
                            int c3_real, const float *w1, const float *b1, const float *w2, const float *b2,
@@ -249,7 +261,7 @@ int sps_sa_group_mlp_packed(int b, int n, int m, int j0, int jcount, int c_feat,
                             const unsigned *meta, const int *ntiles, long long tile_cap, int c1, int c2, int c3,
                             int c3_real, const float *w1, const float *b1, const float *w2, const float *b2,
                             const float *w3, const float *b3, float *out, int out_c_total, int out_c_off,
-                            int split_fp16, int *overflow_flag, sps_stream_t stream);
+                            int split_fp16, int *overflow_flag, const int *run_if, sps_stream_t stream);
 
 /* Aggregation stack (+ confidence head) of an SA layer as one kernel -- replaces, for inference with BatchNorm folded,
  * Conv1d+BN+ReLU (pointnet2_modules.py:213-228, 449-450) and Conv1d+BN+ReLU, Conv1d(bias) (:230-245, 454-455).
@@ -268,7 +280,8 @@ int sps_pointwise_mlp_range(int b, int m, int j0, int jcount, int cin, int c1, i
  * the arithmetic stays fp32 and the class scores are computed from the rounded features), 2 = x is point-major (B, M, cin). */
 int sps_pointwise_mlp_ex(int b, int m, int j0, int jcount, int cin, int c1, int c2, int c3_real, const float *x,
                          const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
-                         const float *b3, void *y1, void *y1_point_major, float *y3, int flags, sps_stream_t stream);
+                         const float *b3, void *y1, void *y1_point_major, float *y3, int flags, const int *run_if,
+                         sps_stream_t stream);
 
 /* farthest_point_sampling_kernel_launcher (sampling_gpu.cu:93-253) with an optional device workspace of
  * b * sps_fps_workspace_floats(n) floats (0 for sizes that need none).  With it, scenes of 16 385 .. 262 144 points

@@ -26,7 +26,7 @@ _PROTOS = {
     "sps_stream_destroy": [_vp],
     "sps_fps_ordered_prefix": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_fps_ordered_prefix_begin": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
-    "sps_fps_ordered_prefix_finish": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_fps_ordered_prefix_finish": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_debug_fps_profile": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_farthest_point_sampling_kernel_launcher": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "sps_furthest_point_sampling_with_dist_kernel_launcher": [_i, _i, _i, _vp, _vp, _vp, _vp],
@@ -53,7 +53,7 @@ _PROTOS = {
     "sps_sa_group_mlp_supported_stream": [_i, _i, _i, _i],
     "sps_fps_with_workspace": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_pointwise_mlp_range": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "sps_pointwise_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "sps_pointwise_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "sps_pointwise_mlp": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_ball_query_grid": [_i, _i, _i, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_ball_query_grid2": [_i, _i, _i, _f, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -86,17 +86,18 @@ _PROTOS = {
                             _vp, _vp, _i, _i, _i, _vp, _vp],
     "sps_pack_columns": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _vp],
     "sps_sa_group_mlp_packed": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _i,
-                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "sps_fps_redo_where": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_fps_publish": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_wait_progress": [_vp, _i, _i, _vp, _vp],
-    "sps_gather_xyz_range": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
-    "sps_ball_query_full2_range": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_gather_xyz_range": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sps_ball_query_full2_range": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_sa_group_mlp_range": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _i, _i, _vp],
 }
 EXPORTS = ["sps_abi_version", "sps_last_error", "sps_opt_n_threads", "sps_fps_workspace_floats",
            "sps_index_add_workspace_ints", "sps_ball_query_grid_workspace_ints", "sps_bn_train_workspace_doubles", "sps_conv1x1_wgrad_workspace_floats",
-           "sps_pack_columns_capacity"] + list(_PROTOS)
+           "sps_pack_columns_capacity", "sps_debug_set_wait_spins"] + list(_PROTOS)
 
 _lib = None
 
@@ -131,6 +132,8 @@ def load():
     lib.sps_conv1x1_wgrad_workspace_floats.argtypes = [_i, _i, _i, ctypes.c_longlong]
     lib.sps_conv1x1_wgrad_workspace_floats.restype = ctypes.c_longlong
     lib.sps_index_add_workspace_ints.argtypes = [_i, _i, _i]
+    lib.sps_debug_set_wait_spins.argtypes = [ctypes.c_uint]
+    lib.sps_debug_set_wait_spins.restype = ctypes.c_uint
     lib.sps_pack_columns_capacity.argtypes = [_i, _i, _i]
     lib.sps_pack_columns_capacity.restype = ctypes.c_longlong
     for name, args in _PROTOS.items():

@@ -157,7 +157,8 @@ template <typename HitT>
 __global__ __launch_bounds__(BQ_LANES *BQ_MAX_SEG_DUAL) void ball_query_dual_kernel(
     int n, int m, int seg_len, float r2a, float r2b, int nsa, int nsb, const float *__restrict__ new_xyz,
     const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b, const int *__restrict__ perm,
-    int jbeg, int jend) {
+    int jbeg, int jend, const int *__restrict__ run_if) {
+    if (run_if && *run_if == 0) return;   // predicated launch (sps_ball_query_full2_range): workgroup-uniform
     extern __shared__ __attribute__((aligned(16))) int bq_lds[];
     const int S = blockDim.x / BQ_LANES;
     const int lane = threadIdx.x & 63;
@@ -292,7 +293,9 @@ constexpr int BQW_UNROLL = 4;  // 64-point steps in flight per loop trip
 
 __global__ __launch_bounds__(64 * BQW_WAVES) void ball_query_wave_dual_kernel(
     int n, int m, float r2a, float r2b, int nsa, int nsb, const float *__restrict__ new_xyz,
-    const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b, int jbeg, int jend) {
+    const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b, int jbeg, int jend,
+    const int *__restrict__ run_if) {
+    if (run_if && *run_if == 0) return;
     const int scene = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int j = jbeg + blockIdx.x * BQW_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -348,9 +351,11 @@ constexpr int BQS_SEG = 4;
 constexpr int BQS_MAX_NS = 64;
 __global__ __launch_bounds__(64 * BQS_SEG) void ball_query_wave_seg_kernel(
     int n, int m, float r2a, float r2b, int nsa, int nsb, const float *__restrict__ new_xyz,
-    const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b, int jbeg) {
+    const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b, int jbeg,
+    const int *__restrict__ run_if) {
     __shared__ int hits[2][BQS_SEG][BQS_MAX_NS];
     __shared__ int cnt[2][BQS_SEG];
+    if (run_if && *run_if == 0) return;
     const int scene = blockIdx.y, j = jbeg + blockIdx.x;
     const int lane = threadIdx.x & 63, seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     xyz += (size_t)scene * n * 3;
@@ -503,12 +508,12 @@ extern "C" int sps_ball_query_full2(int b, int n, int m, float radius_a, int nsa
                                     const float *new_xyz, const float *xyz, int *idx_a, int *idx_b, int *perm_work,
                                     sps_stream_t stream) {
     return sps_ball_query_full2_range(b, n, m, 0, m, radius_a, nsample_a, radius_b, nsample_b, new_xyz, xyz, idx_a, idx_b,
-                                      perm_work, stream);
+                                      perm_work, nullptr, stream);
 }
 
 extern "C" int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcount, float radius_a, int nsample_a,
                                           float radius_b, int nsample_b, const float *new_xyz, const float *xyz,
-                                          int *idx_a, int *idx_b, int *perm_work, sps_stream_t stream) {
+                                          int *idx_a, int *idx_b, int *perm_work, const int *run_if, sps_stream_t stream) {
     using namespace sps;
     if (b < 0 || n < 0 || m < 0 || nsample_a <= 0 || nsample_b <= 0 || j0 < 0 || jcount < 0 || j0 + jcount > m)
         return fail(SPS_ERR_INVALID, "ball_query_full2: bad shape b=%d n=%d m=%d ns=(%d,%d) range [%d,+%d)", b, n, m,
@@ -525,13 +530,13 @@ extern "C" int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcoun
     if (per_wave && (long long)b * jcount <= BQ_SEG_MAX_CENTROIDS && nsample_a <= BQS_MAX_NS && nsample_b <= BQS_MAX_NS &&
         n >= 4096) {
         hipLaunchKernelGGL(ball_query_wave_seg_kernel, dim3(jcount, b), dim3(64 * BQS_SEG), 0, as_stream(stream), n, m,
-                           radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, j0);
+                           radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, j0, run_if);
         return check_launch("ball_query_wave_seg_kernel");
     }
     if (per_wave) {
         hipLaunchKernelGGL(ball_query_wave_dual_kernel, dim3(divup(jcount, BQW_WAVES), b), dim3(64 * BQW_WAVES), 0,
                            as_stream(stream), n, m, radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz,
-                           xyz, idx_a, idx_b, j0, j0 + jcount);
+                           xyz, idx_a, idx_b, j0, j0 + jcount, run_if);
         return check_launch("ball_query_wave_dual_kernel");
     }
     const int groups = divup(jcount, BQ_LANES);
@@ -564,7 +569,8 @@ extern "C" int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcoun
         if (rc != SPS_OK) return rc;
         perm = perm_work;
     }
-    typedef void (*dual_fn)(int, int, int, float, float, int, int, const float *, const float *, int *, int *, const int *, int, int);
+    typedef void (*dual_fn)(int, int, int, float, float, int, int, const float *, const float *, int *, int *, const int *, int, int,
+                            const int *);
     const dual_fn fn = seg_len <= 65536 ? ball_query_dual_kernel<unsigned short> : ball_query_dual_kernel<int>;
     if (lds_bytes(S) > 64 * 1024) {
         static LdsLimitOnce raised[2];
@@ -573,7 +579,7 @@ extern "C" int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcoun
     }
     hipLaunchKernelGGL(fn, dim3(groups, b), dim3(BQ_LANES * S), lds_bytes(S), as_stream(stream), n, m, seg_len,
                        radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, perm, j0,
-                       j0 + jcount);
+                       j0 + jcount, run_if);
     return check_launch("ball_query_dual_kernel");
 }
 
@@ -588,7 +594,8 @@ extern "C" int sps_ball_query_full2_wave(int b, int n, int m, float radius_a, in
     if (!new_xyz || !xyz || !idx_a || !idx_b) return fail(SPS_ERR_INVALID, "ball_query_full2_wave: null pointer");
     if (b > 65535) return fail(SPS_ERR_INVALID, "ball_query_full2_wave: batch %d exceeds the grid limit", b);
     hipLaunchKernelGGL(ball_query_wave_dual_kernel, dim3(divup(m, BQW_WAVES), b), dim3(64 * BQW_WAVES), 0, as_stream(stream),
-                       n, m, radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, 0, m);
+                       n, m, radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, 0, m,
+                       (const int *)nullptr);
     return check_launch("ball_query_wave_dual_kernel");
 }
 

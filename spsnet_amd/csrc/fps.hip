@@ -266,7 +266,17 @@ extern "C" int sps_debug_fps_profile(int b, int n, int m, const float *dataset, 
 }
 
 // One workgroup, one wave: spin (bounded, with s_sleep) until every scene has published `need` samples.
-__global__ __launch_bounds__(64) void wait_progress_kernel(const int *progress, int b, int need, int *timed_out) {
+static unsigned g_wait_spins = 1u << 22;   // seconds: the producer is gone
+
+// DIAGNOSTIC: the spin bound of sps_wait_progress (0 restores the default).  A tiny bound makes every wait give up at once,
+// which is how the tests drive sa_stack's redo path.  Returns the previous bound.
+extern "C" unsigned sps_debug_set_wait_spins(unsigned spins) {
+    const unsigned old = g_wait_spins;
+    g_wait_spins = spins ? spins : (1u << 22);
+    return old;
+}
+
+__global__ __launch_bounds__(64) void wait_progress_kernel(const int *progress, int b, int need, int *timed_out, unsigned bound) {
     const int lane = threadIdx.x;
     for (int base = 0; base < b; base += 64) {
         const int sc = base + lane;
@@ -274,8 +284,8 @@ __global__ __launch_bounds__(64) void wait_progress_kernel(const int *progress, 
         for (unsigned spins = 0;; ++spins) {
             if (!done) done = __hip_atomic_load(&progress[sc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
             if (__all(done)) break;
-            if (spins > (1u << 22)) {  // seconds: the producer is gone
-                if (lane == 0) *timed_out = 1;
+            if (spins >= bound) {
+                for (int s2 = lane; s2 < b; s2 += 64) timed_out[s2] = 1;   // one flag per scene (all set: the batch is redone)
                 return;
             }
             __builtin_amdgcn_s_sleep(64);
@@ -302,8 +312,20 @@ extern "C" int sps_fps_publish(int b, int n, int m, const float *dataset, float 
 extern "C" int sps_wait_progress(const int *progress, int b, int need, int *timed_out, sps_stream_t stream) {
     using namespace sps;
     if (b <= 0 || !progress || !timed_out) return fail(SPS_ERR_INVALID, "wait_progress: bad arguments");
-    hipLaunchKernelGGL(wait_progress_kernel, dim3(1), dim3(64), 0, as_stream(stream), progress, b, need, timed_out);
+    hipLaunchKernelGGL(wait_progress_kernel, dim3(1), dim3(64), 0, as_stream(stream), progress, b, need, timed_out, g_wait_spins);
     return check_launch("wait_progress_kernel");
+}
+
+// The ordinary FPS for the scenes with redo[scene] != 0 only; the others keep idxs and temp as they are.  With redo = the
+// per-scene timed_out flags of sps_wait_progress this is the predicated repair of a D-FPS result that was derived from
+// samples a timed-out wait let through (sa_stack._streamed_first_layer): normally one launch that does nothing.
+extern "C" int sps_fps_redo_where(int b, int n, int m, const float *dataset, float *temp, int *idxs, const int *redo,
+                                  sps_stream_t stream) {
+    using namespace sps;
+    if (b < 0 || n <= 0 || m < 0) return fail(SPS_ERR_INVALID, "fps_redo_where: bad shape b=%d n=%d m=%d", b, n, m);
+    if (b == 0 || m == 0) return SPS_OK;
+    if (!dataset || !temp || !idxs || !redo) return fail(SPS_ERR_INVALID, "fps_redo_where: null pointer");
+    return launch_fps_resolve(b, n, m, dataset, temp, idxs, redo, temp, as_stream(stream));   // temp_done = temp: kept as is
 }
 
 extern "C" int sps_opt_n_threads(int work_size) {

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(FV_THREADS) void fps_prefix_dist_kernel(int n, int 
 // pass 2: point k replays its running distance and checks every step of the guess
 __global__ __launch_bounds__(FV_THREADS) void fps_prefix_check_kernel(
     int n, int m, int bs, int l2, int rb, const float *__restrict__ xyz, const float *__restrict__ temp,
-    const float *__restrict__ T, float *__restrict__ temp_done, int *__restrict__ idx, int *__restrict__ bad) {
+    const float *__restrict__ T, float *__restrict__ temp_done, int *__restrict__ idx, int *__restrict__ bad,
+    const int *__restrict__ force_bad) {
     __shared__ float4 step[FV_MAX_M];  // step j (1 <= j < m): {centre j-1, T[j]} at step[j-1]
     __shared__ unsigned srank[FV_MAX_M];  // tie-break rank of point j, at srank[j-1]
     __shared__ float segmin[FV_SEG][64];
@@ -115,6 +116,9 @@ __global__ __launch_bounds__(FV_THREADS) void fps_prefix_check_kernel(
         }
         if (violated) bad[scene] = 1;
     }
+    // the caller knows the inputs of pass 1 were not ready (a streamed layer's bounded wait gave up): every scene is
+    // recomputed by the ordinary kernel, whatever this check concluded from them
+    if (force_bad && threadIdx.x == 0 && *force_bad != 0) bad[scene] = 1;
 }
 
 }  // namespace sps
@@ -146,7 +150,8 @@ extern "C" int sps_fps_ordered_prefix_begin(int b, int n, int m, const float *xy
 }
 
 extern "C" int sps_fps_ordered_prefix_finish(int b, int n, int m, const float *xyz, float *temp, int *idxs,
-                                             const float *work_T, float *work_temp, int *flags, sps_stream_t stream) {
+                                             const float *work_T, float *work_temp, int *flags, const int *force_redo,
+                                             sps_stream_t stream) {
     using namespace sps;
     int rc = fv_check_args("fps_ordered_prefix_finish", b, n, m, xyz, temp, work_T, flags);
     if (rc != SPS_OK || b == 0 || m == 0) return rc;
@@ -158,7 +163,7 @@ extern "C" int sps_fps_ordered_prefix_finish(int b, int n, int m, const float *x
     int rb = 0;
     while ((1 << rb) < divup(n, bs)) ++rb;
     hipLaunchKernelGGL(fps_prefix_check_kernel, dim3(divup(n, 64), b), dim3(FV_THREADS), 0, st, n, m, bs, l2, rb, xyz,
-                       temp, work_T, work_temp, idxs, flags);
+                       temp, work_T, work_temp, idxs, flags, force_redo);
     rc = check_launch("fps_prefix_check_kernel");
     if (rc != SPS_OK) return rc;
     // confirmed scenes: copy work_temp -> temp and stop; flagged scenes: the ordinary FPS kernel recomputes them
@@ -175,5 +180,5 @@ extern "C" int sps_fps_ordered_prefix(int b, int n, int m, const float *xyz, flo
     if (m > FV_MAX_M) return sps_farthest_point_sampling_kernel_launcher(b, n, m, xyz, temp, idxs, stream);
     const int rc = sps_fps_ordered_prefix_begin(b, n, m, xyz, temp, work_T, flags, stream);
     if (rc != SPS_OK) return rc;
-    return sps_fps_ordered_prefix_finish(b, n, m, xyz, temp, idxs, work_T, work_temp, flags, stream);
+    return sps_fps_ordered_prefix_finish(b, n, m, xyz, temp, idxs, work_T, work_temp, flags, nullptr, stream);
 }

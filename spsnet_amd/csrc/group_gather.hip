@@ -80,13 +80,20 @@ __global__ __launch_bounds__(GGL_THREADS) void group_grad_lds_kernel(int c, int 
 
 // new_xyz[b,j,:] = xyz[b,idx[b,j],:] on the native (B,N,3) layout: what the reference obtains with
 // transpose + gather_operation + transpose (pointnet2_modules.py:261,423-424), without the two copies
+// run_if: a device flag; the launch does nothing when it is zero (sa_stack's redo of a streamed layer whose bounded wait
+// gave up).  The index is clamped into the cloud: a consumer that ran ahead of its producer reads garbage indices, which
+// must not become wild addresses (the redo repairs the values).
 __global__ __launch_bounds__(GG_THREADS) void gather_xyz_kernel(int n, int m, int j0, int jcount,
                                                                  const float *__restrict__ xyz,
-                                                                 const int *__restrict__ idx, float *__restrict__ out) {
+                                                                 const int *__restrict__ idx, float *__restrict__ out,
+                                                                 const int *__restrict__ run_if) {
+    if (run_if && *run_if == 0) return;
     const int scene = blockIdx.y;
     const int j = j0 + blockIdx.x * GG_THREADS + threadIdx.x;
     if (j >= j0 + jcount) return;
-    const float *p = xyz + ((size_t)scene * n + idx[(size_t)scene * m + j]) * 3;
+    int src = idx[(size_t)scene * m + j];
+    src = src < 0 ? 0 : (src >= n ? n - 1 : src);
+    const float *p = xyz + ((size_t)scene * n + src) * 3;
     float *o = out + ((size_t)scene * m + j) * 3;
     o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
 }
@@ -121,11 +128,11 @@ static int launch_group(bool grad, const char *what, int b, int c, int n, int np
 }  // namespace sps
 
 extern "C" int sps_gather_xyz(int b, int n, int m, const float *xyz, const int *idx, float *out, sps_stream_t stream) {
-    return sps_gather_xyz_range(b, n, m, 0, m, xyz, idx, out, stream);
+    return sps_gather_xyz_range(b, n, m, 0, m, xyz, idx, out, nullptr, stream);
 }
 
 extern "C" int sps_gather_xyz_range(int b, int n, int m, int j0, int jcount, const float *xyz, const int *idx, float *out,
-                                    sps_stream_t stream) {
+                                    const int *run_if, sps_stream_t stream) {
     using namespace sps;
     if (b < 0 || n < 0 || m < 0 || j0 < 0 || jcount < 0 || j0 + jcount > m)
         return fail(SPS_ERR_INVALID, "gather_xyz: bad shape b=%d n=%d m=%d range [%d,+%d)", b, n, m, j0, jcount);
@@ -134,7 +141,7 @@ extern "C" int sps_gather_xyz_range(int b, int n, int m, int j0, int jcount, con
     if (!xyz || !idx || !out) return fail(SPS_ERR_INVALID, "gather_xyz: null pointer");
     if (b > 65535) return fail(SPS_ERR_INVALID, "gather_xyz: grid too large");
     hipLaunchKernelGGL(gather_xyz_kernel, dim3(divup(jcount, GG_THREADS), b), dim3(GG_THREADS), 0, as_stream(stream), n, m, j0,
-                       jcount, xyz, idx, out);
+                       jcount, xyz, idx, out, run_if);
     return check_launch("gather_xyz_kernel");
 }
 

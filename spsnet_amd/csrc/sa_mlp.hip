@@ -53,6 +53,7 @@ __device__ __forceinline__ f32x4 wload4(__amdgpu_buffer_rsrc_t r, int voff, int 
 // NS: nsample (16, 32 or 64), with 16*NT >= NS: a unit is 16*NT columns = 16*NT/NS whole centroids.
 template <int C1, int C2, int NT, int NS, bool PACKED>
 __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
+    if (a.run_if && *a.run_if == 0) return;
     constexpr int T1 = C1 / 16, T2 = C2 / 16;
     constexpr int COLS = 16 * NT;
     constexpr int UNIT = COLS;
@@ -323,19 +324,20 @@ extern "C" int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int 
                                    int out_c_off, int split_fp16, int *overflow_flag, sps_stream_t stream) {
     return sps_sa_group_mlp_packed(b, n, m, j0, jcount, c_feat, nsample, xyz, new_xyz, features, idx, nullptr, nullptr, nullptr,
                                    0, c1, c2, c3, c3_real, w1, b1, w2, b2, w3, b3, out, out_c_total, out_c_off, split_fp16,
-                                   overflow_flag, stream);
+                                   overflow_flag, nullptr, stream);
 }
 
 // The general entry point.  Either idx (b, m, nsample) and the centroid range [j0, j0 + jcount), or -- cols != NULL -- the
 // packed column stream of sps_pack_columns (cols / meta / *ntiles on the device, tile_cap = the capacity the pack call was
 // given; idx, j0 and jcount are then ignored).  mode = the split_fp16 word of sps_sa_group_mlp_ex, + 8: `out` is point-major
-// (b, m, out_c_total) instead of (b, out_c_total, m).  Packed columns are served by modes 0, 1 and 3.
+// (b, m, out_c_total) instead of (b, out_c_total, m).  Packed columns are served by modes 0, 1 and 3.  run_if (device, may be
+// NULL): the launch does nothing when *run_if == 0 -- the redo of a streamed layer whose bounded progress wait gave up.
 extern "C" int sps_sa_group_mlp_packed(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,
                                        const float *new_xyz, const float *features, const int *idx, const int *cols,
                                        const unsigned *meta, const int *ntiles, long long tile_cap, int c1, int c2, int c3,
                                        int c3_real, const float *w1, const float *b1, const float *w2, const float *b2,
                                        const float *w3, const float *b3, float *out, int out_c_total, int out_c_off,
-                                       int split_fp16, int *overflow_flag, sps_stream_t stream) {
+                                       int split_fp16, int *overflow_flag, const int *run_if, sps_stream_t stream) {
     using namespace sps;
     if (b < 0 || n <= 0 || m < 0 || c_feat < 0 || nsample <= 0 || c3 <= 0 || (c3 % 16) || c3_real > c3 ||
         out_c_off < 0 || out_c_off + c3_real > out_c_total || j0 < 0 || jcount < 0 || j0 + jcount > m)
@@ -359,6 +361,7 @@ extern "C" int sps_sa_group_mlp_packed(int b, int n, int m, int j0, int jcount, 
     a.j0 = j0;
     a.cols = cols; a.meta = meta; a.ntiles = ntiles;
     a.out_pm = (split_fp16 & 8) ? 1 : 0;
+    a.run_if = run_if;
     a.ks1 = (3 + c_feat + 3) / 4;
     a.c3 = c3; a.c3_real = c3_real; a.out_c_total = out_c_total; a.out_c_off = out_c_off;
     a.xyz = xyz; a.new_xyz = new_xyz; a.feat = features; a.idx = idx;

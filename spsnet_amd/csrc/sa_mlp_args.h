@@ -24,6 +24,7 @@ struct SaMlpArgs {
     const unsigned *meta;
     const int *ntiles;
     int out_pm;                    // 1: `out` is point-major (B, M, out_c_total): a centroid's pooled rows are contiguous
+    const int *run_if;             // predicated launch: the kernel returns at once when *run_if == 0 (NULL: always runs)
 };
 
 

@@ -93,6 +93,7 @@ __device__ __forceinline__ void mac3(const WFrag &w, const h8 (&xh)[NT], const h
 // per product block instead of three; coordinates are still differenced in fp32 and rounded once.
 template <int C1, int C2, int NT, int NS, bool WLDS, bool PURE, bool PACKED>
 __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMlpArgs a) {
+    if (a.run_if && *a.run_if == 0) return;   // workgroup-uniform, before any barrier
     constexpr int FRAG = frag_bytes<PURE>();
     const _Float16 *feat_h = reinterpret_cast<const _Float16 *>(a.feat);
     constexpr int T1 = C1 / 16, T2 = C2 / 16;

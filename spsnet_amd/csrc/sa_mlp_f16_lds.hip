@@ -72,6 +72,7 @@ __device__ __forceinline__ void wait_vm() {
 // a.w1 = the concatenated fragment stream; a.ks1 = layer-1 k-steps of 32 grouped channels.
 template <int C1, int C2, int C3, int NT, int NS, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa_group_mlp_f16_lds_kernel(SaMlpArgs a) {
+    if (a.run_if && *a.run_if == 0) return;   // workgroup-uniform, before any barrier or DMA request
     constexpr int PIECES = 8 / WAVES;  // 1-KiB pieces of a chunk each wave fetches
     static_assert(WAVES == 4 || WAVES == 8, "4 waves x 2 pieces or 8 waves x 1 piece");
     constexpr int T1 = C1 / 16, T2 = C2 / 16, MT3 = C3 / 16;   // 16-row output tiles

@@ -369,9 +369,10 @@ class OrderedPrefix:
         self.work_t = torch.empty((B, max(npoint, 1)), dtype=F32, device=dev)
         self.work_temp = torch.empty((B, N), dtype=F32, device=dev)
         self.flags = torch.empty((B,), dtype=I32, device=dev)
+        self.temp_redo = torch.full((B, N), 1e10, dtype=F32, device=dev)   # for fps_redo_where, filled off the critical path
 
     def tensors(self):
-        return (self.temp, self.idx, self.work_t, self.work_temp, self.flags)
+        return (self.temp, self.idx, self.work_t, self.work_temp, self.flags, self.temp_redo)
 
     def begin(self):
         B, N, _ = self.xyz.shape
@@ -380,12 +381,14 @@ class OrderedPrefix:
                                                         self.work_t.data_ptr(), self.flags.data_ptr(), _stream(self.xyz)),
                        "fps_ordered_prefix_begin")
 
-    def finish(self):
+    def finish(self, force_redo=None):
+        """force_redo: device int32; non-zero = the inputs of begin() were not ready, recompute every scene."""
         B, N, _ = self.xyz.shape
         with _on(self.xyz):
             _lib.check(_L.sps_fps_ordered_prefix_finish(B, N, self.npoint, _ptr(self.xyz, F32, "xyz"), self.temp.data_ptr(),
                                                          self.idx.data_ptr(), self.work_t.data_ptr(),
                                                          self.work_temp.data_ptr(), self.flags.data_ptr(),
+                                                         0 if force_redo is None else _ptr(force_redo, I32, "force_redo"),
                                                          _stream(self.xyz)), "fps_ordered_prefix_finish")
         return self.idx
 
@@ -402,27 +405,45 @@ def fps_publish(xyz, temp, idx, progress):
                                       _ptr(idx, I32, "idx"), _ptr(progress, I32, "progress"), _stream(xyz)), "fps_publish")
 
 
+def fps_redo_where(xyz, idx, redo, temp=None):
+    """The ordinary D-FPS of xyz (B,N,3) into idx (B,m) for the scenes with redo[scene] != 0 (device int32 (B,)); the others
+    keep their idx.  Normally a launch that does nothing (see sa_stack._streamed_first_layer).  temp: (B,N) filled with 1e10."""
+    B, N, _ = xyz.shape
+    if temp is None:
+        temp = torch.full((B, N), 1e10, dtype=F32, device=xyz.device)
+    with _on(xyz):
+        _lib.check(_L.sps_fps_redo_where(B, N, idx.shape[1], _ptr(xyz, F32, "xyz"), temp.data_ptr(), _ptr(idx, I32, "idx"),
+                                         _ptr(redo, I32, "redo"), _stream(xyz)), "fps_redo_where")
+
+
 def wait_progress(progress, need, timed_out):
-    """Enqueue a bounded device-side wait on the current stream until all scenes published `need` samples."""
+    """Enqueue a bounded device-side wait on the current stream until all scenes published `need` samples; on giving up
+    it sets timed_out (B,) -- every entry."""
     with _on(progress):
+        _need(timed_out, progress.numel(), "timed_out")
         _lib.check(_L.sps_wait_progress(_ptr(progress, I32, "progress"), progress.numel(), need,
                                         _ptr(timed_out, I32, "timed_out"), _stream(progress)), "wait_progress")
 
 
-def gather_xyz_range(xyz, idx, out, j0, jcount):
+def _flag(run_if):
+    return 0 if run_if is None else _ptr(run_if, I32, "run_if")
+
+
+def gather_xyz_range(xyz, idx, out, j0, jcount, run_if=None):
+    """run_if (device int32): the launch does nothing while it is zero (sa_stack's redo after a timed-out wait)."""
     B, N, _ = xyz.shape
     with _on(xyz):
         _lib.check(_L.sps_gather_xyz_range(B, N, idx.shape[1], j0, jcount, _ptr(xyz, F32, "xyz"), _ptr(idx, I32, "idx"),
-                                           _ptr(out, F32, "out"), _stream(xyz)), "gather_xyz_range")
+                                           _ptr(out, F32, "out"), _flag(run_if), _stream(xyz)), "gather_xyz_range")
 
 
-def ball_query_full2_range(radius_a, radius_b, xyz, new_xyz, idx_a, idx_b, j0, jcount):
+def ball_query_full2_range(radius_a, radius_b, xyz, new_xyz, idx_a, idx_b, j0, jcount, run_if=None):
     B, N, _ = xyz.shape
     with _on(xyz):
         _lib.check(_L.sps_ball_query_full2_range(B, N, new_xyz.shape[1], j0, jcount, radius_a, idx_a.shape[2], radius_b,
                                                  idx_b.shape[2], _ptr(new_xyz, F32, "new_xyz"), _ptr(xyz, F32, "xyz"),
-                                                 _ptr(idx_a, I32, "idx_a"), _ptr(idx_b, I32, "idx_b"), 0, _stream(xyz)),
-                   "ball_query_full2_range")
+                                                 _ptr(idx_a, I32, "idx_a"), _ptr(idx_b, I32, "idx_b"), 0, _flag(run_if),
+                                                 _stream(xyz)), "ball_query_full2_range")
 
 
 def gather_xyz(xyz, idx):
