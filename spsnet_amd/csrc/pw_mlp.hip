@@ -31,6 +31,12 @@ struct PwArgs {
     const int *run_if;   // predicated launch: nothing happens when *run_if == 0
 };
 
+// ReLU as an integer max: keeps +Inf / +NaN where v_max_f32 would drop a NaN (torch's ReLU propagates it)
+__device__ __forceinline__ float pw_relu(float x) {
+    const int b = __float_as_int(x);
+    return __int_as_float(b > 0 ? b : 0);
+}
+
 __device__ __forceinline__ f32x4 pw_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // one 16-row output tile: acc += W[tile] * act (act = LDS image [k][17]), four 16-channel steps per trip so that four
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void pw_mlp_kernel(PwArgs a) {
             acc = pw_tile(reinterpret_cast<const f32x4 *>(a.w1) + (size_t)t * k16n * 64 + lane, xt, k16n, q, c, acc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                acc[r] = fmaxf(acc[r], 0.f);
+                acc[r] = pw_relu(acc[r]);
                 const int row = 16 * t + 4 * q + r;
                 const size_t at = ((size_t)scene * a.c1 + row) * a.m + m0 + c;
                 if (a.out_h16) {
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void pw_mlp_kernel(PwArgs a) {
             f32x4 acc = *reinterpret_cast<const f32x4 *>(a.b2 + 16 * t + 4 * q);
             acc = pw_tile(reinterpret_cast<const f32x4 *>(a.w2) + (size_t)t * k16n * 64 + lane, act1, k16n, q, c, acc);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) act2[(16 * t + 4 * q + r) * PW_PAD + c] = fmaxf(acc[r], 0.f);
+            for (int r = 0; r < 4; ++r) act2[(16 * t + 4 * q + r) * PW_PAD + c] = pw_relu(acc[r]);
         }
     }
     __syncthreads();

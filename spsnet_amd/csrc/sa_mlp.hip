@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) h1[t][nt][r] = fmaxf(h1[t][nt][r], 0.f);
+                    for (int r = 0; r < 4; ++r) h1[t][nt][r] = relu_keep_nan(h1[t][nt][r]);
 
             // ---------------- layer 2: activations chain register-to-register ----------------
             // Weight fragments stream from L2 in chunks of KCH k-steps, double-buffered in registers: the
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) h2[mt][nt][r] = fmaxf(acc[nt][r], 0.f);
+                            for (int r = 0; r < 4; ++r) h2[mt][nt][r] = relu_keep_nan(acc[nt][r]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -227,19 +227,21 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
                 }
                 f32x4 best[CPP];
 #pragma unroll
-                for (int cc = 0; cc < CPP; ++cc) best[cc] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                // ReLU and pooling as ONE integer max starting from +0 (relu(max x) == max(0, x...)): NaN-keeping, see
+                // relu_keep_nan
+                for (int cc = 0; cc < CPP; ++cc) best[cc] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int cc = PART ? 0 : (nt * 16) / NS;  // which centroid of the unit this tile belongs to
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) best[cc][r] = fmaxf(best[cc][r], acc[nt][r]);
+                    for (int r = 0; r < 4; ++r) best[cc][r] = imaxf(best[cc][r], acc[nt][r]);
                 }
 #pragma unroll
                 for (int cc = 0; cc < CPP; ++cc) {
-                    const f32x4 pooled4 = row_allmax4(best[cc]);  // pool, then ReLU
+                    const f32x4 pooled4 = row_allmax4i(best[cc]);
                     float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(pooled4[r], 0.f);
+                    for (int r = 0; r < 4; ++r) v[r] = pooled4[r];
                     if (c == 0) {
                         const long long cen = bj0 + cc;
                         const int b = ub, j = (int)(cen - (long long)ub * a.m);  // no 64-bit division: the unit lies inside scene ub

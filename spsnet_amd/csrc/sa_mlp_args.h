@@ -48,6 +48,33 @@ __device__ __forceinline__ sps_f32x4 row_allmax4(sps_f32x4 v) {
     return (sps_f32x4){a, b, c, d};
 }
 
+// ReLU and max-pooling in the INTEGER domain.  Non-negative floats (and +Inf, +NaN) order like their bit patterns as signed
+// ints, everything with the sign bit set is a negative int: max_i32(bits(x), 0) is ReLU, and it keeps +Inf / +NaN where
+// v_max_f32 would drop a NaN -- torch's ReLU and max_pool2d propagate NaN (pointnet2_modules.py:432-440 runs them).
+// (A NaN with the sign bit set becomes 0; the arithmetic here produces the default +NaN.)
+__device__ __forceinline__ float relu_keep_nan(float x) {
+    const int b = __float_as_int(x);
+    return __int_as_float(b > 0 ? b : 0);
+}
+__device__ __forceinline__ float imaxf(float a, float b) {   // both >= 0 (or +Inf / +NaN) as floats
+    const int x = __float_as_int(a), y = __float_as_int(b);
+    return __int_as_float(x > y ? x : y);
+}
+// row_allmax4 on non-negative values, NaN-keeping: v_max_i32_dpp
+__device__ __forceinline__ sps_f32x4 row_allmax4i(sps_f32x4 v) {
+    float a = v[0], b = v[1], c = v[2], d = v[3];
+#define SPS_DPP_MAX4(CTRL)                                                    \
+    "v_max_i32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n"           \
+    "v_max_i32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n"           \
+    "v_max_i32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n"           \
+    "v_max_i32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n"
+    asm volatile("s_nop 1\n" SPS_DPP_MAX4("quad_perm:[1,0,3,2]") SPS_DPP_MAX4("quad_perm:[2,3,0,1]")
+                 SPS_DPP_MAX4("row_half_mirror") SPS_DPP_MAX4("row_mirror")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef SPS_DPP_MAX4
+    return (sps_f32x4){a, b, c, d};
+}
+
 // ---- packed-column epilogue shared by the per-wave kernels (sa_mlp.hip, sa_mlp_f16.hip) ------------------------------------
 // meta word of a column: centroid j within its scene [19:0], scene [27:20], log2(slot) [30:28], unused [31].  A unit keeps
 // only these words (one VGPR per tile) across the three layers; everything else is decoded where it is used.
@@ -71,17 +98,17 @@ __device__ __forceinline__ void load_packed_unit(const SaMlpArgs &a, int unit, i
     }
 }
 
-// row_allmax4 restricted to each lane's slot of 2^lg columns: step s of the xor butterfly runs only in the lanes with
+// row_allmax4i (values already >= 0: ReLU applied) restricted to each lane's slot of 2^lg columns: step s of the xor butterfly runs only in the lanes with
 // lg > s (EXEC masked; the mask comes from one v_cmp per step); their partners lie in the same aligned slot, hence are
 // enabled too.  Afterwards every lane of a slot holds the slot's maximum.
 __device__ __forceinline__ sps_f32x4 slot_allmax4(sps_f32x4 v, unsigned lg) {
     float a = v[0], b = v[1], c = v[2], d = v[3];
     unsigned long long saved, mask;
 #define SPS_DPP_MAX4(CTRL)                                                    \
-    "v_max_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n"           \
-    "v_max_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n"           \
-    "v_max_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n"           \
-    "v_max_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n"
+    "v_max_i32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n"           \
+    "v_max_i32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n"           \
+    "v_max_i32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n"           \
+    "v_max_i32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n"
 #define SPS_SLOT_STEP(S, CTRL)                                                \
     "v_cmp_lt_u32_e64 %5, " S ", %6\n"                                        \
     "s_and_saveexec_b64 %4, %5\n"                                             \
@@ -126,20 +153,22 @@ __device__ __forceinline__ void store_pooled_rows(const SaMlpArgs &a, int b, int
         }
 }
 
-// Pool one 16-row output tile of a PACKED unit over each centroid's slot, ReLU, write.
+// Pool one 16-row output tile of a PACKED unit over each centroid's slot (ReLU folded into the integer max), write.
+// poison: the unit met an operand it could not represent (split-fp16 kernels): its rows are written as NaN, never clamped.
 template <int NT>
 __device__ __forceinline__ void pool_write_packed(const SaMlpArgs &a, const sps_f32x4 (&acc)[NT], const PackedUnit<NT> &pu,
-                                                  int mt, int q, int c) {
+                                                  int mt, int q, int c, bool poison = false) {
     const int lg0 = __builtin_amdgcn_readfirstlane((int)((pu.w[0] >> 28) & 7u));
     const int scene = __builtin_amdgcn_readfirstlane((int)((pu.w[0] >> 20) & 0xFFu));
+    const float nan = __int_as_float(0x7fc00000);
     if (lg0 >= 5) {   // the whole unit is (part of) ONE centroid's slot of 32 or 64 columns
-        sps_f32x4 best = acc[0];
+        sps_f32x4 best = (sps_f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int nt = 1; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) best[r] = fmaxf(best[r], acc[nt][r]);
-        const sps_f32x4 p = row_allmax4(best);
-        const float v[4] = {fmaxf(p[0], 0.f), fmaxf(p[1], 0.f), fmaxf(p[2], 0.f), fmaxf(p[3], 0.f)};
+            for (int r = 0; r < 4; ++r) best[r] = imaxf(best[r], acc[nt][r]);
+        const sps_f32x4 p = row_allmax4i(best);
+        const float v[4] = {poison ? nan : p[0], poison ? nan : p[1], poison ? nan : p[2], poison ? nan : p[3]};
         // 64 columns = two units: they meet through an atomic max on the zero-filled `out` (values >= 0 order like ints)
         if (c == 0) store_pooled_rows<true>(a, scene, (int)(pu.w[0] & 0xFFFFFu), mt, q, v, lg0 >= 6);
         return;
@@ -147,8 +176,10 @@ __device__ __forceinline__ void pool_write_packed(const SaMlpArgs &a, const sps_
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const unsigned w = pu.w[nt], lg = (w >> 28) & 7u;
-        const sps_f32x4 p = slot_allmax4(acc[nt], lg);
-        const float v[4] = {fmaxf(p[0], 0.f), fmaxf(p[1], 0.f), fmaxf(p[2], 0.f), fmaxf(p[3], 0.f)};
+        const sps_f32x4 relu = (sps_f32x4){relu_keep_nan(acc[nt][0]), relu_keep_nan(acc[nt][1]), relu_keep_nan(acc[nt][2]),
+                                           relu_keep_nan(acc[nt][3])};
+        const sps_f32x4 p = slot_allmax4(relu, lg);
+        const float v[4] = {poison ? nan : p[0], poison ? nan : p[1], poison ? nan : p[2], poison ? nan : p[3]};
         const bool writer = (w >> 31) == 0u && (c & ((1 << lg) - 1)) == 0;   // first lane of a slot, never an unused lane
         if (writer) store_pooled_rows<true>(a, scene, (int)(w & 0xFFFFFu), mt, q, v, false);
     }

@@ -32,6 +32,12 @@ template <int OFF, bool RELU, bool PURE = false>
 __device__ __forceinline__ void split4(const f32x4 v, h8 &hi, h8 &lo, float &mx) {
     mx = __builtin_amdgcn_fmed3f(mx, INFINITY, fmaxf(fabsf(v[0]), fabsf(v[1])));  // max3(mx, |v0|, |v1|) for mx >= 0
     mx = __builtin_amdgcn_fmed3f(mx, INFINITY, fmaxf(fabsf(v[2]), fabsf(v[3])));
+    if constexpr (!RELU) {
+        // layer-1 inputs come from outside: v_max drops a NaN, so NaN / Inf are caught by 0 * v (NaN for both), which sends
+        // mx to +Inf.  Activations (RELU) can only turn NaN after an Inf that mx has seen.
+        const float z = __builtin_fmaf(v[0], 0.f, __builtin_fmaf(v[1], 0.f, __builtin_fmaf(v[2], 0.f, v[3] * 0.f)));
+        mx = (z == 0.f) ? mx : INFINITY;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float c = __builtin_amdgcn_fmed3f(v[r], RELU ? 0.f : -65504.f, 65504.f);
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
             ws3.rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.w3, 0, n3, 0x00020000);
         }
     }
-    float mx = 0.f;  // largest operand magnitude this lane has split
+    bool any_bad = false;   // some unit of this wave met an operand beyond the representable range (or NaN / Inf)
     constexpr bool packed = PACKED;   // a separate instantiation: the padded form keeps its register budget
     const int nunits = packed ? (*a.ntiles) / NT : a.units;   // packed: as many units as pack_columns produced tiles for
     for (int unit = wave; unit < nunits; unit += nwaves) {
@@ -137,6 +143,7 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
         const long long col0 = ((long long)ub * a.m + a.j0) * NS + (long long)(unit - ub * a.ups) * UNIT;
         h8 h2hi[S2][NT], h2lo[S2][NT];
         PackedUnit<NT> pu;
+        float mx = 0.f;  // largest operand magnitude this lane has split in this unit
         {
             int src[NT];
             long long bj[NT];
@@ -277,6 +284,12 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
             }
         }
 
+        // Every operand of this unit has been split by now (layer 3's outputs go to the pool as fp32).  One beyond the
+        // exactly representable range -- or NaN / Inf in the gathered inputs -- POISONS the unit: its pooled rows are written
+        // as NaN instead of a silently clamped value, and the launch reports it (fused.check_overflow).
+        const bool poison = __builtin_amdgcn_ballot_w64(mx > 65504.f) != 0ull;
+        any_bad |= poison;
+        const float nan_or = __int_as_float(0x7fc00000);
         // ---------------- layer 3 (runtime width) + max-pool ----------------
         const long long bj0 = col0 / NS;
         {
@@ -311,24 +324,24 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (packed) {
-                    pool_write_packed<NT>(a, acc, pu, mt, q, c);
+                    pool_write_packed<NT>(a, acc, pu, mt, q, c, poison);
                     continue;
                 }
                 f32x4 best[CPP];
 #pragma unroll
-                for (int cc = 0; cc < CPP; ++cc) best[cc] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                for (int cc = 0; cc < CPP; ++cc) best[cc] = (f32x4){0.f, 0.f, 0.f, 0.f};   // ReLU + pool = one integer max from +0
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int cc = PART ? 0 : (nt * 16) / NS;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) best[cc][r] = fmaxf(best[cc][r], acc[nt][r]);
+                    for (int r = 0; r < 4; ++r) best[cc][r] = imaxf(best[cc][r], acc[nt][r]);
                 }
 #pragma unroll
                 for (int cc = 0; cc < CPP; ++cc) {
-                    const f32x4 pooled4 = row_allmax4(best[cc]);  // pool, then ReLU
+                    const f32x4 pooled4 = row_allmax4i(best[cc]);
                     float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(pooled4[r], 0.f);
+                    for (int r = 0; r < 4; ++r) v[r] = poison ? nan_or : pooled4[r];
                     if (c == 0) {
                         const long long cen = bj0 + cc;
                         const int b = ub, j = (int)(cen - (long long)ub * a.m);  // no 64-bit division: the unit lies inside scene ub
@@ -348,7 +361,7 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
             }
         }
     }
-    if (mx > 65504.f && a.overflow) *a.overflow = 1;
+    if (any_bad && a.overflow) *a.overflow = 1;
 }
 
 template <int C1, int C2, int NT, int NS, bool PURE>

@@ -46,6 +46,10 @@ template <int OFF, bool RELU>
 __device__ __forceinline__ void split4(const f32x4 v, h8 &hi, h8 &lo, float &mx) {
     mx = __builtin_amdgcn_fmed3f(mx, INFINITY, fmaxf(fabsf(v[0]), fabsf(v[1])));  // max3(mx, |v0|, |v1|) for mx >= 0
     mx = __builtin_amdgcn_fmed3f(mx, INFINITY, fmaxf(fabsf(v[2]), fabsf(v[3])));
+    if constexpr (!RELU) {   // gathered inputs: NaN / Inf are caught by 0 * v (v_max drops a NaN); see sa_mlp_f16.hip
+        const float z = __builtin_fmaf(v[0], 0.f, __builtin_fmaf(v[1], 0.f, __builtin_fmaf(v[2], 0.f, v[3] * 0.f)));
+        mx = (z == 0.f) ? mx : INFINITY;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float c = __builtin_amdgcn_fmed3f(v[r], RELU ? 0.f : -65504.f, 65504.f);
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa
         for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32h(w.lo, xh[nt], acc[nt]);
     };
 
-    float mx = 0.f;  // largest operand magnitude this lane has split
+    bool any_bad = false;   // some unit of this wave met an operand beyond the representable range (or NaN / Inf)
     // units are handed out per workgroup so that its four waves stay in lockstep on the shared stream; a wave without a
     // unit of its own recomputes the last one and writes nothing
     const int ngroups = (a.units + WAVES - 1) / WAVES;
@@ -184,6 +188,7 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa
         const int unit = valid ? unit_raw : a.units - 1;
         const int ub = unit / a.ups;
         const long long col0 = ((long long)ub * a.m + a.j0) * NS + (long long)(unit - ub * a.ups) * UNIT;
+        float mx = 0.f;  // largest operand magnitude this lane has split in this unit
         {
             int src[NT];
             long long bj[NT];
@@ -308,23 +313,26 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa
                     }
                 }
             }
-            // ---------------- ReLU + max-pool over the samples of each centroid ----------------
+            // ---------------- ReLU + max-pool over the samples of each centroid (one integer max from +0) ----------------
+            // A unit that met an unrepresentable operand (or NaN / Inf inputs) is POISONED: NaN rows, never a clamped value.
+            const bool poison = __builtin_amdgcn_ballot_w64(mx > 65504.f) != 0ull;
+            any_bad |= poison;
 #pragma unroll
             for (int mt = 0; mt < MT3; ++mt) {
                 f32x4 best[CPP];
 #pragma unroll
-                for (int cc = 0; cc < CPP; ++cc) best[cc] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                for (int cc = 0; cc < CPP; ++cc) best[cc] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int cc = SPLIT > 1 ? 0 : (nt * 16) / NS;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) best[cc][r] = fmaxf(best[cc][r], acc3[mt][nt][r]);
+                    for (int r = 0; r < 4; ++r) best[cc][r] = imaxf(best[cc][r], acc3[mt][nt][r]);
                 }
 #pragma unroll
                 for (int cc = 0; cc < CPP; ++cc) {
-                    f32x4 v = row_allmax4(best[cc]);
+                    f32x4 v = row_allmax4i(best[cc]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    for (int r = 0; r < 4; ++r) v[r] = poison ? __int_as_float(0x7fc00000) : v[r];
                     if (c == 0) *reinterpret_cast<f32x4 *>(my_stage + (size_t)cc * C3 + 16 * mt + 4 * q) = v;
                 }
             }
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa
                 const int b = ub, j = (int)(cen - (long long)ub * a.m);  // no 64-bit division: the unit lies inside scene ub
                 float v = my_stage[(size_t)cc * C3 + row];
 #pragma unroll
-                for (int o = 1; o < SPLIT; ++o) v = fmaxf(v, my_stage[(size_t)(o * CPP + cc) * C3 + row]);
+                for (int o = 1; o < SPLIT; ++o) v = imaxf(v, my_stage[(size_t)(o * CPP + cc) * C3 + row]);   // NaN-keeping
                 if (a.out_pm) a.out[((size_t)b * a.m + j) * a.out_c_total + a.out_c_off + row] = v;   // lanes <-> rows: contiguous
                 else a.out[((size_t)b * a.out_c_total + a.out_c_off + row) * a.m + j] = v;
             }
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa
         wait_vm<0>();  // stores retire out of order with loads: let them (and the requests) finish before counting again
     }
     wait_vm<0>();
-    if (mx > 65504.f && a.overflow) *a.overflow = 1;
+    if (any_bad && a.overflow) *a.overflow = 1;
 }
 
 template <int C1, int C2, int C3, int NT, int NS, int WAVES>

@@ -861,25 +861,74 @@ def test_fused_group_mlp_split_fp16(ext, G, dev, c_feat, widths, ns, radius):
     assert not fused.check_overflow()
 
 
-def test_split_fp16_flags_out_of_range_operands(ext, G, dev):
-    """Operands beyond the exactly splittable range are clamped (finite output) and reported, never silent."""
+def test_split_fp16_never_clamps_silently(ext, G, dev):
+    """An operand beyond the exactly splittable range POISONS the centroids it reaches -- NaN rows, not clamped values --
+    and is reported; centroids it does not reach equal the fp32 kernel's rows to the usual tolerance."""
     from spsnet_amd import fused, pointnet2_modules as M
     torch.manual_seed(0)
     mod = M.PointnetSAModuleMSG_WithSampling(
         npoint_list=[256], sample_range_list=[-1], sample_type_list=['D-FPS'], radii=[1.0], nsamples=[32],
         mlps=[[5, 32, 32, 64]], use_xyz=True, dilated_group=False, aggregation_mlp=None, confidence_mlp=None,
         num_class=3).to(dev).eval()
-    xyz = G.t(cloud(np.random.default_rng(0), 2, 2000))
-    feats = torch.full((2, 5, 2000), 3.0e5, device=dev)
-    old = fused.set_precision("fp16x2")
+    rng = np.random.default_rng(0)
+    xyz = G.t(cloud(rng, 2, 2000))
+    feats = G.t(rng.normal(size=(2, 5, 2000)).astype(np.float32))
+    feats[0, 2, 100:140] = 3.0e5                       # forty out-of-range points in scene 0; scene 1 stays clean
+    old = fused.set_precision("fp32")
+    try:
+        with torch.no_grad():
+            _, ref, _, _, _ = mod(xyz, feats)
+            fused.set_precision("fp16x2")
+            fused.check_overflow()
+            _, out, _, _, _ = mod(xyz, feats)
+        assert fused.check_overflow()
+        assert not fused.check_overflow()  # the flag resets
+        bad = torch.isnan(out).any(dim=1)                # (B, M): poisoned centroids
+        assert bad[0].any() and not bad[1].any() and torch.isfinite(ref).all()
+        assert torch.isnan(out[0][:, bad[0]]).all()      # a poisoned centroid is NaN in every channel
+        clean = ~bad
+        scale = float(ref.abs().max())
+        assert float((out.transpose(1, 2)[clean] - ref.transpose(1, 2)[clean]).abs().max()) <= 1e-4 * scale
+    finally:
+        fused.check_overflow()
+        fused.set_precision(old)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x2"])
+def test_nan_inputs_propagate_through_the_layer(ext, G, dev, precision):
+    """torch's Conv / ReLU / max_pool2d / Conv1d chain propagates a NaN feature to every centroid whose ball holds the point;
+    so does the fused path (integer-domain ReLU / pooling in the fp32 kernels, poisoned units in the split-fp16 ones), through
+    the aggregation stack as well -- and nowhere else."""
+    from spsnet_amd import fused, pointnet2_modules as M, pointnet2_utils as U
+    torch.manual_seed(1)
+    mod = M.PointnetSAModuleMSG_WithSampling(
+        npoint_list=[256], sample_range_list=[-1], sample_type_list=['D-FPS'], radii=[0.8, 1.6], nsamples=[16, 32],
+        mlps=[[64, 64, 64, 128], [64, 64, 96, 128]], use_xyz=True, dilated_group=False, aggregation_mlp=[128], confidence_mlp=[],
+        num_class=3).to(dev).eval()
+    rng = np.random.default_rng(3)
+    xyz = G.t(cloud(rng, 2, 2048))
+    feats = G.t(rng.normal(size=(2, 64, 2048)).astype(np.float32))
+    feats[1, 7, 300] = float("nan")
+    old = fused.set_precision(precision)
     try:
         with torch.no_grad():
             fused.check_overflow()
-            _, out, _, _, _ = mod(xyz, feats)
-        assert torch.isfinite(out).all()
-        assert fused.check_overflow()
-        assert not fused.check_overflow()  # the flag resets
+            new_xyz, out, _, idx, _ = mod(xyz, feats)
+            # which centroids hold point 300 of scene 1 in either ball?
+            reach = torch.zeros(out.shape[0], out.shape[2], dtype=torch.bool, device=dev)
+            for g in mod.groupers:
+                rows = U.ball_query(g.radius, g.nsample, xyz, new_xyz)
+                reach[1] |= (rows[1] == 300).any(dim=1)
+        got = torch.isnan(out).any(dim=1)
+        assert reach[1].any() and not (reach & ~got).any()      # every centroid the NaN reaches is NaN ...
+        if precision == "fp32":
+            assert torch.equal(got, reach)                       # ... and, in the exact kernels, no other
+        else:                                                    # split-fp16 poisons whole kernel units: with 16 samples a
+            partner = torch.zeros_like(reach)                    # unit of 32 columns holds centroids 2k and 2k + 1
+            partner[:, 0::2], partner[:, 1::2] = reach[:, 1::2], reach[:, 0::2]
+            assert not (got & ~(reach | partner)).any() and not got[0].any()
     finally:
+        fused.check_overflow()
         fused.set_precision(old)
 
 
