@@ -216,9 +216,12 @@ unsigned sps_debug_set_wait_spins(unsigned spins);
  * them); the other scenes keep idxs / temp untouched. */
 int sps_fps_redo_where(int b, int n, int m, const float *dataset, float *temp, int *idxs, const int *redo,
                        sps_stream_t stream);
+/* temp may be NULL in sps_fps_publish: the running distances start at 1e10 and are not written back. */
 int sps_fps_publish(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress,
                     sps_stream_t stream);
 int sps_wait_progress(const int *progress, int b, int need, int *timed_out, sps_stream_t stream);
+/* patient != 0: the wait for the producer's last sample -- ~64 x the bound, not affected by sps_debug_set_wait_spins. */
+int sps_wait_progress_ex(const int *progress, int b, int need, int *timed_out, int patient, sps_stream_t stream);
 int sps_gather_xyz_range(int b, int n, int m, int j0, int jcount, const float *xyz, const int *idx, float *out,
                          const int *run_if, sps_stream_t stream);
 int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcount, float radius_a, int nsample_a,

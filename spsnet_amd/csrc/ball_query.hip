@@ -416,6 +416,98 @@ __global__ __launch_bounds__(64 * BQS_SEG) void ball_query_wave_seg_kernel(
     }
 }
 
+// Several centroids per wave.  The per-centroid kernels above re-read the cloud once per centroid: 2048 centroids x 16 384
+// points (the last chunk of a streamed layer) or 8192 x 4096 (IA-SSD layer 1) pull ~400 MB through L2 per launch -- at 27-30 us
+// that IS the L2 bandwidth.  Here a wave takes C consecutive centroids of a scene (centres in SGPRs) and tests every 64-point
+// step it loads against all of them; SEG waves of a workgroup split the point range, their ordered hit lists meet in LDS and
+// are concatenated in segment order (= index order), as in ball_query_wave_seg_kernel.  Same rows, C times less traffic.
+template <int C, int SEG, int UNR>
+__global__ __launch_bounds__(64 * SEG) void ball_query_wave_multi_kernel(
+    int n, int m, float r2a, float r2b, int nsa, int nsb, const float *__restrict__ new_xyz,
+    const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b, int jbeg,
+    const int *__restrict__ run_if) {
+    __shared__ int hits[2][C][SEG][BQS_MAX_NS];
+    __shared__ int cnt[2][C][SEG];
+    if (run_if && *run_if == 0) return;
+    const int scene = blockIdx.y, j0 = jbeg + blockIdx.x * C;
+    const int lane = threadIdx.x & 63, seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    xyz += (size_t)scene * n * 3;
+    float cx[C], cy[C], cz[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float *ctr = new_xyz + ((size_t)scene * m + j0 + c) * 3;
+        cx[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ctr[0])));
+        cy[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ctr[1])));
+        cz[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ctr[2])));
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int seg_len = ((n + SEG - 1) / SEG + 63) & ~63;
+    const int kbeg = seg * seg_len, kend = (kbeg + seg_len < n) ? kbeg + seg_len : n;
+    int ca[C], cb[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) ca[c] = cb[c] = 0;
+    // UNR 64-point steps are in flight per trip: the scan is a chain of L2 round trips, so their number sets the launch time
+    for (int base = kbeg; base < kend; base += 64 * UNR) {
+        float px[UNR], py[UNR], pz[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int k = base + u * 64 + lane;
+            const int kk = k < n ? k : n - 1;
+            px[u] = xyz[kk * 3 + 0]; py[u] = xyz[kk * 3 + 1]; pz[u] = xyz[kk * 3 + 2];
+        }
+        bool all_full = true;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int k = base + u * 64 + lane;
+            const bool in = k < kend;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float d2 = sqdist(cx[c], cy[c], cz[c], px[u], py[u], pz[u]);
+                const bool ha = in && d2 < r2a, hb = in && d2 < r2b;
+                const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
+                if (ma != 0ull && ca[c] < nsa) {
+                    const int pos = ca[c] + __builtin_popcountll(ma & below);
+                    if (ha && pos < nsa) hits[0][c][seg][pos] = k;
+                    ca[c] += __builtin_popcountll(ma);
+                }
+                if (mb != 0ull && cb[c] < nsb) {
+                    const int pos = cb[c] + __builtin_popcountll(mb & below);
+                    if (hb && pos < nsb) hits[1][c][seg][pos] = k;
+                    cb[c] += __builtin_popcountll(mb);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) all_full = all_full && ca[c] >= nsa && cb[c] >= nsb;
+        if (all_full) break;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) { cnt[0][c][seg] = ca[c] < nsa ? ca[c] : nsa; cnt[1][c][seg] = cb[c] < nsb ? cb[c] : nsb; }
+    }
+    __syncthreads();
+    for (int pair = seg; pair < 2 * C; pair += SEG) {   // (radius, centroid) rows, concatenated in segment = index order
+        const int which = pair & 1, c = pair >> 1;
+        const int ns = which ? nsb : nsa;
+        int *row = (which ? idx_b : idx_a) + ((size_t)scene * m + j0 + c) * ns;
+        int cs[SEG], total = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < SEG; ++s2) { cs[s2] = cnt[which][c][s2]; total += cs[s2]; }
+        int first = 0;  // empty ball: zeros
+#pragma unroll
+        for (int s2 = SEG - 1; s2 >= 0; --s2) first = cs[s2] > 0 ? hits[which][c][s2][0] : first;
+        for (int p = lane; p < ns; p += 64) {
+            int v = first, q = p;
+#pragma unroll
+            for (int s2 = 0; s2 < SEG; ++s2) {
+                if (q >= 0 && q < cs[s2]) v = hits[which][c][s2][q];
+                q = (q >= 0 && q < cs[s2]) ? -1 : q - cs[s2];
+            }
+            row[p] = p < total ? v : first;
+        }
+    }
+}
+
 // perm[b, :] = the scene's centroids sorted by 12-bit cell key (counting sort in LDS, one workgroup per scene;
 // order inside a cell is arbitrary -- it only affects speed, never results).
 constexpr int CO_THREADS = 512;
@@ -527,6 +619,22 @@ extern "C" int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcoun
     // segments are waves of one workgroup); one wave per centroid spreads the same work over the chip.
     bool per_wave = !perm_work && (long long)b * jcount <= BQ_WAVE_MAX_CENTROIDS;
     if (const char *force = getenv("SPS_BQ_WAVE")) per_wave = force[0] == '1';  // diagnostic override (tools/bq_time.py)
+    static const bool multi_ok = !(getenv("SPS_BQ_MULTI") && getenv("SPS_BQ_MULTI")[0] == '0');
+    if (per_wave && multi_ok && jcount % 4 == 0 && nsample_a <= BQS_MAX_NS && nsample_b <= BQS_MAX_NS && n >= 256) {
+        // four centroids per wave share every point load; the point range is split so that the launch still has waves
+        const float ra2 = radius_a * radius_a, rb2 = radius_b * radius_b;
+        const dim3 grid(jcount / 4, b);
+        if (n >= 8192)
+            hipLaunchKernelGGL((ball_query_wave_multi_kernel<4, 8, 8>), grid, dim3(64 * 8), 0, as_stream(stream), n, m, ra2, rb2,
+                               nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, j0, run_if);
+        else if (n >= 2048)
+            hipLaunchKernelGGL((ball_query_wave_multi_kernel<4, 4, 8>), grid, dim3(64 * 4), 0, as_stream(stream), n, m, ra2, rb2,
+                               nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, j0, run_if);
+        else
+            hipLaunchKernelGGL((ball_query_wave_multi_kernel<4, 4, 4>), grid, dim3(64 * 4), 0, as_stream(stream), n, m, ra2, rb2,
+                               nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, j0, run_if);
+        return check_launch("ball_query_wave_multi_kernel");
+    }
     if (per_wave && (long long)b * jcount <= BQ_SEG_MAX_CENTROIDS && nsample_a <= BQS_MAX_NS && nsample_b <= BQS_MAX_NS &&
         n >= 4096) {
         hipLaunchKernelGGL(ball_query_wave_seg_kernel, dim3(jcount, b), dim3(64 * BQS_SEG), 0, as_stream(stream), n, m,

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64) void wait_progress_kernel(const int *progress, 
 extern "C" int sps_fps_publish(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress,
                                sps_stream_t stream) {
     using namespace sps;
-    if (b <= 0 || n <= 0 || m <= 0 || !dataset || !temp || !idxs || !progress)
+    if (b <= 0 || n <= 0 || m <= 0 || !dataset || !idxs || !progress)   // temp may be NULL: start from 1e10, no write-back
         return fail(SPS_ERR_INVALID, "fps_publish: bad arguments");
     hipStream_t st = as_stream(stream);
     const int rc = launch_fps_pruned_publish(b, n, m, dataset, temp, idxs, progress, st);
@@ -310,9 +310,17 @@ extern "C" int sps_fps_publish(int b, int n, int m, const float *dataset, float 
 // Block `stream` until every scene's progress counter reaches `need` (a tiny spinning kernel, bounded).
 // timed_out (device i32, caller-zeroed) is set to 1 if the bound was hit.
 extern "C" int sps_wait_progress(const int *progress, int b, int need, int *timed_out, sps_stream_t stream) {
+    return sps_wait_progress_ex(progress, b, need, timed_out, 0, stream);
+}
+
+// patient != 0: the wait for the producer's LAST sample.  It spins ~64 times longer (minutes) and ignores the diagnostic bound:
+// everything behind it -- the predicated repair of earlier waits included -- relies on the samples being complete, and a
+// producer that has not finished after minutes means a hung device whatever this wait does.
+extern "C" int sps_wait_progress_ex(const int *progress, int b, int need, int *timed_out, int patient, sps_stream_t stream) {
     using namespace sps;
     if (b <= 0 || !progress || !timed_out) return fail(SPS_ERR_INVALID, "wait_progress: bad arguments");
-    hipLaunchKernelGGL(wait_progress_kernel, dim3(1), dim3(64), 0, as_stream(stream), progress, b, need, timed_out, g_wait_spins);
+    hipLaunchKernelGGL(wait_progress_kernel, dim3(1), dim3(64), 0, as_stream(stream), progress, b, need, timed_out,
+                       patient ? (1u << 28) : g_wait_spins);
     return check_launch("wait_progress_kernel");
 }
 

@@ -62,7 +62,11 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
         if (fps_already_done(redo, temp_done, temp, scene, n)) return;
     }
     const float *xyz = dataset + (size_t)scene * n * 3;
-    temp += (size_t)scene * n;
+    // PUBLISH launches may pass temp == nullptr: "all running distances start at 1e10 (what the reference's caller fills in,
+    // pointnet2_utils.py:26) and nobody wants them back" -- the streamed layer then needs neither the fill launch in front of
+    // the producer nor the write-back behind it
+    const bool has_temp = !PUBLISH || temp != nullptr;
+    if (has_temp) temp += (size_t)scene * n;
     idxs += (size_t)scene * m;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
         x[s] = ok ? xyz[k * 3 + 0] : NAN;  // NaN coordinates: never inside a box, distance stays -1
         y[s] = ok ? xyz[k * 3 + 1] : NAN;
         z[s] = ok ? xyz[k * 3 + 2] : NAN;
-        t[s] = ok ? temp[k] : -1.f;
+        t[s] = ok ? (has_temp ? temp[k] : 1e10f) : -1.f;
     }
 
     // per-bucket metadata, bucket s of this wave in lane s
@@ -462,10 +466,12 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
     }
 
     // the reference leaves the final running min-distances in `temp`
+    if (has_temp) {
 #pragma unroll
-    for (int s = 0; s < P; ++s) {
-        const int pos = (s * PF_WAVES + wave) * 64 + lane;
-        if (pos < n) temp[sorted[pos]] = t[s];
+        for (int s = 0; s < P; ++s) {
+            const int pos = (s * PF_WAVES + wave) * 64 + lane;
+            if (pos < n) temp[sorted[pos]] = t[s];
+        }
     }
 }
 

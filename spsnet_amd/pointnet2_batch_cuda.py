@@ -369,10 +369,9 @@ class OrderedPrefix:
         self.work_t = torch.empty((B, max(npoint, 1)), dtype=F32, device=dev)
         self.work_temp = torch.empty((B, N), dtype=F32, device=dev)
         self.flags = torch.empty((B,), dtype=I32, device=dev)
-        self.temp_redo = torch.full((B, N), 1e10, dtype=F32, device=dev)   # for fps_redo_where, filled off the critical path
 
     def tensors(self):
-        return (self.temp, self.idx, self.work_t, self.work_temp, self.flags, self.temp_redo)
+        return (self.temp, self.idx, self.work_t, self.work_temp, self.flags)
 
     def begin(self):
         B, N, _ = self.xyz.shape
@@ -398,10 +397,11 @@ def current_stream_handle(t):
 
 
 def fps_publish(xyz, temp, idx, progress):
-    """Launch the publishing FPS (sps_fps_publish) on the current stream; all tensors are caller-allocated."""
+    """Launch the publishing FPS (sps_fps_publish) on the current stream; all tensors are caller-allocated.  temp = None: the
+    running distances start at 1e10 and are not handed back (no fill launch in front of the producer)."""
     B, N, _ = xyz.shape
     with _on(xyz):
-        _lib.check(_L.sps_fps_publish(B, N, idx.shape[1], _ptr(xyz, F32, "xyz"), _ptr(temp, F32, "temp"),
+        _lib.check(_L.sps_fps_publish(B, N, idx.shape[1], _ptr(xyz, F32, "xyz"), 0 if temp is None else _ptr(temp, F32, "temp"),
                                       _ptr(idx, I32, "idx"), _ptr(progress, I32, "progress"), _stream(xyz)), "fps_publish")
 
 
@@ -416,13 +416,14 @@ def fps_redo_where(xyz, idx, redo, temp=None):
                                          _ptr(redo, I32, "redo"), _stream(xyz)), "fps_redo_where")
 
 
-def wait_progress(progress, need, timed_out):
+def wait_progress(progress, need, timed_out, patient=False):
     """Enqueue a bounded device-side wait on the current stream until all scenes published `need` samples; on giving up
     it sets timed_out (B,) -- every entry."""
     with _on(progress):
         _need(timed_out, progress.numel(), "timed_out")
-        _lib.check(_L.sps_wait_progress(_ptr(progress, I32, "progress"), progress.numel(), need,
-                                        _ptr(timed_out, I32, "timed_out"), _stream(progress)), "wait_progress")
+        _lib.check(_L.sps_wait_progress_ex(_ptr(progress, I32, "progress"), progress.numel(), need,
+                                           _ptr(timed_out, I32, "timed_out"), 1 if patient else 0, _stream(progress)),
+                   "wait_progress")
 
 
 def _flag(run_if):

@@ -69,7 +69,7 @@ def build_sa_layers(modules_pkg, cfg=IASSD_KITTI, input_channels=4, num_class=3,
     return layers.eval()
 
 
-CONSUMER_ON_MAIN = __import__("os").environ.get("SPS_CONSUMER_ON_MAIN", "1") != "0"
+HYBRID = False          # see _streamed_first_layer
 _SIDE_STREAMS = {}
 _FENCES = {}          # (device index, main stream handle) -> CuFence
 
@@ -230,20 +230,23 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
     ga, gb = layer.groupers
     main = torch.cuda.current_stream(dev)
     fps_stream = _helper_stream(dev, "fps")              # None unless a CuFence is registered for `main`
-    # Which of the two runs on the caller's stream?  The consumer (default): everything after the layer depends on ITS last
-    # kernel, so nothing downstream has to hop streams; the producer then gets a helper stream.  (The other way round the
-    # pass paid a cross-stream dependency between the last chunk and the next layer.)
-    if CONSUMER_ON_MAIN:
-        side = main
-        if fps_stream is None:
-            fps_stream = _helper_stream(dev, "producer")
-    else:
-        side = _helper_stream(dev, "chunks")
+    # Who runs where (measured, tools/hop_cost.py: a kernel boundary costs ~4 us, a cross-stream dependency that is actually
+    # waited for ~12 us more, one that was satisfied long before nothing):
+    #   default   every chunk on the caller's stream behind bounded waits (nothing downstream has to hop streams); the producer on
+    #             a helper stream -- with a CuFence registered, on a stream of its own compute units.  One live dependency: the
+    #             producer's start.                                                      2.264 ms per pass at the bench shape
+    #   HYBRID    the producer on the caller's stream, the chunks that overlap it on a helper stream, the last chunk back on
+    #             the caller's stream in order behind the producer (no wait kernel, no live dependency).  Measured SLOWER,
+    #             2.296 ms: the last chunk then starts at the producer kernel's end instead of at its last published sample.
+    if fps_stream is None and not HYBRID:
+        fps_stream = _helper_stream(dev, "producer")
+    fenced = fps_stream is not None
+    side = main if fenced else _helper_stream(dev, "chunks")
 
     idx = torch.empty((B, M), dtype=torch.int32, device=dev)
-    temp = torch.full((B, N), 1e10, dtype=torch.float32, device=dev)
-    zeros = torch.zeros((2 * B,), dtype=torch.int32, device=dev)  # one fill, on `main` BEFORE the consumer is released
-    progress, timed_out = zeros[:B], zeros[B:]                       # timed_out: one flag per scene, set together
+    temp = None                                          # the producer starts from 1e10 by itself and hands nothing back
+    zeros = _zeroed_ints(dev, 2 * B)                     # zero BEFORE the consumer is released; no fill launch per pass
+    progress, timed_out = zeros[:B], zeros[B:]           # timed_out: one flag per scene, set together
     idx_a = torch.empty((B, M, ga.nsample), dtype=torch.int32, device=dev)
     idx_b = torch.empty((B, M, gb.nsample), dtype=torch.int32, device=dev)
     out = (torch.zeros if max(ga.nsample, gb.nsample) > 32 else torch.empty)(
@@ -261,16 +264,13 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
     _fused._overflow_flag(dev)                           # (created on first use: also before `start`)
     start = torch.cuda.Event()
     start.record(main)
-    fps_done = torch.cuda.Event()
-    if fps_stream is None:
-        _ext.fps_publish(xyz, temp, idx, progress)      # producer, on the main stream
-        fps_done.record(main)
-    else:                                                # ... or on a helper stream (with a CuFence: on CUs of its own)
+    if not fenced:
+        _ext.fps_publish(xyz, temp, idx, progress)      # producer, on the caller's stream
+    else:
         fps_stream.wait_event(start)
         with torch.cuda.stream(fps_stream):
             _ext.fps_publish(xyz, temp, idx, progress)
-            fps_done.record(fps_stream)
-        for t in (xyz, temp, idx, progress):
+        for t in (xyz, idx, progress):
             t.record_stream(fps_stream)
     if after_producer is not None:
         after_producer()
@@ -286,36 +286,47 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
             verify = _ext.OrderedPrefix(new_xyz, nxt.npoint_list[0])
         for t in verify.tensors():
             t.record_stream(main)
-    with torch.cuda.stream(side):                        # consumer
+
+    def consume(j0, j1, wait):
+        """gather -> ball query -> grouped MLPs -> aggregation for the centroids [j0, j1) of every scene, on the current stream"""
+        nonlocal xyz_ready
+        chunk = j1 - j0
+        if wait:
+            _ext.wait_progress(progress, j1, timed_out, patient=(j1 == M))
+        _ext.gather_xyz_range(xyz, idx, new_xyz, j0, chunk)
+        if verify is not None and j0 < verify.npoint <= j1:
+            verify.begin()
+        if j1 == M:
+            # every sample exists now: centroids that an earlier, timed-out wait let through are gathered again before
+            # anybody else looks at them (a launch that does nothing otherwise)
+            _ext.gather_xyz_range(xyz, idx, new_xyz, 0, M, run_if=timed_out)
+            xyz_ready = torch.cuda.Event()
+            xyz_ready.record(torch.cuda.current_stream(dev))
+        _ext.ball_query_full2_range(ga.radius, gb.radius, xyz, new_xyz, idx_a, idx_b, j0, chunk)
+        off = 0
+        for ix, packed in zip((idx_a, idx_b), plan):
+            _fused.group_mlp_pool(xyz, new_xyz, features, ix, packed, out, off, j0, chunk)
+            off += packed.c3_real
+        if tail is not None:
+            tail.run(j0, chunk)
+
+    xyz_ready = None
+    bounds = list(zip([0] + ends[:-1], ends))
+    with torch.cuda.stream(side):                        # the chunks that run beside the producer
         if side is not main:
             side.wait_event(start)
-        for c, j1 in enumerate(ends):
-            j0 = ends[c - 1] if c else 0
-            chunk = j1 - j0
-            _ext.wait_progress(progress, j1, timed_out)
-            _ext.gather_xyz_range(xyz, idx, new_xyz, j0, chunk)
-            if verify is not None and j0 < verify.npoint <= j1:
-                verify.begin()
-            if j1 == M:
-                xyz_ready = torch.cuda.Event()
-                xyz_ready.record(side)
-            _ext.ball_query_full2_range(ga.radius, gb.radius, xyz, new_xyz, idx_a, idx_b, j0, chunk)
-            off = 0
-            for ix, packed in zip((idx_a, idx_b), plan):
-                _fused.group_mlp_pool(xyz, new_xyz, features, ix, packed, out, off, j0, chunk)
-                off += packed.c3_real
-            if tail is not None:
-                tail.run(j0, chunk)
-        # Correct or redo, never invalid: the waits above are bounded (a producer that never publishes must not hang the
-        # device); one that gave up let its consumers run on samples that had not been written.  Behind the producer the
-        # whole layer is issued once more with run_if = timed_out: launches that do nothing when every wait was served
-        # (~2 us each), the repair otherwise.
-        side.wait_event(fps_done)
-        _redo_layer(layer, plan, tail, xyz, idx, new_xyz, features, idx_a, idx_b, out, timed_out)
-        done = torch.cuda.Event()
-        done.record(side)
-    if side is not main:
-        main.wait_event(xyz_ready)                       # all centroids exist: the next layer's FPS check can finish
+        for j0, j1 in (bounds if fenced else bounds[:-1]):
+            consume(j0, j1, wait=True)
+        if side is not main:
+            early = torch.cuda.Event()
+            early.record(side)
+    if not fenced:                                       # the last chunk: behind the producer, on the caller's stream
+        main.wait_event(early)                           # (satisfied long before the producer ends: costs nothing)
+        consume(bounds[-1][0], M, wait=False)
+    # Correct or redo, never invalid: the waits are bounded (a producer that stalls must not hang the device); one that gave
+    # up let its consumers run on samples that had not been written.  Behind the producer's last sample the whole layer is
+    # issued once more with run_if = timed_out: launches that do nothing when every wait was served, the repair otherwise.
+    _redo_layer(layer, plan, tail, xyz, new_xyz, features, idx_a, idx_b, out, timed_out)
     if verify is not None:
         third = _side_stream(dev)                        # beside the last chunk's ball query, not behind it
         with torch.cuda.stream(third):
@@ -325,33 +336,36 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
             vdone.record(third)
         for t in verify.tensors() + (new_xyz,):
             t.record_stream(third)
-        if side is not main:
-            main.wait_event(done)
-        # ... and the next layer's D-FPS, which the verification derived from the same samples: recomputed for the
-        # flagged scenes (all or none) once the repaired centroids exist
-        main.wait_event(vdone)
-        _ext.fps_redo_where(new_xyz, nidx, timed_out, verify.temp_redo)
-        vdone = torch.cuda.Event()
-        vdone.record(main)
-        nxt._presampled = (nidx, vdone, new_xyz)
-    else:
-        if side is not main:
-            main.wait_event(done)
-        if nxt is not None and _can_prefetch(layer, nxt):
-            _prefetch_dfps(nxt, new_xyz, True)
+        nxt._presampled = (nidx, vdone, new_xyz)   # (derived from the repaired centroids; flagged scenes are recomputed)
+    elif nxt is not None and _can_prefetch(layer, nxt):
+        _prefetch_dfps(nxt, new_xyz, True)
     new_features, cls = tail.result() if tail is not None else layer._tail(out, half)
     if stds is not None:  # the layer's sampler thins the stability scores with its picks (reference :307-310)
         stds = pointnet2_utils.gather_operation(stds.view(B, 1, -1).contiguous(), idx).squeeze()
     return new_xyz, new_features, cls, idx, stds
 
 
-def _redo_layer(layer, plan, tail, xyz, idx, new_xyz, features, idx_a, idx_b, out, timed_out):
-    """The whole layer once more, every launch predicated on the device flags `timed_out` (see _streamed_first_layer)."""
+_ZERO_POOL = {}
+
+
+def _zeroed_ints(device, count):
+    """`count` zeroed int32 that nobody has written yet: slices of a pre-zeroed buffer (one fill launch per 4096 ints handed
+    out instead of one per pass, which sat in front of the FPS producer)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf, used = _ZERO_POOL.get(key, (None, 1 << 30))
+    if buf is None or used + count > buf.numel():
+        buf, used = torch.zeros((max(4096, count),), dtype=torch.int32, device=device), 0
+    _ZERO_POOL[key] = (buf, used + count)
+    return buf[used:used + count]
+
+
+def _redo_layer(layer, plan, tail, xyz, new_xyz, features, idx_a, idx_b, out, timed_out):
+    """The whole layer once more (behind the repaired centroids), every launch predicated on the device flags `timed_out`
+    (see _streamed_first_layer)."""
     from . import fused as _fused
     from . import pointnet2_batch_cuda as _ext
     ga, gb = layer.groupers
     M = new_xyz.shape[1]
-    _ext.gather_xyz_range(xyz, idx, new_xyz, 0, M, run_if=timed_out)
     if max(ga.nsample, gb.nsample) > 32:   # units of one centroid meet through an atomic max: the repair needs zeros again
         out.mul_((1 - timed_out[:1]).to(out.dtype))
     _ext.ball_query_full2_range(ga.radius, gb.radius, xyz, new_xyz, idx_a, idx_b, 0, M, run_if=timed_out)
