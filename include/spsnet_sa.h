@@ -145,6 +145,10 @@ int sps_fps_ordered_prefix_finish(int b, int n, int m, const float *xyz, float *
  * score_out (B,N) f32 (may be NULL) receives the scores.  Requires K <= N <= 16384. */
 int sps_score_topk(int b, int n, int c, int k, const float *cls, const float *stds, int *idx,
                    float *score_out, sps_stream_t stream);
+/* The same with the sampler's centroid gather fused (pointnet2_modules.py:423-424): new_xyz (b, k, 3) = xyz (b, n, 3)[idx];
+ * xyz / new_xyz may be NULL.  Scenes of up to 2048 points are ranked by 16 x more workgroups instead of sorted by one. */
+int sps_score_topk_gather(int b, int n, int c, int k, const float *cls, const float *stds, const float *xyz, int *idx,
+                          float *new_xyz, float *score_out, sps_stream_t stream);
 
 /* Fused QueryAndGroup (pointnet2_utils.py:299-322): ball query, grouping of xyz (centred
  * on new_xyz) and of `features`, concatenated along channels, in one pass.

@@ -40,6 +40,7 @@ _PROTOS = {
     "sps_three_interpolate_kernel_launcher_fast": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_three_interpolate_grad_kernel_launcher_fast": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_score_topk": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sps_score_topk_gather": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_query_and_group": [_i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_gather_xyz": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "sps_ball_query_full": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp],

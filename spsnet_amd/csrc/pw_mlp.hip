@@ -39,20 +39,34 @@ __device__ __forceinline__ float pw_relu(float x) {
 
 __device__ __forceinline__ f32x4 pw_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// one 16-row output tile: acc += W[tile] * act (act = LDS image [k][17]), four 16-channel steps per trip so that four
-// weight fragments are in flight
+// one 16-row output tile: acc += W[tile] * act (act = LDS image [k][17]).  A tile is a serial chain of MFMAs fed by weight
+// fragments streamed from L2 (~1-2 us per round trip under load): the fragments of the NEXT eight 16-channel steps are
+// requested before the current eight are multiplied, so that only the first round trip of a tile is exposed (four steps
+// per trip and no overlap cost 8 + 4 + 4 exposed round trips per workgroup at IA-SSD layer 2: 26 us -> see DESIGN.md 4.5).
 __device__ __forceinline__ f32x4 pw_tile(const f32x4 *__restrict__ wp, const float *__restrict__ act, int k16n, int q, int c,
                                          f32x4 acc) {
+    constexpr int G = 8;
     const float *ap = act + q * PW_PAD + c;
+    f32x4 cur[G], nxt[G];
     int k = 0;
-    for (; k + 3 < k16n; k += 4) {
-        f32x4 w[4];
+    if (k16n >= G) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = wp[(size_t)(k + u) * 64];
+        for (int u = 0; u < G; ++u) cur[u] = wp[(size_t)u * 64];
+        for (; k + G <= k16n; k += G) {
+            const bool more = k + 2 * G <= k16n;
+            if (more) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < G; ++u) nxt[u] = wp[(size_t)(k + G + u) * 64];
+            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc = pw_mfma(w[u][r], ap[(16 * (k + u) + 4 * r) * PW_PAD], acc);
+            for (int u = 0; u < G; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = pw_mfma(cur[u][r], ap[(16 * (k + u) + 4 * r) * PW_PAD], acc);
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) cur[u] = nxt[u];
+            }
+        }
     }
     for (; k < k16n; ++k) {
         const f32x4 w = wp[(size_t)k * 64];

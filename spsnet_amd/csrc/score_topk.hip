@@ -77,7 +77,85 @@ __global__ __launch_bounds__(1024) void score_topk_kernel(
         idx[(size_t)scene * k + r] = (int)(~(unsigned)(keys[r] & 0xFFFFFFFFull));
 }
 
+// The same result by RANKING instead of sorting, for scenes of up to 2048 points (IA-SSD layers 2-3: 1024 / 512): a
+// workgroup of 4 waves owns 64 points; every wave counts, over a quarter of the scene, the keys greater than its lane's key
+// (the rank in the descending order -- keys are distinct); the four partial ranks meet in LDS and the points ranked below k
+// write idx[rank] -- and, fused, the centroid row new_xyz[rank] = xyz[point] (the gather_operation that follows the sampler,
+// pointnet2_modules.py:423-424).  The bitonic sort above is 55 barrier-separated passes of one workgroup per scene (18 us
+// at 1024 points); this is one pass over 16 x more workgroups.
+constexpr int RANK_MAX_N = 2048;
+__global__ __launch_bounds__(256) void score_topk_rank_kernel(
+    int n, int c, int k, const float *__restrict__ cls, const float *__restrict__ stds, const float *__restrict__ xyz,
+    int *__restrict__ idx, float *__restrict__ new_xyz, float *__restrict__ score_out) {
+    __shared__ __attribute__((aligned(16))) unsigned sbits[RANK_MAX_N + 4];
+    __shared__ int partial[4][64];
+    const int scene = blockIdx.y;
+    cls += (size_t)scene * n * c;
+    const int npad = (n + 3) & ~3;
+    for (int e = threadIdx.x; e < npad; e += blockDim.x) {
+        unsigned bits = 0u;   // padding: score +0 with index >= n never outranks a real entry of equal score (index rule)
+        if (e < n) {
+            float mx = cls[(size_t)e * c];
+            for (int ch = 1; ch < c; ++ch) mx = fmaxf(mx, cls[(size_t)e * c + ch]);
+            float s = sps_sigmoid(mx);
+            if (stds) {
+                const float sta = 1.0f - sps_sigmoid(stds[(size_t)scene * n + e] / 8.0f - 3.0f);
+                s = s * sta;
+            }
+            if (score_out && blockIdx.x == 0) score_out[(size_t)scene * n + e] = s;
+            bits = (unsigned)__float_as_int(s);
+        }
+        sbits[e] = bits;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;                  // my point
+    const unsigned si = i < n ? sbits[i] : 0u;
+    const int quarter = ((npad / 4) + 3) & ~3;
+    const int jbeg = seg * quarter, jend = min(n, jbeg + quarter);
+    int rank = 0;
+    for (int j = jbeg; j < jend; j += 4) {                  // LDS broadcast reads: every lane compares with the same four keys
+        const uint4 v = *reinterpret_cast<const uint4 *>(&sbits[j]);
+        // key_j > key_i  <=>  s_j > s_i, or s_j == s_i and j < i   (key = score bits : ~index)
+        rank += (int)((v.x > si) | ((v.x == si) & (j + 0 < i))) & (int)(j + 0 < jend);
+        rank += (int)((v.y > si) | ((v.y == si) & (j + 1 < i))) & (int)(j + 1 < jend);
+        rank += (int)((v.z > si) | ((v.z == si) & (j + 2 < i))) & (int)(j + 2 < jend);
+        rank += (int)((v.w > si) | ((v.w == si) & (j + 3 < i))) & (int)(j + 3 < jend);
+    }
+    partial[seg][lane] = rank;
+    __syncthreads();
+    if (seg == 0 && i < n) {
+        rank = partial[0][lane] + partial[1][lane] + partial[2][lane] + partial[3][lane];
+        if (rank < k) {
+            idx[(size_t)scene * k + rank] = i;
+            if (new_xyz) {
+                const float *p = xyz + ((size_t)scene * n + i) * 3;
+                float *o = new_xyz + ((size_t)scene * k + rank) * 3;
+                o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+            }
+        }
+    }
+}
+
 }  // namespace sps
+
+// sps_score_topk with the centroid gather fused: xyz (b, n, 3) -> new_xyz (b, k, 3) = xyz[idx] (both may be NULL).
+extern "C" int sps_score_topk_gather(int b, int n, int c, int k, const float *cls, const float *stds, const float *xyz,
+                                     int *idx, float *new_xyz, float *score_out, sps_stream_t stream) {
+    using namespace sps;
+    if (b < 0 || n <= 0 || c <= 0 || k < 0 || k > n)
+        return fail(SPS_ERR_INVALID, "score_topk: bad shape b=%d n=%d c=%d k=%d", b, n, c, k);
+    if (b == 0) return SPS_OK;
+    if (!cls || (!idx && k > 0) || (new_xyz && !xyz)) return fail(SPS_ERR_INVALID, "score_topk: null pointer");
+    if (n > RANK_MAX_N || b > 65535) {   // large scenes: the sorting kernel, then the plain gather
+        const int rc = sps_score_topk(b, n, c, k, cls, stds, idx, score_out, stream);
+        if (rc != SPS_OK || !new_xyz) return rc;
+        return sps_gather_xyz(b, n, k, xyz, idx, new_xyz, stream);
+    }
+    hipLaunchKernelGGL(score_topk_rank_kernel, dim3(divup(n, 64), b), dim3(256), 0, as_stream(stream), n, c, k, cls, stds, xyz,
+                       idx, new_xyz, score_out);
+    return check_launch("score_topk_rank_kernel");
+}
 
 extern "C" int sps_score_topk(int b, int n, int c, int k, const float *cls, const float *stds, int *idx,
                               float *score_out, sps_stream_t stream) {

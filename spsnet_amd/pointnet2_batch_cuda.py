@@ -321,8 +321,10 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out_tensor, idx_tensor, weig
 
 # ---- fused entry points (not part of the reference extension) -----------------------------
 
-def score_topk(cls_features, npoint, stds=None, return_scores=False):
-    """Fused sampler of pointnet2_modules.py:287-303: cls (B,N,C) [, stds (B,N)] -> idx (B,npoint) i32."""
+def score_topk(cls_features, npoint, stds=None, return_scores=False, xyz=None):
+    """Fused sampler of pointnet2_modules.py:287-303: cls (B,N,C) [, stds (B,N)] -> idx (B,npoint) i32.
+    xyz (B,N,3): also return the centroid rows xyz[idx] (B,npoint,3) from the same launch (the gather that follows the
+    sampler, :423-424) -> (idx, new_xyz)."""
     c = _ptr(cls_features, F32, "cls_features")
     B, N, C = cls_features.shape
     s = 0
@@ -331,11 +333,17 @@ def score_topk(cls_features, npoint, stds=None, return_scores=False):
         _need(stds, B * N, "stds")
     idx = torch.empty((B, npoint), dtype=I32, device=cls_features.device)
     scores = torch.empty((B, N), dtype=F32, device=cls_features.device) if return_scores else None
+    new_xyz = None
+    if xyz is not None:
+        _need(xyz, B * N * 3, "xyz")
+        new_xyz = torch.empty((B, npoint, 3), dtype=F32, device=cls_features.device)
     with _on(cls_features):
-        _lib.check(_L.sps_score_topk(B, N, C, npoint, c, s, idx.data_ptr(),
-                                     scores.data_ptr() if scores is not None else 0, _stream(cls_features)),
+        _lib.check(_L.sps_score_topk_gather(B, N, C, npoint, c, s, 0 if xyz is None else _ptr(xyz, F32, "xyz"), idx.data_ptr(),
+                                            0 if new_xyz is None else new_xyz.data_ptr(),
+                                            scores.data_ptr() if scores is not None else 0, _stream(cls_features)),
                    "score_topk")
-    return (idx, scores) if return_scores else idx
+    out = (idx, scores) if return_scores else idx
+    return (out, new_xyz) if xyz is not None else out
 
 
 def fps_ordered_prefix(xyz, npoint, return_flags=False):

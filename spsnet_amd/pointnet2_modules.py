@@ -271,12 +271,14 @@ class PointnetSAModuleMSG(_PointnetSAModuleBase):
 # strategies that thin `stds` update ctx.stds.
 # ------------------------------------------------------------------------------------------
 class _SampleInput:
-    __slots__ = ("xyz", "xyz_full", "_features", "_window", "_contig", "cls", "npoint", "stds")
+    __slots__ = ("xyz", "xyz_full", "_features", "_window", "_contig", "cls", "npoint", "stds", "whole", "new_xyz")
 
-    def __init__(self, xyz, xyz_full, features, window, contig, cls, npoint, stds):
+    def __init__(self, xyz, xyz_full, features, window, contig, cls, npoint, stds, whole=False):
         self.xyz, self.xyz_full = xyz, xyz_full
         self._features, self._window, self._contig = features, window, contig
         self.cls, self.npoint, self.stds = cls, npoint, stds
+        self.whole = whole        # the window is the whole cloud: a strategy may hand back the centroid rows as well
+        self.new_xyz = None       # ... here: xyz_full[idx], produced by the sampling launch itself
 
     @property
     def xyz_flipped(self):
@@ -296,8 +298,17 @@ def _thin_stds(ctx: _SampleInput, idx):
     ctx.stds = pointnet2_utils.gather_operation(ctx.stds.view(batch, 1, -1).contiguous(), idx).squeeze()
 
 
+def _fusable_gather(ctx):
+    x = ctx.xyz_full
+    return ctx.whole and x.is_cuda and x.is_contiguous() and not (torch.is_grad_enabled() and x.requires_grad)
+
+
 def _sample_score(mod, ctx):
-    """'cls'/'ctr' aware: top-k of sigmoid(max_c logits) (reference :287-291), fused."""
+    """'cls'/'ctr' aware: top-k of sigmoid(max_c logits) (reference :287-291), fused -- with the centroid gather that
+    follows it (:423-424) when the window is the whole cloud."""
+    if _fusable_gather(ctx):
+        idx, ctx.new_xyz = _ext.score_topk(ctx.cls.contiguous(), ctx.npoint, xyz=ctx.xyz_full)
+        return idx
     return _ext.score_topk(ctx.cls.contiguous(), ctx.npoint)
 
 
@@ -307,7 +318,11 @@ def _sample_stability(mod, ctx):
     if ctx.stds is None:
         raise NotImplementedError
     batch, n = ctx.cls.shape[0], ctx.cls.shape[1]
-    idx = _ext.score_topk(ctx.cls.contiguous(), ctx.npoint, stds=ctx.stds.reshape(batch, n).contiguous())
+    stds = ctx.stds.reshape(batch, n).contiguous()
+    if _fusable_gather(ctx):
+        idx, ctx.new_xyz = _ext.score_topk(ctx.cls.contiguous(), ctx.npoint, stds=stds, xyz=ctx.xyz_full)
+    else:
+        idx = _ext.score_topk(ctx.cls.contiguous(), ctx.npoint, stds=stds)
     _thin_stds(ctx, idx)
     return idx
 
@@ -449,6 +464,7 @@ class _SamplingSAModule(_PointnetSAModuleBase):
     def _sample(self, xyz, features, cls_features, stds):
         """-> (sampled_idx (B, sum npoint) int32, stds).  Reference :270-424 / :709-726."""
         chunks = []
+        fused_xyz = None
         begin = 0
         for sample_type, sample_range, npoint in zip(self.sample_type_list, self.sample_range_list,
                                                      self.npoint_list):
@@ -469,14 +485,17 @@ class _SamplingSAModule(_PointnetSAModuleBase):
                 continue
             for accepts, strategy in _SAMPLERS:
                 if accepts(sample_type) and (self._allowed_samplers is None or strategy in self._allowed_samplers):
-                    ctx = _SampleInput(xyz_w, xyz, features, window, sample_range == -1, cls_w, npoint, stds)
+                    ctx = _SampleInput(xyz_w, xyz, features, window, sample_range == -1, cls_w, npoint, stds, whole)
                     chunks.append(strategy(self, ctx))
                     stds = ctx.stds
+                    fused_xyz = ctx.new_xyz
                     break
             else:
                 raise NotImplementedError(f"sampling method {sample_type!r}")
         sampled_idx = chunks[0] if len(chunks) == 1 else torch.cat(chunks, dim=-1)
-        if xyz.is_cuda and not (torch.is_grad_enabled() and xyz.requires_grad):
+        if len(chunks) == 1 and fused_xyz is not None:
+            new_xyz = fused_xyz                                     # the sampler's launch gathered the centroids already
+        elif xyz.is_cuda and not (torch.is_grad_enabled() and xyz.requires_grad):
             new_xyz = _ext.gather_xyz(xyz.contiguous(), sampled_idx.contiguous())  # (B,N,3) rows, no transposes
         else:
             new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(),
