@@ -210,9 +210,11 @@ int sps_set_mlp_precision(int mode);
  * for the ball query / MLP); buffers keep their full (B, M, ...) shapes.
  * Correct-or-redo: a bounded wait that gives up sets *timed_out and its consumers run on samples that were never written
  * (harmless: indices are clamped into the cloud).  The range kernels, sps_sa_group_mlp_packed and sps_pointwise_mlp_ex take
- * `run_if` (device i32, may be NULL): a launch with *run_if == 0 returns at once.  The caller re-issues the whole layer
- * behind the producer with run_if = timed_out -- a few empty launches normally, the repair when a wait did give up --
- * and hands force_redo = timed_out to sps_fps_ordered_prefix_finish, which then recomputes every scene.
+ * `run_if` (device i32, may be NULL): a launch with *run_if == 0 returns at once; and `full_range_if` (device i32, may be
+ * NULL): a launch with *full_range_if != 0 covers all centroids [0, m) of every scene instead of its range.  The LAST
+ * chunk of a streamed layer -- whose wait is patient, so its inputs are final -- passes full_range_if = timed_out: it
+ * redoes every chunk when a wait did give up and costs nothing otherwise (one predicated centroid gather is the only extra
+ * launch).  force_redo = timed_out goes to sps_fps_ordered_prefix_finish, which then recomputes every scene.
  * sps_debug_set_wait_spins: DIAGNOSTIC, the spin bound of sps_wait_progress (tests force the redo path with it). */
 unsigned sps_debug_set_wait_spins(unsigned spins);
 /* sps_wait_progress sets timed_out[0 .. b) (one flag per scene, all of them) when it gives up.
@@ -230,7 +232,8 @@ int sps_gather_xyz_range(int b, int n, int m, int j0, int jcount, const float *x
                          const int *run_if, sps_stream_t stream);
 int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcount, float radius_a, int nsample_a,
                                float radius_b, int nsample_b, const float *new_xyz, const float *xyz, int *idx_a,
-                               int *idx_b, int *perm_work, const int *run_if, sps_stream_t stream);
+                               int *idx_b, int *perm_work, const int *run_if, const int *full_range_if,
+                               sps_stream_t stream);
 int sps_sa_group_mlp_range(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,
                            const float *new_xyz, const float *features, const int *idx, int c1, int c2, int c3,
                            int c3_real, const float *w1, const float *b1, const float *w2, const float *b2,
@@ -268,7 +271,8 @@ int sps_sa_group_mlp_packed(int b, int n, int m, int j0, int jcount, int c_feat,
                             const unsigned *meta, const int *ntiles, long long tile_cap, int c1, int c2, int c3,
                             int c3_real, const float *w1, const float *b1, const float *w2, const float *b2,
                             const float *w3, const float *b3, float *out, int out_c_total, int out_c_off,
-                            int split_fp16, int *overflow_flag, const int *run_if, sps_stream_t stream);
+                            int split_fp16, int *overflow_flag, const int *run_if, const int *full_range_if,
+                            sps_stream_t stream);
 
 /* Aggregation stack (+ confidence head) of an SA layer as one kernel -- replaces, for inference with BatchNorm folded,
  * Conv1d+BN+ReLU (pointnet2_modules.py:213-228, 449-450) and Conv1d+BN+ReLU, Conv1d(bias) (:230-245, 454-455).
@@ -288,7 +292,7 @@ int sps_pointwise_mlp_range(int b, int m, int j0, int jcount, int cin, int c1, i
 int sps_pointwise_mlp_ex(int b, int m, int j0, int jcount, int cin, int c1, int c2, int c3_real, const float *x,
                          const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                          const float *b3, void *y1, void *y1_point_major, float *y3, int flags, const int *run_if,
-                         sps_stream_t stream);
+                         const int *full_range_if, sps_stream_t stream);
 
 /* farthest_point_sampling_kernel_launcher (sampling_gpu.cu:93-253) with an optional device workspace of
  * b * sps_fps_workspace_floats(n) floats (0 for sizes that need none).  With it, scenes of 16 385 .. 262 144 points

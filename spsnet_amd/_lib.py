@@ -54,7 +54,7 @@ _PROTOS = {
     "sps_sa_group_mlp_supported_stream": [_i, _i, _i, _i],
     "sps_fps_with_workspace": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_pointwise_mlp_range": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "sps_pointwise_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "sps_pointwise_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "sps_pointwise_mlp": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_ball_query_grid": [_i, _i, _i, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_ball_query_grid2": [_i, _i, _i, _f, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -87,13 +87,13 @@ _PROTOS = {
                             _vp, _vp, _i, _i, _i, _vp, _vp],
     "sps_pack_columns": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _vp],
     "sps_sa_group_mlp_packed": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _i,
-                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sps_fps_redo_where": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_fps_publish": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_wait_progress": [_vp, _i, _i, _vp, _vp],
     "sps_wait_progress_ex": [_vp, _i, _i, _vp, _i, _vp],
     "sps_gather_xyz_range": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
-    "sps_ball_query_full2_range": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_ball_query_full2_range": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_sa_group_mlp_range": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _i, _i, _vp],
 }

@@ -425,13 +425,19 @@ template <int C, int SEG, int UNR>
 __global__ __launch_bounds__(64 * SEG) void ball_query_wave_multi_kernel(
     int n, int m, float r2a, float r2b, int nsa, int nsb, const float *__restrict__ new_xyz,
     const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b, int jbeg,
-    const int *__restrict__ run_if) {
+    const int *__restrict__ run_if, const int *__restrict__ alt) {
     __shared__ int hits[2][C][SEG][BQS_MAX_NS];
     __shared__ int cnt[2][C][SEG];
     if (run_if && *run_if == 0) return;
-    const int scene = blockIdx.y, j0 = jbeg + blockIdx.x * C;
+    // *alt != 0: all m centroids of every scene instead of [jbeg, jbeg + C gridDim.x) (self-repairing range launch)
+    const bool whole = alt && *alt != 0;
+    const int jfirst = whole ? 0 : jbeg, groups = whole ? m / C : (int)gridDim.x;
+    const int scene = blockIdx.y;
     const int lane = threadIdx.x & 63, seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     xyz += (size_t)scene * n * 3;
+    for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    const int j0 = jfirst + grp * C;
+    __syncthreads();   // the previous group's hit lists are dead
     float cx[C], cy[C], cz[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -506,6 +512,7 @@ __global__ __launch_bounds__(64 * SEG) void ball_query_wave_multi_kernel(
             row[p] = p < total ? v : first;
         }
     }
+    }   // group loop
 }
 
 // perm[b, :] = the scene's centroids sorted by 12-bit cell key (counting sort in LDS, one workgroup per scene;
@@ -600,12 +607,13 @@ extern "C" int sps_ball_query_full2(int b, int n, int m, float radius_a, int nsa
                                     const float *new_xyz, const float *xyz, int *idx_a, int *idx_b, int *perm_work,
                                     sps_stream_t stream) {
     return sps_ball_query_full2_range(b, n, m, 0, m, radius_a, nsample_a, radius_b, nsample_b, new_xyz, xyz, idx_a, idx_b,
-                                      perm_work, nullptr, stream);
+                                      perm_work, nullptr, nullptr, stream);
 }
 
 extern "C" int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcount, float radius_a, int nsample_a,
                                           float radius_b, int nsample_b, const float *new_xyz, const float *xyz,
-                                          int *idx_a, int *idx_b, int *perm_work, const int *run_if, sps_stream_t stream) {
+                                          int *idx_a, int *idx_b, int *perm_work, const int *run_if, const int *full_range_if,
+                                          sps_stream_t stream) {
     using namespace sps;
     if (b < 0 || n < 0 || m < 0 || nsample_a <= 0 || nsample_b <= 0 || j0 < 0 || jcount < 0 || j0 + jcount > m)
         return fail(SPS_ERR_INVALID, "ball_query_full2: bad shape b=%d n=%d m=%d ns=(%d,%d) range [%d,+%d)", b, n, m,
@@ -620,19 +628,21 @@ extern "C" int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcoun
     bool per_wave = !perm_work && (long long)b * jcount <= BQ_WAVE_MAX_CENTROIDS;
     if (const char *force = getenv("SPS_BQ_WAVE")) per_wave = force[0] == '1';  // diagnostic override (tools/bq_time.py)
     static const bool multi_ok = !(getenv("SPS_BQ_MULTI") && getenv("SPS_BQ_MULTI")[0] == '0');
-    if (per_wave && multi_ok && jcount % 4 == 0 && nsample_a <= BQS_MAX_NS && nsample_b <= BQS_MAX_NS && n >= 256) {
+    if (full_range_if && !(jcount % 4 == 0 && m % 4 == 0 && (long long)b * jcount <= BQ_WAVE_MAX_CENTROIDS && !perm_work))
+        return fail(SPS_ERR_INVALID, "ball_query_full2: full_range_if needs a per-wave launch with jcount and m multiples of 4");
+    if (per_wave && (multi_ok || full_range_if) && jcount % 4 == 0 && nsample_a <= BQS_MAX_NS && nsample_b <= BQS_MAX_NS && n >= 256) {
         // four centroids per wave share every point load; the point range is split so that the launch still has waves
         const float ra2 = radius_a * radius_a, rb2 = radius_b * radius_b;
         const dim3 grid(jcount / 4, b);
         if (n >= 8192)
             hipLaunchKernelGGL((ball_query_wave_multi_kernel<4, 8, 8>), grid, dim3(64 * 8), 0, as_stream(stream), n, m, ra2, rb2,
-                               nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, j0, run_if);
+                               nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, j0, run_if, full_range_if);
         else if (n >= 2048)
             hipLaunchKernelGGL((ball_query_wave_multi_kernel<4, 4, 8>), grid, dim3(64 * 4), 0, as_stream(stream), n, m, ra2, rb2,
-                               nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, j0, run_if);
+                               nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, j0, run_if, full_range_if);
         else
             hipLaunchKernelGGL((ball_query_wave_multi_kernel<4, 4, 4>), grid, dim3(64 * 4), 0, as_stream(stream), n, m, ra2, rb2,
-                               nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, j0, run_if);
+                               nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, j0, run_if, full_range_if);
         return check_launch("ball_query_wave_multi_kernel");
     }
     if (per_wave && (long long)b * jcount <= BQ_SEG_MAX_CENTROIDS && nsample_a <= BQS_MAX_NS && nsample_b <= BQS_MAX_NS &&

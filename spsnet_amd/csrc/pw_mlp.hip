@@ -29,6 +29,7 @@ struct PwArgs {
     int out_h16;   // y1 / y1t are written as halves (fp16 features in HBM, BASELINE configs[4]); arithmetic stays fp32
     int x_pm;      // x is point-major (B, M, cin) instead of (B, cin, M)
     const int *run_if;   // predicated launch: nothing happens when *run_if == 0
+    const int *alt;      // *alt != 0: all m points of every scene instead of [j0, j0 + 16 gridDim.x) (self-repairing range launch)
 };
 
 // ReLU as an integer max: keeps +Inf / +NaN where v_max_f32 would drop a NaN (torch's ReLU propagates it)
@@ -84,7 +85,12 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void pw_mlp_kernel(PwArgs a) {
     float *xt = pw_lds, *act2 = pw_lds, *act1 = pw_lds + r0;
     const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
-    const int scene = blockIdx.y, m0 = a.j0 + blockIdx.x * 16;
+    const int scene = blockIdx.y;
+    const bool whole = a.alt && *a.alt != 0;
+    const int first = whole ? 0 : a.j0, tiles = whole ? a.m / 16 : (int)gridDim.x;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int m0 = first + tile * 16;
+    __syncthreads();   // the previous tile's LDS images are dead
 
     // ---- stage the 16 input columns: cin rows of 64 bytes (or, point-major, 16 rows of cin floats), coalesced ----
     if (a.x_pm) {
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void pw_mlp_kernel(PwArgs a) {
             }
         }
     }
-    if (!a.w2) return;
+    if (!a.w2) continue;
     __syncthreads();
     // ---- layer 2: act1 -> act2 ----
     {
@@ -159,6 +165,7 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void pw_mlp_kernel(PwArgs a) {
             if (row < a.c3_real) a.y3[((size_t)scene * a.m + m0 + c) * a.c3_real + row] = acc[r];
         }
     }
+    }   // tile loop
 }
 
 }  // namespace sps
@@ -167,14 +174,14 @@ extern "C" int sps_pointwise_mlp_range(int b, int m, int j0, int jcount, int cin
                                        const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                                        const float *b3, float *y1, float *y1_point_major, float *y3, sps_stream_t stream) {
     return sps_pointwise_mlp_ex(b, m, j0, jcount, cin, c1, c2, c3_real, x, w1, b1, w2, b2, w3, b3, y1, y1_point_major, y3, 0,
-                                nullptr, stream);
+                                nullptr, nullptr, stream);
 }
 
 // flags: 1 = y1 / y1_point_major are fp16 buffers (halves), 2 = x is point-major (B, M, cin)
 extern "C" int sps_pointwise_mlp_ex(int b, int m, int j0, int jcount, int cin, int c1, int c2, int c3_real, const float *x,
                                     const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                                     const float *b3, void *y1, void *y1_point_major, float *y3, int flags,
-                                    const int *run_if, sps_stream_t stream) {
+                                    const int *run_if, const int *full_range_if, sps_stream_t stream) {
     using namespace sps;
     if (b < 0 || m < 0 || cin <= 0 || c1 <= 0) return fail(SPS_ERR_INVALID, "pointwise_mlp: bad shape b=%d m=%d cin=%d c1=%d", b, m, cin, c1);
     if (j0 < 0 || jcount < 0 || j0 + jcount > m || j0 % 16 || jcount % 16)
@@ -191,7 +198,7 @@ extern "C" int sps_pointwise_mlp_ex(int b, int m, int j0, int jcount, int cin, i
     PwArgs a;
     a.m = m; a.j0 = j0; a.cin = cin; a.c1 = c1; a.c2 = deep ? c2 : 0; a.c3 = 16; a.c3_real = deep ? c3_real : 0;
     a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = deep ? w2 : nullptr; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.y1 = (float *)y1; a.y1t = (float *)y1_point_major; a.y3 = y3;
-    a.out_h16 = flags & 1; a.x_pm = (flags >> 1) & 1; a.run_if = run_if;
+    a.out_h16 = flags & 1; a.x_pm = (flags >> 1) & 1; a.run_if = run_if; a.alt = full_range_if;
     const int wide = (deep && c2 > cin) ? c2 : cin;
     const size_t lds = sizeof(float) * (size_t)PW_PAD * ((size_t)wide + c1);
     if (lds > 150 * 1024) return fail(SPS_ERR_INVALID, "pointwise_mlp: widths (%d, %d, %d) need more LDS than a workgroup has", cin, c1, c2);

@@ -67,11 +67,12 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
     const int nwaves = gridDim.x * (blockDim.x >> 6);
 
     constexpr bool packed = PACKED;   // a separate instantiation: the padded form keeps its register budget
-    const int nunits = packed ? (*a.ntiles) / NT : a.units;   // packed: as many units as pack_columns produced tiles for
+    const MlpRange rg = mlp_range(a);
+    const int nunits = packed ? (*a.ntiles) / NT : rg.units;   // packed: as many units as pack_columns produced tiles for
     for (int unit = wave; unit < nunits; unit += nwaves) {
         // first flattened (b, j, s) column of the unit: scene = unit / ups, centroids from j0 on
-        const int ub = packed ? 0 : unit / a.ups;
-        const long long col0 = ((long long)ub * a.m + a.j0) * NS + (long long)(unit - ub * a.ups) * UNIT;
+        const int ub = packed ? 0 : unit / rg.ups;
+        const long long col0 = ((long long)ub * a.m + rg.j0) * NS + (long long)(unit - ub * rg.ups) * UNIT;
         f32x4 h2[T2][NT];
         PackedUnit<NT> pu;
         {
@@ -277,6 +278,11 @@ static int launch_variant(const SaMlpArgs &a, hipStream_t st) {
             return fail(SPS_ERR_INVALID, "sa_group_mlp: centroids*nsample per scene (%lld) not a multiple of %d", cols_scene, UNIT);
         k.ups = (int)(cols_scene / UNIT);
         k.units = a.units * k.ups;
+        k.alt_j0 = 0;                                     // the whole layer: (scenes) x (all m centroids)
+        k.alt_ups = (int)((long long)a.m * NS / UNIT);
+        k.alt_units = a.units * k.alt_ups;
+        if (a.alt && ((long long)a.m * NS) % UNIT != 0)
+            return fail(SPS_ERR_INVALID, "sa_group_mlp: centroids*nsample per scene not a multiple of %d", UNIT);
     }
     const int waves_per_block = 4;
     int blocks = divup(k.units, waves_per_block);
@@ -326,20 +332,23 @@ extern "C" int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int 
                                    int out_c_off, int split_fp16, int *overflow_flag, sps_stream_t stream) {
     return sps_sa_group_mlp_packed(b, n, m, j0, jcount, c_feat, nsample, xyz, new_xyz, features, idx, nullptr, nullptr, nullptr,
                                    0, c1, c2, c3, c3_real, w1, b1, w2, b2, w3, b3, out, out_c_total, out_c_off, split_fp16,
-                                   overflow_flag, nullptr, stream);
+                                   overflow_flag, nullptr, nullptr, stream);
 }
 
 // The general entry point.  Either idx (b, m, nsample) and the centroid range [j0, j0 + jcount), or -- cols != NULL -- the
 // packed column stream of sps_pack_columns (cols / meta / *ntiles on the device, tile_cap = the capacity the pack call was
 // given; idx, j0 and jcount are then ignored).  mode = the split_fp16 word of sps_sa_group_mlp_ex, + 8: `out` is point-major
 // (b, m, out_c_total) instead of (b, out_c_total, m).  Packed columns are served by modes 0, 1 and 3.  run_if (device, may be
-// NULL): the launch does nothing when *run_if == 0 -- the redo of a streamed layer whose bounded progress wait gave up.
+// NULL): the launch does nothing when *run_if == 0.  full_range_if (device, may be NULL; idx form only): when
+// *full_range_if != 0 the launch covers all centroids [0, m) of every scene instead of [j0, j0 + jcount) -- the last chunk of
+// a streamed layer repairs the chunks whose bounded progress wait gave up, at no cost when none did.
 extern "C" int sps_sa_group_mlp_packed(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,
                                        const float *new_xyz, const float *features, const int *idx, const int *cols,
                                        const unsigned *meta, const int *ntiles, long long tile_cap, int c1, int c2, int c3,
                                        int c3_real, const float *w1, const float *b1, const float *w2, const float *b2,
                                        const float *w3, const float *b3, float *out, int out_c_total, int out_c_off,
-                                       int split_fp16, int *overflow_flag, const int *run_if, sps_stream_t stream) {
+                                       int split_fp16, int *overflow_flag, const int *run_if, const int *full_range_if,
+                                       sps_stream_t stream) {
     using namespace sps;
     if (b < 0 || n <= 0 || m < 0 || c_feat < 0 || nsample <= 0 || c3 <= 0 || (c3 % 16) || c3_real > c3 ||
         out_c_off < 0 || out_c_off + c3_real > out_c_total || j0 < 0 || jcount < 0 || j0 + jcount > m)
@@ -364,6 +373,8 @@ extern "C" int sps_sa_group_mlp_packed(int b, int n, int m, int j0, int jcount, 
     a.cols = cols; a.meta = meta; a.ntiles = ntiles;
     a.out_pm = (split_fp16 & 8) ? 1 : 0;
     a.run_if = run_if;
+    a.alt = cols ? nullptr : full_range_if;
+    a.alt_j0 = 0; a.alt_ups = 0; a.alt_units = 0;
     a.ks1 = (3 + c_feat + 3) / 4;
     a.c3 = c3; a.c3_real = c3_real; a.out_c_total = out_c_total; a.out_c_off = out_c_off;
     a.xyz = xyz; a.new_xyz = new_xyz; a.feat = features; a.idx = idx;

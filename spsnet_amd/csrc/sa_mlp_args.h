@@ -25,7 +25,22 @@ struct SaMlpArgs {
     const int *ntiles;
     int out_pm;                    // 1: `out` is point-major (B, M, out_c_total): a centroid's pooled rows are contiguous
     const int *run_if;             // predicated launch: the kernel returns at once when *run_if == 0 (NULL: always runs)
+    // Self-repairing range launch: when *alt != 0 the kernel covers ALL centroids of every scene (alt_j0 = 0, alt_ups,
+    // alt_units) instead of its range -- the last chunk of a streamed layer redoes the chunks whose bounded wait gave up,
+    // without any extra launch when none did.  The unit loops are grid-stride, so the chunk's grid serves either range.
+    const int *alt;
+    int alt_j0, alt_ups, alt_units;
 };
+
+// the (units, units per scene, first centroid) a launch works on: its range, or the whole layer when *alt is set
+struct MlpRange { int units, ups, j0; };
+#ifdef __HIPCC__
+__device__ __forceinline__ MlpRange mlp_range(const SaMlpArgs &a) {
+    MlpRange r = {a.units, a.ups, a.j0};
+    if (a.alt && *a.alt != 0) { r.units = a.alt_units; r.ups = a.alt_ups; r.j0 = a.alt_j0; }
+    return r;
+}
+#endif
 
 
 // max over the 16 lanes of each DPP row (= the 16 columns of an MFMA tile) for the four rows a lane holds, valid in

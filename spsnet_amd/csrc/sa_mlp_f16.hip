@@ -137,10 +137,11 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
     }
     bool any_bad = false;   // some unit of this wave met an operand beyond the representable range (or NaN / Inf)
     constexpr bool packed = PACKED;   // a separate instantiation: the padded form keeps its register budget
-    const int nunits = packed ? (*a.ntiles) / NT : a.units;   // packed: as many units as pack_columns produced tiles for
+    const MlpRange rg = mlp_range(a);
+    const int nunits = packed ? (*a.ntiles) / NT : rg.units;   // packed: as many units as pack_columns produced tiles for
     for (int unit = wave; unit < nunits; unit += nwaves) {
-        const int ub = packed ? 0 : unit / a.ups;
-        const long long col0 = ((long long)ub * a.m + a.j0) * NS + (long long)(unit - ub * a.ups) * UNIT;
+        const int ub = packed ? 0 : unit / rg.ups;
+        const long long col0 = ((long long)ub * a.m + rg.j0) * NS + (long long)(unit - ub * rg.ups) * UNIT;
         h8 h2hi[S2][NT], h2lo[S2][NT];
         PackedUnit<NT> pu;
         float mx = 0.f;  // largest operand magnitude this lane has split in this unit
@@ -378,6 +379,11 @@ static int launch_f16_variant(const SaMlpArgs &a, hipStream_t st) {
             return fail(SPS_ERR_INVALID, "sa_group_mlp(f16): centroids*nsample per scene (%lld) not a multiple of %d", cols_scene, UNIT);
         k.ups = (int)(cols_scene / UNIT);
         k.units = a.units * k.ups;
+        k.alt_j0 = 0;                                     // the whole layer: (scenes) x (all m centroids)
+        k.alt_ups = (int)((long long)a.m * NS / UNIT);
+        k.alt_units = a.units * k.alt_ups;
+        if (a.alt && ((long long)a.m * NS) % UNIT != 0)
+            return fail(SPS_ERR_INVALID, "sa_group_mlp: centroids*nsample per scene not a multiple of %d", UNIT);
     }
     k.ks1 = (3 + a.c_feat + 31) / 32;
     // all three layers' fragments in LDS when they fit beside nothing else (one workgroup of 8 waves per CU) and the

@@ -181,13 +181,14 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa
     bool any_bad = false;   // some unit of this wave met an operand beyond the representable range (or NaN / Inf)
     // units are handed out per workgroup so that its four waves stay in lockstep on the shared stream; a wave without a
     // unit of its own recomputes the last one and writes nothing
-    const int ngroups = (a.units + WAVES - 1) / WAVES;
+    const MlpRange rg = mlp_range(a);
+    const int ngroups = (rg.units + WAVES - 1) / WAVES;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int unit_raw = grp * WAVES + wv;
-        const bool valid = unit_raw < a.units;
-        const int unit = valid ? unit_raw : a.units - 1;
-        const int ub = unit / a.ups;
-        const long long col0 = ((long long)ub * a.m + a.j0) * NS + (long long)(unit - ub * a.ups) * UNIT;
+        const bool valid = unit_raw < rg.units;
+        const int unit = valid ? unit_raw : rg.units - 1;
+        const int ub = unit / rg.ups;
+        const long long col0 = ((long long)ub * a.m + rg.j0) * NS + (long long)(unit - ub * rg.ups) * UNIT;
         float mx = 0.f;  // largest operand magnitude this lane has split in this unit
         {
             int src[NT];
@@ -377,6 +378,9 @@ static int launch_lds_variant(const SaMlpArgs &a, hipStream_t st) {
         return fail(SPS_ERR_INVALID, "sa_group_mlp(f16/lds): centroids*nsample per scene (%lld) not a multiple of %d", cols_scene, UNIT);
     k.ups = (int)(cols_scene / UNIT);
     k.units = a.units * k.ups;
+    k.alt_j0 = 0;
+    k.alt_ups = (int)((long long)a.m * NS / UNIT);
+    k.alt_units = a.units * k.alt_ups;
     k.ks1 = (3 + a.c_feat + 31) / 32;
     const int groups = divup(k.units, WAVES);
     int blocks = groups < 256 * 2 ? groups : 256 * 2;

@@ -310,12 +310,13 @@ def attach_point_major_twin(features):
 
 
 def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=0, jcount=None, columns=None,
-                   out_point_major=False, run_if=None):
+                   out_point_major=False, run_if=None, full_range_if=None):
     """One launch: gather the nsample neighbours in `idx` (B,M,ns), run the packed 3-layer MLP, max-pool,
     and write channels [channel_offset, channel_offset + c3_real) of out (B, Ctot, M) -- or (B, M, Ctot) with
     out_point_major; optionally only for the centroids [j0, j0+jcount) of every scene.  A scale packed with point_major
     reads the features' (B, N, C) twin.  columns: a PackedColumns of `idx` (pack_columns): only the distinct neighbours of
-    every ball are computed, same result.  run_if (device int32): the launch does nothing while it is zero."""
+    every ball are computed, same result.  run_if (device int32): the launch does nothing while it is zero;
+    full_range_if (device int32): the launch covers all M centroids instead of its range while it is nonzero."""
     B, N, _ = xyz.shape
     M, ns = idx.shape[1], idx.shape[2]
     jcount = M if jcount is None else jcount
@@ -342,7 +343,8 @@ def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=
         idx.data_ptr(), cp[0], cp[1], cp[2], cp[3], packed.c1, packed.c2, packed.c3, packed.c3_real, packed.w1.data_ptr(),
         packed.b1.data_ptr(), packed.w2.data_ptr(), packed.b2.data_ptr(), packed.w3.data_ptr(), packed.b3.data_ptr(),
         out.data_ptr(), c_total, channel_offset, mode,
-        _overflow_flag(xyz.device).data_ptr() if packed.split else 0, 0 if run_if is None else run_if.data_ptr(), stream),
+        _overflow_flag(xyz.device).data_ptr() if packed.split else 0, 0 if run_if is None else run_if.data_ptr(),
+        0 if full_range_if is None else full_range_if.data_ptr(), stream),
         "sa_group_mlp")
 
 
@@ -400,7 +402,7 @@ class TailRunner:
     def tensors(self):
         return tuple(t for t in (self.y1, self.y1t, self.y3) if t is not None)
 
-    def run(self, j0=0, jcount=None, run_if=None):
+    def run(self, j0=0, jcount=None, run_if=None, full_range_if=None):
         p = self.packed
         ptr = lambda t: 0 if t is None else t.data_ptr()
         _lib.check(_L.sps_pointwise_mlp_ex(self.B, self.M, j0, self.M - j0 if jcount is None else jcount, p.cin, p.c1, p.c2,
@@ -408,6 +410,7 @@ class TailRunner:
                                            ptr(p.w3), ptr(p.b3), self.y1.data_ptr(), self.y1t.data_ptr(), ptr(self.y3),
                                            (1 if self.half_out else 0) | (2 if self.x_pm else 0),
                                            0 if run_if is None else run_if.data_ptr(),
+                                           0 if full_range_if is None else full_range_if.data_ptr(),
                                            torch.cuda.current_stream(self.x.device).cuda_stream), "pointwise_mlp")
 
     def result(self):

@@ -302,15 +302,23 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
             _ext.gather_xyz_range(xyz, idx, new_xyz, 0, M, run_if=timed_out)
             xyz_ready = torch.cuda.Event()
             xyz_ready.record(torch.cuda.current_stream(dev))
-        _ext.ball_query_full2_range(ga.radius, gb.radius, xyz, new_xyz, idx_a, idx_b, j0, chunk)
+        # Correct or redo, never invalid: the waits are bounded (a producer that stalls must not hang the device); one that
+        # gave up let its consumers run on samples that had not been written.  The LAST chunk -- behind the patient wait, or
+        # behind the producer itself -- therefore covers the whole layer when a flag is up (full_range_if: the kernels read
+        # it and widen their range; no extra launch, nothing changes when every wait was served).
+        repair = timed_out if (j1 == M and self_repair) else None
+        _ext.ball_query_full2_range(ga.radius, gb.radius, xyz, new_xyz, idx_a, idx_b, j0, chunk, full_range_if=repair)
         off = 0
         for ix, packed in zip((idx_a, idx_b), plan):
-            _fused.group_mlp_pool(xyz, new_xyz, features, ix, packed, out, off, j0, chunk)
+            _fused.group_mlp_pool(xyz, new_xyz, features, ix, packed, out, off, j0, chunk, full_range_if=repair)
             off += packed.c3_real
         if tail is not None:
-            tail.run(j0, chunk)
+            tail.run(j0, chunk, full_range_if=repair)
 
     xyz_ready = None
+    # units of one centroid meet through an atomic max when a ball has more than 32 samples: a repair then needs `out`
+    # zeroed again, which takes the separate predicated launches of _redo_layer
+    self_repair = max(ga.nsample, gb.nsample) <= 32
     bounds = list(zip([0] + ends[:-1], ends))
     with torch.cuda.stream(side):                        # the chunks that run beside the producer
         if side is not main:
@@ -323,10 +331,8 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
     if not fenced:                                       # the last chunk: behind the producer, on the caller's stream
         main.wait_event(early)                           # (satisfied long before the producer ends: costs nothing)
         consume(bounds[-1][0], M, wait=False)
-    # Correct or redo, never invalid: the waits are bounded (a producer that stalls must not hang the device); one that gave
-    # up let its consumers run on samples that had not been written.  Behind the producer's last sample the whole layer is
-    # issued once more with run_if = timed_out: launches that do nothing when every wait was served, the repair otherwise.
-    _redo_layer(layer, plan, tail, xyz, new_xyz, features, idx_a, idx_b, out, timed_out)
+    if not self_repair:   # the whole layer once more with run_if = timed_out: launches that do nothing when every wait was served
+        _redo_layer(layer, plan, tail, xyz, new_xyz, features, idx_a, idx_b, out, timed_out)
     if verify is not None:
         third = _side_stream(dev)                        # beside the last chunk's ball query, not behind it
         with torch.cuda.stream(third):
