@@ -74,7 +74,7 @@ __device__ __forceinline__ void wait_vm() {
 }  // namespace
 
 // a.w1 = the concatenated fragment stream; a.ks1 = layer-1 k-steps of 32 grouped channels.
-template <int C1, int C2, int C3, int NT, int NS, int WAVES>
+template <int C1, int C2, int C3, int NT, int NS, int WAVES, int PIPE_MODE = 2>
 __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa_group_mlp_f16_lds_kernel(SaMlpArgs a) {
     if (a.run_if && *a.run_if == 0) return;   // workgroup-uniform, before any barrier or DMA request
     constexpr int PIECES = 8 / WAVES;  // 1-KiB pieces of a chunk each wave fetches
@@ -141,16 +141,26 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa
         prod_slot = (prod_slot + 1 == RING) ? 0 : prod_slot + 1;
     };
     for (int i = 0; i < RING - 1; ++i) request();
-    auto next_chunk = [&](WFrag (&w)[4]) {
-        wait_vm<PIECES * (RING - 2)>();             // my pieces of the chunk about to be read have landed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();               // ... and everybody else's; everybody is done with the previous chunk
-        asm volatile("" ::: "memory");
-        request();                                  // refill the slot the previous chunk occupied
-        // the reads are asm as well: hipcc hoisted plain LDS loads above the waits and the barrier (it does not treat
-        // them as ordered against the asm statements), i.e. before the data was guaranteed to be there
+    // PIPE: the ring reads run ONE CHUNK AHEAD of the matrix instructions.  next_chunk hands out the fragments it asked for
+    // during the previous call and asks for the following chunk's, which then land while this chunk's MFMAs issue -- with
+    // one or two waves per SIMD nobody else hides the LDS latency (~130 cycles + 8 x 4 array cycles per chunk against 12
+    // MFMAs = 192 cycles).  Not for the 1024-row variant, whose 511 registers leave no room for the second fragment set.
+    // The bias of the layer-2 tile that BEGINS with the next chunk travels with that chunk's reads (a ninth ds_read): read by
+    // the compiler it drew an s_waitcnt lgkmcnt(0) right behind the eight reads in flight.  Needs tiles that begin on chunk
+    // boundaries: S1 == 4.
+    constexpr bool PIPE = PIPE_MODE > 0 && C3 <= 256 && NT == 1 && S1 == 4;   // (the NT = 2 variants would drop to one wave per SIMD)
+    constexpr bool PIPE_BIAS = PIPE && PIPE_MODE > 1;
+    const unsigned bias2_base = ring_base + (unsigned)(RING * CHUNK_BYTES + (C1 + 4 * q) * 4);   // &b2l[4 q] as an LDS address
+    f32x4 nbias = {0.f, 0.f, 0.f, 0.f}, cur_bias = {0.f, 0.f, 0.f, 0.f};
+    i32x4 n0, n1, n2, n3, n4, n5, n6, n7;   // the fragments in flight (PIPE)
+    auto issue_reads = [&](int next_tile) {   // next_tile: the layer-2 tile whose k-steps fill the chunk being read, or -1
+        if (PIPE_BIAS && next_tile >= 0) {
+            const unsigned baddr = bias2_base + (unsigned)(64 * next_tile);
+            asm volatile("ds_read_b128 %0, %1" : "=&v"(nbias) : "v"(baddr) : "memory");
+        }
+        // asm: hipcc hoisted plain LDS loads above the waits and the barrier (it does not treat them as ordered against
+        // the asm statements), i.e. before the data was guaranteed to be there
         const unsigned src = ring_base + (unsigned)(cons_slot * CHUNK_BYTES + lane * 16);
-        i32x4 r0, r1, r2, r3, r4, r5, r6, r7;
         asm volatile("ds_read_b128 %0, %8\n\t"
                      "ds_read_b128 %1, %8 offset:1024\n\t"
                      "ds_read_b128 %2, %8 offset:2048\n\t"
@@ -158,15 +168,62 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa
                      "ds_read_b128 %4, %8 offset:4096\n\t"
                      "ds_read_b128 %5, %8 offset:5120\n\t"
                      "ds_read_b128 %6, %8 offset:6144\n\t"
-                     "ds_read_b128 %7, %8 offset:7168\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+                     "ds_read_b128 %7, %8 offset:7168"
+                     : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3), "=&v"(n4), "=&v"(n5), "=&v"(n6), "=&v"(n7)
                      : "v"(src)
                      : "memory");
-        union U { i32x4 i; h8 h; };
-        U a0{r0}, a1{r1}, a2{r2}, a3{r3}, a4{r4}, a5{r5}, a6{r6}, a7{r7};
-        w[0] = WFrag{a0.h, a1.h}; w[1] = WFrag{a2.h, a3.h}; w[2] = WFrag{a4.h, a5.h}; w[3] = WFrag{a6.h, a7.h};
         cons_slot = (cons_slot + 1 == RING) ? 0 : cons_slot + 1;
+    };
+    auto land_reads = [&](WFrag (&w)[4]) {   // the registers are only valid behind this wait: it is their last writer
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4), "+v"(n5), "+v"(n6), "+v"(n7), "+v"(nbias)
+                     :
+                     : "memory");
+        cur_bias = nbias;
+        union U { i32x4 i; h8 h; };
+        U a0{n0}, a1{n1}, a2{n2}, a3{n3}, a4{n4}, a5{n5}, a6{n6}, a7{n7};
+        w[0] = WFrag{a0.h, a1.h}; w[1] = WFrag{a2.h, a3.h}; w[2] = WFrag{a4.h, a5.h}; w[3] = WFrag{a6.h, a7.h};
+    };
+    if constexpr (PIPE) {   // prime: chunk 0 on its way to the registers, RING-1 chunks behind it on their way to the ring
+        wait_vm<PIECES * (RING - 2)>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue_reads(-1);
+        request();
+    }
+    auto next_chunk = [&](WFrag (&w)[4], int next_tile) {
+        if constexpr (PIPE) {
+            land_reads(w);                          // chunk g: asked for during the previous call; my reads of it are over
+            wait_vm<PIECES * (RING - 2)>();         // my pieces of chunk g+1 have landed
+            __builtin_amdgcn_s_barrier();           // ... and everybody else's; everybody holds chunk g in registers
+            asm volatile("" ::: "memory");
+            issue_reads(next_tile);                 // chunk g+1, consumed by the next call
+            request();                              // refill the slot chunk g occupied
+        } else {
+            wait_vm<PIECES * (RING - 2)>();         // my pieces of the chunk about to be read have landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();           // ... and everybody else's; everybody is done with the previous chunk
+            asm volatile("" ::: "memory");
+            request();                              // refill the slot the previous chunk occupied
+            const unsigned src = ring_base + (unsigned)(cons_slot * CHUNK_BYTES + lane * 16);
+            i32x4 r0, r1, r2, r3, r4, r5, r6, r7;
+            asm volatile("ds_read_b128 %0, %8\n\t"
+                         "ds_read_b128 %1, %8 offset:1024\n\t"
+                         "ds_read_b128 %2, %8 offset:2048\n\t"
+                         "ds_read_b128 %3, %8 offset:3072\n\t"
+                         "ds_read_b128 %4, %8 offset:4096\n\t"
+                         "ds_read_b128 %5, %8 offset:5120\n\t"
+                         "ds_read_b128 %6, %8 offset:6144\n\t"
+                         "ds_read_b128 %7, %8 offset:7168\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+                         : "v"(src)
+                         : "memory");
+            union U { i32x4 i; h8 h; };
+            U a0{r0}, a1{r1}, a2{r2}, a3{r3}, a4{r4}, a5{r5}, a6{r6}, a7{r7};
+            w[0] = WFrag{a0.h, a1.h}; w[1] = WFrag{a2.h, a3.h}; w[2] = WFrag{a4.h, a5.h}; w[3] = WFrag{a6.h, a7.h};
+            cons_slot = (cons_slot + 1 == RING) ? 0 : cons_slot + 1;
+        }
     };
     // hi*hi + hi*lo + lo*hi for all NT column tiles
     auto mac = [&](const WFrag &w, const h8 (&xh)[NT], const h8 (&xl)[NT], f32x4 (&acc)[NT]) {
@@ -262,7 +319,7 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa
 #pragma unroll
                 for (int tc = 0; tc < T1 / 4; ++tc) {
                     WFrag w[4];
-                    next_chunk(w);
+                    next_chunk(w, tc == T1 / 4 - 1 ? 0 : -1);   // (behind the last k-step: layer-2 tile 0 is next)
 #pragma unroll
                     for (int u = 0; u < 4; ++u) mac(w[u], xhi, xlo, acc1[tc * 4 + u]);
                 }
@@ -293,11 +350,15 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa
                 WFrag w[4];
 #pragma unroll
                 for (int f = 0; f < BLOCK_FRAGS; ++f) {
-                    if (f % 4 == 0) next_chunk(w);
+                    if (f % 4 == 0) {
+                        // what the NEXT chunk holds: the second tile of this block, layer-3 fragments, or the next block's first tile
+                        const int nf = f + 4;
+                        next_chunk(w, nf < 2 * S1 ? 2 * s + nf / S1 : (nf == BLOCK_FRAGS && s + 1 < S2 ? 2 * s + 2 : -1));
+                    }
                     if (f < 2 * S1) {
                         const int half = f / S1, s1 = f % S1, mt = 2 * s + half;
                         if (s1 == 0) {
-                            const f32x4 bias = *reinterpret_cast<const f32x4 *>(b2l + 16 * mt + 4 * q);
+                            const f32x4 bias = PIPE_BIAS ? cur_bias : *reinterpret_cast<const f32x4 *>(b2l + 16 * mt + 4 * q);
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt) acc[nt] = bias;
                         }
@@ -369,7 +430,7 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa
     if (any_bad && a.overflow) *a.overflow = 1;
 }
 
-template <int C1, int C2, int C3, int NT, int NS, int WAVES>
+template <int C1, int C2, int C3, int NT, int NS, int WAVES, int PIPE_MODE = 2>
 static int launch_lds_variant(const SaMlpArgs &a, hipStream_t st) {
     constexpr int UNIT = 16 * NT;
     SaMlpArgs k = a;
@@ -383,15 +444,16 @@ static int launch_lds_variant(const SaMlpArgs &a, hipStream_t st) {
     k.alt_units = a.units * k.alt_ups;
     k.ks1 = (3 + a.c_feat + 31) / 32;
     const int groups = divup(k.units, WAVES);
-    int blocks = groups < 256 * 2 ? groups : 256 * 2;
+    const int resident = WAVES == 8 ? 256 : 512;   // eight waves = two per SIMD fill a CU
+    int blocks = groups < resident ? groups : resident;
     const size_t lds = (size_t)RING * CHUNK_BYTES + sizeof(float) * ((size_t)C1 + C2 + C3 + (size_t)WAVES * (UNIT >= NS ? UNIT / NS : 1) * C3);
     static LdsLimitOnce raised;  // one per instantiation
     if (lds > 64 * 1024) {
-        const int rc = raise_lds_limit((const void *)sa_group_mlp_f16_lds_kernel<C1, C2, C3, NT, NS, WAVES>, 150 * 1024, raised,
+        const int rc = raise_lds_limit((const void *)sa_group_mlp_f16_lds_kernel<C1, C2, C3, NT, NS, WAVES, PIPE_MODE>, 150 * 1024, raised,
                                        "sa_group_mlp(f16/lds)");
         if (rc != SPS_OK) return rc;
     }
-    hipLaunchKernelGGL((sa_group_mlp_f16_lds_kernel<C1, C2, C3, NT, NS, WAVES>), dim3(blocks), dim3(64 * WAVES), lds, st, k);
+    hipLaunchKernelGGL((sa_group_mlp_f16_lds_kernel<C1, C2, C3, NT, NS, WAVES, PIPE_MODE>), dim3(blocks), dim3(64 * WAVES), lds, st, k);
     return check_launch("sa_group_mlp_f16_lds_kernel");
 }
 
@@ -402,7 +464,9 @@ int launch_sa_mlp_f16_lds(const SaMlpArgs &a, int c1, int c2, int nsample, hipSt
     SPS_MLPL_CASE(64, 64, 128, 2, 16, 4)
     SPS_MLPL_CASE(64, 96, 128, 2, 32, 4)
     SPS_MLPL_CASE(128, 128, 256, 1, 16, 4)
-    SPS_MLPL_CASE(128, 256, 256, 1, 32, 4)   // (NT = 2 here and one line up: 512 registers + spills, 2.30 -> 2.35 ms per pass)
+    SPS_MLPL_CASE(128, 256, 256, 1, 32, 4)   // (NT = 2 here and one line up: 512 registers + spills, 2.30 -> 2.35 ms per pass;
+                                             //  8 waves per workgroup = half the L2 stream: 111.6 -> 112.4 us, not the bound;
+                                             //  ring reads one chunk ahead: 114 -> 108 us, PIPE_MODE 0 / 2 on one box)
     SPS_MLPL_CASE(256, 256, 512, 1, 16, 4)   // IA-SSD layer 5 [259,256,256,512]: 4 waves = 512 registers each
     SPS_MLPL_CASE(256, 512, 1024, 1, 32, 4)  // IA-SSD layer 5 [259,256,512,1024]
     SPS_MLPL_CASE(128, 128, 256, 1, 64, 8)   // nsample 64: a centroid spans four waves
