@@ -17,6 +17,9 @@
 // 16 384 on MI355X; this kernel's rounds cost a few microseconds for ~6 picks.
 #include "fps_pruned_util.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <type_traits>
 #include <utility>
 
@@ -44,10 +47,10 @@ __device__ __forceinline__ void rows_each(F &fn) {
 
 }  // namespace
 
-// work: per scene 5 arrays of npad elements: x, y, z, t (float), rank (int); npad = 64 * number of buckets
+// work: per scene `stride` floats, of which 5 arrays of npad elements: x, y, z, t (float), rank (int); npad = 64 * number of buckets
 template <int ROWS>
 __global__ __launch_bounds__(PF_THREADS) void fps_pruned_big_kernel(int n, int m, int bs, int l2, int rb, int npad,
-                                                                    const float *__restrict__ dataset,
+                                                                    long long stride, const float *__restrict__ dataset,
                                                                     float *__restrict__ temp, int *__restrict__ idxs,
                                                                     float *__restrict__ work) {
     if (m <= 0) return;
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_big_kernel(int n, int m
     const float *xyz = dataset + (size_t)scene * n * 3;
     temp += (size_t)scene * n;
     idxs += (size_t)scene * m;
-    float *sx = work + (size_t)scene * 5 * npad, *sy = sx + npad, *sz = sy + npad, *st = sz + npad;
+    float *sx = work + (size_t)scene * stride, *sy = sx + npad, *sz = sy + npad, *st = sz + npad;
     int *srk = reinterpret_cast<int *>(st + npad);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -382,10 +385,34 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_big_kernel(int n, int m
     }
 }
 
-// workspace floats per scene for sps_fps_with_workspace (0: this size is served without one)
+size_t fps_cluster_exchange_floats();
+int launch_fps_pruned_cluster(int b, int K, int T, int n, int m, const float *dataset, float *temp, int *idxs, float *work,
+                              long long stride, hipStream_t st);
+
+// workspace floats per scene for sps_fps_with_workspace (0: this size is served without one): the sorted points and,
+// behind them, the record exchange area of fps_pruned_cluster.hip
 size_t fps_big_workspace_elems(int n) {
     if (n <= 32 * PF_THREADS || n > 8 * 64 * 64 * PF_WAVES) return 0;
-    return (size_t)5 * ((size_t)divup(n, 64) * 64);
+    return (size_t)5 * ((size_t)divup(n, 64) * 64) + fps_cluster_exchange_floats();
+}
+
+// Workgroups per scene (K) and records each publishes per round (T <= 8, K T <= 32); SPS_FPS_CLUSTER="K,T" overrides
+// ("1" = one workgroup, the kernel below).  Measured on MI355X (tools/fps_cluster_probe.py; one workgroup = 1.00):
+//   180 000 -> 16 384, 1 scene    K,T = 2,8  0.71   4,8  0.46   8,3  0.43   8,4  0.39  (32.8 -> 12.7 ms)
+//    65 536 -> 16 384, 2 scenes         2,8  0.97   4,8  0.72   8,3  0.77   8,4  0.66
+//    32 768 ->  8 192, 8 scenes         2,8  1.04   4,8  0.84   8,3  0.93   8,4  0.81
+// The K workgroups of a scene spin on each other's records, so all b K must be resident at once: at most 64 (a CU each).
+static void fps_cluster_shape(int b, int n, int &K, int &T) {
+    K = 8;
+    while (K > 1 && b * K > 64) K >>= 1;
+    if (K == 2 && n < 65536) K = 1;
+    T = K >= 8 ? 4 : 8;
+    const char *env = getenv("SPS_FPS_CLUSTER");   // (read per launch: tests switch it)
+    if (env && *env) {
+        int k = 1, t = 8;
+        if (sscanf(env, "%d,%d", &k, &t) >= 1) { K = k; T = t; }
+        while (K > 1 && b * K > 64) K >>= 1;
+    }
 }
 
 int launch_fps_pruned_big(int b, int n, int m, const float *dataset, float *temp, int *idxs, float *work, hipStream_t st) {
@@ -396,11 +423,18 @@ int launch_fps_pruned_big(int b, int n, int m, const float *dataset, float *temp
     int rb = 0;
     while ((1 << rb) < divup(n, bs)) ++rb;
     const int npad = divup(n, 64) * 64;
+    const long long stride = (long long)fps_big_workspace_elems(n);
+    int K, T;
+    fps_cluster_shape(b, n, K, T);
+    if (K > 1) {
+        const int rc = launch_fps_pruned_cluster(b, K, T, n, m, dataset, temp, idxs, work, stride, st);
+        if (rc >= 0) return rc;
+    }
     const int rows = divup(npad / 64, 64 * PF_WAVES);
     dim3 grid(b), block(PF_THREADS);
 #define SPS_PB_CASE(R)                                                                                               \
     if (rows <= R) {                                                                                                 \
-        hipLaunchKernelGGL((fps_pruned_big_kernel<R>), grid, block, 0, st, n, m, bs, l2, rb, npad, dataset, temp, idxs, work); \
+        hipLaunchKernelGGL((fps_pruned_big_kernel<R>), grid, block, 0, st, n, m, bs, l2, rb, npad, stride, dataset, temp, idxs, work); \
         return check_launch("fps_pruned_big_kernel");                                                               \
     }
     SPS_PB_CASE(2)

@@ -1,0 +1,509 @@
+// fps_pruned_cluster.hip -- the large-scene farthest point sampling of fps_pruned_big.hip with ONE SCENE SPREAD OVER K
+// COMPUTE UNITS ("split a scene over a few CUs on the same GPU", BASELINE config 5: 180 000 points).
+//
+// Same contract and the same results (indices and final `temp`, bit for bit) as fps_pruned_big.hip / the reference
+// (sampling_gpu.cu:93-253); same buckets, box test, records and acceptance proof.  What changes:
+//   * the scene's buckets are dealt round-robin over the 8 K waves of K workgroups (a wave owns a quarter of the buckets it
+//     owned at K = 4: fewer box tests per centre, fewer fetched buckets per round on the busiest wave);
+//   * every round each workgroup ranks its 16 wave records and PUBLISHES ITS T BEST to the other workgroups; the last of
+//     them carries the value of the best record held back in its bound, so the acceptance argument of fps_pruned.hip
+//     holds unchanged over the K T published records (a candidate behind it must beat everything still hidden);
+//   * the exchange is one hop per round: 8-byte {value, round tag} granules written and polled with agent-scope atomics
+//     (MI355X_MICROARCH.md, hand-off price list: ~1 us; no fence, no separate flag), double-buffered by round parity --
+//     a workgroup can publish round r+2 only after everybody has published r+1, i.e. finished reading r;
+//   * every workgroup evaluates the acceptance of all K T records redundantly (identical inputs, identical result), so
+//     nobody waits for a verdict; each wave then applies the accepted centres to its own buckets only.
+// More records per round and less work per wave: 180 000 -> 16 384 in 31.8 ms on one CU, see DESIGN.md for K = 2, 4.
+// The K workgroups of a scene must be resident together: the launcher uses the cluster only for b K <= 64 workgroups
+// (a CU each; the polls are bounded -- a stuck exchange traps instead of hanging the device).
+#include "fps_pruned_util.h"
+
+#include <type_traits>
+#include <utility>
+
+namespace sps {
+
+namespace {
+
+constexpr int IMIN_C = (int)0x80000000;
+constexpr int PC_MAXK = 8;        // workgroups per scene
+constexpr int PC_MAXT = 8;        // records a workgroup publishes per round
+constexpr int PC_MAXR = 32;       // records per round (K T) at most: two lanes per record in the acceptance
+constexpr int PC_GRANULES = 8 + 2 * PC_MAXR * 6;      // [0]: "sorted" flag (+ padding to a 64-byte line), then [parity][record][field]
+constexpr unsigned PC_SPIN_LIMIT = 1u << 24;          // polls before a stuck exchange traps (~ seconds)
+
+struct PcShared {
+    int hist[PF_BINS];
+    __attribute__((aligned(16))) int soa[2][6][2 * PF_WAVES];  // the workgroup's own 16 records: round parity x field x record
+    __attribute__((aligned(16))) int xr[PF_WAVES][6][PC_MAXR]; // the round's published records, one private copy per wave
+    float red[6][PF_WAVES];
+    int wsum[PF_WAVES];
+};
+
+template <int R, int ROWS, class F>
+__device__ __forceinline__ void rows_each_c(F &fn) {
+    if constexpr (R < ROWS) {
+        fn(std::integral_constant<int, R>{});
+        rows_each_c<R + 1, ROWS>(fn);
+    }
+}
+
+__device__ __forceinline__ void granule_store(unsigned long long *p, int value, unsigned tag) {
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long granule_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace
+
+// work: per scene `stride` floats: 5 arrays of npad elements (x, y, z, t, rank), then the exchange area (zeroed by the launcher)
+template <int ROWS>
+__global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, int K, int T, int n, int m, int bs, int l2, int rb,
+                                                                        int npad, long long stride,
+                                                                        const float *__restrict__ dataset,
+                                                                        float *__restrict__ temp, int *__restrict__ idxs,
+                                                                        float *__restrict__ work) {
+    if (m <= 0) return;
+    __shared__ PcShared sh;
+    // blocks s, s + 8, s + 16, ... share an XCD (observed dispatch order): a scene's K workgroups sit on one L2
+    const int scene = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * K)), cu = (blockIdx.x >> 3) % K;
+    if (scene >= b) return;
+    const float *xyz = dataset + (size_t)scene * n * 3;
+    temp += (size_t)scene * n;
+    idxs += (size_t)scene * m;
+    float *sx = work + (size_t)scene * stride, *sy = sx + npad, *sz = sy + npad, *st = sz + npad;
+    int *srk = reinterpret_cast<int *>(st + npad);
+    unsigned long long *xg = reinterpret_cast<unsigned long long *>(work + (size_t)scene * stride + (size_t)5 * npad);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gwave = cu * PF_WAVES + wave, nwaves = K * PF_WAVES;   // this wave among the scene's waves
+    const int nb = npad / 64;  // buckets
+    const int R = K * T;       // records per round
+
+    if (cu == 0) {
+        // ------------------------------------------------------------------ spatial sort (once, by the first workgroup)
+        float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k0 = tid; k0 < n; k0 += 8 * PF_THREADS) {
+            float v[8][3];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * PF_THREADS;
+                const int kk = k < n ? k : k0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) v[u][a] = xyz[(size_t)kk * 3 + a];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { lo3[a] = fminf(lo3[a], v[u][a]); hi3[a] = fmaxf(hi3[a], v[u][a]); }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo3[a] = wave_allmin_f32(lo3[a]);
+            hi3[a] = wave_allmax_f32(hi3[a]);
+            if (lane == 0) { sh.red[a][wave] = lo3[a]; sh.red[3 + a][wave] = hi3[a]; }
+        }
+        for (int i = tid; i < PF_BINS; i += PF_THREADS) sh.hist[i] = 0;
+        __syncthreads();
+        float glo[3], ghi[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float l = sh.red[a][0], h = sh.red[3 + a][0];
+#pragma unroll
+            for (int w = 1; w < PF_WAVES; ++w) { l = fminf(l, sh.red[a][w]); h = fmaxf(h, sh.red[3 + a][w]); }
+            glo[a] = l; ghi[a] = h;
+        }
+        const PfGrid grid = pf_make_grid(glo, ghi);
+        for (int k0 = tid; k0 < n; k0 += 8 * PF_THREADS) {
+            float v[8][3];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * PF_THREADS;
+                const int kk = k < n ? k : k0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) v[u][a] = xyz[(size_t)kk * 3 + a];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + u * PF_THREADS < n) atomicAdd(&sh.hist[pf_cell_key(grid, v[u][0], v[u][1], v[u][2])], 1);
+        }
+        __syncthreads();
+        {   // exclusive prefix sum of the histogram
+            constexpr int PER = PF_BINS / PF_THREADS;
+            int loc[PER], sum = 0;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) { loc[i] = sh.hist[tid * PER + i]; sum += loc[i]; }
+            int incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            if (lane == 63) sh.wsum[wave] = incl;
+            __syncthreads();
+            int base = 0;
+            for (int w = 0; w < wave; ++w) base += sh.wsum[w];
+            int run = base + incl - sum;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) { sh.hist[tid * PER + i] = run; run += loc[i]; }
+        }
+        __syncthreads();
+        for (int k0 = tid; k0 < n; k0 += 8 * PF_THREADS) {
+            float v[8][3], tv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * PF_THREADS;
+                const int kk = k < n ? k : k0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) v[u][a] = xyz[(size_t)kk * 3 + a];
+                tv[u] = temp[kk];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * PF_THREADS;
+                if (k < n) {
+                    const int pos = atomicAdd(&sh.hist[pf_cell_key(grid, v[u][0], v[u][1], v[u][2])], 1);
+                    sx[pos] = v[u][0]; sy[pos] = v[u][1]; sz[pos] = v[u][2]; st[pos] = tv[u];
+                    srk[pos] = (int)pf_rank((unsigned)k, bs, l2, rb);
+                }
+            }
+        }
+        for (int p = n + tid; p < npad; p += PF_THREADS) {  // padding: never inside a box, distance stays -1, worst rank
+            sx[p] = NAN; sy[p] = NAN; sz[p] = NAN; st[p] = -1.f; srk[p] = 0x0FFFFFFF;
+        }
+        // hand the sorted scene to the other workgroups: every storing wave drained, the workgroup's barrier, one agent-scope
+        // release (write back this XCD's L2), the flag (MI355X_MICROARCH.md, inter-workgroup visibility: the valid form)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            granule_store(xg, 1, 1u);
+        }
+    } else {
+        if (tid == 0) {
+            unsigned spins = 0;
+            while ((granule_load(xg) >> 32) != 1u) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > PC_SPIN_LIMIT) __builtin_trap();
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();   // (the invalidate of this CU's vector L1 has completed: plain loads of the workspace from here on)
+    }
+
+    // ------------------------------------------------------------------ bucket metadata
+    // bucket g = v * nwaves + gwave is slot v of this wave: row v / 64, lane v % 64
+    typedef float vfR __attribute__((ext_vector_type(ROWS)));
+    typedef int viR __attribute__((ext_vector_type(ROWS)));
+    vfR blo_x, blo_y, blo_z, bhi_x, bhi_y, bhi_z, bpx, bpy, bpz;
+    viR bmax, bsec, bkeylo;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {  // no bucket: a box the test always rules out
+        blo_x[r] = blo_y[r] = blo_z[r] = bhi_x[r] = bhi_y[r] = bhi_z[r] = INFINITY;
+        bpx[r] = bpy[r] = bpz[r] = 0.f;
+        bmax[r] = __float_as_int(-1.f); bsec[r] = __float_as_int(-1.f); bkeylo[r] = 0;
+    }
+    int r_vmax = 0, r_sec = 0, r_keylo = 0, r_px = 0, r_py = 0, r_pz = 0;
+    auto refresh = [&](float tv, int rv, float xv, float yv, float zv) {
+        const int tb = __float_as_int(tv);
+        const int vmax = wave_max_i32_id(tb);
+        const unsigned long long eq = __ballot(tb == vmax);
+        int wl = __builtin_ctzll(eq);
+        if (__builtin_popcountll(eq) > 1) {  // equal distances: the reference's tie rule decides
+            const int inv = (tb == vmax) ? (0x0FFFFFFF - rv) : -1;
+            const int best = wave_max_i32_id(inv);
+            wl = __builtin_ctzll(__ballot(inv == best));
+        }
+        r_sec = wave_max_i32_id(lane != wl ? tb : IMIN_C);
+        const int rank = __builtin_amdgcn_readlane(rv, wl);
+        r_px = __builtin_amdgcn_readlane(__float_as_int(xv), wl);
+        r_py = __builtin_amdgcn_readlane(__float_as_int(yv), wl);
+        r_pz = __builtin_amdgcn_readlane(__float_as_int(zv), wl);
+        r_vmax = vmax;
+        r_keylo = (int)((0x0FFFFFFFu - (unsigned)rank) << 4);
+    };
+    auto commit = [&](auto rc, int l) {  // metadata of (row, lane l) <- the scalars refresh() left
+        constexpr int RW = decltype(rc)::value;
+        int a0 = bmax[RW], a1 = bsec[RW], a2 = bkeylo[RW], a3 = __float_as_int(bpx[RW]), a4 = __float_as_int(bpy[RW]), a5 = __float_as_int(bpz[RW]);
+        unsigned keep;
+        asm volatile("s_mov_b32 %6, m0\n\t"
+                     "s_mov_b32 m0, %13\n\t"
+                     "s_nop 3\n\t"
+                     "v_writelane_b32 %0, %7, m0\n\t"
+                     "v_writelane_b32 %1, %8, m0\n\t"
+                     "v_writelane_b32 %2, %9, m0\n\t"
+                     "v_writelane_b32 %3, %10, m0\n\t"
+                     "v_writelane_b32 %4, %11, m0\n\t"
+                     "v_writelane_b32 %5, %12, m0\n\t"
+                     "s_mov_b32 m0, %6"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "=&s"(keep)
+                     : "s"(r_vmax), "s"(r_sec), "s"(r_keylo), "s"(r_px), "s"(r_py), "s"(r_pz), "s"(__builtin_amdgcn_readfirstlane(l)));
+        bmax[RW] = a0; bsec[RW] = a1; bkeylo[RW] = a2; bpx[RW] = __int_as_float(a3); bpy[RW] = __int_as_float(a4); bpz[RW] = __int_as_float(a5);
+    };
+    auto for_rows = [&](auto &&fn) { rows_each_c<0, ROWS>(fn); };
+    for_rows([&](auto rc) {
+        constexpr int RW = decltype(rc)::value;
+        for (int l = 0; l < 64; ++l) {
+            const int g = (RW * 64 + l) * nwaves + gwave;
+            if (g >= nb) break;
+            const size_t p = (size_t)g * 64 + lane;
+            const float xv = sx[p], yv = sy[p], zv = sz[p], tv = st[p];
+            const int rv = srk[p];
+            float lx = xv, ly = yv, lz = zv, hx = xv, hy = yv, hz = zv;
+            wave_box6(lx, ly, lz, hx, hy, hz);
+            if (lane == l) { blo_x[RW] = lx; blo_y[RW] = ly; blo_z[RW] = lz; bhi_x[RW] = hx; bhi_y[RW] = hy; bhi_z[RW] = hz; }
+            refresh(tv, rv, xv, yv, zv);
+            commit(rc, l);
+        }
+    });
+
+    if (cu == 0 && tid == 0) idxs[0] = 0;
+    // record slots beyond R never come before anything (most negative distance, lowest key)
+    for (int i = lane; i < 6 * PC_MAXR; i += 64) sh.xr[wave][i / PC_MAXR][i % PC_MAXR] = (i / PC_MAXR == 0) ? IMIN_C : 0;
+    __syncthreads();
+
+    // ------------------------------------------------------------------ sampling loop
+    int crec = 0;
+    bool cand_stale = true;
+    int cand_e1 = -1, cand_e2 = -1;
+    float ax = xyz[0], ay = xyz[1], az = xyz[2];
+    unsigned long long pend = m > 1 ? 1ull : 0ull;
+    int j = 1, round = 0;
+    const bool younger = wave >= PF_WAVES / 2;
+    for (;;) {
+        if (younger) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        while (pend) {
+            const int rr = __builtin_ctzll(pend);
+            pend &= pend - 1;
+            const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax), rr));
+            const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay), rr));
+            const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(az), rr));
+            for_rows([&](auto rc) {
+                constexpr int RW = decltype(rc)::value;
+                const float qx = __builtin_amdgcn_fmed3f(cx, blo_x[RW], bhi_x[RW]);
+                const float qy = __builtin_amdgcn_fmed3f(cy, blo_y[RW], bhi_y[RW]);
+                const float qz = __builtin_amdgcn_fmed3f(cz, blo_z[RW], bhi_z[RW]);
+                const float lb = sqdist(qx, qy, qz, cx, cy, cz);
+                const bool skip = lb >= __int_as_float(bmax[RW]);  // NaN -> not skipped
+                unsigned long long todo = __ballot(!skip);
+                while (todo) {
+                    const int l = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const int g = (RW * 64 + l) * nwaves + gwave;
+                    const size_t p = (size_t)g * 64 + lane;
+                    const float xv = sx[p], yv = sy[p], zv = sz[p];
+                    const float tv = __hip_atomic_load(st + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float d = sqdist(xv, yv, zv, cx, cy, cz);
+                    if (__ballot(d < tv) != 0ull) {
+                        const float tn = fmin_raw(d, tv);
+                        __hip_atomic_store(st + p, tn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int rv = srk[p];
+                        refresh(tn, rv, xv, yv, zv);
+                        commit(rc, l);
+                        const int e = (RW << 6) | l;
+                        if (e == cand_e1 || e == cand_e2) cand_stale = true;
+                    }
+                }
+            });
+        }
+        if (j >= m) break;
+        // the wave's two records (fps_pruned_big.hip)
+        if (cand_stale) {
+            auto best_entry = [&](int excl1, int excl2, int &vmax, int &row) -> int {
+                int lv = IMIN_C, lk = -1, lr = 0;
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const int e = (r << 6) | lane;
+                    const bool ok = e != excl1 && e != excl2;
+                    const int v = bmax[r], k = (int)((unsigned)bkeylo[r] >> 4);
+                    const bool better = ok && (v > lv || (v == lv && k > lk));
+                    lv = better ? v : lv; lk = better ? k : lk; lr = better ? r : lr;
+                }
+                vmax = wave_max_i32_id(lv);
+                const unsigned long long eq = __ballot(lv == vmax);
+                int wl = __builtin_ctzll(eq);
+                if (__builtin_popcountll(eq) > 1) {
+                    const int kl = (lv == vmax) ? lk : -1;
+                    const int kbest = wave_max_i32_id(kl);
+                    wl = __builtin_ctzll(__ballot(kl == kbest));
+                }
+                row = __builtin_amdgcn_readlane(lr, wl);
+                return wl;
+            };
+            int v1, v2, v3, r1, r2, r3;
+            const int wl1 = best_entry(-1, -1, v1, r1);
+            const int e1 = (r1 << 6) | wl1;
+            const int wl2 = best_entry(e1, -1, v2, r2);
+            const int e2 = (r2 << 6) | wl2;
+            (void)best_entry(e1, e2, v3, r3);
+            auto record = [&](int row, int wl, int vmax, int others, auto rcn) {
+                constexpr int RN = decltype(rcn)::value;
+                int klo = 0, px = 0, py = 0, pz = 0, sec = IMIN_C;
+                for_rows([&](auto rc) {
+                    constexpr int RW = decltype(rc)::value;
+                    if (row == RW) {
+                        klo = __builtin_amdgcn_readlane(bkeylo[RW], wl);
+                        px = __builtin_amdgcn_readlane(__float_as_int(bpx[RW]), wl);
+                        py = __builtin_amdgcn_readlane(__float_as_int(bpy[RW]), wl);
+                        pz = __builtin_amdgcn_readlane(__float_as_int(bpz[RW]), wl);
+                        sec = __builtin_amdgcn_readlane(bsec[RW], wl);
+                    }
+                });
+                const float fx = __int_as_float(px), fy = __int_as_float(py), fz = __int_as_float(pz);
+                const float own = fmin_raw(sqdist(fx, fy, fz, fx, fy, fz), __int_as_float(vmax));
+                const int bound = imax(imax(others, sec), __builtin_amdgcn_readfirstlane(__float_as_int(own)));
+                put_lane<0 + RN>(crec, vmax);
+                put_lane<2 + RN>(crec, klo);
+                put_lane<4 + RN>(crec, px);
+                put_lane<6 + RN>(crec, py);
+                put_lane<8 + RN>(crec, pz);
+                put_lane<10 + RN>(crec, bound);
+            };
+            record(r1, wl1, v1, IMIN_C, std::integral_constant<int, 0>{});
+            record(r2, wl2, v2, v3, std::integral_constant<int, 1>{});
+            cand_e1 = e1; cand_e2 = e2;
+            cand_stale = false;
+        }
+        // ---- the workgroup's 16 records meet in LDS; its first wave ranks them and publishes the T best
+        const int buf = round & 1;
+        const unsigned tag = (unsigned)round + 2u;   // (1 is the "sorted" flag's tag, 0 the zeroed area)
+        unsigned long long *xround = xg + 8 + (size_t)buf * (PC_MAXR * 6);
+        if (lane < 12) sh.soa[buf][lane >> 1][2 * wave + (lane & 1)] = crec;
+        __syncthreads();
+        if (younger) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
+        if (wave == 0) {
+            // position of record rj among the workgroup's 16: records before it under (distance, key), equal ones (only empty
+            // records are) in index order -- a permutation of 0 .. 15
+            const int rj = lane >> 2, rb4 = lane & 3;
+            const int4 id = *(const int4 *)&sh.soa[buf][0][rb4 * 4], ik = *(const int4 *)&sh.soa[buf][1][rb4 * 4];
+            const int jd = sh.soa[buf][0][rj], jk = sh.soa[buf][1][rj];
+            int nbef = 0;
+            auto before = [&](int idist, int iklo, int ii) {
+                const bool same = (idist == jd) & (iklo == jk);
+                nbef += ((idist > jd) | ((idist == jd) & ((unsigned)iklo > (unsigned)jk)) | (same & (ii < rj))) ? 1 : 0;
+            };
+            before(id.x, ik.x, rb4 * 4 + 0); before(id.y, ik.y, rb4 * 4 + 1);
+            before(id.z, ik.z, rb4 * 4 + 2); before(id.w, ik.w, rb4 * 4 + 3);
+            nbef += __builtin_amdgcn_update_dpp(0, nbef, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+            nbef += __builtin_amdgcn_update_dpp(0, nbef, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+            const int hid = wave_max_i32_id(nbef == T ? jd : IMIN_C);   // the best record held back (none: -0.0)
+            if (rb4 == 0 && nbef < T) {
+                int bound = sh.soa[buf][5][rj];
+                if (nbef == T - 1) bound = imax(bound, hid);   // whoever comes behind my last record must beat what I hide
+                unsigned long long *dst = xround + (size_t)(cu * T + nbef) * 6;
+                granule_store(dst + 0, jd, tag);
+                granule_store(dst + 1, jk, tag);
+                granule_store(dst + 2, sh.soa[buf][2][rj], tag);
+                granule_store(dst + 3, sh.soa[buf][3][rj], tag);
+                granule_store(dst + 4, sh.soa[buf][4][rj], tag);
+                granule_store(dst + 5, bound, tag);
+            }
+        }
+        // ---- every wave polls the K T published records (granule = {value, tag}: nothing else to order)
+        {
+            const int ng = R * 6;
+            unsigned spins = 0;
+            for (int gi = lane; gi < ng; gi += 64) {
+                unsigned long long g = granule_load(xround + gi);
+                while ((unsigned)(g >> 32) != tag) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > PC_SPIN_LIMIT) __builtin_trap();
+                    g = granule_load(xround + gi);
+                }
+                sh.xr[wave][gi % 6][gi / 6] = (int)(unsigned)g;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes, read back below (same wave: in order)
+        // ---- acceptance over the R records: lane (rj, h) evaluates record rj against the i-records of half h
+        const int rj = lane >> 1, h = lane & 1;
+        const int jd = sh.xr[wave][0][rj], jk = sh.xr[wave][1][rj];
+        const float jx = __int_as_float(sh.xr[wave][2][rj]), jy = __int_as_float(sh.xr[wave][3][rj]);
+        const float jz = __int_as_float(sh.xr[wave][4][rj]);
+        const float jt = __int_as_float(jd);
+        int nbef = 0, nbad = 0;
+        auto pair = [&](int idist, int iklo, int ixb, int iyb, int izb, int ibound) {
+            const bool before = (idist > jd) | ((idist == jd) & ((unsigned)iklo > (unsigned)jk));
+            const float dij = sqdist(jx, jy, jz, __int_as_float(ixb), __int_as_float(iyb), __int_as_float(izb));
+            const bool lowered = !(dij >= jt);
+            const bool hidden = !(jt > __int_as_float(ibound));
+            nbef += before ? 1 : 0;
+            nbad += (before & (lowered | hidden)) ? 1 : 0;
+        };
+#pragma unroll
+        for (int q4 = 0; q4 < PC_MAXR / 8; ++q4) {
+            const int i0 = h * (PC_MAXR / 2) + q4 * 4;
+            // (slots beyond R hold records that are never "before" anything)
+            const int4 id = *(const int4 *)&sh.xr[wave][0][i0], ik = *(const int4 *)&sh.xr[wave][1][i0];
+            const int4 ixv = *(const int4 *)&sh.xr[wave][2][i0], iyv = *(const int4 *)&sh.xr[wave][3][i0];
+            const int4 izv = *(const int4 *)&sh.xr[wave][4][i0], ibv = *(const int4 *)&sh.xr[wave][5][i0];
+            pair(id.x, ik.x, ixv.x, iyv.x, izv.x, ibv.x);
+            pair(id.y, ik.y, ixv.y, iyv.y, izv.y, ibv.y);
+            pair(id.z, ik.z, ixv.z, iyv.z, izv.z, ibv.z);
+            pair(id.w, ik.w, ixv.w, iyv.w, izv.w, ibv.w);
+        }
+        int cnt = nbef | (nbad << 8);
+        cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]: the other half
+        const int pos = cnt & 0xFF;
+        const bool real = rj < R;
+        const int firstbad = -wave_max_i32_id((real && (cnt >> 8)) ? -pos : -R);   // nobody bad: all R records
+        const int L = firstbad < m - j ? firstbad : m - j;
+        const bool taken = h == 0 && real && pos < L;
+        if (cu == 0 && wave == 0 && taken) {
+            const unsigned rank = 0x0FFFFFFFu - ((unsigned)jk >> 4);
+            idxs[j + pos] = (int)pf_unrank(rank, l2, rb);
+        }
+        pend = __ballot(taken && (j + pos) != m - 1);  // the reference never applies its last pick to `temp`
+        ax = jx; ay = jy; az = jz;
+        j += L;
+        round += 1;
+    }
+
+    // the reference leaves the final running min-distances in `temp` (original order): every wave writes its own buckets
+    for (int v = 0; v < 64 * ROWS; ++v) {
+        const int g = v * nwaves + gwave;
+        if (g >= nb) break;
+        const size_t p = (size_t)g * 64 + lane;
+        if (p < (size_t)n) {
+            const float tv = __hip_atomic_load(st + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            temp[pf_unrank((unsigned)srk[p], l2, rb)] = tv;
+        }
+    }
+}
+
+// floats of the exchange area behind a scene's 5 npad workspace floats
+size_t fps_cluster_exchange_floats() { return (size_t)2 * PC_GRANULES; }
+
+// K workgroups per scene publishing T records each; -1: shape not served
+int launch_fps_pruned_cluster(int b, int K, int T, int n, int m, const float *dataset, float *temp, int *idxs, float *work,
+                              long long stride, hipStream_t st) {
+    if (K < 2 || K > PC_MAXK || T < 1 || T > PC_MAXT || K * T > PC_MAXR || b * K > 64 || !work) return -1;
+    const int bs = sps_opt_n_threads(n);
+    int l2 = 0;
+    while ((1 << (l2 + 1)) <= bs) ++l2;
+    int rb = 0;
+    while ((1 << rb) < divup(n, bs)) ++rb;
+    const int npad = divup(n, 64) * 64;
+    const int rows = divup(npad / 64, 64 * PF_WAVES * K);
+    if (rows > 8) return -1;
+    // the exchange areas start zeroed (tags of an earlier launch must not be mistaken for this one's)
+    hipError_t e = hipMemset2DAsync(work + (size_t)5 * npad, (size_t)stride * sizeof(float), 0,
+                                    fps_cluster_exchange_floats() * sizeof(float), (size_t)b, st);
+    if (e != hipSuccess) return fail(SPS_ERR_LAUNCH, "fps(cluster): hipMemset2DAsync: %s", hipGetErrorString(e));
+    dim3 grid(8 * K * divup(b, 8)), block(PF_THREADS);
+#define SPS_PC_CASE(RW)                                                                                                \
+    if (rows <= RW) {                                                                                                  \
+        hipLaunchKernelGGL((fps_pruned_cluster_kernel<RW>), grid, block, 0, st, b, K, T, n, m, bs, l2, rb, npad, stride, \
+                           dataset, temp, idxs, work);                                                                 \
+        return check_launch("fps_pruned_cluster_kernel");                                                             \
+    }
+    SPS_PC_CASE(2)
+    SPS_PC_CASE(4)
+    SPS_PC_CASE(8)
+#undef SPS_PC_CASE
+    return -1;
+}
+
+}  // namespace sps

@@ -991,13 +991,23 @@ def test_ball_query_range_small_launch_kernels(ext, G, oracle, N, M, j0, cnt, ra
 
 
 # ------------------------------------------------------------------ pruned FPS for scenes beyond one CU's registers
+@pytest.mark.parametrize("cluster", ["1", "", "2,8", "4,5", "3,8", "8,1"])
 @pytest.mark.parametrize("N,m,kind", [(20000, 700, "lattice"), (40000, 2000, "dup"), (65536, 4096, "kitti"),
                                       (70001, 1500, "uniform"), (180000, 2500, "kitti"), (16385, 16385, "dup")])
-def test_fps_large_scene_kernel(ext, G, oracle, N, m, kind):
-    """fps_pruned_big.hip (points in a workspace, bucket metadata in registers, several picks per barrier) against the
-    oracle and against the brute-force streaming kernel: indices AND final running distances bit-exact.  Sizes cover
-    the three metadata-row variants (<= 65 536, <= 131 072, <= 262 144 points), ragged last buckets and m = n."""
+def test_fps_large_scene_kernel(ext, G, oracle, N, m, kind, cluster, monkeypatch):
+    """fps_pruned_big.hip (points in a workspace, bucket metadata in registers, several picks per barrier) and
+    fps_pruned_cluster.hip (the same scene spread over K workgroups that exchange their T best records per round)
+    against the oracle and against the brute-force streaming kernel: indices AND final running distances bit-exact.
+    Sizes cover the three metadata-row variants (<= 65 536, <= 131 072, <= 262 144 points), ragged last buckets and
+    m = n; cluster = "K,T" forces a shape ("1": one workgroup, "": the launcher's choice), including odd K, a single
+    published record per workgroup (everything else hidden behind its bound) and exact ties (lattice)."""
     from spsnet_amd import _lib, scenes
+    if cluster:
+        monkeypatch.setenv("SPS_FPS_CLUSTER", cluster)
+    else:
+        monkeypatch.delenv("SPS_FPS_CLUSTER", raising=False)
+    if cluster not in ("1", "") and (N, m) == (16385, 16385):
+        pytest.skip("m = n at 16 385 rounds per forced shape: covered by the launcher's choice and one workgroup")
     rng = np.random.default_rng(N + m)
     if kind == "lattice":
         xyz = cloud(rng, 2, N, lattice=True)
