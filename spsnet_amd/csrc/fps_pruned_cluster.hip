@@ -11,9 +11,12 @@
 //   * the exchange is one hop per round: 8-byte {value, round tag} granules written and polled with agent-scope atomics
 //     (MI355X_MICROARCH.md, hand-off price list: ~1 us; no fence, no separate flag), double-buffered by round parity --
 //     a workgroup can publish round r+2 only after everybody has published r+1, i.e. finished reading r;
-//   * every workgroup evaluates the acceptance of all K T records redundantly (identical inputs, identical result), so
+//   * a workgroup polls the K T records with one granule per lane (192 lanes at 32 records: one round trip; eight waves
+//     each polling everything cost 1 ms of 13 more) into LDS, a second barrier hands them to its waves;
+//   * every wave evaluates the acceptance of all K T records redundantly (identical inputs, identical result), so
 //     nobody waits for a verdict; each wave then applies the accepted centres to its own buckets only.
-// More records per round and less work per wave: 180 000 -> 16 384 in 31.8 ms on one CU, see DESIGN.md for K = 2, 4.
+// More records per round and less work per wave: 180 000 -> 16 384 in 11.9 ms at K = 8 against 32.4 ms on one CU
+// (fps_pruned_big.hip's launcher holds the measured table and picks K, T).
 // The K workgroups of a scene must be resident together: the launcher uses the cluster only for b K <= 64 workgroups
 // (a CU each; the polls are bounded -- a stuck exchange traps instead of hanging the device).
 #include "fps_pruned_util.h"
@@ -35,7 +38,7 @@ constexpr unsigned PC_SPIN_LIMIT = 1u << 24;          // polls before a stuck ex
 struct PcShared {
     int hist[PF_BINS];
     __attribute__((aligned(16))) int soa[2][6][2 * PF_WAVES];  // the workgroup's own 16 records: round parity x field x record
-    __attribute__((aligned(16))) int xr[PF_WAVES][6][PC_MAXR]; // the round's published records, one private copy per wave
+    __attribute__((aligned(16))) int xr[6][PC_MAXR];           // the round's published records of all K workgroups
     float red[6][PF_WAVES];
     int wsum[PF_WAVES];
 };
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
 
     if (cu == 0 && tid == 0) idxs[0] = 0;
     // record slots beyond R never come before anything (most negative distance, lowest key)
-    for (int i = lane; i < 6 * PC_MAXR; i += 64) sh.xr[wave][i / PC_MAXR][i % PC_MAXR] = (i / PC_MAXR == 0) ? IMIN_C : 0;
+    for (int i = tid; i < 6 * PC_MAXR; i += PF_THREADS) sh.xr[i / PC_MAXR][i % PC_MAXR] = (i / PC_MAXR == 0) ? IMIN_C : 0;
     __syncthreads();
 
     // ------------------------------------------------------------------ sampling loop
@@ -402,26 +405,27 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
                 granule_store(dst + 5, bound, tag);
             }
         }
-        // ---- every wave polls the K T published records (granule = {value, tag}: nothing else to order)
+        // ---- the workgroup polls the K T published records, one granule per lane (granule = {value, tag}: nothing else to
+        // order), into ONE copy in LDS; a second barrier hands it to every wave
         {
             const int ng = R * 6;
-            unsigned spins = 0;
-            for (int gi = lane; gi < ng; gi += 64) {
-                unsigned long long g = granule_load(xround + gi);
+            if (tid < ng) {
+                unsigned spins = 0;
+                unsigned long long g = granule_load(xround + tid);
                 while ((unsigned)(g >> 32) != tag) {
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > PC_SPIN_LIMIT) __builtin_trap();
-                    g = granule_load(xround + gi);
+                    g = granule_load(xround + tid);
                 }
-                sh.xr[wave][gi % 6][gi / 6] = (int)(unsigned)g;
+                sh.xr[tid % 6][tid / 6] = (int)(unsigned)g;
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes, read back below (same wave: in order)
+        __syncthreads();
         // ---- acceptance over the R records: lane (rj, h) evaluates record rj against the i-records of half h
         const int rj = lane >> 1, h = lane & 1;
-        const int jd = sh.xr[wave][0][rj], jk = sh.xr[wave][1][rj];
-        const float jx = __int_as_float(sh.xr[wave][2][rj]), jy = __int_as_float(sh.xr[wave][3][rj]);
-        const float jz = __int_as_float(sh.xr[wave][4][rj]);
+        const int jd = sh.xr[0][rj], jk = sh.xr[1][rj];
+        const float jx = __int_as_float(sh.xr[2][rj]), jy = __int_as_float(sh.xr[3][rj]);
+        const float jz = __int_as_float(sh.xr[4][rj]);
         const float jt = __int_as_float(jd);
         int nbef = 0, nbad = 0;
         auto pair = [&](int idist, int iklo, int ixb, int iyb, int izb, int ibound) {
@@ -436,9 +440,9 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
         for (int q4 = 0; q4 < PC_MAXR / 8; ++q4) {
             const int i0 = h * (PC_MAXR / 2) + q4 * 4;
             // (slots beyond R hold records that are never "before" anything)
-            const int4 id = *(const int4 *)&sh.xr[wave][0][i0], ik = *(const int4 *)&sh.xr[wave][1][i0];
-            const int4 ixv = *(const int4 *)&sh.xr[wave][2][i0], iyv = *(const int4 *)&sh.xr[wave][3][i0];
-            const int4 izv = *(const int4 *)&sh.xr[wave][4][i0], ibv = *(const int4 *)&sh.xr[wave][5][i0];
+            const int4 id = *(const int4 *)&sh.xr[0][i0], ik = *(const int4 *)&sh.xr[1][i0];
+            const int4 ixv = *(const int4 *)&sh.xr[2][i0], iyv = *(const int4 *)&sh.xr[3][i0];
+            const int4 izv = *(const int4 *)&sh.xr[4][i0], ibv = *(const int4 *)&sh.xr[5][i0];
             pair(id.x, ik.x, ixv.x, iyv.x, izv.x, ibv.x);
             pair(id.y, ik.y, ixv.y, iyv.y, izv.y, ibv.y);
             pair(id.z, ik.z, ixv.z, iyv.z, izv.z, ibv.z);
