@@ -419,7 +419,8 @@ def main():
             mean_ms, min_ms, b, n, m = fps
             touched = 20.0 * n * (m - 1) * b  # 12 B xyz + 4 B read + 4 B write per point per iteration
             ach = touched / (mean_ms * 1e-3) / 1e9
-            kname = "fps_pruned_kernel<32>" if n <= 16384 else "fps_pruned_big_kernel"
+            # (scenes beyond 16 384 points: spread over up to 8 workgroups each, fps_pruned_cluster.hip)
+            kname = "fps_pruned_kernel<32>" if n <= 16384 else ("fps_pruned_cluster_kernel" if b <= 32 else "fps_pruned_big_kernel")
             line["roofline"] = {"bound": "hbm", "kernel": f"{kname} (layer-0 D-FPS, {n}->{m})",
                                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                 "traffic": pmc_traffic_bytes(kname, b, n, m),
