@@ -148,6 +148,32 @@ def samplers(M):
     _sa_case(M, "sampler_fs", xyz_s, feats_s, dict(npoint_list=[32], sample_type_list=['FS'], **small), seed=8)
 
 
+def samplers_partitioned(M):
+    """The remaining branches of the sampling dispatcher (pointnet2_modules.py:314-419): S-FPS on both sides of its
+    hard-coded 3500-distinct-points fallback, ds-FPS and ry-FPS."""
+    rng = np.random.default_rng(11)
+    small = dict(sample_range_list=[-1], radii=[1.6], nsamples=[8], mlps=[[2, 8, 8]], use_xyz=True, dilated_group=False,
+                 aggregation_mlp=None, confidence_mlp=None, num_class=3)
+    xyz, _ = scenes.make_batch("kitti-lidar-v1", 2, 1024, seed0=400)
+    feats = rng.normal(size=(2, 2, 1024)).astype(np.float32)
+    stds = torch.from_numpy(rng.uniform(0, 40, (2, 1024)).astype(np.float32))
+    # 256 picks: fewer than 3500 distinct -> the picks fall back to plain FPS, `stds` keeps the stable picks' values
+    _sa_case(M, "sampler_sfps_fallback", xyz, feats, dict(npoint_list=[256], sample_type_list=['S-FPS'], ss_radii=[0.8],
+             ss_nsamples=[8], **small), fwd_kw=dict(stds=stds), seed=12)
+    _sa_case(M, "sampler_dsfps", xyz, feats, dict(npoint_list=[256], sample_type_list=['ds-FPS'], **small), seed=13)
+    _sa_case(M, "sampler_ryfps", xyz, feats, dict(npoint_list=[256], sample_type_list=['ry-FPS'], **small), seed=14)
+    # 4096 of 8192 picks with a tight stability ball: scene 0 keeps >= 3500 distinct picks -> the stable picks are used
+    xyz_l, _ = scenes.make_batch("kitti-lidar-v1", 2, 8192, seed0=401)
+    feats_l = rng.normal(size=(2, 2, 8192)).astype(np.float32)
+    stds_l = torch.from_numpy(rng.uniform(0, 40, (2, 8192)).astype(np.float32))
+    _sa_case(M, "sampler_sfps", xyz_l, feats_l, dict(npoint_list=[4096], sample_type_list=['S-FPS'], ss_radii=[0.15],
+             ss_nsamples=[4], **small), fwd_kw=dict(stds=stds_l), seed=15)
+    g = np.load(os.path.join(OUT, "sampler_sfps.npz"))
+    distinct = np.unique(g["idx"][0]).size
+    assert distinct >= 3500, f"sampler_sfps fell back to plain FPS ({distinct} distinct picks): tighten ss_radii"
+    print("sampler_sfps: distinct picks in scene 0:", distinct)
+
+
 def stack3(M):
     """Three chained SA layers (D-FPS, D-FPS, ctr_aware) at reduced size/width: the IA-SSD pattern."""
     from spsnet_amd import sa_stack
@@ -289,9 +315,13 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     U, M = ref_harness.load_reference()
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "samplers_partitioned":   # (added later: regenerate only these)
+        samplers_partitioned(M)
+        return
     ops_small(U)
     config1(M)
     samplers(M)
+    samplers_partitioned(M)
     stack3(M)
     generator_layer(M)
     fp_module(M)

@@ -35,6 +35,13 @@ __device__ __forceinline__ float sps_exp(float x) {
 
 __device__ __forceinline__ float sps_sigmoid(float x) { return 1.0f / (1.0f + sps_exp(-x)); }
 
+// torch.max keeps a NaN (pointnet2_modules.py:288, 296) and torch.topk ranks NaN above every number: a point whose class
+// scores or stability hold a NaN is sampled first.  fmaxf would drop the NaN and sample by the remaining classes.
+__device__ __forceinline__ float nan_max(float m, float v) { return (v > m || v != v) ? v : m; }
+// scores are products of sigmoids, >= +0: their bit patterns order like the numbers; every NaN becomes the one quiet NaN
+// pattern, which lies above all of them (ties among NaNs: lower index first, like any other tie)
+__device__ __forceinline__ unsigned score_bits(float s) { return s != s ? 0x7fc00000u : (unsigned)__float_as_int(s); }
+
 constexpr int TOPK_MAX_N = 16384;
 
 __global__ __launch_bounds__(1024) void score_topk_kernel(
@@ -47,14 +54,14 @@ __global__ __launch_bounds__(1024) void score_topk_kernel(
         unsigned long long key = 0ull;  // padding sorts below every real entry
         if (e < n) {
             float mx = cls[(size_t)e * c];
-            for (int ch = 1; ch < c; ++ch) mx = fmaxf(mx, cls[(size_t)e * c + ch]);
+            for (int ch = 1; ch < c; ++ch) mx = nan_max(mx, cls[(size_t)e * c + ch]);
             float s = sps_sigmoid(mx);
             if (stds) {
                 const float sta = 1.0f - sps_sigmoid(stds[(size_t)scene * n + e] / 8.0f - 3.0f);
                 s = s * sta;
             }
             if (score_out) score_out[(size_t)scene * n + e] = s;
-            key = ((unsigned long long)(unsigned)__float_as_int(s) << 32) | (unsigned)(~e);
+            key = ((unsigned long long)score_bits(s) << 32) | (unsigned)(~e);
         }
         keys[e] = key;
     }
@@ -96,14 +103,14 @@ __global__ __launch_bounds__(256) void score_topk_rank_kernel(
         unsigned bits = 0u;   // padding: score +0 with index >= n never outranks a real entry of equal score (index rule)
         if (e < n) {
             float mx = cls[(size_t)e * c];
-            for (int ch = 1; ch < c; ++ch) mx = fmaxf(mx, cls[(size_t)e * c + ch]);
+            for (int ch = 1; ch < c; ++ch) mx = nan_max(mx, cls[(size_t)e * c + ch]);
             float s = sps_sigmoid(mx);
             if (stds) {
                 const float sta = 1.0f - sps_sigmoid(stds[(size_t)scene * n + e] / 8.0f - 3.0f);
                 s = s * sta;
             }
             if (score_out && blockIdx.x == 0) score_out[(size_t)scene * n + e] = s;
-            bits = (unsigned)__float_as_int(s);
+            bits = score_bits(s);
         }
         sbits[e] = bits;
     }

@@ -101,6 +101,43 @@ def test_ffps_fs_samplers(oracle):
             np.testing.assert_array_equal(np.concatenate([by_feat, oracle.fps(g["xyz"], npoint)], -1), g["idx"])
 
 
+def test_sfps_samplers(oracle):
+    """S-FPS (pointnet2_modules.py:314-353): FPS seeds, the steadiest point of each seed's ball, and the hard-coded
+    fallback to the seeds when scene 0 keeps fewer than 3500 distinct picks (`stds` keeps the steadiest picks' values
+    either way)."""
+    for name, radius, ns in (("sampler_sfps_fallback", 0.8, 8), ("sampler_sfps", 0.15, 4)):
+        g = load(name)
+        xyz, stds, m = g["xyz"], g["kw_stds"], g["idx"].shape[1]
+        seeds = oracle.fps(xyz, m)
+        ball = oracle.ball_query(radius, ns, xyz, gather_xyz(xyz, seeds))
+        ball_stds = np.take_along_axis(stds[:, None, :], ball.reshape(ball.shape[0], 1, -1).astype(np.int64), 2)
+        steadiest = ball_stds.reshape(ball.shape).argmin(-1)          # first minimum, like torch.argmin
+        picks = np.take_along_axis(ball, steadiest[..., None], 2)[..., 0]
+        fell_back = np.unique(picks[0]).size < 3500
+        assert fell_back == (name == "sampler_sfps_fallback")
+        np.testing.assert_array_equal(seeds if fell_back else picks, g["idx"])
+        np.testing.assert_array_equal(np.take_along_axis(stds, picks.astype(np.int64), 1), g["stds_out"])
+
+
+@pytest.mark.parametrize("name", ["sampler_dsfps", "sampler_ryfps"])
+def test_partitioned_fps_samplers(oracle, name):
+    """ds-FPS / ry-FPS (pointnet2_modules.py:370-419): each scene sorted by range-5 (or atan(x/y)), cut into four equal
+    parts, FPS of npoint/4 inside each, indices mapped back."""
+    import torch
+    g = load(name)
+    xyz, m = g["xyz"], g["idx"].shape[1]
+    out = []
+    for b in range(xyz.shape[0]):
+        p = torch.from_numpy(xyz[b])
+        key = p.norm(dim=-1) - 5 if name == "sampler_dsfps" else torch.atan(p[:, 0] / p[:, 1])
+        order = key.sort(dim=0, descending=False)[1].numpy()
+        parts = order.reshape(4, -1)
+        picks = oracle.fps(np.ascontiguousarray(xyz[b][parts]), m // 4)          # (4, m/4) inside the parts
+        out.append(np.take_along_axis(parts, picks.astype(np.int64), 1).reshape(-1))
+    np.testing.assert_array_equal(np.stack(out).astype(np.int32), g["idx"])
+    np.testing.assert_array_equal(gather_xyz(xyz, g["idx"]), g["new_xyz"])
+
+
 def test_generator_layer_identity_sampling(oracle):
     g = load("generator_layer")
     assert (g["idx"] == np.arange(512, dtype=np.int32)[None]).all()

@@ -297,6 +297,26 @@ def test_score_topk_saturated_logits(ext, G, oracle):
     np.testing.assert_array_equal(G.n(idx), oracle.topk_desc(oracle.score_ctr(cls), 6))
 
 
+@pytest.mark.parametrize("N,K", [(600, 64), (1024, 512), (5000, 1000)])
+def test_score_topk_nan_scores_are_sampled_first(ext, G, oracle, N, K):
+    """torch.max keeps a NaN class score and torch.topk ranks NaN above every number (pointnet2_modules.py:288-291,
+    296-302): points with a NaN among their class scores -- or a NaN stability -- lead the sample, in index order; both
+    kernels (ranking up to 2048 points, bitonic sort beyond) against the oracle."""
+    rng = np.random.default_rng(N)
+    cls = rng.normal(size=(2, N, 3)).astype(np.float32)
+    stds = rng.uniform(0, 40, (2, N)).astype(np.float32)
+    cls[0, [5, 77, N - 1], [0, 2, 1]] = np.nan
+    cls[1, 9, 1] = -np.nan
+    stds[1, 300] = np.nan
+    for kw in ({}, {"stds": G.t(stds)}):
+        idx, sc = ext.score_topk(G.t(cls), K, return_scores=True, **kw)
+        want_s = oracle.score_stability(cls, stds) if kw else oracle.score_ctr(cls)
+        np.testing.assert_array_equal(np.isnan(G.n(sc)), np.isnan(want_s))
+        np.testing.assert_array_equal(G.n(idx), oracle.topk_desc(want_s, K))
+        assert G.n(idx)[0, :3].tolist() == [5, 77, N - 1]
+        assert G.n(idx)[1, :2].tolist() == ([9, 300] if kw else [9, int(G.n(idx)[1, 1])])
+
+
 # ------------------------------------------------------------------ fused query+group
 @pytest.mark.parametrize("C,use_xyz", [(0, True), (1, True), (5, True), (64, True), (7, False)])
 def test_query_and_group_fused(ext, G, oracle, C, use_xyz):
@@ -379,6 +399,17 @@ SA_CASES = {
                          mlps=[[4, 8, 8]], aggregation_mlp=None, confidence_mlp=None),
     "sampler_fs": dict(npoint_list=[32], sample_range_list=[-1], sample_type_list=['FS'], radii=[8.0], nsamples=[8],
                        mlps=[[4, 8, 8]], aggregation_mlp=None, confidence_mlp=None),
+    # the dispatcher's remaining branches (reference :314-419): S-FPS below / above its 3500-distinct-picks fallback,
+    # ds-FPS and ry-FPS (FPS inside four sorted partitions)
+    "sampler_sfps_fallback": dict(npoint_list=[256], sample_range_list=[-1], sample_type_list=['S-FPS'], radii=[1.6],
+                                  nsamples=[8], mlps=[[2, 8, 8]], aggregation_mlp=None, confidence_mlp=None,
+                                  ss_radii=[0.8], ss_nsamples=[8]),
+    "sampler_sfps": dict(npoint_list=[4096], sample_range_list=[-1], sample_type_list=['S-FPS'], radii=[1.6], nsamples=[8],
+                         mlps=[[2, 8, 8]], aggregation_mlp=None, confidence_mlp=None, ss_radii=[0.15], ss_nsamples=[4]),
+    "sampler_dsfps": dict(npoint_list=[256], sample_range_list=[-1], sample_type_list=['ds-FPS'], radii=[1.6], nsamples=[8],
+                          mlps=[[2, 8, 8]], aggregation_mlp=None, confidence_mlp=None),
+    "sampler_ryfps": dict(npoint_list=[256], sample_range_list=[-1], sample_type_list=['ry-FPS'], radii=[1.6], nsamples=[8],
+                          mlps=[[2, 8, 8]], aggregation_mlp=None, confidence_mlp=None),
 }
 
 
