@@ -4,7 +4,9 @@
 // Same contract and the same results (indices and final `temp`, bit for bit) as fps_pruned_big.hip / the reference
 // (sampling_gpu.cu:93-253); same buckets, box test, records and acceptance proof.  What changes:
 //   * the scene's buckets are dealt round-robin over the 8 K waves of K workgroups (a wave owns a quarter of the buckets it
-//     owned at K = 4: fewer box tests per centre, fewer fetched buckets per round on the busiest wave);
+//     owned at K = 4: fewer box tests per centre, fewer fetched buckets per round on the busiest wave); with so few
+//     touched buckets per wave the apply phase is a chain of L2 round trips, so a round's centres are applied PER BUCKET
+//     (fetched once, minimum over its centres in registers, refreshed once) with the next bucket's loads in flight;
 //   * every round each workgroup ranks its 16 wave records and PUBLISHES ITS T BEST to the other workgroups; the last of
 //     them carries the value of the best record held back in its bound, so the acceptance argument of fps_pruned.hip
 //     holds unchanged over the K T published records (a candidate behind it must beat everything still hidden);
@@ -278,39 +280,76 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
     const bool younger = wave >= PF_WAVES / 2;
     for (;;) {
         if (younger) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-        while (pend) {
-            const int rr = __builtin_ctzll(pend);
-            pend &= pend - 1;
-            const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax), rr));
-            const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay), rr));
-            const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(az), rr));
+        // ---- apply the round's accepted centres (lanes `pend`, always even: bit rr / 2 names a centre) to my buckets.
+        // With ~1.5 touched buckets per wave and round the phase is a chain of L2 round trips, so: (1) all box tests first --
+        // lane l collects, per row, the centres its bucket cannot rule out; (2) every touched bucket is fetched ONCE
+        // (x, y, z, t and the ranks together), takes the minimum over its centres in registers and is refreshed once;
+        // (3) the next touched bucket's loads are in flight meanwhile.  Same minima as one centre at a time: the box tests
+        // use the bucket maxima of the round's start (a superset of what the sequential order would fetch).
+        if (pend) {
             for_rows([&](auto rc) {
                 constexpr int RW = decltype(rc)::value;
-                const float qx = __builtin_amdgcn_fmed3f(cx, blo_x[RW], bhi_x[RW]);
-                const float qy = __builtin_amdgcn_fmed3f(cy, blo_y[RW], bhi_y[RW]);
-                const float qz = __builtin_amdgcn_fmed3f(cz, blo_z[RW], bhi_z[RW]);
-                const float lb = sqdist(qx, qy, qz, cx, cy, cz);
-                const bool skip = lb >= __int_as_float(bmax[RW]);  // NaN -> not skipped
-                unsigned long long todo = __ballot(!skip);
-                while (todo) {
-                    const int l = __builtin_ctzll(todo);
+                unsigned cm = 0u;
+                for (unsigned long long pm = pend; pm; pm &= pm - 1) {
+                    const int rr = __builtin_ctzll(pm);
+                    const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax), rr));
+                    const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay), rr));
+                    const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(az), rr));
+                    const float qx = __builtin_amdgcn_fmed3f(cx, blo_x[RW], bhi_x[RW]);
+                    const float qy = __builtin_amdgcn_fmed3f(cy, blo_y[RW], bhi_y[RW]);
+                    const float qz = __builtin_amdgcn_fmed3f(cz, blo_z[RW], bhi_z[RW]);
+                    const float lb = sqdist(qx, qy, qz, cx, cy, cz);
+                    const bool skip = lb >= __int_as_float(bmax[RW]);  // NaN -> not skipped
+                    cm |= skip ? 0u : (1u << (rr >> 1));
+                }
+                unsigned long long todo = __ballot(cm != 0u);
+                if (todo) {
+                    struct Bucket { float x, y, z, t; int rk; };
+                    auto fetch = [&](int l) -> Bucket {
+                        const size_t p = (size_t)((RW * 64 + l) * nwaves + gwave) * 64 + lane;
+                        Bucket bk;
+                        bk.x = sx[p]; bk.y = sy[p]; bk.z = sz[p];
+                        bk.t = __hip_atomic_load(st + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        bk.rk = srk[p];
+                        return bk;
+                    };
+                    int l = __builtin_ctzll(todo);
                     todo &= todo - 1;
-                    const int g = (RW * 64 + l) * nwaves + gwave;
-                    const size_t p = (size_t)g * 64 + lane;
-                    const float xv = sx[p], yv = sy[p], zv = sz[p];
-                    const float tv = __hip_atomic_load(st + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const float d = sqdist(xv, yv, zv, cx, cy, cz);
-                    if (__ballot(d < tv) != 0ull) {
-                        const float tn = fmin_raw(d, tv);
-                        __hip_atomic_store(st + p, tn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const int rv = srk[p];
-                        refresh(tn, rv, xv, yv, zv);
-                        commit(rc, l);
-                        const int e = (RW << 6) | l;
-                        if (e == cand_e1 || e == cand_e2) cand_stale = true;
+                    Bucket cur = fetch(l);
+                    for (;;) {
+                        const bool more = todo != 0ull;
+                        const int ln = more ? __builtin_ctzll(todo) : l;
+                        todo &= todo - 1;                       // (0 stays 0)
+                        Bucket nxt = cur;
+                        if (more) nxt = fetch(ln);              // in flight while this bucket is worked on
+                        unsigned mc = (unsigned)__builtin_amdgcn_readlane((int)cm, l);
+                        float tn = cur.t;
+                        bool moved = false;
+                        while (mc) {
+                            const int rr = 2 * __builtin_ctz(mc);
+                            mc &= mc - 1;
+                            const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax), rr));
+                            const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay), rr));
+                            const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(az), rr));
+                            const float d = sqdist(cur.x, cur.y, cur.z, cx, cy, cz);
+                            moved |= __ballot(d < tn) != 0ull;   // some point moved closer to a sample
+                            tn = fmin_raw(d, tn);
+                        }
+                        if (moved) {
+                            const size_t p = (size_t)((RW * 64 + l) * nwaves + gwave) * 64 + lane;
+                            __hip_atomic_store(st + p, tn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            refresh(tn, cur.rk, cur.x, cur.y, cur.z);
+                            commit(rc, l);
+                            const int e = (RW << 6) | l;
+                            if (e == cand_e1 || e == cand_e2) cand_stale = true;
+                        }
+                        if (!more) break;
+                        l = ln;
+                        cur = nxt;
                     }
                 }
             });
+            pend = 0ull;
         }
         if (j >= m) break;
         // the wave's two records (fps_pruned_big.hip)
@@ -503,6 +542,7 @@ int launch_fps_pruned_cluster(int b, int K, int T, int n, int m, const float *da
                            dataset, temp, idxs, work);                                                                 \
         return check_launch("fps_pruned_cluster_kernel");                                                             \
     }
+    SPS_PC_CASE(1)
     SPS_PC_CASE(2)
     SPS_PC_CASE(4)
     SPS_PC_CASE(8)
