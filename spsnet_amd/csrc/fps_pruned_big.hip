@@ -398,9 +398,10 @@ size_t fps_big_workspace_elems(int n) {
 
 // Workgroups per scene (K) and records each publishes per round (T <= 8, K T <= 32); SPS_FPS_CLUSTER="K,T" overrides
 // ("1" = one workgroup, the kernel below).  Measured on MI355X (tools/fps_cluster_probe.py; one workgroup = 1.00):
-//   180 000 -> 16 384, 1 scene    K,T = 2,8  0.71   4,8  0.44   8,3  0.40   8,4  0.37  (32.4 -> 11.9 ms; 8 scenes 34.6 -> 12.7)
-//    65 536 -> 16 384, 2 scenes         2,8  0.97   4,8  0.68              8,4  0.61  (16.4 -> 10.0 ms)
-//    32 768 ->  8 192, 8 scenes         2,8  1.04   4,8  0.76              8,4  0.70  ( 7.5 ->  5.3 ms)
+//   180 000 -> 16 384, 1 scene    K,T = 2,8  0.71   4,8  0.41   8,3  0.33   8,4  0.30  (32.8 -> 9.95 ms)
+//    65 536 -> 16 384, 2 scenes         2,8  0.97   4,8  0.56              8,4  0.50  (16.4 -> 8.27 ms)
+//    32 768 ->  8 192, 8 scenes         2,8  1.04   4,8  0.64              8,4  0.59  ( 7.5 -> 4.43 ms)
+// (K = 2 columns measured before the per-bucket application of a round's centres, the others with it.)
 // The K workgroups of a scene spin on each other's records, so all b K must be resident at once: at most 64 (a CU each).
 static void fps_cluster_shape(int b, int n, int &K, int &T) {
     K = 8;

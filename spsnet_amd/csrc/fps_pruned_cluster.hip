@@ -17,7 +17,7 @@
 //     each polling everything cost 1 ms of 13 more) into LDS, a second barrier hands them to its waves;
 //   * every wave evaluates the acceptance of all K T records redundantly (identical inputs, identical result), so
 //     nobody waits for a verdict; each wave then applies the accepted centres to its own buckets only.
-// More records per round and less work per wave: 180 000 -> 16 384 in 11.9 ms at K = 8 against 32.4 ms on one CU
+// More records per round and less work per wave: 180 000 -> 16 384 in 9.95 ms at K = 8 against 32.8 ms on one CU
 // (fps_pruned_big.hip's launcher holds the measured table and picks K, T).
 // The K workgroups of a scene must be resident together: the launcher uses the cluster only for b K <= 64 workgroups
 // (a CU each; the polls are bounded -- a stuck exchange traps instead of hanging the device).
