@@ -225,6 +225,11 @@ int sps_fps_redo_where(int b, int n, int m, const float *dataset, float *temp, i
 /* temp may be NULL in sps_fps_publish: the running distances start at 1e10 and are not written back. */
 int sps_fps_publish(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress,
                     sps_stream_t stream);
+/* The same for scenes of 16 385 .. 262 144 points (sampling_gpu.cu:93-253 again): `work` = b * sps_fps_workspace_floats(n)
+ * floats; served by the clustered large-scene kernel for batches of at most 64 / K workgroups, SPS_ERR_INVALID otherwise
+ * (the caller then runs the layer unstreamed).  n <= 16 384: sps_fps_publish, `work` unused. */
+int sps_fps_publish_ws(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress, float *work,
+                       sps_stream_t stream);
 int sps_wait_progress(const int *progress, int b, int need, int *timed_out, sps_stream_t stream);
 /* patient != 0: the wait for the producer's last sample -- ~64 x the bound, not affected by sps_debug_set_wait_spins. */
 int sps_wait_progress_ex(const int *progress, int b, int need, int *timed_out, int patient, sps_stream_t stream);

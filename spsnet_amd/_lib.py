@@ -90,6 +90,7 @@ _PROTOS = {
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sps_fps_redo_where": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_fps_publish": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sps_fps_publish_ws": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_wait_progress": [_vp, _i, _i, _vp, _vp],
     "sps_wait_progress_ex": [_vp, _i, _i, _vp, _i, _vp],
     "sps_gather_xyz_range": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],

@@ -307,6 +307,20 @@ extern "C" int sps_fps_publish(int b, int n, int m, const float *dataset, float 
     return rc;
 }
 
+// The same for scenes of 16 385 .. 262 144 points: `work` = b * sps_fps_workspace_floats(n) floats (the clustered
+// large-scene kernel publishes; batches it does not take -- more than 64 workgroups -- return SPS_ERR_INVALID and the caller
+// runs the layer unstreamed).  Smaller scenes: sps_fps_publish, `work` unused.
+extern "C" int sps_fps_publish_ws(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress,
+                                  float *work, sps_stream_t stream) {
+    using namespace sps;
+    if (n <= 32 * 512) return sps_fps_publish(b, n, m, dataset, temp, idxs, progress, stream);
+    if (b <= 0 || m <= 0 || !dataset || !idxs || !progress || !work) return fail(SPS_ERR_INVALID, "fps_publish_ws: bad arguments");
+    if (fps_mode() != 0) return fail(SPS_ERR_INVALID, "fps_publish_ws: brute-force mode has no publishing kernel");
+    const int rc = launch_fps_big_publish(b, n, m, dataset, temp, idxs, progress, work, as_stream(stream));
+    if (rc < 0) return fail(SPS_ERR_INVALID, "fps_publish_ws: no publishing kernel for b=%d n=%d", b, n);
+    return rc;
+}
+
 // Block `stream` until every scene's progress counter reaches `need` (a tiny spinning kernel, bounded).
 // timed_out (device i32, caller-zeroed) is set to 1 if the bound was hit.
 extern "C" int sps_wait_progress(const int *progress, int b, int need, int *timed_out, sps_stream_t stream) {

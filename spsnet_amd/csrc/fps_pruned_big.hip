@@ -387,7 +387,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_big_kernel(int n, int m
 
 size_t fps_cluster_exchange_floats();
 int launch_fps_pruned_cluster(int b, int K, int T, int n, int m, const float *dataset, float *temp, int *idxs, float *work,
-                              long long stride, hipStream_t st);
+                              long long stride, int *progress, hipStream_t st);
 
 // workspace floats per scene for sps_fps_with_workspace (0: this size is served without one): the sorted points and,
 // behind them, the record exchange area of fps_pruned_cluster.hip
@@ -428,7 +428,7 @@ int launch_fps_pruned_big(int b, int n, int m, const float *dataset, float *temp
     int K, T;
     fps_cluster_shape(b, n, K, T);
     if (K > 1) {
-        const int rc = launch_fps_pruned_cluster(b, K, T, n, m, dataset, temp, idxs, work, stride, st);
+        const int rc = launch_fps_pruned_cluster(b, K, T, n, m, dataset, temp, idxs, work, stride, nullptr, st);
         if (rc >= 0) return rc;
     }
     const int rows = divup(npad / 64, 64 * PF_WAVES);
@@ -443,6 +443,16 @@ int launch_fps_pruned_big(int b, int n, int m, const float *dataset, float *temp
     SPS_PB_CASE(8)
 #undef SPS_PB_CASE
     return -1;
+}
+
+// publishing variant for chunked consumers (large scenes: the clustered kernel only); -1 if it does not apply
+int launch_fps_big_publish(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress, float *work,
+                           hipStream_t st) {
+    if (fps_big_workspace_elems(n) == 0 || !work || m < 2) return -1;
+    int K, T;
+    fps_cluster_shape(b, n, K, T);
+    if (K < 2) return -1;
+    return launch_fps_pruned_cluster(b, K, T, n, m, dataset, temp, idxs, work, (long long)fps_big_workspace_elems(n), progress, st);
 }
 
 }  // namespace sps

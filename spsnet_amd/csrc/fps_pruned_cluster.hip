@@ -68,14 +68,17 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
                                                                         int npad, long long stride,
                                                                         const float *__restrict__ dataset,
                                                                         float *__restrict__ temp, int *__restrict__ idxs,
-                                                                        float *__restrict__ work) {
+                                                                        float *__restrict__ work, int *__restrict__ progress) {
+    // progress != NULL: consumers on other CUs read idxs while this kernel runs (sa_stack's streamed first layer) -- picks
+    // are stored write-through and progress[scene] counts the published ones (every 64 picks; fps_pruned.hip's protocol).
+    // temp may then be NULL: all running distances start at 1e10 and are not handed back.
     if (m <= 0) return;
     __shared__ PcShared sh;
     // blocks s, s + 8, s + 16, ... share an XCD (observed dispatch order): a scene's K workgroups sit on one L2
     const int scene = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * K)), cu = (blockIdx.x >> 3) % K;
     if (scene >= b) return;
     const float *xyz = dataset + (size_t)scene * n * 3;
-    temp += (size_t)scene * n;
+    if (temp) temp += (size_t)scene * n;
     idxs += (size_t)scene * m;
     float *sx = work + (size_t)scene * stride, *sy = sx + npad, *sz = sy + npad, *st = sz + npad;
     int *srk = reinterpret_cast<int *>(st + npad);
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
                 const int kk = k < n ? k : k0;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) v[u][a] = xyz[(size_t)kk * 3 + a];
-                tv[u] = temp[kk];
+                tv[u] = temp ? temp[kk] : 1e10f;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
         }
     });
 
-    if (cu == 0 && tid == 0) idxs[0] = 0;
+    if (cu == 0 && tid == 0) __hip_atomic_store(&idxs[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // record slots beyond R never come before anything (most negative distance, lowest key)
     for (int i = tid; i < 6 * PC_MAXR; i += PF_THREADS) sh.xr[i / PC_MAXR][i % PC_MAXR] = (i / PC_MAXR == 0) ? IMIN_C : 0;
     __syncthreads();
@@ -494,9 +497,15 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
         const int firstbad = -wave_max_i32_id((real && (cnt >> 8)) ? -pos : -R);   // nobody bad: all R records
         const int L = firstbad < m - j ? firstbad : m - j;
         const bool taken = h == 0 && real && pos < L;
-        if (cu == 0 && wave == 0 && taken) {
-            const unsigned rank = 0x0FFFFFFFu - ((unsigned)jk >> 4);
-            idxs[j + pos] = (int)pf_unrank(rank, l2, rb);
+        if (cu == 0 && wave == 0) {
+            if (taken) {
+                const unsigned rank = 0x0FFFFFFFu - ((unsigned)jk >> 4);
+                __hip_atomic_store(&idxs[j + pos], (int)pf_unrank(rank, l2, rb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (progress && lane == 0 && (((j + L) >> 6) != (j >> 6) || j + L == m)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left
+                __hip_atomic_store(&progress[scene], j + L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         pend = __ballot(taken && (j + pos) != m - 1);  // the reference never applies its last pick to `temp`
         ax = jx; ay = jy; az = jz;
@@ -505,6 +514,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
     }
 
     // the reference leaves the final running min-distances in `temp` (original order): every wave writes its own buckets
+    if (temp)
     for (int v = 0; v < 64 * ROWS; ++v) {
         const int g = v * nwaves + gwave;
         if (g >= nb) break;
@@ -521,7 +531,7 @@ size_t fps_cluster_exchange_floats() { return (size_t)2 * PC_GRANULES; }
 
 // K workgroups per scene publishing T records each; -1: shape not served
 int launch_fps_pruned_cluster(int b, int K, int T, int n, int m, const float *dataset, float *temp, int *idxs, float *work,
-                              long long stride, hipStream_t st) {
+                              long long stride, int *progress, hipStream_t st) {
     if (K < 2 || K > PC_MAXK || T < 1 || T > PC_MAXT || K * T > PC_MAXR || b * K > 64 || !work) return -1;
     const int bs = sps_opt_n_threads(n);
     int l2 = 0;
@@ -539,7 +549,7 @@ int launch_fps_pruned_cluster(int b, int K, int T, int n, int m, const float *da
 #define SPS_PC_CASE(RW)                                                                                                \
     if (rows <= RW) {                                                                                                  \
         hipLaunchKernelGGL((fps_pruned_cluster_kernel<RW>), grid, block, 0, st, b, K, T, n, m, bs, l2, rb, npad, stride, \
-                           dataset, temp, idxs, work);                                                                 \
+                           dataset, temp, idxs, work, progress);                                                       \
         return check_launch("fps_pruned_cluster_kernel");                                                             \
     }
     SPS_PC_CASE(1)

@@ -20,7 +20,7 @@ namespace sps {
 
 constexpr int FV_SEG = 8;                    // waves per workgroup = segments of the centre range
 constexpr int FV_THREADS = 64 * FV_SEG;
-constexpr int FV_MAX_M = 2048;               // centres staged in LDS (32 KiB as float4)
+constexpr int FV_MAX_M = 7168;               // centres staged in LDS: 20 B each (+ 2 KiB) of the 160 KiB, dynamic
 
 __device__ __forceinline__ unsigned fv_rank(unsigned k, int bs, int l2, int rb) {
     const unsigned lowrev = (l2 == 0) ? 0u : (__brev(k & (unsigned)(bs - 1)) >> (32 - l2));
@@ -38,8 +38,9 @@ __device__ __forceinline__ unsigned fv_rank(unsigned k, int bs, int l2, int rb) 
 // pass 1: T[j] = min(temp[j], min_{i<j} d(j, i)) for j < m
 __global__ __launch_bounds__(FV_THREADS) void fps_prefix_dist_kernel(int n, int m, const float *__restrict__ xyz,
                                                                      const float *__restrict__ temp, float *__restrict__ T) {
-    __shared__ float4 ctr[FV_MAX_M];
-    __shared__ float segmin[FV_SEG][64];
+    extern __shared__ __attribute__((aligned(16))) char fv_smem[];
+    float4 *ctr = reinterpret_cast<float4 *>(fv_smem);                                   // [m]
+    float (*segmin)[64] = reinterpret_cast<float (*)[64]>(fv_smem + (size_t)m * 16);     // [FV_SEG][64]
     const int scene = blockIdx.y;
     const int lane = threadIdx.x & 63, seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j0 = blockIdx.x * 64, j = j0 + lane;
@@ -73,9 +74,10 @@ __global__ __launch_bounds__(FV_THREADS) void fps_prefix_check_kernel(
     int n, int m, int bs, int l2, int rb, const float *__restrict__ xyz, const float *__restrict__ temp,
     const float *__restrict__ T, float *__restrict__ temp_done, int *__restrict__ idx, int *__restrict__ bad,
     const int *__restrict__ force_bad) {
-    __shared__ float4 step[FV_MAX_M];  // step j (1 <= j < m): {centre j-1, T[j]} at step[j-1]
-    __shared__ unsigned srank[FV_MAX_M];  // tie-break rank of point j, at srank[j-1]
-    __shared__ float segmin[FV_SEG][64];
+    extern __shared__ __attribute__((aligned(16))) char fv_smem[];
+    float4 *step = reinterpret_cast<float4 *>(fv_smem);                                   // step j (1 <= j < m): {centre j-1, T[j]} at step[j-1]
+    unsigned *srank = reinterpret_cast<unsigned *>(fv_smem + (size_t)m * 16);            // tie-break rank of point j, at srank[j-1]
+    float (*segmin)[64] = reinterpret_cast<float (*)[64]>(fv_smem + (size_t)m * 20);     // [FV_SEG][64]
     const int scene = blockIdx.y;
     const int lane = threadIdx.x & 63, seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int k = blockIdx.x * 64 + lane;
@@ -145,7 +147,13 @@ extern "C" int sps_fps_ordered_prefix_begin(int b, int n, int m, const float *xy
     if (rc != SPS_OK || b == 0 || m == 0) return rc;
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(flags, 0, sizeof(int) * (size_t)b, st) != hipSuccess) return fail(SPS_ERR_LAUNCH, "fps_ordered_prefix: memset failed");
-    hipLaunchKernelGGL(fps_prefix_dist_kernel, dim3(divup(m, 64), b), dim3(FV_THREADS), 0, st, n, m, xyz, temp, work_T);
+    const size_t lds = (size_t)m * 16 + sizeof(float) * FV_SEG * 64;
+    static LdsLimitOnce raised;
+    if (lds > 64 * 1024) {
+        rc = raise_lds_limit((const void *)fps_prefix_dist_kernel, 160 * 1024, raised, "fps_prefix_dist_kernel");
+        if (rc != SPS_OK) return rc;
+    }
+    hipLaunchKernelGGL(fps_prefix_dist_kernel, dim3(divup(m, 64), b), dim3(FV_THREADS), lds, st, n, m, xyz, temp, work_T);
     return check_launch("fps_prefix_dist_kernel");
 }
 
@@ -162,7 +170,13 @@ extern "C" int sps_fps_ordered_prefix_finish(int b, int n, int m, const float *x
     while ((1 << (l2 + 1)) <= bs) ++l2;
     int rb = 0;
     while ((1 << rb) < divup(n, bs)) ++rb;
-    hipLaunchKernelGGL(fps_prefix_check_kernel, dim3(divup(n, 64), b), dim3(FV_THREADS), 0, st, n, m, bs, l2, rb, xyz,
+    const size_t lds = (size_t)m * 20 + sizeof(float) * FV_SEG * 64;
+    static LdsLimitOnce raised;
+    if (lds > 64 * 1024) {
+        rc = raise_lds_limit((const void *)fps_prefix_check_kernel, 160 * 1024, raised, "fps_prefix_check_kernel");
+        if (rc != SPS_OK) return rc;
+    }
+    hipLaunchKernelGGL(fps_prefix_check_kernel, dim3(divup(n, 64), b), dim3(FV_THREADS), lds, st, n, m, bs, l2, rb, xyz,
                        temp, work_T, work_temp, idxs, flags, force_redo);
     rc = check_launch("fps_prefix_check_kernel");
     if (rc != SPS_OK) return rc;

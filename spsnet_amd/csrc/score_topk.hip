@@ -90,7 +90,7 @@ __global__ __launch_bounds__(1024) void score_topk_kernel(
 // write idx[rank] -- and, fused, the centroid row new_xyz[rank] = xyz[point] (the gather_operation that follows the sampler,
 // pointnet2_modules.py:423-424).  The bitonic sort above is 55 barrier-separated passes of one workgroup per scene (18 us
 // at 1024 points); this is one pass over 16 x more workgroups.
-constexpr int RANK_MAX_N = 2048;
+constexpr int RANK_MAX_N = 4096;   // (16 KiB of keys)
 __global__ __launch_bounds__(256) void score_topk_rank_kernel(
     int n, int c, int k, const float *__restrict__ cls, const float *__restrict__ stds, const float *__restrict__ xyz,
     int *__restrict__ idx, float *__restrict__ new_xyz, float *__restrict__ score_out) {

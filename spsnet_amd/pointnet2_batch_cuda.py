@@ -404,13 +404,31 @@ def current_stream_handle(t):
     return _stream(t)
 
 
+ORDERED_PREFIX_MAX = 7168   # centres the identity-prefix verification stages in LDS (fps_verify.hip FV_MAX_M)
+
+
 def fps_publish(xyz, temp, idx, progress):
-    """Launch the publishing FPS (sps_fps_publish) on the current stream; all tensors are caller-allocated.  temp = None: the
-    running distances start at 1e10 and are not handed back (no fill launch in front of the producer)."""
+    """Launch the publishing FPS (sps_fps_publish / sps_fps_publish_ws) on the current stream; all tensors are
+    caller-allocated.  temp = None: the running distances start at 1e10 and are not handed back (no fill launch in front of
+    the producer).  Scenes of more than 16 384 points take the clustered large-scene kernel, whose workspace is returned
+    (keep it alive until the producer has finished; record_stream it)."""
     B, N, _ = xyz.shape
+    tp = 0 if temp is None else _ptr(temp, F32, "temp")
     with _on(xyz):
-        _lib.check(_L.sps_fps_publish(B, N, idx.shape[1], _ptr(xyz, F32, "xyz"), 0 if temp is None else _ptr(temp, F32, "temp"),
-                                      _ptr(idx, I32, "idx"), _ptr(progress, I32, "progress"), _stream(xyz)), "fps_publish")
+        if N > 16384:
+            work = torch.empty((B * int(_L.sps_fps_workspace_floats(N)),), dtype=F32, device=xyz.device)
+            _lib.check(_L.sps_fps_publish_ws(B, N, idx.shape[1], _ptr(xyz, F32, "xyz"), tp, _ptr(idx, I32, "idx"),
+                                             _ptr(progress, I32, "progress"), work.data_ptr(), _stream(xyz)), "fps_publish")
+            return work
+        _lib.check(_L.sps_fps_publish(B, N, idx.shape[1], _ptr(xyz, F32, "xyz"), tp, _ptr(idx, I32, "idx"),
+                                      _ptr(progress, I32, "progress"), _stream(xyz)), "fps_publish")
+    return None
+
+
+def fps_can_publish(B, N):
+    """Is there a publishing FPS kernel for B scenes of N points?  (6144 .. 16 384 points: the register-resident kernel;
+    up to 262 144: the clustered kernel, which needs every scene's workgroups resident at once: B <= 16.)"""
+    return 6144 <= N <= 16384 or (16384 < N <= 262144 and B <= 16)
 
 
 def fps_redo_where(xyz, idx, redo, temp=None):

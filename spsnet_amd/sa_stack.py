@@ -218,7 +218,7 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
     from . import pointnet2_utils
     B, N, _ = xyz.shape
     M = layer.npoint_list[0]
-    if not (_is_plain_dfps(layer, N) and 6144 <= N <= 16384 and M % (64 * 16) == 0 and len(layer.groupers) == 2):
+    if not (_is_plain_dfps(layer, N) and _ext.fps_can_publish(B, N) and M % (64 * 16) == 0 and len(layer.groupers) == 2):
         return None
     if layer.training or features is None or not xyz.is_contiguous() or not features.is_contiguous():
         return None
@@ -269,8 +269,8 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
     else:
         fps_stream.wait_event(start)
         with torch.cuda.stream(fps_stream):
-            _ext.fps_publish(xyz, temp, idx, progress)
-        for t in (xyz, idx, progress):
+            work = _ext.fps_publish(xyz, temp, idx, progress)   # (large scenes: the sorted-point workspace)
+        for t in (xyz, idx, progress) + (() if work is None else (work,)):
             t.record_stream(fps_stream)
     if after_producer is not None:
         after_producer()
@@ -281,7 +281,7 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
     # the next layer's D-FPS over these centroids is the verified identity prefix (fps_verify.hip): its first pass
     # needs only the first npoint centroids and runs as soon as they exist, its second when the last one does
     verify = None
-    if nxt is not None and _can_prefetch(layer, nxt) and nxt.npoint_list[0] <= 2048:
+    if nxt is not None and _can_prefetch(layer, nxt) and nxt.npoint_list[0] <= _ext.ORDERED_PREFIX_MAX:
         with torch.cuda.stream(side):
             verify = _ext.OrderedPrefix(new_xyz, nxt.npoint_list[0])
         for t in verify.tensors():

@@ -754,6 +754,22 @@ def test_fps_ordered_prefix_shortcut(ext, G, oracle):
     np.testing.assert_array_equal(G.fps(ext, x1, 512)[0], want)
 
 
+def test_fps_ordered_prefix_many_centres(ext, G, oracle):
+    """Config-5 sized prefix: 16 384 FPS-ordered points -> 4 096 (the centres are staged in dynamic LDS, up to 7 168 of
+    them; more fall through to the ordinary kernel), confirmed and destroyed scenes, against the oracle."""
+    from spsnet_amd import scenes
+    xyz, _ = scenes.make_batch("kitti-lidar-v1", 2, 40000, seed0=77)
+    x1 = gather_xyz(xyz, oracle.fps(xyz, 16384))
+    x1[1] = x1[1][np.random.default_rng(1).permutation(16384)]
+    for m in (4096, 7168, 7169):
+        want, want_t = oracle.fps(x1, m, return_temp=True)
+        idx, flags, temp = ext.fps_ordered_prefix(G.t(x1), m, return_flags=True)
+        np.testing.assert_array_equal(G.n(idx), want)
+        np.testing.assert_array_equal(G.n(temp), want_t)
+        if m <= 7168:
+            assert G.n(flags).tolist() == [0, 1]
+
+
 @pytest.mark.parametrize("N,m", [(600, 300), (4096, 1024), (4096, 4096), (5000, 100)])
 def test_fps_ordered_prefix_with_ties(ext, G, oracle, N, m):
     """Lattice clouds: equal distances everywhere, the two runs' tie rules differ, so the guess often fails --
