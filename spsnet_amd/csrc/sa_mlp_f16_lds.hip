@@ -62,7 +62,9 @@ __device__ __forceinline__ void split4(const f32x4 v, h8 &hi, h8 &lo, float &mx)
 struct WFrag { h8 hi, lo; };
 
 
-constexpr int RING = 6;             // LDS slots of one chunk (8 KiB) each
+// LDS slots of one chunk (8 KiB) each.  (12 slots = 88 KiB in flight for the one-workgroup-per-CU variants: no change, 370 vs
+// 375 us at layer 5 -- the DMA stream is not what they wait for.)
+template <int C3> constexpr int ring_slots() { return 6; }
 constexpr int FRAG_BYTES = 2048;    // [hi x8 | lo x8] per lane, as two lane-linear 1-KiB pieces
 constexpr int CHUNK_BYTES = 4 * FRAG_BYTES;  // a chunk = 4 fragments = 8 pieces of 1 KiB, fetched by 4 or 8 waves
 
@@ -78,6 +80,7 @@ template <int C1, int C2, int C3, int NT, int NS, int WAVES, int PIPE_MODE = 2>
 __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa_group_mlp_f16_lds_kernel(SaMlpArgs a) {
     if (a.run_if && *a.run_if == 0) return;   // workgroup-uniform, before any barrier or DMA request
     constexpr int PIECES = 8 / WAVES;  // 1-KiB pieces of a chunk each wave fetches
+    constexpr int RING = ring_slots<C3>();
     static_assert(WAVES == 4 || WAVES == 8, "4 waves x 2 pieces or 8 waves x 1 piece");
     constexpr int T1 = C1 / 16, T2 = C2 / 16, MT3 = C3 / 16;   // 16-row output tiles
     constexpr int S1 = T1 / 2, S2 = T2 / 2;                    // k32-steps over the previous layer's channels
@@ -148,8 +151,10 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 1 && C3 <= 256) ? 2 : 1) void sa
     // The bias of the layer-2 tile that BEGINS with the next chunk travels with that chunk's reads (a ninth ds_read): read by
     // the compiler it drew an s_waitcnt lgkmcnt(0) right behind the eight reads in flight.  Needs tiles that begin on chunk
     // boundaries: S1 == 4.
-    constexpr bool PIPE = PIPE_MODE > 0 && C3 <= 256 && NT == 1 && S1 == 4;   // (the NT = 2 variants would drop to one wave per SIMD)
-    constexpr bool PIPE_BIAS = PIPE && PIPE_MODE > 1;
+    // (the NT = 2 variants would drop to one wave per SIMD; the 512- / 1024-row variants of IA-SSD layer 5, one wave per SIMD
+    //  anyway: 86.0 -> 80.9 us and 385 -> 370 us)
+    constexpr bool PIPE = PIPE_MODE > 0 && NT == 1 && (S1 == 4 || C3 > 256);
+    constexpr bool PIPE_BIAS = PIPE && PIPE_MODE > 1 && S1 == 4;
     const unsigned bias2_base = ring_base + (unsigned)(RING * CHUNK_BYTES + (C1 + 4 * q) * 4);   // &b2l[4 q] as an LDS address
     f32x4 nbias = {0.f, 0.f, 0.f, 0.f}, cur_bias = {0.f, 0.f, 0.f, 0.f};
     i32x4 n0, n1, n2, n3, n4, n5, n6, n7;   // the fragments in flight (PIPE)
@@ -446,7 +451,7 @@ static int launch_lds_variant(const SaMlpArgs &a, hipStream_t st) {
     const int groups = divup(k.units, WAVES);
     const int resident = WAVES == 8 ? 256 : 512;   // eight waves = two per SIMD fill a CU
     int blocks = groups < resident ? groups : resident;
-    const size_t lds = (size_t)RING * CHUNK_BYTES + sizeof(float) * ((size_t)C1 + C2 + C3 + (size_t)WAVES * (UNIT >= NS ? UNIT / NS : 1) * C3);
+    const size_t lds = (size_t)ring_slots<C3>() * CHUNK_BYTES + sizeof(float) * ((size_t)C1 + C2 + C3 + (size_t)WAVES * (UNIT >= NS ? UNIT / NS : 1) * C3);
     static LdsLimitOnce raised;  // one per instantiation
     if (lds > 64 * 1024) {
         const int rc = raise_lds_limit((const void *)sa_group_mlp_f16_lds_kernel<C1, C2, C3, NT, NS, WAVES, PIPE_MODE>, 150 * 1024, raised,

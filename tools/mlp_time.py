@@ -1,0 +1,39 @@
+"""Time ONE grouped-MLP launch (gather + 3 layers + max-pool) at a given shape, HIP events over 30 launches.
+Default: IA-SSD layer 5 (8 scenes, 512 points with 256 features -> 256 vote centres), both scales.
+usage: python tools/mlp_time.py [B N M c_feat]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from spsnet_amd import fused, pointnet2_modules as M, pointnet2_utils as U
+
+B, N, Mc, c_feat = (int(a) for a in sys.argv[1:5]) if len(sys.argv) >= 5 else (8, 512, 256, 256)
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+rng = np.random.default_rng(0)
+xyz = torch.from_numpy(rng.uniform(-20, 20, (B, N, 3)).astype(np.float32)).to(dev)
+feats = fused.attach_point_major_twin(torch.randn(B, c_feat, N, device=dev))
+new_xyz = xyz[:, :Mc].contiguous()
+for widths, ns, radius in (([256, 256, 512], 16, 4.8), ([256, 512, 1024], 32, 6.4)):
+    mod = M.PointnetSAModuleMSG_WithSampling(
+        npoint_list=[Mc], sample_range_list=[-1], sample_type_list=['D-FPS'], radii=[radius], nsamples=[ns],
+        mlps=[[c_feat] + widths], use_xyz=True, dilated_group=False, aggregation_mlp=None, confidence_mlp=None,
+        num_class=3).to(dev).eval()
+    with torch.no_grad():
+        plan = mod._fused_plan(xyz, new_xyz, feats)
+        assert plan, "no fused kernel for this scale"
+        idx = U.ball_query(radius, ns, xyz, new_xyz)
+        out = torch.zeros((B, widths[-1], Mc), device=dev)
+        for _ in range(3):
+            fused.group_mlp_pool(xyz, new_xyz, feats, idx, plan[0], out, 0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(30):
+            fused.group_mlp_pool(xyz, new_xyz, feats, idx, plan[0], out, 0)
+        e1.record()
+        torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 30 * 1e3
+    flop = 2.0 * B * Mc * ns * ((c_feat + 3) * widths[0] + widths[0] * widths[1] + widths[1] * widths[2])
+    print(f"{c_feat + 3}->{widths} ns {ns}: {us:8.1f} us  {flop / us / 1e6:7.1f} TFLOP/s algorithmic "
+          f"(split-fp16: x3 issued = {3 * flop / us / 1e6 / 2500 * 100:.1f} % of the 2.5 PF peak)", flush=True)
