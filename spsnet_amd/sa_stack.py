@@ -230,6 +230,10 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
     ga, gb = layer.groupers
     main = torch.cuda.current_stream(dev)
     fps_stream = _helper_stream(dev, "fps")              # None unless a CuFence is registered for `main`
+    if fps_stream is not None and N > 16384:
+        # the clustered large-scene producer spins on its sibling workgroups: all B K of them must be resident at once, which a
+        # stream confined to a few compute units does not promise -- large scenes run unstreamed under a CuFence
+        return None
     # Who runs where (measured, tools/hop_cost.py: a kernel boundary costs ~4 us, a cross-stream dependency that is actually
     # waited for ~12 us more, one that was satisfied long before nothing):
     #   default   every chunk on the caller's stream behind bounded waits (nothing downstream has to hop streams); the producer on
