@@ -34,7 +34,11 @@ constexpr int IMIN_C = (int)0x80000000;
 constexpr int PC_MAXK = 8;        // workgroups per scene
 constexpr int PC_MAXT = 8;        // records a workgroup publishes per round
 constexpr int PC_MAXR = 32;       // records per round (K T) at most: two lanes per record in the acceptance
-constexpr int PC_GRANULES = 8 + 2 * PC_MAXR * 6;      // [0]: "sorted" flag (+ padding to a 64-byte line), then [parity][record][field]
+// the exchange area in 8-byte granules: [8 ..): the rounds' records [parity][record][field]; the sort's bounding boxes [K][6];
+// its two rounds of flags [2][K]; behind the granules the K cell histograms of the sort (ints)
+constexpr int PC_BOX_AT = 8 + 2 * PC_MAXR * 6;
+constexpr int PC_FLAG_AT = PC_BOX_AT + PC_MAXK * 6;
+constexpr int PC_GRANULES = PC_FLAG_AT + 2 * PC_MAXK + 8;
 constexpr unsigned PC_SPIN_LIMIT = 1u << 24;          // polls before a stuck exchange traps (~ seconds)
 
 struct PcShared {
@@ -89,15 +93,45 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
     const int nb = npad / 64;  // buckets
     const int R = K * T;       // records per round
 
-    if (cu == 0) {
-        // ------------------------------------------------------------------ spatial sort (once, by the first workgroup)
+    // ------------------------------------------------------------------ spatial sort (once), split over the K workgroups
+    // Workgroup c owns the points [n c / K, n (c+1) / K): (A) its bounding box -> K x 6 tagged granules, everybody takes the
+    // union; (B) its cell histogram -> ghist[c][.] in the workspace, release + flag; everybody adds the K histograms up
+    // (exclusive scan over the cells + the counts of the workgroups before it = its own first slot in every cell);
+    // (C) it scatters its points with LDS atomics on those slots; release + flag, everybody acquires.  The order inside a
+    // cell is as arbitrary as with one workgroup's atomics and as irrelevant (ties are decided by rank).
+    {
+        unsigned long long *xbox = xg + PC_BOX_AT, *xflag = xg + PC_FLAG_AT;
+        int *ghist = reinterpret_cast<int *>(xg + PC_GRANULES);
+        const int s_beg = (int)((long long)n * cu / K), s_end = (int)((long long)n * (cu + 1) / K);
+        auto flag_and_wait = [&](int slot, unsigned tg) {   // my stores -> visible; then wait for everybody's
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                granule_store(xflag + slot * PC_MAXK + cu, 1, tg);
+            }
+            if (wave == 0) {
+                if (lane < K) {
+                    unsigned spins = 0;
+                    while ((unsigned)(granule_load(xflag + slot * PC_MAXK + lane) >> 32) != tg) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > PC_SPIN_LIMIT) __builtin_trap();
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();   // (this CU's vector L1 is invalidated: plain loads of the others' stores from here on)
+        };
+        // (A) bounding box
         float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int k0 = tid; k0 < n; k0 += 8 * PF_THREADS) {
+        for (int k0 = s_beg + tid; k0 < s_end; k0 += 8 * PF_THREADS) {
             float v[8][3];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int k = k0 + u * PF_THREADS;
-                const int kk = k < n ? k : k0;
+                const int kk = k < s_end ? k : k0;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) v[u][a] = xyz[(size_t)kk * 3 + a];
             }
@@ -114,34 +148,60 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
         }
         for (int i = tid; i < PF_BINS; i += PF_THREADS) sh.hist[i] = 0;
         __syncthreads();
+        if (tid < 6) {
+            float r = sh.red[tid][0];
+            for (int w = 1; w < PF_WAVES; ++w) r = tid < 3 ? fminf(r, sh.red[tid][w]) : fmaxf(r, sh.red[tid][w]);
+            granule_store(xbox + cu * 6 + tid, __float_as_int(r), 1u);
+        }
+        if (tid < K * 6) {
+            unsigned spins = 0;
+            unsigned long long g = granule_load(xbox + tid);
+            while ((unsigned)(g >> 32) != 1u) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > PC_SPIN_LIMIT) __builtin_trap();
+                g = granule_load(xbox + tid);
+            }
+            sh.xr[tid % 6][tid / 6] = (int)(unsigned)g;   // (the record area is free until the sampling loop)
+        }
+        __syncthreads();
         float glo[3], ghi[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            float l = sh.red[a][0], h = sh.red[3 + a][0];
-#pragma unroll
-            for (int w = 1; w < PF_WAVES; ++w) { l = fminf(l, sh.red[a][w]); h = fmaxf(h, sh.red[3 + a][w]); }
+            float l = __int_as_float(sh.xr[a][0]), h = __int_as_float(sh.xr[3 + a][0]);
+            for (int c = 1; c < K; ++c) { l = fminf(l, __int_as_float(sh.xr[a][c])); h = fmaxf(h, __int_as_float(sh.xr[3 + a][c])); }
             glo[a] = l; ghi[a] = h;
         }
         const PfGrid grid = pf_make_grid(glo, ghi);
-        for (int k0 = tid; k0 < n; k0 += 8 * PF_THREADS) {
+        // (B) my histogram, then everybody's
+        for (int k0 = s_beg + tid; k0 < s_end; k0 += 8 * PF_THREADS) {
             float v[8][3];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int k = k0 + u * PF_THREADS;
-                const int kk = k < n ? k : k0;
+                const int kk = k < s_end ? k : k0;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) v[u][a] = xyz[(size_t)kk * 3 + a];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (k0 + u * PF_THREADS < n) atomicAdd(&sh.hist[pf_cell_key(grid, v[u][0], v[u][1], v[u][2])], 1);
+                if (k0 + u * PF_THREADS < s_end) atomicAdd(&sh.hist[pf_cell_key(grid, v[u][0], v[u][1], v[u][2])], 1);
         }
         __syncthreads();
-        {   // exclusive prefix sum of the histogram
-            constexpr int PER = PF_BINS / PF_THREADS;
-            int loc[PER], sum = 0;
+        constexpr int PER = PF_BINS / PF_THREADS;
+        for (int i = 0; i < PER; ++i) ghist[(size_t)cu * PF_BINS + i * PF_THREADS + tid] = sh.hist[i * PF_THREADS + tid];
+        flag_and_wait(0, 2u);
+        {   // exclusive prefix sum over the cells of the summed histograms, plus what the workgroups before me put in each cell
+            int loc[PER], before[PER], sum = 0;
 #pragma unroll
-            for (int i = 0; i < PER; ++i) { loc[i] = sh.hist[tid * PER + i]; sum += loc[i]; }
+            for (int i = 0; i < PER; ++i) {
+                int tot = 0, bef = 0;
+                for (int c = 0; c < K; ++c) {
+                    const int h = ghist[(size_t)c * PF_BINS + tid * PER + i];
+                    tot += h;
+                    bef += c < cu ? h : 0;
+                }
+                loc[i] = tot; before[i] = bef; sum += tot;
+            }
             int incl = sum;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -154,15 +214,16 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
             for (int w = 0; w < wave; ++w) base += sh.wsum[w];
             int run = base + incl - sum;
 #pragma unroll
-            for (int i = 0; i < PER; ++i) { sh.hist[tid * PER + i] = run; run += loc[i]; }
+            for (int i = 0; i < PER; ++i) { sh.hist[tid * PER + i] = run + before[i]; run += loc[i]; }
         }
         __syncthreads();
-        for (int k0 = tid; k0 < n; k0 += 8 * PF_THREADS) {
+        // (C) scatter my points
+        for (int k0 = s_beg + tid; k0 < s_end; k0 += 8 * PF_THREADS) {
             float v[8][3], tv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int k = k0 + u * PF_THREADS;
-                const int kk = k < n ? k : k0;
+                const int kk = k < s_end ? k : k0;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) v[u][a] = xyz[(size_t)kk * 3 + a];
                 tv[u] = temp ? temp[kk] : 1e10f;
@@ -170,36 +231,18 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int k = k0 + u * PF_THREADS;
-                if (k < n) {
+                if (k < s_end) {
                     const int pos = atomicAdd(&sh.hist[pf_cell_key(grid, v[u][0], v[u][1], v[u][2])], 1);
                     sx[pos] = v[u][0]; sy[pos] = v[u][1]; sz[pos] = v[u][2]; st[pos] = tv[u];
                     srk[pos] = (int)pf_rank((unsigned)k, bs, l2, rb);
                 }
             }
         }
-        for (int p = n + tid; p < npad; p += PF_THREADS) {  // padding: never inside a box, distance stays -1, worst rank
-            sx[p] = NAN; sy[p] = NAN; sz[p] = NAN; st[p] = -1.f; srk[p] = 0x0FFFFFFF;
-        }
-        // hand the sorted scene to the other workgroups: every storing wave drained, the workgroup's barrier, one agent-scope
-        // release (write back this XCD's L2), the flag (MI355X_MICROARCH.md, inter-workgroup visibility: the valid form)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            granule_store(xg, 1, 1u);
-        }
-    } else {
-        if (tid == 0) {
-            unsigned spins = 0;
-            while ((granule_load(xg) >> 32) != 1u) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > PC_SPIN_LIMIT) __builtin_trap();
+        if (cu == 0)
+            for (int p = n + tid; p < npad; p += PF_THREADS) {  // padding: never inside a box, distance stays -1, worst rank
+                sx[p] = NAN; sy[p] = NAN; sz[p] = NAN; st[p] = -1.f; srk[p] = 0x0FFFFFFF;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();   // (the invalidate of this CU's vector L1 has completed: plain loads of the workspace from here on)
+        flag_and_wait(1, 3u);
     }
 
     // ------------------------------------------------------------------ bucket metadata
@@ -527,7 +570,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
 }
 
 // floats of the exchange area behind a scene's 5 npad workspace floats
-size_t fps_cluster_exchange_floats() { return (size_t)2 * PC_GRANULES; }
+size_t fps_cluster_exchange_floats() { return (size_t)2 * PC_GRANULES + (size_t)PC_MAXK * PF_BINS; }
 
 // K workgroups per scene publishing T records each; -1: shape not served
 int launch_fps_pruned_cluster(int b, int K, int T, int n, int m, const float *dataset, float *temp, int *idxs, float *work,
