@@ -313,8 +313,15 @@ extern "C" int sps_fps_publish(int b, int n, int m, const float *dataset, float 
 extern "C" int sps_fps_publish_ws(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress,
                                   float *work, sps_stream_t stream) {
     using namespace sps;
-    if (n <= 32 * 512) return sps_fps_publish(b, n, m, dataset, temp, idxs, progress, stream);
-    if (b <= 0 || m <= 0 || !dataset || !idxs || !progress || !work) return fail(SPS_ERR_INVALID, "fps_publish_ws: bad arguments");
+    if (b <= 0 || n <= 0 || m <= 0 || !dataset || !idxs || !progress) return fail(SPS_ERR_INVALID, "fps_publish_ws: bad arguments");
+    if (n <= 32 * 512) {   // register-resident kernel; with a workspace its scenes are sorted by a pre-pass (fps_presort.hip)
+        if (!work || fps_mode() != 0) return sps_fps_publish(b, n, m, dataset, temp, idxs, progress, stream);
+        const int rc = launch_fps_pruned_publish(b, n, m, dataset, temp, idxs, progress, as_stream(stream), work,
+                                                 sps_fps_workspace_floats(n));
+        if (rc < 0) return fail(SPS_ERR_INVALID, "fps_publish_ws: no publishing kernel for n=%d", n);
+        return rc;
+    }
+    if (!work) return fail(SPS_ERR_INVALID, "fps_publish_ws: bad arguments");
     if (fps_mode() != 0) return fail(SPS_ERR_INVALID, "fps_publish_ws: brute-force mode has no publishing kernel");
     const int rc = launch_fps_big_publish(b, n, m, dataset, temp, idxs, progress, work, as_stream(stream));
     if (rc < 0) return fail(SPS_ERR_INVALID, "fps_publish_ws: no publishing kernel for b=%d n=%d", b, n);

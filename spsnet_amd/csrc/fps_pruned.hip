@@ -48,14 +48,18 @@ struct PfShared {
 // the samples are stored write-through (sc1) by ONE lane, and after every 64th that lane drains its stores
 // (s_waitcnt vmcnt(0)) and stores progress[scene] = number of samples written, also sc1 -- the R1 hand-off of
 // cdna_hip_programming.md Guideline 16 (one lane signals for all its own stores; consumers poll relaxed).
-template <int P, bool PROF = false, bool RESOLVE = false, bool PUBLISH = false>
+// PRESORT = the scene arrives sorted: `presorted` holds, per scene, `pstride` floats of which 5 arrays of npad = 64 ceil(n / 64)
+// elements {x, y, z, running distance, rank} in bucket order, padding included (fps_presort.hip) -- the set-up is 5 P
+// coalesced loads per lane instead of the in-kernel sort.
+template <int P, bool PROF = false, bool RESOLVE = false, bool PUBLISH = false, bool PRESORT = false>
 __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
     int n, int m, int bs, int l2, int rb, const float *__restrict__ dataset, float *__restrict__ temp,
     int *__restrict__ idxs, unsigned long long *__restrict__ dbg = nullptr, const int *__restrict__ redo = nullptr,
-    const float *__restrict__ temp_done = nullptr, int *__restrict__ progress = nullptr) {
+    const float *__restrict__ temp_done = nullptr, int *__restrict__ progress = nullptr,
+    const float *__restrict__ presorted = nullptr, long long pstride = 0) {
     if (m <= 0) return;
     __shared__ PfShared sh;
-    __shared__ unsigned short sorted[P * PF_THREADS];
+    __shared__ unsigned short sorted[PRESORT ? 64 : P * PF_THREADS];
 
     const int scene = blockIdx.x;
     if constexpr (RESOLVE) {
@@ -71,93 +75,95 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ------------------------------------------------------------------ spatial sort (once)
-    float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
-    // eight points per trip: their 24 loads are in flight together (a plain strided loop waits ~1 us per iteration)
-    for (int k0 = tid; k0 < n; k0 += 8 * PF_THREADS) {
-        float v[8][3];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = k0 + u * PF_THREADS;
-            const int kk = k < n ? k : k0;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) v[u][a] = xyz[kk * 3 + a];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                lo3[a] = fminf(lo3[a], v[u][a]);
-                hi3[a] = fmaxf(hi3[a], v[u][a]);
+    if constexpr (!PRESORT) {
+        // ------------------------------------------------------------------ spatial sort (once)
+        float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
+        // eight points per trip: their 24 loads are in flight together (a plain strided loop waits ~1 us per iteration)
+        for (int k0 = tid; k0 < n; k0 += 8 * PF_THREADS) {
+            float v[8][3];
+    #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * PF_THREADS;
+                const int kk = k < n ? k : k0;
+    #pragma unroll
+                for (int a = 0; a < 3; ++a) v[u][a] = xyz[kk * 3 + a];
             }
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        lo3[a] = wave_allmin_f32(lo3[a]);
-        hi3[a] = wave_allmax_f32(hi3[a]);
-        if (lane == 0) { sh.red[a][wave] = lo3[a]; sh.red[3 + a][wave] = hi3[a]; }
-    }
-    for (int i = tid; i < PF_BINS; i += PF_THREADS) sh.hist[i] = 0;
-    __syncthreads();
-    float glo[3], ghi[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float l = sh.red[a][0], h = sh.red[3 + a][0];
-#pragma unroll
-        for (int w = 1; w < PF_WAVES; ++w) { l = fminf(l, sh.red[a][w]); h = fmaxf(h, sh.red[3 + a][w]); }
-        glo[a] = l; ghi[a] = h;
-    }
-    const PfGrid grid = pf_make_grid(glo, ghi);
-    // cell keys of this thread's points stay in registers between the histogram and the scatter pass
-    int ckey[P];
-    constexpr int KB = P % 8 == 0 ? 8 : 4;  // points per batch: loads first (unconditional, clamped), then keys + atomics
-#pragma unroll
-    for (int i0 = 0; i0 < P; i0 += KB) {
-        float v[KB][3];
-#pragma unroll
-        for (int u = 0; u < KB; ++u) {
-            const int k = tid + (i0 + u) * PF_THREADS;
-            const int kk = k < n ? k : 0;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) v[u][a] = xyz[kk * 3 + a];
+    #pragma unroll
+            for (int u = 0; u < 8; ++u)
+    #pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    lo3[a] = fminf(lo3[a], v[u][a]);
+                    hi3[a] = fmaxf(hi3[a], v[u][a]);
+                }
         }
-#pragma unroll
-        for (int u = 0; u < KB; ++u) {
-            const int k = tid + (i0 + u) * PF_THREADS;
-            ckey[i0 + u] = 0;
-            if (k < n) {
-                ckey[i0 + u] = pf_cell_key(grid, v[u][0], v[u][1], v[u][2]);
-                atomicAdd(&sh.hist[ckey[i0 + u]], 1);
-            }
+    #pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo3[a] = wave_allmin_f32(lo3[a]);
+            hi3[a] = wave_allmax_f32(hi3[a]);
+            if (lane == 0) { sh.red[a][wave] = lo3[a]; sh.red[3 + a][wave] = hi3[a]; }
         }
-    }
-    __syncthreads();
-    {   // exclusive prefix sum of the histogram: 8 bins per thread, wave scan, cross-wave offsets
-        constexpr int PER = PF_BINS / PF_THREADS;
-        int loc[PER], sum = 0;
-#pragma unroll
-        for (int i = 0; i < PER; ++i) { loc[i] = sh.hist[tid * PER + i]; sum += loc[i]; }
-        int incl = sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        if (lane == 63) sh.wsum[wave] = incl;
+        for (int i = tid; i < PF_BINS; i += PF_THREADS) sh.hist[i] = 0;
         __syncthreads();
-        int base = 0;
-        for (int w = 0; w < wave; ++w) base += sh.wsum[w];
-        int run = base + incl - sum;
-#pragma unroll
-        for (int i = 0; i < PER; ++i) { sh.hist[tid * PER + i] = run; run += loc[i]; }
+        float glo[3], ghi[3];
+    #pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float l = sh.red[a][0], h = sh.red[3 + a][0];
+    #pragma unroll
+            for (int w = 1; w < PF_WAVES; ++w) { l = fminf(l, sh.red[a][w]); h = fmaxf(h, sh.red[3 + a][w]); }
+            glo[a] = l; ghi[a] = h;
+        }
+        const PfGrid grid = pf_make_grid(glo, ghi);
+        // cell keys of this thread's points stay in registers between the histogram and the scatter pass
+        int ckey[P];
+        constexpr int KB = P % 8 == 0 ? 8 : 4;  // points per batch: loads first (unconditional, clamped), then keys + atomics
+    #pragma unroll
+        for (int i0 = 0; i0 < P; i0 += KB) {
+            float v[KB][3];
+    #pragma unroll
+            for (int u = 0; u < KB; ++u) {
+                const int k = tid + (i0 + u) * PF_THREADS;
+                const int kk = k < n ? k : 0;
+    #pragma unroll
+                for (int a = 0; a < 3; ++a) v[u][a] = xyz[kk * 3 + a];
+            }
+    #pragma unroll
+            for (int u = 0; u < KB; ++u) {
+                const int k = tid + (i0 + u) * PF_THREADS;
+                ckey[i0 + u] = 0;
+                if (k < n) {
+                    ckey[i0 + u] = pf_cell_key(grid, v[u][0], v[u][1], v[u][2]);
+                    atomicAdd(&sh.hist[ckey[i0 + u]], 1);
+                }
+            }
+        }
+        __syncthreads();
+        {   // exclusive prefix sum of the histogram: 8 bins per thread, wave scan, cross-wave offsets
+            constexpr int PER = PF_BINS / PF_THREADS;
+            int loc[PER], sum = 0;
+    #pragma unroll
+            for (int i = 0; i < PER; ++i) { loc[i] = sh.hist[tid * PER + i]; sum += loc[i]; }
+            int incl = sum;
+    #pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            if (lane == 63) sh.wsum[wave] = incl;
+            __syncthreads();
+            int base = 0;
+            for (int w = 0; w < wave; ++w) base += sh.wsum[w];
+            int run = base + incl - sum;
+    #pragma unroll
+            for (int i = 0; i < PER; ++i) { sh.hist[tid * PER + i] = run; run += loc[i]; }
+        }
+        __syncthreads();
+    #pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int k = tid + i * PF_THREADS;
+            if (k < n) sorted[atomicAdd(&sh.hist[ckey[i]], 1)] = (unsigned short)k;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        const int k = tid + i * PF_THREADS;
-        if (k < n) sorted[atomicAdd(&sh.hist[ckey[i]], 1)] = (unsigned short)k;
-    }
-    __syncthreads();
 
     // ------------------------------------------------------------------ load the wave's buckets
     // bucket g = s * PF_WAVES + wave lives in slot s; lane l holds sorted position g*64 + l
@@ -168,16 +174,33 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
     typedef int viP __attribute__((ext_vector_type(P)));
     vfP x, y, z, t;
     viP rk;  // tie-break rank of the point (0x0FFFFFFF for padding lanes)
+    if constexpr (PRESORT) {
+        const int npad = ((n + 63) >> 6) << 6;
+        const float *px = presorted + (size_t)scene * pstride, *py = px + npad, *pz = py + npad, *pt = pz + npad;
+        const int *prk = reinterpret_cast<const int *>(pt + npad);
 #pragma unroll
-    for (int s = 0; s < P; ++s) {
-        const int pos = (s * PF_WAVES + wave) * 64 + lane;
-        const bool ok = pos < n;
-        const int k = ok ? (int)sorted[pos] : 0;
-        rk[s] = ok ? (int)pf_rank((unsigned)k, bs, l2, rb) : 0x0FFFFFFF;
-        x[s] = ok ? xyz[k * 3 + 0] : NAN;  // NaN coordinates: never inside a box, distance stays -1
-        y[s] = ok ? xyz[k * 3 + 1] : NAN;
-        z[s] = ok ? xyz[k * 3 + 2] : NAN;
-        t[s] = ok ? (has_temp ? temp[k] : 1e10f) : -1.f;
+        for (int s = 0; s < P; ++s) {
+            const int pos = (s * PF_WAVES + wave) * 64 + lane;
+            const bool ok = pos < npad;      // (entries n .. npad-1 are the pre-pass's padding: NaN, -1, worst rank)
+            const int q = ok ? pos : 0;
+            x[s] = ok ? px[q] : NAN;
+            y[s] = ok ? py[q] : NAN;
+            z[s] = ok ? pz[q] : NAN;
+            t[s] = ok ? pt[q] : -1.f;
+            rk[s] = ok ? prk[q] : 0x0FFFFFFF;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+            const int pos = (s * PF_WAVES + wave) * 64 + lane;
+            const bool ok = pos < n;
+            const int k = ok ? (int)sorted[pos] : 0;
+            rk[s] = ok ? (int)pf_rank((unsigned)k, bs, l2, rb) : 0x0FFFFFFF;
+            x[s] = ok ? xyz[k * 3 + 0] : NAN;  // NaN coordinates: never inside a box, distance stays -1
+            y[s] = ok ? xyz[k * 3 + 1] : NAN;
+            z[s] = ok ? xyz[k * 3 + 2] : NAN;
+            t[s] = ok ? (has_temp ? temp[k] : 1e10f) : -1.f;
+        }
     }
 
     // per-bucket metadata, bucket s of this wave in lane s
@@ -470,7 +493,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
 #pragma unroll
         for (int s = 0; s < P; ++s) {
             const int pos = (s * PF_WAVES + wave) * 64 + lane;
-            if (pos < n) temp[sorted[pos]] = t[s];
+            if (pos < n) temp[PRESORT ? (int)pf_unrank((unsigned)rk[s], l2, rb) : (int)sorted[pos]] = t[s];
         }
     }
 }
@@ -490,8 +513,10 @@ int launch_fps_pruned_profile(int b, int n, int m, const float *dataset, float *
 }
 
 // publishing variant for chunked consumers; -1 if the pruned kernel does not apply to this size
+int launch_fps_presort(int b, int n, const float *dataset, const float *temp, float *work, long long stride, hipStream_t st);
+
 int launch_fps_pruned_publish(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress,
-                              hipStream_t st) {
+                              hipStream_t st, float *work, long long stride) {
     if (n < 6144 || n > 32 * PF_THREADS || m < 2) return -1;
     const int bs = sps_opt_n_threads(n);
     int l2 = 0;
@@ -500,6 +525,18 @@ int launch_fps_pruned_publish(int b, int n, int m, const float *dataset, float *
     while ((1 << rb) < divup(n, bs)) ++rb;
     const int P = divup(n, PF_THREADS);
     dim3 grid(b), block(PF_THREADS);
+    if (work && launch_fps_presort(b, n, dataset, temp, work, stride, st) == SPS_OK) {   // sorted by a pre-pass of K workgroups per scene
+#define SPS_PFS_CASE(PP)                                                                                         \
+        if (P <= PP) {                                                                                           \
+            hipLaunchKernelGGL((fps_pruned_kernel<PP, false, false, true, true>), grid, block, 0, st, n, m, bs, l2, rb, dataset, \
+                               temp, idxs, (unsigned long long *)nullptr, (const int *)nullptr, (const float *)nullptr, \
+                               progress, (const float *)work, stride);                                           \
+            return check_launch("fps_pruned_kernel<publish, presorted>");                                       \
+        }
+        SPS_PFS_CASE(16)
+        SPS_PFS_CASE(32)
+#undef SPS_PFS_CASE
+    }
 #define SPS_PFP_CASE(PP)                                                                                         \
     if (P <= PP) {                                                                                               \
         hipLaunchKernelGGL((fps_pruned_kernel<PP, false, false, true>), grid, block, 0, st, n, m, bs, l2, rb, dataset, \
@@ -515,7 +552,7 @@ int launch_fps_pruned_publish(int b, int n, int m, const float *dataset, float *
 
 // returns SPS_OK after launching, or -1 if this variant does not apply (caller falls back to fps.hip)
 int launch_fps_pruned(int b, int n, int m, const float *dataset, float *temp, int *idxs, hipStream_t st,
-                      const int *redo, const float *temp_done) {
+                      const int *redo, const float *temp_done, float *work, long long stride) {
     // measured cross-over (tools/fps_time.py): below ~6k points the brute-force register kernel's iteration
     // (N/1024 points per lane) is shorter than the pruned kernel's fixed test/reduce chain
     if (n < 6144 || n > 32 * PF_THREADS) return -1;  // 32 bucket slots per wave = 16 384 points
@@ -526,6 +563,18 @@ int launch_fps_pruned(int b, int n, int m, const float *dataset, float *temp, in
     while ((1 << rb) < divup(n, bs)) ++rb;
     const int P = divup(n, PF_THREADS);
     dim3 grid(b), block(PF_THREADS);
+    if (work && !redo && P > 8 && launch_fps_presort(b, n, dataset, temp, work, stride, st) == SPS_OK) {
+#define SPS_PFS_CASE(PP)                                                                                       \
+        if (P <= PP) {                                                                                         \
+            hipLaunchKernelGGL((fps_pruned_kernel<PP, false, false, false, true>), grid, block, 0, st, n, m, bs, l2, rb, dataset, \
+                               temp, idxs, (unsigned long long *)nullptr, (const int *)nullptr, (const float *)nullptr, \
+                               (int *)nullptr, (const float *)work, stride);                                   \
+            return check_launch("fps_pruned_kernel<presorted>");                                              \
+        }
+        SPS_PFS_CASE(16)
+        SPS_PFS_CASE(32)
+#undef SPS_PFS_CASE
+    }
 #define SPS_PF_CASE(PP)                                                                                        \
     if (P <= PP) {                                                                                             \
         if (redo)                                                                                              \

@@ -392,7 +392,8 @@ int launch_fps_pruned_cluster(int b, int K, int T, int n, int m, const float *da
 // workspace floats per scene for sps_fps_with_workspace (0: this size is served without one): the sorted points and,
 // behind them, the record exchange area of fps_pruned_cluster.hip
 size_t fps_big_workspace_elems(int n) {
-    if (n <= 32 * PF_THREADS || n > 8 * 64 * 64 * PF_WAVES) return 0;
+    // (6144 .. 16 384 points: the register-resident kernel, whose scenes a pre-pass sorts into the workspace, fps_presort.hip)
+    if (n < 6144 || n > 8 * 64 * 64 * PF_WAVES) return 0;
     return (size_t)5 * ((size_t)divup(n, 64) * 64) + fps_cluster_exchange_floats();
 }
 
@@ -418,6 +419,8 @@ static void fps_cluster_shape(int b, int n, int &K, int &T) {
 
 int launch_fps_pruned_big(int b, int n, int m, const float *dataset, float *temp, int *idxs, float *work, hipStream_t st) {
     if (fps_big_workspace_elems(n) == 0 || !work) return -1;
+    if (n <= 32 * PF_THREADS)   // register-resident kernel behind the sorting pre-pass (-1: shape not served, caller falls back)
+        return launch_fps_pruned(b, n, m, dataset, temp, idxs, st, nullptr, nullptr, work, (long long)fps_big_workspace_elems(n));
     const int bs = sps_opt_n_threads(n);
     int l2 = 0;
     while ((1 << (l2 + 1)) <= bs) ++l2;
@@ -449,6 +452,7 @@ int launch_fps_pruned_big(int b, int n, int m, const float *dataset, float *temp
 int launch_fps_big_publish(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress, float *work,
                            hipStream_t st) {
     if (fps_big_workspace_elems(n) == 0 || !work || m < 2) return -1;
+    if (n <= 32 * PF_THREADS) return -1;
     int K, T;
     fps_cluster_shape(b, n, K, T);
     if (K < 2) return -1;

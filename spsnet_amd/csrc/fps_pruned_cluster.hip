@@ -21,7 +21,7 @@
 // (fps_pruned_big.hip's launcher holds the measured table and picks K, T).
 // The K workgroups of a scene must be resident together: the launcher uses the cluster only for b K <= 64 workgroups
 // (a CU each; the polls are bounded -- a stuck exchange traps instead of hanging the device).
-#include "fps_pruned_util.h"
+#include "fps_sort_split.h"
 
 #include <type_traits>
 #include <utility>
@@ -31,22 +31,11 @@ namespace sps {
 namespace {
 
 constexpr int IMIN_C = (int)0x80000000;
-constexpr int PC_MAXK = 8;        // workgroups per scene
-constexpr int PC_MAXT = 8;        // records a workgroup publishes per round
-constexpr int PC_MAXR = 32;       // records per round (K T) at most: two lanes per record in the acceptance
-// the exchange area in 8-byte granules: [8 ..): the rounds' records [parity][record][field]; the sort's bounding boxes [K][6];
-// its two rounds of flags [2][K]; behind the granules the K cell histograms of the sort (ints)
-constexpr int PC_BOX_AT = 8 + 2 * PC_MAXR * 6;
-constexpr int PC_FLAG_AT = PC_BOX_AT + PC_MAXK * 6;
-constexpr int PC_GRANULES = PC_FLAG_AT + 2 * PC_MAXK + 8;
-constexpr unsigned PC_SPIN_LIMIT = 1u << 24;          // polls before a stuck exchange traps (~ seconds)
 
 struct PcShared {
-    int hist[PF_BINS];
+    PcSortShared sort;
     __attribute__((aligned(16))) int soa[2][6][2 * PF_WAVES];  // the workgroup's own 16 records: round parity x field x record
     __attribute__((aligned(16))) int xr[6][PC_MAXR];           // the round's published records of all K workgroups
-    float red[6][PF_WAVES];
-    int wsum[PF_WAVES];
 };
 
 template <int R, int ROWS, class F>
@@ -55,13 +44,6 @@ __device__ __forceinline__ void rows_each_c(F &fn) {
         fn(std::integral_constant<int, R>{});
         rows_each_c<R + 1, ROWS>(fn);
     }
-}
-
-__device__ __forceinline__ void granule_store(unsigned long long *p, int value, unsigned tag) {
-    __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long granule_load(const unsigned long long *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace
@@ -94,156 +76,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
     const int R = K * T;       // records per round
 
     // ------------------------------------------------------------------ spatial sort (once), split over the K workgroups
-    // Workgroup c owns the points [n c / K, n (c+1) / K): (A) its bounding box -> K x 6 tagged granules, everybody takes the
-    // union; (B) its cell histogram -> ghist[c][.] in the workspace, release + flag; everybody adds the K histograms up
-    // (exclusive scan over the cells + the counts of the workgroups before it = its own first slot in every cell);
-    // (C) it scatters its points with LDS atomics on those slots; release + flag, everybody acquires.  The order inside a
-    // cell is as arbitrary as with one workgroup's atomics and as irrelevant (ties are decided by rank).
-    {
-        unsigned long long *xbox = xg + PC_BOX_AT, *xflag = xg + PC_FLAG_AT;
-        int *ghist = reinterpret_cast<int *>(xg + PC_GRANULES);
-        const int s_beg = (int)((long long)n * cu / K), s_end = (int)((long long)n * (cu + 1) / K);
-        auto flag_and_wait = [&](int slot, unsigned tg) {   // my stores -> visible; then wait for everybody's
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                granule_store(xflag + slot * PC_MAXK + cu, 1, tg);
-            }
-            if (wave == 0) {
-                if (lane < K) {
-                    unsigned spins = 0;
-                    while ((unsigned)(granule_load(xflag + slot * PC_MAXK + lane) >> 32) != tg) {
-                        __builtin_amdgcn_s_sleep(4);
-                        if (++spins > PC_SPIN_LIMIT) __builtin_trap();
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();   // (this CU's vector L1 is invalidated: plain loads of the others' stores from here on)
-        };
-        // (A) bounding box
-        float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int k0 = s_beg + tid; k0 < s_end; k0 += 8 * PF_THREADS) {
-            float v[8][3];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u * PF_THREADS;
-                const int kk = k < s_end ? k : k0;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) v[u][a] = xyz[(size_t)kk * 3 + a];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int a = 0; a < 3; ++a) { lo3[a] = fminf(lo3[a], v[u][a]); hi3[a] = fmaxf(hi3[a], v[u][a]); }
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            lo3[a] = wave_allmin_f32(lo3[a]);
-            hi3[a] = wave_allmax_f32(hi3[a]);
-            if (lane == 0) { sh.red[a][wave] = lo3[a]; sh.red[3 + a][wave] = hi3[a]; }
-        }
-        for (int i = tid; i < PF_BINS; i += PF_THREADS) sh.hist[i] = 0;
-        __syncthreads();
-        if (tid < 6) {
-            float r = sh.red[tid][0];
-            for (int w = 1; w < PF_WAVES; ++w) r = tid < 3 ? fminf(r, sh.red[tid][w]) : fmaxf(r, sh.red[tid][w]);
-            granule_store(xbox + cu * 6 + tid, __float_as_int(r), 1u);
-        }
-        if (tid < K * 6) {
-            unsigned spins = 0;
-            unsigned long long g = granule_load(xbox + tid);
-            while ((unsigned)(g >> 32) != 1u) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > PC_SPIN_LIMIT) __builtin_trap();
-                g = granule_load(xbox + tid);
-            }
-            sh.xr[tid % 6][tid / 6] = (int)(unsigned)g;   // (the record area is free until the sampling loop)
-        }
-        __syncthreads();
-        float glo[3], ghi[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            float l = __int_as_float(sh.xr[a][0]), h = __int_as_float(sh.xr[3 + a][0]);
-            for (int c = 1; c < K; ++c) { l = fminf(l, __int_as_float(sh.xr[a][c])); h = fmaxf(h, __int_as_float(sh.xr[3 + a][c])); }
-            glo[a] = l; ghi[a] = h;
-        }
-        const PfGrid grid = pf_make_grid(glo, ghi);
-        // (B) my histogram, then everybody's
-        for (int k0 = s_beg + tid; k0 < s_end; k0 += 8 * PF_THREADS) {
-            float v[8][3];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u * PF_THREADS;
-                const int kk = k < s_end ? k : k0;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) v[u][a] = xyz[(size_t)kk * 3 + a];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (k0 + u * PF_THREADS < s_end) atomicAdd(&sh.hist[pf_cell_key(grid, v[u][0], v[u][1], v[u][2])], 1);
-        }
-        __syncthreads();
-        constexpr int PER = PF_BINS / PF_THREADS;
-        for (int i = 0; i < PER; ++i) ghist[(size_t)cu * PF_BINS + i * PF_THREADS + tid] = sh.hist[i * PF_THREADS + tid];
-        flag_and_wait(0, 2u);
-        {   // exclusive prefix sum over the cells of the summed histograms, plus what the workgroups before me put in each cell
-            int loc[PER], before[PER], sum = 0;
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                int tot = 0, bef = 0;
-                for (int c = 0; c < K; ++c) {
-                    const int h = ghist[(size_t)c * PF_BINS + tid * PER + i];
-                    tot += h;
-                    bef += c < cu ? h : 0;
-                }
-                loc[i] = tot; before[i] = bef; sum += tot;
-            }
-            int incl = sum;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int v = __shfl_up(incl, o);
-                if (lane >= o) incl += v;
-            }
-            if (lane == 63) sh.wsum[wave] = incl;
-            __syncthreads();
-            int base = 0;
-            for (int w = 0; w < wave; ++w) base += sh.wsum[w];
-            int run = base + incl - sum;
-#pragma unroll
-            for (int i = 0; i < PER; ++i) { sh.hist[tid * PER + i] = run + before[i]; run += loc[i]; }
-        }
-        __syncthreads();
-        // (C) scatter my points
-        for (int k0 = s_beg + tid; k0 < s_end; k0 += 8 * PF_THREADS) {
-            float v[8][3], tv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u * PF_THREADS;
-                const int kk = k < s_end ? k : k0;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) v[u][a] = xyz[(size_t)kk * 3 + a];
-                tv[u] = temp ? temp[kk] : 1e10f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u * PF_THREADS;
-                if (k < s_end) {
-                    const int pos = atomicAdd(&sh.hist[pf_cell_key(grid, v[u][0], v[u][1], v[u][2])], 1);
-                    sx[pos] = v[u][0]; sy[pos] = v[u][1]; sz[pos] = v[u][2]; st[pos] = tv[u];
-                    srk[pos] = (int)pf_rank((unsigned)k, bs, l2, rb);
-                }
-            }
-        }
-        if (cu == 0)
-            for (int p = n + tid; p < npad; p += PF_THREADS) {  // padding: never inside a box, distance stays -1, worst rank
-                sx[p] = NAN; sy[p] = NAN; sz[p] = NAN; st[p] = -1.f; srk[p] = 0x0FFFFFFF;
-            }
-        flag_and_wait(1, 3u);
-    }
+    pc_sort_split(sh.sort, cu, K, n, npad, bs, l2, rb, xyz, temp, xg, sx, sy, sz, st, srk, true);
 
     // ------------------------------------------------------------------ bucket metadata
     // bucket g = v * nwaves + gwave is slot v of this wave: row v / 64, lane v % 64
@@ -586,7 +419,7 @@ int launch_fps_pruned_cluster(int b, int K, int T, int n, int m, const float *da
     if (rows > 8) return -1;
     // the exchange areas start zeroed (tags of an earlier launch must not be mistaken for this one's)
     hipError_t e = hipMemset2DAsync(work + (size_t)5 * npad, (size_t)stride * sizeof(float), 0,
-                                    fps_cluster_exchange_floats() * sizeof(float), (size_t)b, st);
+                                    (size_t)PC_GRANULES * 8, (size_t)b, st);   // (the granules; the histograms behind them are written before they are read)
     if (e != hipSuccess) return fail(SPS_ERR_LAUNCH, "fps(cluster): hipMemset2DAsync: %s", hipGetErrorString(e));
     dim3 grid(8 * K * divup(b, 8)), block(PF_THREADS);
 #define SPS_PC_CASE(RW)                                                                                                \

@@ -1,0 +1,200 @@
+// fps_sort_split.h -- the spatial counting sort of the pruned FPS kernels, split over the K workgroups of a scene
+// (fps_pruned_cluster.hip: the K workgroups that go on to sample the scene; fps_presort.hip: a pre-pass in front of the
+// register-resident kernel).
+//
+// Workgroup c owns the points [n c / K, n (c+1) / K): (A) every workgroup takes the bounding box of the same strided sample
+// of the cloud; (B) its cell histogram -> ghist[c][.] in the workspace (write-through stores + flag); everybody adds the K
+// histograms up (exclusive scan over the cells + the counts of the workgroups before it = its own first slot in every cell);
+// (C) it scatters its points {x, y, z, running distance, rank} with LDS atomics on those slots; optionally release + flag
+// again so that every workgroup may read the whole sorted scene.  The order inside a cell is as arbitrary as with one
+// workgroup's atomics and as irrelevant (ties are decided by rank).  The exchange area must be zeroed before the launch;
+// all K workgroups of a scene must be resident at once (they spin on each other, bounded: a stuck exchange traps).
+#pragma once
+#include "fps_pruned_util.h"
+
+namespace sps {
+
+constexpr int PC_MAXK = 8;        // workgroups per scene
+constexpr int PC_MAXT = 8;        // records a workgroup publishes per round (fps_pruned_cluster.hip)
+constexpr int PC_MAXR = 32;       // records per round (K T) at most: two lanes per record in the acceptance
+// the exchange area in 8-byte granules: [8 ..): the rounds' records [parity][record][field]; the sort's bounding boxes [K][6];
+// its two rounds of flags [2][K]; behind the granules the K cell histograms of the sort (ints)
+constexpr int PC_BOX_AT = 8 + 2 * PC_MAXR * 6;
+constexpr int PC_FLAG_AT = PC_BOX_AT + PC_MAXK * 6;
+constexpr int PC_GRANULES = PC_FLAG_AT + 2 * PC_MAXK + 8;
+constexpr unsigned PC_SPIN_LIMIT = 1u << 24;          // polls before a stuck exchange traps (~ seconds)
+
+__device__ __forceinline__ void granule_store(unsigned long long *p, int value, unsigned tag) {
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long granule_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// LDS the sort needs (a member of the caller's shared struct)
+struct PcSortShared {
+    int hist[PF_BINS];
+    float red[6][PF_WAVES];
+    int wsum[PF_WAVES];
+};
+
+// xg: the scene's exchange area; sx .. srk: the scene's sorted arrays (npad entries each); hand_over: every workgroup
+// waits until ALL of them have scattered (needed when they go on to read each other's points in the same launch)
+__device__ __forceinline__ void pc_sort_split(PcSortShared &sh, int cu, int K, int n, int npad, int bs, int l2, int rb,
+                                              const float *__restrict__ xyz, const float *__restrict__ temp,
+                                              unsigned long long *xg, float *sx, float *sy, float *sz, float *st, int *srk,
+                                              bool hand_over) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        unsigned long long *xflag = xg + PC_FLAG_AT;
+        int *ghist = reinterpret_cast<int *>(xg + PC_GRANULES);
+        const int s_beg = (int)((long long)n * cu / K), s_end = (int)((long long)n * (cu + 1) / K);
+        auto flag_and_wait = [&](int slot, unsigned tg) {   // my stores -> visible; then wait for everybody's
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                granule_store(xflag + slot * PC_MAXK + cu, 1, tg);
+            }
+            if (wave == 0) {
+                if (lane < K) {
+                    unsigned spins = 0;
+                    while ((unsigned)(granule_load(xflag + slot * PC_MAXK + lane) >> 32) != tg) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > PC_SPIN_LIMIT) __builtin_trap();
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();   // (this CU's vector L1 is invalidated: plain loads of the others' stores from here on)
+        };
+        // (A) bounding box of every K-th point, computed by every workgroup for itself (no exchange): the box only shapes the
+        // sort cells -- keys are clamped into it, and no result depends on how good the sort is -- and a strided sample sees the
+        // whole index range whatever order the cloud comes in
+        float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
+        const int nsample = (n + K - 1) / K;
+        for (int k0 = tid; k0 < nsample; k0 += 8 * PF_THREADS) {
+            float v[8][3];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * PF_THREADS;
+                const size_t kk = (size_t)(k < nsample ? k : k0) * K;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) v[u][a] = xyz[kk * 3 + a];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { lo3[a] = fminf(lo3[a], v[u][a]); hi3[a] = fmaxf(hi3[a], v[u][a]); }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo3[a] = wave_allmin_f32(lo3[a]);
+            hi3[a] = wave_allmax_f32(hi3[a]);
+            if (lane == 0) { sh.red[a][wave] = lo3[a]; sh.red[3 + a][wave] = hi3[a]; }
+        }
+        for (int i = tid; i < PF_BINS; i += PF_THREADS) sh.hist[i] = 0;
+        __syncthreads();
+        float glo[3], ghi[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float l = sh.red[a][0], h = sh.red[3 + a][0];
+#pragma unroll
+            for (int w = 1; w < PF_WAVES; ++w) { l = fminf(l, sh.red[a][w]); h = fmaxf(h, sh.red[3 + a][w]); }
+            glo[a] = l; ghi[a] = h;
+        }
+        const PfGrid grid = pf_make_grid(glo, ghi);
+        // (B) my histogram, then everybody's
+        for (int k0 = s_beg + tid; k0 < s_end; k0 += 8 * PF_THREADS) {
+            float v[8][3];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * PF_THREADS;
+                const int kk = k < s_end ? k : k0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) v[u][a] = xyz[(size_t)kk * 3 + a];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + u * PF_THREADS < s_end) atomicAdd(&sh.hist[pf_cell_key(grid, v[u][0], v[u][1], v[u][2])], 1);
+        }
+        __syncthreads();
+        constexpr int PER = PF_BINS / PF_THREADS;
+        // write-through (sc1) stores, drained by every wave, the workgroup's barrier, then the flag; the readers poll the K
+        // flags and read with sc1 loads -- no L2 write-back / L1 invalidate on either side (MI355X_MICROARCH.md, hand-offs
+        // measured with sc1 loads in place of the acquire)
+        for (int i = 0; i < PER; ++i)
+            __hip_atomic_store(&ghist[(size_t)cu * PF_BINS + i * PF_THREADS + tid], sh.hist[i * PF_THREADS + tid], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) granule_store(xflag + cu, 1, 2u);
+        if (wave == 0 && lane < K) {
+            unsigned spins = 0;
+            while ((unsigned)(granule_load(xflag + lane) >> 32) != 2u) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > PC_SPIN_LIMIT) __builtin_trap();
+            }
+        }
+        __syncthreads();
+        {   // exclusive prefix sum over the cells of the summed histograms, plus what the workgroups before me put in each cell
+            int loc[PER], before[PER], sum = 0;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                int tot = 0, bef = 0;
+                for (int c = 0; c < K; ++c) {
+                    const int h = __hip_atomic_load(&ghist[(size_t)c * PF_BINS + tid * PER + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    tot += h;
+                    bef += c < cu ? h : 0;
+                }
+                loc[i] = tot; before[i] = bef; sum += tot;
+            }
+            int incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            if (lane == 63) sh.wsum[wave] = incl;
+            __syncthreads();
+            int base = 0;
+            for (int w = 0; w < wave; ++w) base += sh.wsum[w];
+            int run = base + incl - sum;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) { sh.hist[tid * PER + i] = run + before[i]; run += loc[i]; }
+        }
+        __syncthreads();
+        // (C) scatter my points
+        for (int k0 = s_beg + tid; k0 < s_end; k0 += 8 * PF_THREADS) {
+            float v[8][3], tv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * PF_THREADS;
+                const int kk = k < s_end ? k : k0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) v[u][a] = xyz[(size_t)kk * 3 + a];
+                tv[u] = temp ? temp[kk] : 1e10f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * PF_THREADS;
+                if (k < s_end) {
+                    const int pos = atomicAdd(&sh.hist[pf_cell_key(grid, v[u][0], v[u][1], v[u][2])], 1);
+                    sx[pos] = v[u][0]; sy[pos] = v[u][1]; sz[pos] = v[u][2]; st[pos] = tv[u];
+                    srk[pos] = (int)pf_rank((unsigned)k, bs, l2, rb);
+                }
+            }
+        }
+        if (cu == 0)
+            for (int p = n + tid; p < npad; p += PF_THREADS) {  // padding: never inside a box, distance stays -1, worst rank
+                sx[p] = NAN; sy[p] = NAN; sz[p] = NAN; st[p] = -1.f; srk[p] = 0x0FFFFFFF;
+            }
+        if (hand_over) flag_and_wait(1, 3u);
+    }
+}
+
+}  // namespace sps
+

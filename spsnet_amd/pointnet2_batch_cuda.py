@@ -11,6 +11,8 @@ Differences from the reference, both deliberate:
   * a failed check or launch raises (TypeError / ValueError / SpsError) instead of exit(-1);
   * kernels run on torch's *current* stream rather than the legacy default stream.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -66,7 +68,9 @@ def farthest_point_sampling_wrapper(b, n, m, points_tensor, temp_tensor, idx_ten
     _need(points_tensor, b * n * 3, "points"); _need(temp_tensor, b * n, "temp"); _need(idx_tensor, b * m, "idx")
     # scenes too large for the register-resident kernel (16 384 < n <= 262 144) take the pruned large-scene kernel,
     # which sorts the points into a workspace (20 B per point) -- torch's caching allocator hands it out
-    work_floats = int(_L.sps_fps_workspace_floats(n)) if m > 1 else 0
+    # (6144 .. 16 384 points: a workspace would select the sorting pre-pass; measured, it pays for the publishing kernel of the
+    #  streamed layer only -- 8 x 16 384 -> 4 096 through this wrapper 1.790 ms without, 1.813 ms with)
+    work_floats = int(_L.sps_fps_workspace_floats(n)) if m > 1 and n > 16384 else 0
     with _on(points_tensor):
         if work_floats:
             work = torch.empty((b * work_floats,), dtype=F32, device=points_tensor.device)
@@ -404,6 +408,9 @@ def current_stream_handle(t):
     return _stream(t)
 
 
+# sort the scenes of the register-resident PUBLISHING FPS (streamed first layer) in a pre-pass of 8 workgroups per scene
+# (fps_presort.hip): 2.219 -> 2.194 ms per pass at the bench shape
+PRESORT = os.environ.get("SPS_FPS_PRESORT", "1") != "0"
 ORDERED_PREFIX_MAX = 7168   # centres the identity-prefix verification stages in LDS (fps_verify.hip FV_MAX_M)
 
 
@@ -415,8 +422,9 @@ def fps_publish(xyz, temp, idx, progress):
     B, N, _ = xyz.shape
     tp = 0 if temp is None else _ptr(temp, F32, "temp")
     with _on(xyz):
-        if N > 16384:
-            work = torch.empty((B * int(_L.sps_fps_workspace_floats(N)),), dtype=F32, device=xyz.device)
+        wf = int(_L.sps_fps_workspace_floats(N))
+        if wf > 0 and (N > 16384 or PRESORT):   # large scenes: sorted points; 6144 .. 16 384: the sorting pre-pass's output
+            work = torch.empty((B * wf,), dtype=F32, device=xyz.device)
             _lib.check(_L.sps_fps_publish_ws(B, N, idx.shape[1], _ptr(xyz, F32, "xyz"), tp, _ptr(idx, I32, "idx"),
                                              _ptr(progress, I32, "progress"), work.data_ptr(), _stream(xyz)), "fps_publish")
             return work

@@ -1080,6 +1080,29 @@ def test_fps_large_scene_kernel(ext, G, oracle, N, m, kind, cluster, monkeypatch
         np.testing.assert_array_equal(got_t, want_t)
 
 
+@pytest.mark.parametrize("N,m,B", [(16384, 1024, 3), (7000, 700, 2), (12000, 12000, 1), (16384, 300, 9)])
+def test_fps_presorted_register_kernel(ext, G, oracle, N, m, B):
+    """fps_presort.hip + the PRESORT instantiation of fps_pruned_kernel (the scenes sorted by a pre-pass of K workgroups per
+    scene, K = 8 / 4 by batch size): sps_fps_with_workspace with a workspace at 6144 .. 16 384 points against the oracle --
+    indices and final running distances bit-exact; duplicates and a lattice scene (exact ties) included."""
+    from spsnet_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(N + m)
+    xyz = cloud(rng, B, N, dup=0.1)
+    xyz[0] = cloud(rng, 1, N, lattice=True)[0]
+    x = G.t(xyz)
+    temp = torch.full((B, N), 1e10, dtype=torch.float32, device=x.device)
+    idx = torch.empty((B, m), dtype=torch.int32, device=x.device)
+    wf = int(L.sps_fps_workspace_floats(N))
+    assert wf > 0
+    work = torch.empty((B * wf,), dtype=torch.float32, device=x.device)
+    _lib.check(L.sps_fps_with_workspace(B, N, m, x.data_ptr(), temp.data_ptr(), idx.data_ptr(), work.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream), "fps")
+    want, want_t = oracle.fps(xyz, m, return_temp=True)
+    np.testing.assert_array_equal(G.n(idx), want)
+    np.testing.assert_array_equal(G.n(temp), want_t)
+
+
 # ------------------------------------------------------------------ deterministic gradients (SURVEY 8 f-1)
 @pytest.mark.parametrize("B,C,N,M,ns", [(2, 5, 700, 96, 16), (3, 67, 4096, 1024, 32), (1, 16, 300, 300, 1), (2, 8, 64, 512, 8)])
 def test_deterministic_group_and_gather_grads(ext, G, oracle, B, C, N, M, ns):
