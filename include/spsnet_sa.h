@@ -237,10 +237,13 @@ int sps_wait_progress(const int *progress, int b, int need, int *timed_out, sps_
 int sps_wait_progress_ex(const int *progress, int b, int need, int *timed_out, int patient, sps_stream_t stream);
 int sps_gather_xyz_range(int b, int n, int m, int j0, int jcount, const float *xyz, const int *idx, float *out,
                          const int *run_if, sps_stream_t stream);
+/* gather_idx (device i32 (b, m), may be NULL; per-wave launches only): the centroids of the range are
+ * xyz[gather_idx[scene][j]] and the launch also WRITES them to new_xyz (gather_operation fused in, pointnet2_modules.py:423-424;
+ * indices are clamped into the cloud). */
 int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcount, float radius_a, int nsample_a,
                                float radius_b, int nsample_b, const float *new_xyz, const float *xyz, int *idx_a,
                                int *idx_b, int *perm_work, const int *run_if, const int *full_range_if,
-                               sps_stream_t stream);
+                               const int *gather_idx, sps_stream_t stream);
 int sps_sa_group_mlp_range(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,
                            const float *new_xyz, const float *features, const int *idx, int c1, int c2, int c3,
                            int c3_real, const float *w1, const float *b1, const float *w2, const float *b2,

@@ -94,7 +94,7 @@ _PROTOS = {
     "sps_wait_progress": [_vp, _i, _i, _vp, _vp],
     "sps_wait_progress_ex": [_vp, _i, _i, _vp, _i, _vp],
     "sps_gather_xyz_range": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
-    "sps_ball_query_full2_range": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_ball_query_full2_range": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_sa_group_mlp_range": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _i, _i, _vp],
 }

@@ -425,7 +425,10 @@ template <int C, int SEG, int UNR>
 __global__ __launch_bounds__(64 * SEG) void ball_query_wave_multi_kernel(
     int n, int m, float r2a, float r2b, int nsa, int nsb, const float *__restrict__ new_xyz,
     const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b, int jbeg,
-    const int *__restrict__ run_if, const int *__restrict__ alt) {
+    const int *__restrict__ run_if, const int *__restrict__ alt, const int *__restrict__ gather_idx) {
+    // gather_idx != NULL: the centroids are xyz[gather_idx[scene][j]] (the sampler's picks, clamped into the cloud) and this
+    // launch ALSO writes them to new_xyz -- the gather_operation between sampler and query (pointnet2_modules.py:423-424)
+    // fused in, one launch less on the critical chain of a layer
     __shared__ int hits[2][C][SEG][BQS_MAX_NS];
     __shared__ int cnt[2][C][SEG];
     if (run_if && *run_if == 0) return;
@@ -442,9 +445,18 @@ __global__ __launch_bounds__(64 * SEG) void ball_query_wave_multi_kernel(
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const float *ctr = new_xyz + ((size_t)scene * m + j0 + c) * 3;
+        if (gather_idx) {
+            int src = __builtin_amdgcn_readfirstlane(gather_idx[(size_t)scene * m + j0 + c]);
+            src = src < 0 ? 0 : (src >= n ? n - 1 : src);
+            ctr = xyz + (size_t)src * 3;
+        }
         cx[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ctr[0])));
         cy[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ctr[1])));
         cz[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ctr[2])));
+        if (gather_idx && seg == 0 && lane == 0) {
+            float *dst = const_cast<float *>(new_xyz) + ((size_t)scene * m + j0 + c) * 3;
+            dst[0] = cx[c]; dst[1] = cy[c]; dst[2] = cz[c];
+        }
     }
     const unsigned long long below = (1ull << lane) - 1ull;
     const int seg_len = ((n + SEG - 1) / SEG + 63) & ~63;
@@ -607,13 +619,13 @@ extern "C" int sps_ball_query_full2(int b, int n, int m, float radius_a, int nsa
                                     const float *new_xyz, const float *xyz, int *idx_a, int *idx_b, int *perm_work,
                                     sps_stream_t stream) {
     return sps_ball_query_full2_range(b, n, m, 0, m, radius_a, nsample_a, radius_b, nsample_b, new_xyz, xyz, idx_a, idx_b,
-                                      perm_work, nullptr, nullptr, stream);
+                                      perm_work, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcount, float radius_a, int nsample_a,
                                           float radius_b, int nsample_b, const float *new_xyz, const float *xyz,
                                           int *idx_a, int *idx_b, int *perm_work, const int *run_if, const int *full_range_if,
-                                          sps_stream_t stream) {
+                                          const int *gather_idx, sps_stream_t stream) {
     using namespace sps;
     if (b < 0 || n < 0 || m < 0 || nsample_a <= 0 || nsample_b <= 0 || j0 < 0 || jcount < 0 || j0 + jcount > m)
         return fail(SPS_ERR_INVALID, "ball_query_full2: bad shape b=%d n=%d m=%d ns=(%d,%d) range [%d,+%d)", b, n, m,
@@ -630,19 +642,23 @@ extern "C" int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcoun
     static const bool multi_ok = !(getenv("SPS_BQ_MULTI") && getenv("SPS_BQ_MULTI")[0] == '0');
     if (full_range_if && !(jcount % 4 == 0 && m % 4 == 0 && (long long)b * jcount <= BQ_WAVE_MAX_CENTROIDS && !perm_work))
         return fail(SPS_ERR_INVALID, "ball_query_full2: full_range_if needs a per-wave launch with jcount and m multiples of 4");
-    if (per_wave && (multi_ok || full_range_if) && jcount % 4 == 0 && nsample_a <= BQS_MAX_NS && nsample_b <= BQS_MAX_NS && n >= 256) {
+    if (gather_idx && !(jcount % 4 == 0 && (long long)b * jcount <= BQ_WAVE_MAX_CENTROIDS && !perm_work && n >= 256 &&
+                        nsample_a <= BQS_MAX_NS && nsample_b <= BQS_MAX_NS))
+        return fail(SPS_ERR_INVALID, "ball_query_full2: gather_idx needs a per-wave launch (range of at most %d centroids, a multiple of 4)",
+                    BQ_WAVE_MAX_CENTROIDS);
+    if (per_wave && (multi_ok || full_range_if || gather_idx) && jcount % 4 == 0 && nsample_a <= BQS_MAX_NS && nsample_b <= BQS_MAX_NS && n >= 256) {
         // four centroids per wave share every point load; the point range is split so that the launch still has waves
         const float ra2 = radius_a * radius_a, rb2 = radius_b * radius_b;
         const dim3 grid(jcount / 4, b);
         if (n >= 8192)
             hipLaunchKernelGGL((ball_query_wave_multi_kernel<4, 8, 8>), grid, dim3(64 * 8), 0, as_stream(stream), n, m, ra2, rb2,
-                               nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, j0, run_if, full_range_if);
+                               nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, j0, run_if, full_range_if, gather_idx);
         else if (n >= 2048)
             hipLaunchKernelGGL((ball_query_wave_multi_kernel<4, 4, 8>), grid, dim3(64 * 4), 0, as_stream(stream), n, m, ra2, rb2,
-                               nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, j0, run_if, full_range_if);
+                               nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, j0, run_if, full_range_if, gather_idx);
         else
             hipLaunchKernelGGL((ball_query_wave_multi_kernel<4, 4, 4>), grid, dim3(64 * 4), 0, as_stream(stream), n, m, ra2, rb2,
-                               nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, j0, run_if, full_range_if);
+                               nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, j0, run_if, full_range_if, gather_idx);
         return check_launch("ball_query_wave_multi_kernel");
     }
     if (per_wave && (long long)b * jcount <= BQ_SEG_MAX_CENTROIDS && nsample_a <= BQS_MAX_NS && nsample_b <= BQS_MAX_NS &&

@@ -472,13 +472,17 @@ def gather_xyz_range(xyz, idx, out, j0, jcount, run_if=None):
                                            _ptr(out, F32, "out"), _flag(run_if), _stream(xyz)), "gather_xyz_range")
 
 
-def ball_query_full2_range(radius_a, radius_b, xyz, new_xyz, idx_a, idx_b, j0, jcount, run_if=None, full_range_if=None):
+def ball_query_full2_range(radius_a, radius_b, xyz, new_xyz, idx_a, idx_b, j0, jcount, run_if=None, full_range_if=None,
+                           gather_idx=None):
+    """gather_idx (B, M) int32: the centroids of the range are xyz[gather_idx] and the launch writes them to new_xyz too."""
     B, N, _ = xyz.shape
     with _on(xyz):
         _lib.check(_L.sps_ball_query_full2_range(B, N, new_xyz.shape[1], j0, jcount, radius_a, idx_a.shape[2], radius_b,
                                                  idx_b.shape[2], _ptr(new_xyz, F32, "new_xyz"), _ptr(xyz, F32, "xyz"),
                                                  _ptr(idx_a, I32, "idx_a"), _ptr(idx_b, I32, "idx_b"), 0, _flag(run_if),
-                                                 _flag(full_range_if), _stream(xyz)), "ball_query_full2_range")
+                                                 _flag(full_range_if),
+                                                 0 if gather_idx is None else _ptr(gather_idx, I32, "gather_idx"),
+                                                 _stream(xyz)), "ball_query_full2_range")
 
 
 def gather_xyz(xyz, idx):

@@ -9,6 +9,8 @@ Only the SA layers are built -- heads, losses and the voting branch stay out of 
 import copy
 from typing import List, Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -70,6 +72,7 @@ def build_sa_layers(modules_pkg, cfg=IASSD_KITTI, input_channels=4, num_class=3,
 
 
 HYBRID = False          # see _streamed_first_layer
+FUSE_GATHER = os.environ.get("SPS_FUSE_GATHER", "1") != "0"   # streamed chunks: the ball query gathers its own centroids
 _SIDE_STREAMS = {}
 _FENCES = {}          # (device index, main stream handle) -> CuFence
 
@@ -297,21 +300,28 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
         chunk = j1 - j0
         if wait:
             _ext.wait_progress(progress, j1, timed_out, patient=(j1 == M))
-        _ext.gather_xyz_range(xyz, idx, new_xyz, j0, chunk)
-        if verify is not None and j0 < verify.npoint <= j1:
-            verify.begin()
-        if j1 == M:
-            # every sample exists now: centroids that an earlier, timed-out wait let through are gathered again before
-            # anybody else looks at them (a launch that does nothing otherwise)
-            _ext.gather_xyz_range(xyz, idx, new_xyz, 0, M, run_if=timed_out)
-            xyz_ready = torch.cuda.Event()
-            xyz_ready.record(torch.cuda.current_stream(dev))
         # Correct or redo, never invalid: the waits are bounded (a producer that stalls must not hang the device); one that
         # gave up let its consumers run on samples that had not been written.  The LAST chunk -- behind the patient wait, or
         # behind the producer itself -- therefore covers the whole layer when a flag is up (full_range_if: the kernels read
         # it and widen their range; no extra launch, nothing changes when every wait was served).
         repair = timed_out if (j1 == M and self_repair) else None
-        _ext.ball_query_full2_range(ga.radius, gb.radius, xyz, new_xyz, idx_a, idx_b, j0, chunk, full_range_if=repair)
+        if fuse_gather:
+            # the ball query gathers its centroids itself (and writes new_xyz): one launch less per chunk -- and in the last
+            # chunk the widened range re-gathers every centroid, so the predicated repair gather goes too
+            _ext.ball_query_full2_range(ga.radius, gb.radius, xyz, new_xyz, idx_a, idx_b, j0, chunk, full_range_if=repair,
+                                        gather_idx=idx)
+        else:
+            _ext.gather_xyz_range(xyz, idx, new_xyz, j0, chunk)
+            if j1 == M:
+                # every sample exists now: centroids that an earlier, timed-out wait let through are gathered again before
+                # anybody else looks at them (a launch that does nothing otherwise)
+                _ext.gather_xyz_range(xyz, idx, new_xyz, 0, M, run_if=timed_out)
+            _ext.ball_query_full2_range(ga.radius, gb.radius, xyz, new_xyz, idx_a, idx_b, j0, chunk, full_range_if=repair)
+        if verify is not None and j0 < verify.npoint <= j1:
+            verify.begin()
+        if j1 == M:
+            xyz_ready = torch.cuda.Event()
+            xyz_ready.record(torch.cuda.current_stream(dev))
         off = 0
         for ix, packed in zip((idx_a, idx_b), plan):
             _fused.group_mlp_pool(xyz, new_xyz, features, ix, packed, out, off, j0, chunk, full_range_if=repair)
@@ -324,6 +334,7 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
     # zeroed again, which takes the separate predicated launches of _redo_layer
     self_repair = max(ga.nsample, gb.nsample) <= 32
     bounds = list(zip([0] + ends[:-1], ends))
+    fuse_gather = FUSE_GATHER and self_repair and N >= 256 and all((j1 - j0) % 4 == 0 and B * (j1 - j0) <= 8192 for j0, j1 in bounds)
     with torch.cuda.stream(side):                        # the chunks that run beside the producer
         if side is not main:
             side.wait_event(start)
