@@ -112,15 +112,17 @@ class FpsProbe:
         self.pairs.append((s, e, b, n, m))
         return r
 
-    def publish(self, xyz, temp, idx, progress):
-        """Same probe around the publishing launch used by the streamed first layer (same kernel, same stream)."""
+    def publish(self, xyz, temp, idx, progress, **kw):
+        """Same probe around the publishing launch used by the streamed first layer (same stream; the bracket holds the
+        producer's sorting pre-pass too, where one is used: the figure is the whole producer, not the kernel alone)."""
         if not (self.on and xyz.shape[1] == self.n):
-            return self.orig_publish(xyz, temp, idx, progress)
+            return self.orig_publish(xyz, temp, idx, progress, **kw)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        self.orig_publish(xyz, temp, idx, progress)
+        work = self.orig_publish(xyz, temp, idx, progress, **kw)
         e.record()
         self.pairs.append((s, e, xyz.shape[0], xyz.shape[1], idx.shape[1]))
+        return work
 
     def summary(self):
         if not self.pairs:

@@ -414,16 +414,17 @@ PRESORT = os.environ.get("SPS_FPS_PRESORT", "1") != "0"
 ORDERED_PREFIX_MAX = 7168   # centres the identity-prefix verification stages in LDS (fps_verify.hip FV_MAX_M)
 
 
-def fps_publish(xyz, temp, idx, progress):
+def fps_publish(xyz, temp, idx, progress, presort=True):
     """Launch the publishing FPS (sps_fps_publish / sps_fps_publish_ws) on the current stream; all tensors are
     caller-allocated.  temp = None: the running distances start at 1e10 and are not handed back (no fill launch in front of
     the producer).  Scenes of more than 16 384 points take the clustered large-scene kernel, whose workspace is returned
-    (keep it alive until the producer has finished; record_stream it)."""
+    (keep it alive until the producer has finished; record_stream it).  presort=False: no sorting pre-pass for scenes of
+    up to 16 384 points (its workgroups spin on each other and must all be resident: not on a CU-masked stream)."""
     B, N, _ = xyz.shape
     tp = 0 if temp is None else _ptr(temp, F32, "temp")
     with _on(xyz):
         wf = int(_L.sps_fps_workspace_floats(N))
-        if wf > 0 and (N > 16384 or PRESORT):   # large scenes: sorted points; 6144 .. 16 384: the sorting pre-pass's output
+        if wf > 0 and (N > 16384 or (PRESORT and presort)):   # large scenes: sorted points; 6144 .. 16 384: the sorting pre-pass's output
             work = torch.empty((B * wf,), dtype=F32, device=xyz.device)
             _lib.check(_L.sps_fps_publish_ws(B, N, idx.shape[1], _ptr(xyz, F32, "xyz"), tp, _ptr(idx, I32, "idx"),
                                              _ptr(progress, I32, "progress"), work.data_ptr(), _stream(xyz)), "fps_publish")

@@ -245,6 +245,7 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
     #   HYBRID    the producer on the caller's stream, the chunks that overlap it on a helper stream, the last chunk back on
     #             the caller's stream in order behind the producer (no wait kernel, no live dependency).  Measured SLOWER,
     #             2.296 ms: the last chunk then starts at the producer kernel's end instead of at its last published sample.
+    masked = fps_stream is not None                      # a CuFence stream: a few compute units only
     if fps_stream is None and not HYBRID:
         fps_stream = _helper_stream(dev, "producer")
     fenced = fps_stream is not None
@@ -276,7 +277,9 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
     else:
         fps_stream.wait_event(start)
         with torch.cuda.stream(fps_stream):
-            work = _ext.fps_publish(xyz, temp, idx, progress)   # (large scenes: the sorted-point workspace)
+            # (the workspace of the sorting pre-pass / of the large-scene kernel; no pre-pass on a CU-masked stream: its
+            #  workgroups spin on each other and must all be resident)
+            work = _ext.fps_publish(xyz, temp, idx, progress, presort=not masked)
         for t in (xyz, idx, progress) + (() if work is None else (work,)):
             t.record_stream(fps_stream)
     if after_producer is not None:
