@@ -798,6 +798,25 @@ def test_ball_query_dual_radius(ext, G, oracle, N, M, ra, nsa, rb, nsb):
         np.testing.assert_array_equal(G.n(ib), oracle.ball_query(rb, nsb, xyz, new_xyz))
 
 
+def test_fenced_passes_in_flight_equal_sequential(ext, G, dev):
+    """Two passes in flight on streams whose FPS producers are fenced onto compute units of their own (sa_stack.CuFence /
+    pipelined_bench, hipExtStreamCreateWithCUMask): every output of the last pass bit-identical to a sequential,
+    unstreamed pass; no wait timed out.  (The producers' sorting pre-pass must stay off the masked streams.)"""
+    from spsnet_amd import pointnet2_modules as M, sa_stack, scenes
+    layers = sa_stack.build_sa_layers(M, sa_stack.IASSD_KITTI, seed=4).to(dev)
+    xyz, feats = scenes.make_batch("kitti-lidar-v1", 4, 16384, seed0=51)
+    x, f = G.t(xyz), G.t(feats)
+    with torch.no_grad():
+        want = sa_stack.run_sa_layers(layers, x, f, overlap=False, stream_first_layer=False)
+        res = sa_stack.pipelined_bench(lambda: sa_stack.run_sa_layers(layers, x, f), 6, torch.device(dev), in_flight=2, scenes=4)
+    torch.cuda.synchronize()
+    assert not sa_stack.check_timeouts()
+    for a, b in zip(res["last_outputs"], want):
+        for u, v in zip(a[:4], b[:4]):
+            if u is not None:
+                assert torch.equal(u, v)
+
+
 @pytest.mark.parametrize("with_stds", [False, True])
 def test_streamed_first_layer_equals_sequential(ext, G, dev, with_stds):
     """Layer 0 with its grouping/MLP consuming the FPS output while FPS runs (progress hand-off) against the plain
