@@ -854,6 +854,31 @@ def test_streamed_first_layer_equals_sequential(ext, G, dev, with_stds):
                 assert torch.equal(ta, tb)
 
 
+@pytest.mark.parametrize("B,N,npts,ns", [(2, 40000, [4096, 1024, 256], None), (3, 70000, [8192, 2048, 512], [(64, 64)] * 3),
+                                         (10, 20000, [2048, 512, 128], None)])
+def test_streamed_large_scenes_equal_sequential(ext, G, dev, B, N, npts, ns):
+    """Scenes beyond 16 384 points: layer 0 streamed behind the PUBLISHING clustered FPS (fps_pruned_cluster.hip, K = 8 / 4
+    workgroups per scene by batch size; nsample 16 & 32 with the self-repairing last chunk, nsample 64 with the predicated
+    re-issue) and the next layer's D-FPS as a verified identity prefix of up to 7168 centres -- against the sequential,
+    unstreamed schedule: every output of every layer bit-identical, twice, allocator poisoned, no wait timed out."""
+    from spsnet_amd import pointnet2_modules as M, sa_stack, scenes
+    layers = sa_stack.build_sa_layers(M, sa_stack.scaled_config(npoints=npts, nsamples=ns), seed=9).to(dev)
+    xyz, feats = scenes.make_batch("kitti-lidar-v1", B, N, seed0=41, dup_fraction=0.01)
+    x, f = G.t(xyz), G.t(feats)
+    with torch.no_grad():
+        want = sa_stack.run_sa_layers(layers, x, f, overlap=False, stream_first_layer=False)
+        for rep in range(2):
+            junk_i = torch.full((32 << 20,), 1 + rep, dtype=torch.int32, device=dev)
+            junk_f = torch.full((32 << 20,), 0.5 + rep, dtype=torch.float32, device=dev)
+            del junk_i, junk_f
+            got = sa_stack.run_sa_layers(layers, x, f, stream_first_layer=True)
+            torch.cuda.synchronize()
+            assert not sa_stack.check_timeouts()
+            for la, lb in zip(got, want):
+                for ta, tb in zip(la, lb):
+                    assert (ta is None and tb is None) or torch.equal(ta, tb), f"repetition {rep}"
+
+
 @pytest.mark.parametrize("npts,ns,half", [(None, None, False), ([2048, 512, 128], [(64, 64)] * 3, False),
                                           ([2048, 512, 128], [(64, 64)] * 3, True)])
 def test_streamed_first_layer_first_call_of_fresh_modules(G, dev, npts, ns, half):
@@ -1059,7 +1084,8 @@ def test_ball_query_range_small_launch_kernels(ext, G, oracle, N, M, j0, cnt, ra
 # ------------------------------------------------------------------ pruned FPS for scenes beyond one CU's registers
 @pytest.mark.parametrize("cluster", ["1", "", "2,8", "4,5", "3,8", "8,1"])
 @pytest.mark.parametrize("N,m,kind", [(20000, 700, "lattice"), (40000, 2000, "dup"), (65536, 4096, "kitti"),
-                                      (70001, 1500, "uniform"), (180000, 2500, "kitti"), (16385, 16385, "dup")])
+                                      (70001, 1500, "uniform"), (180000, 2500, "kitti"), (16385, 16385, "dup"),
+                                      (30000, 900, "batch11")])
 def test_fps_large_scene_kernel(ext, G, oracle, N, m, kind, cluster, monkeypatch):
     """fps_pruned_big.hip (points in a workspace, bucket metadata in registers, several picks per barrier) and
     fps_pruned_cluster.hip (the same scene spread over K workgroups that exchange their T best records per round)
@@ -1081,6 +1107,8 @@ def test_fps_large_scene_kernel(ext, G, oracle, N, m, kind, cluster, monkeypatch
         xyz, _ = scenes.make_batch("kitti-lidar-v1", 2 if N < 100000 else 1, N, seed0=21, dup_fraction=0.01)
     elif kind == "uniform":
         xyz, _ = scenes.make_batch("uniform-v1", 2, N, seed0=22)
+    elif kind == "batch11":   # more than 8 scenes: the second block of 8 K workgroups, K halved by the residency rule
+        xyz, _ = scenes.make_batch("kitti-lidar-v1", 11, N, seed0=23)
     else:
         xyz = cloud(rng, 2, N, dup=0.2)
     L = _lib.load()
