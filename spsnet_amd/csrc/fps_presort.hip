@@ -13,10 +13,14 @@ namespace sps {
 // work: per scene `stride` floats: 5 arrays of npad elements (x, y, z, t, rank), then the exchange area (zeroed by the launcher)
 __global__ __launch_bounds__(PF_THREADS) void fps_presort_kernel(int b, int K, int n, int bs, int l2, int rb, int npad,
                                                                  long long stride, const float *__restrict__ dataset,
-                                                                 const float *__restrict__ temp, float *__restrict__ work) {
+                                                                 const float *__restrict__ temp, float *__restrict__ work,
+                                                                 int spread) {
     __shared__ PcSortShared sh;
     // blocks s, s + 8, s + 16, ... share an XCD (observed dispatch order): a scene's K workgroups sit on one L2
-    const int scene = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * K)), cu = (blockIdx.x >> 3) % K;
+    // (spread: DIAGNOSTIC mapping that puts a scene's workgroups on consecutive blocks = different XCDs; tests run the
+    //  cross-XCD form of every exchange with it)
+    const int scene = spread ? (int)blockIdx.x / K : (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * K));
+    const int cu = spread ? (int)blockIdx.x % K : (blockIdx.x >> 3) % K;
     if (scene >= b) return;
     const float *xyz = dataset + (size_t)scene * n * 3;
     if (temp) temp += (size_t)scene * n;
@@ -27,6 +31,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_presort_kernel(int b, int K, i
 }
 
 size_t fps_cluster_exchange_floats();   // fps_pruned_cluster.hip
+int fps_cluster_spread();
 
 // sorted scenes -> work (b * stride floats); temp may be NULL (all running distances 1e10)
 int launch_fps_presort(int b, int n, const float *dataset, const float *temp, float *work, long long stride, hipStream_t st) {
@@ -43,7 +48,7 @@ int launch_fps_presort(int b, int n, const float *dataset, const float *temp, fl
                                     (size_t)PC_GRANULES * 8, (size_t)b, st);   // (the granules; the histograms behind them are written before they are read)
     if (e != hipSuccess) return fail(SPS_ERR_LAUNCH, "fps(presort): hipMemset2DAsync: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(fps_presort_kernel, dim3(8 * K * divup(b, 8)), dim3(PF_THREADS), 0, st, b, K, n, bs, l2, rb, npad, stride,
-                       dataset, temp, work);
+                       dataset, temp, work, fps_cluster_spread());
     return check_launch("fps_presort_kernel");
 }
 

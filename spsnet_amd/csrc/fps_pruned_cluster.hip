@@ -23,6 +23,7 @@
 // (a CU each; the polls are bounded -- a stuck exchange traps instead of hanging the device).
 #include "fps_sort_split.h"
 
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -54,14 +55,18 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
                                                                         int npad, long long stride,
                                                                         const float *__restrict__ dataset,
                                                                         float *__restrict__ temp, int *__restrict__ idxs,
-                                                                        float *__restrict__ work, int *__restrict__ progress) {
+                                                                        float *__restrict__ work, int *__restrict__ progress,
+                                                                        int spread) {
     // progress != NULL: consumers on other CUs read idxs while this kernel runs (sa_stack's streamed first layer) -- picks
     // are stored write-through and progress[scene] counts the published ones (every 64 picks; fps_pruned.hip's protocol).
     // temp may then be NULL: all running distances start at 1e10 and are not handed back.
     if (m <= 0) return;
     __shared__ PcShared sh;
     // blocks s, s + 8, s + 16, ... share an XCD (observed dispatch order): a scene's K workgroups sit on one L2
-    const int scene = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * K)), cu = (blockIdx.x >> 3) % K;
+    // (spread: DIAGNOSTIC mapping that puts a scene's workgroups on consecutive blocks = different XCDs; tests run the
+    //  cross-XCD form of every exchange with it)
+    const int scene = spread ? (int)blockIdx.x / K : (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * K));
+    const int cu = spread ? (int)blockIdx.x % K : (blockIdx.x >> 3) % K;
     if (scene >= b) return;
     const float *xyz = dataset + (size_t)scene * n * 3;
     if (temp) temp += (size_t)scene * n;
@@ -405,6 +410,12 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
 // floats of the exchange area behind a scene's 5 npad workspace floats
 size_t fps_cluster_exchange_floats() { return (size_t)2 * PC_GRANULES + (size_t)PC_MAXK * PF_BINS; }
 
+// SPS_FPS_CLUSTER_SPREAD=1 (read per launch): the diagnostic block mapping
+int fps_cluster_spread() {
+    const char *e = getenv("SPS_FPS_CLUSTER_SPREAD");
+    return e && *e && *e != '0';
+}
+
 // K workgroups per scene publishing T records each; -1: shape not served
 int launch_fps_pruned_cluster(int b, int K, int T, int n, int m, const float *dataset, float *temp, int *idxs, float *work,
                               long long stride, int *progress, hipStream_t st) {
@@ -425,7 +436,7 @@ int launch_fps_pruned_cluster(int b, int K, int T, int n, int m, const float *da
 #define SPS_PC_CASE(RW)                                                                                                \
     if (rows <= RW) {                                                                                                  \
         hipLaunchKernelGGL((fps_pruned_cluster_kernel<RW>), grid, block, 0, st, b, K, T, n, m, bs, l2, rb, npad, stride, \
-                           dataset, temp, idxs, work, progress);                                                       \
+                           dataset, temp, idxs, work, progress, fps_cluster_spread());                                 \
         return check_launch("fps_pruned_cluster_kernel");                                                             \
     }
     SPS_PC_CASE(1)

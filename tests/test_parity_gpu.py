@@ -1127,6 +1127,28 @@ def test_fps_large_scene_kernel(ext, G, oracle, N, m, kind, cluster, monkeypatch
         np.testing.assert_array_equal(got_t, want_t)
 
 
+@pytest.mark.parametrize("N,m,B", [(50000, 3000, 2), (16384, 512, 3)])
+def test_fps_workgroup_exchanges_across_xcds(ext, G, oracle, N, m, B, monkeypatch):
+    """SPS_FPS_CLUSTER_SPREAD=1 deals a scene's workgroups onto consecutive blocks = different XCDs (by default they share
+    one): the record granules, the histogram exchange (write-through stores + sc1 loads) and the release / acquire hand-over
+    of the sorted points then cross XCDs.  Clustered large-scene kernel and the sorting pre-pass, against the oracle."""
+    from spsnet_amd import _lib, scenes
+    monkeypatch.setenv("SPS_FPS_CLUSTER_SPREAD", "1")
+    L = _lib.load()
+    xyz, _ = scenes.make_batch("kitti-lidar-v1", B, N, seed0=61, dup_fraction=0.02)
+    x = G.t(xyz)
+    temp = torch.full((B, N), 1e10, dtype=torch.float32, device=x.device)
+    idx = torch.empty((B, m), dtype=torch.int32, device=x.device)
+    work = torch.empty((B * int(L.sps_fps_workspace_floats(N)),), dtype=torch.float32, device=x.device)
+    for rep in range(3):   # (the workspace is reused: stale tags and histograms of the previous launch are in it)
+        temp.fill_(1e10)
+        _lib.check(L.sps_fps_with_workspace(B, N, m, x.data_ptr(), temp.data_ptr(), idx.data_ptr(), work.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream), "fps")
+        want, want_t = oracle.fps(xyz, m, return_temp=True)
+        np.testing.assert_array_equal(G.n(idx), want)
+        np.testing.assert_array_equal(G.n(temp), want_t)
+
+
 @pytest.mark.parametrize("N,m,B", [(16384, 1024, 3), (7000, 700, 2), (12000, 12000, 1), (16384, 300, 9)])
 def test_fps_presorted_register_kernel(ext, G, oracle, N, m, B):
     """fps_presort.hip + the PRESORT instantiation of fps_pruned_kernel (the scenes sorted by a pre-pass of K workgroups per
