@@ -126,9 +126,16 @@ __device__ __forceinline__ void pc_sort_split(PcSortShared &sh, int cu, int K, i
         // write-through (sc1) stores, drained by every wave, the workgroup's barrier, then the flag; the readers poll the K
         // flags and read with sc1 loads -- no L2 write-back / L1 invalidate on either side (MI355X_MICROARCH.md, hand-offs
         // measured with sc1 loads in place of the acquire)
-        for (int i = 0; i < PER; ++i)
-            __hip_atomic_store(&ghist[(size_t)cu * PF_BINS + i * PF_THREADS + tid], sh.hist[i * PF_THREADS + tid], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+        // (a thread's PER = 8 cells as four 8-byte stores, and below as 4 K 8-byte loads all in flight together: a dword
+        //  at a time the exchange was a chain of K round trips, ~16 us of a 31 us pre-pass)
+        static_assert(PER % 2 == 0, "cells are exchanged in pairs");
+        unsigned long long *gh64 = reinterpret_cast<unsigned long long *>(ghist);
+#pragma unroll
+        for (int i = 0; i < PER / 2; ++i) {
+            const unsigned lo = (unsigned)sh.hist[tid * PER + 2 * i], hi = (unsigned)sh.hist[tid * PER + 2 * i + 1];
+            __hip_atomic_store(&gh64[((size_t)cu * PF_BINS + tid * PER) / 2 + i], ((unsigned long long)hi << 32) | lo,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) granule_store(xflag + cu, 1, 2u);
@@ -142,11 +149,20 @@ __device__ __forceinline__ void pc_sort_split(PcSortShared &sh, int cu, int K, i
         __syncthreads();
         {   // exclusive prefix sum over the cells of the summed histograms, plus what the workgroups before me put in each cell
             int loc[PER], before[PER], sum = 0;
+            unsigned long long h64[PC_MAXK][PER / 2];
+#pragma unroll
+            for (int c = 0; c < PC_MAXK; ++c)
+#pragma unroll
+                for (int i = 0; i < PER / 2; ++i)
+                    h64[c][i] = c < K ? __hip_atomic_load(&gh64[((size_t)c * PF_BINS + tid * PER) / 2 + i], __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT)
+                                      : 0ull;
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 int tot = 0, bef = 0;
-                for (int c = 0; c < K; ++c) {
-                    const int h = __hip_atomic_load(&ghist[(size_t)c * PF_BINS + tid * PER + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int c = 0; c < PC_MAXK; ++c) {
+                    const int h = (int)(unsigned)(h64[c][i / 2] >> (32 * (i & 1)));
                     tot += h;
                     bef += c < cu ? h : 0;
                 }
