@@ -7,7 +7,7 @@
 // histograms up (exclusive scan over the cells + the counts of the workgroups before it = its own first slot in every cell);
 // (C) it scatters its points {x, y, z, running distance, rank} with LDS atomics on those slots; optionally release + flag
 // again so that every workgroup may read the whole sorted scene.  The order inside a cell is as arbitrary as with one
-// workgroup's atomics and as irrelevant (ties are decided by rank).  The exchange area must be zeroed before the launch;
+// workgroup's atomics and as irrelevant (ties are decided by rank).  The granules must be zeroed before the launch;
 // all K workgroups of a scene must be resident at once (they spin on each other, bounded: a stuck exchange traps).
 #pragma once
 #include "fps_pruned_util.h"
@@ -17,10 +17,9 @@ namespace sps {
 constexpr int PC_MAXK = 8;        // workgroups per scene
 constexpr int PC_MAXT = 8;        // records a workgroup publishes per round (fps_pruned_cluster.hip)
 constexpr int PC_MAXR = 32;       // records per round (K T) at most: two lanes per record in the acceptance
-// the exchange area in 8-byte granules: [8 ..): the rounds' records [parity][record][field]; the sort's bounding boxes [K][6];
-// its two rounds of flags [2][K]; behind the granules the K cell histograms of the sort (ints)
-constexpr int PC_BOX_AT = 8 + 2 * PC_MAXR * 6;
-constexpr int PC_FLAG_AT = PC_BOX_AT + PC_MAXK * 6;
+// the exchange area in 8-byte granules: [8 ..): the rounds' records [parity][record][field]; the sort's two rounds of flags
+// [2][K]; behind the granules the K cell histograms of the sort (ints).  The launchers zero the granules per launch.
+constexpr int PC_FLAG_AT = 8 + 2 * PC_MAXR * 6;
 constexpr int PC_GRANULES = PC_FLAG_AT + 2 * PC_MAXK + 8;
 constexpr unsigned PC_SPIN_LIMIT = 1u << 24;          // polls before a stuck exchange traps (~ seconds)
 
