@@ -687,6 +687,27 @@ def test_fps_pruned_degenerate_clouds(ext, G, oracle):
         np.testing.assert_array_equal(got_t, want_t)
 
 
+@pytest.mark.parametrize("cluster", ["1", "8,4", "3,5"])
+def test_fps_large_scene_degenerate_clouds(ext, G, oracle, cluster, monkeypatch):
+    """The same degenerate inputs through the large-scene kernels (one workgroup, and spread over K workgroups: the split
+    sort takes its box from a strided sample, which here is all-equal, collinear or holds NaN / Inf)."""
+    monkeypatch.setenv("SPS_FPS_CLUSTER", cluster)
+    N, m = 20000, 260
+    same = np.ones((1, N, 3), np.float32) * 2.5
+    line = np.zeros((1, N, 3), np.float32)
+    line[0, :, 0] = np.random.default_rng(0).permutation(N).astype(np.float32) * 0.01
+    bad = cloud(np.random.default_rng(1), 1, N)
+    bad[0, 16] = np.nan            # (index 16 is in every K-strided sample)
+    bad[0, 17] = np.nan
+    bad[0, 960, 2] = np.inf
+    bad[0, 1920, 0] = -np.inf
+    for xyz in (same, line, bad):
+        want, want_t = oracle.fps(xyz, m, return_temp=True)
+        got, got_t = G.fps(ext, xyz, m)
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(got_t, want_t)
+
+
 @pytest.mark.parametrize("path", ["fused", "op_by_op", "fused_train"])
 @pytest.mark.parametrize("mode", ["static", "dynamic"])
 def test_golden_surface_feature(ext, G, dev, mode, path, monkeypatch):
