@@ -1193,6 +1193,31 @@ def test_fps_presorted_register_kernel(ext, G, oracle, N, m, B):
     np.testing.assert_array_equal(G.n(temp), want_t)
 
 
+def test_fps_presorted_degenerate_clouds(ext, G, oracle):
+    """All-equal, collinear and NaN / Inf clouds through the sorting pre-pass (its box comes from a strided sample)."""
+    from spsnet_amd import _lib
+    L = _lib.load()
+    N, m = 8192, 300
+    same = np.ones((1, N, 3), np.float32) * 2.5
+    line = np.zeros((1, N, 3), np.float32)
+    line[0, :, 0] = np.random.default_rng(0).permutation(N).astype(np.float32) * 0.01
+    bad = cloud(np.random.default_rng(1), 1, N)
+    bad[0, 16] = np.nan
+    bad[0, 17] = np.nan
+    bad[0, 904, 2] = np.inf
+    bad[0, 1000, 0] = -np.inf
+    work = torch.empty((int(L.sps_fps_workspace_floats(N)),), dtype=torch.float32, device="cuda")
+    for xyz in (same, line, bad):
+        x = G.t(xyz)
+        temp = torch.full((1, N), 1e10, dtype=torch.float32, device=x.device)
+        idx = torch.empty((1, m), dtype=torch.int32, device=x.device)
+        _lib.check(L.sps_fps_with_workspace(1, N, m, x.data_ptr(), temp.data_ptr(), idx.data_ptr(), work.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream), "fps")
+        want, want_t = oracle.fps(xyz, m, return_temp=True)
+        np.testing.assert_array_equal(G.n(idx), want)
+        np.testing.assert_array_equal(G.n(temp), want_t)
+
+
 # ------------------------------------------------------------------ deterministic gradients (SURVEY 8 f-1)
 @pytest.mark.parametrize("B,C,N,M,ns", [(2, 5, 700, 96, 16), (3, 67, 4096, 1024, 32), (1, 16, 300, 300, 1), (2, 8, 64, 512, 8)])
 def test_deterministic_group_and_gather_grads(ext, G, oracle, B, C, N, M, ns):
