@@ -50,8 +50,8 @@ PROFILE_DIRS = ("round2", "round1")
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)      # median of >= 50 runs after 10 warm-ups
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
                     help="BASELINE.json configs[] entry (1-based): 2 = headline, 4 = stability top-k sampler, "
                          "5 = Waymo-shaped 180k-point scenes, nsample 64, fp16 features")
