@@ -1,5 +1,8 @@
+"""Set-up cost of the register-resident FPS (8 x 16 384 points): launch time for m = 2, 8, 64, 512, 4096 picks through the plain
+wrapper (HIP events, best of 5).  m = 2 is essentially the sort + bucket loads + first maxima (~75 us of the 1.79 ms launch).
+usage: python tools/fps_setup_probe.py   (SPS_FPS_PRESORT has no effect here: the plain wrapper never uses the pre-pass)"""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from spsnet_amd import pointnet2_batch_cuda as ext, scenes
 dev = torch.device("cuda:0")
