@@ -162,8 +162,22 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
     unsigned long long pend = m > 1 ? 1ull : 0ull;
     int j = 1, round = 0;
     const bool younger = wave >= PF_WAVES / 2;
+#ifdef SPS_PC_PROFILE
+    unsigned long long pseg[6] = {0, 0, 0, 0, 0, 0};
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long tt;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return tt;
+    };
+#define PC_STAMP(var) const unsigned long long var = stamp()
+#else
+#define PC_STAMP(var)
+#endif
     for (;;) {
         if (younger) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        PC_STAMP(p0);
         // ---- apply the round's accepted centres (lanes `pend`, always even: bit rr / 2 names a centre) to my buckets.
         // With ~1.5 touched buckets per wave and round the phase is a chain of L2 round trips, so: (1) all box tests first --
         // lane l collects, per row, the centres its bucket cannot rule out; (2) every touched bucket is fetched ONCE
@@ -236,6 +250,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
             pend = 0ull;
         }
         if (j >= m) break;
+        PC_STAMP(p1);
         // the wave's two records (fps_pruned_big.hip)
         if (cand_stale) {
             auto best_entry = [&](int excl1, int excl2, int &vmax, int &row) -> int {
@@ -294,11 +309,13 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
             cand_stale = false;
         }
         // ---- the workgroup's 16 records meet in LDS; its first wave ranks them and publishes the T best
+        PC_STAMP(p2);
         const int buf = round & 1;
         const unsigned tag = (unsigned)round + 2u;   // (1 is the "sorted" flag's tag, 0 the zeroed area)
         unsigned long long *xround = xg + 8 + (size_t)buf * (PC_MAXR * 6);
         if (lane < 12) sh.soa[buf][lane >> 1][2 * wave + (lane & 1)] = crec;
         __syncthreads();
+        PC_STAMP(p3);
         if (younger) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
         if (wave == 0) {
             // position of record rj among the workgroup's 16: records before it under (distance, key), equal ones (only empty
@@ -328,6 +345,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
                 granule_store(dst + 5, bound, tag);
             }
         }
+        PC_STAMP(p4);
         // ---- the workgroup polls the K T published records, one granule per lane (granule = {value, tag}: nothing else to
         // order), into ONE copy in LDS; a second barrier hands it to every wave
         {
@@ -344,6 +362,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
             }
         }
         __syncthreads();
+        PC_STAMP(p5);
         // ---- acceptance over the R records: lane (rj, h) evaluates record rj against the i-records of half h
         const int rj = lane >> 1, h = lane & 1;
         const int jd = sh.xr[0][rj], jk = sh.xr[1][rj];
@@ -392,7 +411,21 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
         ax = jx; ay = jy; az = jz;
         j += L;
         round += 1;
+#ifdef SPS_PC_PROFILE
+        {
+            const unsigned long long p6 = stamp();
+            pseg[0] += p1 - p0; pseg[1] += p2 - p1; pseg[2] += p3 - p2; pseg[3] += p4 - p3; pseg[4] += p5 - p4; pseg[5] += p6 - p5;
+        }
+#endif
     }
+#ifdef SPS_PC_PROFILE
+    // (diagnostic build only: s_memtime ticks = 10 ns; per wave: apply, records, barrier 1, rank + publish, poll + barrier 2, accept, rounds)
+    if (lane == 0) {
+        unsigned long long *o = xg + PC_GRANULES + (size_t)PC_MAXK * PF_BINS / 2 - 8 * (size_t)(nwaves - gwave);
+        for (int i = 0; i < 6; ++i) o[i] = pseg[i];
+        o[6] = (unsigned long long)round;
+    }
+#endif
 
     // the reference leaves the final running min-distances in `temp` (original order): every wave writes its own buckets
     if (temp)
