@@ -229,7 +229,8 @@ int sps_fps_publish(int b, int n, int m, const float *dataset, float *temp, int 
  * floats; served by the clustered large-scene kernel for batches of at most 64 / K workgroups, SPS_ERR_INVALID otherwise
  * (the caller then runs the layer unstreamed).  6144 <= n <= 16 384: the register-resident kernel of sps_fps_publish; with
  * a workspace its scenes are sorted by a pre-pass of up to 8 workgroups per scene (fps_presort.hip; same picks), without
- * one (NULL) inside the kernel. */
+ * one (NULL) inside the kernel.  The pre-pass keeps the flags of its one cross-workgroup exchange in a 512 KiB pool the
+ * library allocates once per device on first use (the only allocation inside the library; everything else is the caller's). */
 int sps_fps_publish_ws(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress, float *work,
                        sps_stream_t stream);
 int sps_wait_progress(const int *progress, int b, int need, int *timed_out, sps_stream_t stream);

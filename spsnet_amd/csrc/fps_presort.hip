@@ -8,13 +8,16 @@
 // coalesced loads per lane.  Same sort key, same buckets up to the (arbitrary, irrelevant) order inside a cell.
 #include "fps_sort_split.h"
 
+#include <atomic>
+#include <mutex>
+
 namespace sps {
 
 // work: per scene `stride` floats: 5 arrays of npad elements (x, y, z, t, rank), then the exchange area (zeroed by the launcher)
 __global__ __launch_bounds__(PF_THREADS) void fps_presort_kernel(int b, int K, int n, int bs, int l2, int rb, int npad,
                                                                  long long stride, const float *__restrict__ dataset,
                                                                  const float *__restrict__ temp, float *__restrict__ work,
-                                                                 int spread) {
+                                                                 int spread, unsigned long long *flags, unsigned epoch) {
     __shared__ PcSortShared sh;
     // blocks s, s + 8, s + 16, ... share an XCD (observed dispatch order): a scene's K workgroups sit on one L2
     // (spread: DIAGNOSTIC mapping that puts a scene's workgroups on consecutive blocks = different XCDs; tests run the
@@ -27,28 +30,54 @@ __global__ __launch_bounds__(PF_THREADS) void fps_presort_kernel(int b, int K, i
     float *sx = work + (size_t)scene * stride, *sy = sx + npad, *sz = sy + npad, *st = sz + npad;
     int *srk = reinterpret_cast<int *>(st + npad);
     unsigned long long *xg = reinterpret_cast<unsigned long long *>(work + (size_t)scene * stride + (size_t)5 * npad);
-    pc_sort_split(sh, cu, K, n, npad, bs, l2, rb, xyz, temp, xg, sx, sy, sz, st, srk, false);   // the launch's end hands over
+    // (the launch's end hands the sorted scene over; the flags of the histogram exchange: this launch's slot of the pool)
+    pc_sort_split(sh, cu, K, n, npad, bs, l2, rb, xyz, temp, xg, sx, sy, sz, st, srk, false, flags + (size_t)scene * 2 * PC_MAXK, epoch);
 }
 
 size_t fps_cluster_exchange_floats();   // fps_pruned_cluster.hip
 int fps_cluster_spread();
 
+// The flags of the pre-pass's one exchange live in a pool the library owns (per device, zeroed once): a launch takes the next of
+// PS_SLOTS slots and a fresh 32-bit epoch as its tag, so nothing has to be zeroed per launch (a memset in front of the
+// producer cost ~4 us + a launch gap of every pass).  A stale flag carries an older epoch and never matches; more than
+// PS_SLOTS pre-passes in flight on one device would share a slot -- far beyond the 64-workgroup residency rule anyway.
+constexpr int PS_SLOTS = 64, PS_SCENES = 64;
+static unsigned long long *presort_flag_pool(int dev) {
+    static std::mutex mu;
+    static unsigned long long *pool[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev < 0 || dev >= 64) return nullptr;
+    if (!pool[dev]) {
+        const size_t bytes = (size_t)PS_SLOTS * PS_SCENES * 2 * PC_MAXK * sizeof(unsigned long long);
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        pool[dev] = static_cast<unsigned long long *>(p);
+    }
+    return pool[dev];
+}
+
 // sorted scenes -> work (b * stride floats); temp may be NULL (all running distances 1e10)
 int launch_fps_presort(int b, int n, const float *dataset, const float *temp, float *work, long long stride, hipStream_t st) {
     int K = PC_MAXK;
     while (K > 1 && b * K > 64) K >>= 1;   // the K workgroups of a scene spin on each other: all of them resident
-    if (b * K > 128) return -1;
+    if (b * K > 128 || b > PS_SCENES) return -1;
     const int bs = sps_opt_n_threads(n);
     int l2 = 0;
     while ((1 << (l2 + 1)) <= bs) ++l2;
     int rb = 0;
     while ((1 << rb) < divup(n, bs)) ++rb;
     const int npad = divup(n, 64) * 64;
-    hipError_t e = hipMemset2DAsync(work + (size_t)5 * npad, (size_t)stride * sizeof(float), 0,
-                                    (size_t)PC_GRANULES * 8, (size_t)b, st);   // (the granules; the histograms behind them are written before they are read)
-    if (e != hipSuccess) return fail(SPS_ERR_LAUNCH, "fps(presort): hipMemset2DAsync: %s", hipGetErrorString(e));
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    unsigned long long *pool = presort_flag_pool(dev);
+    if (!pool) return -1;   // (the caller falls back to the in-kernel sort)
+    static std::atomic<unsigned> counter{0};
+    unsigned ticket = counter.fetch_add(1, std::memory_order_relaxed) + 1u;
+    if ((ticket << 1) == 0u) ticket = counter.fetch_add(1, std::memory_order_relaxed) + 1u;   // tag 0 = the zeroed pool
+    unsigned long long *flags = pool + (size_t)(ticket % PS_SLOTS) * PS_SCENES * 2 * PC_MAXK;
     hipLaunchKernelGGL(fps_presort_kernel, dim3(8 * K * divup(b, 8)), dim3(PF_THREADS), 0, st, b, K, n, bs, l2, rb, npad, stride,
-                       dataset, temp, work, fps_cluster_spread());
+                       dataset, temp, work, fps_cluster_spread(), flags, ticket << 1);
     return check_launch("fps_presort_kernel");
 }
 

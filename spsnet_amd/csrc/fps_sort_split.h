@@ -37,16 +37,18 @@ struct PcSortShared {
     int wsum[PF_WAVES];
 };
 
-// xg: the scene's exchange area; sx .. srk: the scene's sorted arrays (npad entries each); hand_over: every workgroup
+// xg: the scene's exchange area (the cell histograms live behind its granules); sx .. srk: the scene's sorted arrays (npad entries each); hand_over: every workgroup
 // waits until ALL of them have scattered (needed when they go on to read each other's points in the same launch)
 __device__ __forceinline__ void pc_sort_split(PcSortShared &sh, int cu, int K, int n, int npad, int bs, int l2, int rb,
                                               const float *__restrict__ xyz, const float *__restrict__ temp,
                                               unsigned long long *xg, float *sx, float *sy, float *sz, float *st, int *srk,
-                                              bool hand_over) {
+                                              bool hand_over, unsigned long long *xflag = nullptr, unsigned tag0 = 2u) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     {
-        unsigned long long *xflag = xg + PC_FLAG_AT;
+        // the two rounds of flags [2][PC_MAXK]: in the (zeroed) exchange area with tags 2 / 3, or wherever the caller keeps
+        // them with a tag of its own (fps_presort.hip: a library-owned pool and a launch epoch -- nothing to zero per launch)
+        if (!xflag) xflag = xg + PC_FLAG_AT;
         int *ghist = reinterpret_cast<int *>(xg + PC_GRANULES);
         const int s_beg = (int)((long long)n * cu / K), s_end = (int)((long long)n * (cu + 1) / K);
         auto flag_and_wait = [&](int slot, unsigned tg) {   // my stores -> visible; then wait for everybody's
@@ -137,10 +139,10 @@ __device__ __forceinline__ void pc_sort_split(PcSortShared &sh, int cu, int K, i
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) granule_store(xflag + cu, 1, 2u);
+        if (tid == 0) granule_store(xflag + cu, 1, tag0);
         if (wave == 0 && lane < K) {
             unsigned spins = 0;
-            while ((unsigned)(granule_load(xflag + lane) >> 32) != 2u) {
+            while ((unsigned)(granule_load(xflag + lane) >> 32) != tag0) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > PC_SPIN_LIMIT) __builtin_trap();
             }
@@ -207,7 +209,7 @@ __device__ __forceinline__ void pc_sort_split(PcSortShared &sh, int cu, int K, i
             for (int p = n + tid; p < npad; p += PF_THREADS) {  // padding: never inside a box, distance stays -1, worst rank
                 sx[p] = NAN; sy[p] = NAN; sz[p] = NAN; st[p] = -1.f; srk[p] = 0x0FFFFFFF;
             }
-        if (hand_over) flag_and_wait(1, 3u);
+        if (hand_over) flag_and_wait(1, tag0 + 1u);
     }
 }
 
