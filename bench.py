@@ -369,10 +369,12 @@ def main():
     fp32_leg = None
     if not args.no_fp32_leg and args.mlp_precision != "fp32" and args.config != 5:
         fused.set_precision("fp32")
+        mlp_probe.best = None            # (the costliest launch of THIS leg: same shape, weights packed for the fp32 kernel)
         el32, per32, outs32 = timed(args.steps, max(args.warmup, 2))
         probe.summary()
         chk32 = validate(outs32)
-        fp32_leg = (el32, per32, chk32)
+        mlp32 = mlp_probe.measure() if world == 1 or rank == 0 else None   # the same launch on the exact fp32 MFMA kernel
+        fp32_leg = (el32, per32, chk32, mlp32)
         fused.set_precision(args.mlp_precision)
 
     # Extra, reported separately (never `value`): the same K complete passes with TWO batches in flight on two
@@ -409,7 +411,7 @@ def main():
         if checked is not None:
             line["validated"] = checked
         if fp32_leg is not None:
-            el32, per32, chk32 = fp32_leg
+            el32, per32, chk32, mlp32 = fp32_leg
             line["value_fp32"] = total_points / el32
             line["ms_per_step_fp32"] = 1e3 * el32 / args.steps
             line["ms_per_step_fp32_median"] = float(statistics.median(per32))
@@ -432,11 +434,11 @@ def main():
                                         "and prunes untouched buckets, so its real HBM traffic (`traffic`, bytes per launch "
                                         "from rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/*/pmc_traffic.json) is the "
                                         "compulsory 16*N+4*m B/scene and the kernel is latency-, not bandwidth-bound"}
-        if mlp is not None:
-            peak = MFMA_PEAK_TF[args.mlp_precision]
+        def mlp_roofline(mlp, precision):
+            peak = MFMA_PEAK_TF[precision]
             ach_tf = mlp["flop"] / (mlp["ms"] * 1e-3) / 1e12
-            busy, src = pmc_mfma_busy(mlp["widths"], mlp["nsample"], args.mlp_precision)
-            line["roofline_mlp"] = {
+            busy, src = pmc_mfma_busy(mlp["widths"], mlp["nsample"], precision)
+            return {
                 "bound": "mfma", "kernel": f"grouped MLP {mlp['widths'][0]}->{mlp['widths'][1]}->{mlp['widths'][2]}->"
                                            f"{mlp['widths'][3]}, nsample {mlp['nsample']}, {mlp['columns']} columns",
                 "achieved": ach_tf, "peak": peak, "unit": "TFLOP/s", "frac": ach_tf / peak, "launch_ms": mlp["ms"],
@@ -448,6 +450,10 @@ def main():
                         "arguments after the timed region; peak = dense MFMA peak of the operand type (fp16x2 issues 3 "
                         "fp16 MFMAs per product block, so its useful ceiling is a third of it); mfma_busy_frac = "
                         "SQ_VALU_MFMA_BUSY_CYCLES / (kernel duration x 1024 SIMDs x 2.4 GHz) from the committed PMC pass"}
+        if mlp is not None:
+            line["roofline_mlp"] = mlp_roofline(mlp, args.mlp_precision)
+        if fp32_leg is not None and fp32_leg[3] is not None:   # the strict-fp32 leg's dominant launch (fp32 MFMA pipe, 157 TF)
+            line["roofline_mlp_fp32"] = mlp_roofline(fp32_leg[3], "fp32")
         if pipelined is not None:
             line["pipelined"] = pipelined
         if world == 1 and not args.no_cpu_baseline:
