@@ -159,6 +159,11 @@ int sps_query_and_group(int b, int n, int m, int c, float radius, int nsample, i
                         const float *xyz, const float *new_xyz, const float *features, int *idx,
                         float *out, sps_stream_t stream);
 
+/* The grouping half of sps_query_and_group for neighbour indices the caller already holds (pointnet2_utils.py:312-320:
+ * grouping_operation x2, subtract, cat): idx (B,M,nsample) i32 -> out as above.  Indices must lie in [0, N). */
+int sps_group_concat(int b, int n, int m, int c, int nsample, int use_xyz, const float *xyz, const float *new_xyz,
+                     const float *features, const int *idx, float *out, sps_stream_t stream);
+
 /* new_xyz (B,M,3) = rows idx (B,M) of xyz (B,N,3): the transpose + gather_points + transpose of
  * pointnet2_modules.py:261,423-424 without the two layout copies (same values, it is a pure copy). */
 int sps_gather_xyz(int b, int n, int m, const float *xyz, const int *idx, float *out, sps_stream_t stream);

@@ -159,6 +159,9 @@ class _PointBackbone(nn.Module):
             res = sa_stack._streamed_first_layer(layer, nxt, xyz_input, feature_input, stds, after_producer=beside_fps)
             if res is not None:
                 return res
+        if (i == 0 and layer.training and xyz_input.is_cuda and cls_pred is None and ctr_xyz is None
+                and self.layer_inputs[0] == 0 and sa_stack.STREAM_TRAINING_QUERIES):
+            sa_stack._streamed_first_layer_queries(layer, xyz_input)   # training: the ball queries run beside the FPS
         if beside_fps is not None:
             beside_fps()   # no streamed layer 0: at least ahead of its kernels
         if nxt is not None and ctr_xyz is None and sa_stack._can_prefetch(layer, nxt):
@@ -171,6 +174,7 @@ class _PointBackbone(nn.Module):
             return layer(xyz_input, feature_input, cls_pred, ctr_xyz=ctr_xyz, **kw)
         finally:
             layer._on_new_xyz = None
+            layer._preball = None
 
     def forward(self, batch_dict):
         """batch_dict: batch_size, points (B*N, 4 + C) [batch_idx, x, y, z, ...] (+ stds for PAGNet) -> batch_dict with

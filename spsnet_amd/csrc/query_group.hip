@@ -70,6 +70,24 @@ extern "C" int sps_query_and_group(int b, int n, int m, int c, float radius, int
     hipStream_t st = as_stream(stream);
     int rc = launch_ball_query(false, /*fill_empty=*/true, b, n, m, radius, 0.f, nsample, new_xyz, xyz, idx, st);
     if (rc != SPS_OK) return rc;
+    return sps_group_concat(b, n, m, c, nsample, use_xyz, xyz, new_xyz, features, idx, out, stream);
+}
+
+// The grouping half of sps_query_and_group on neighbour indices the caller already has (a dual-radius scan, or the
+// streamed queries of a training pass): out (B, 3+C, M, nsample) = [xyz[idx] - new_xyz ; features[idx]].
+extern "C" int sps_group_concat(int b, int n, int m, int c, int nsample, int use_xyz, const float *xyz,
+                                const float *new_xyz, const float *features, const int *idx, float *out,
+                                sps_stream_t stream) {
+    using namespace sps;
+    if (b < 0 || n <= 0 || m < 0 || c < 0 || nsample < 0)
+        return fail(SPS_ERR_INVALID, "group_concat: bad shape b=%d n=%d m=%d c=%d nsample=%d", b, n, m, c, nsample);
+    if (!use_xyz && c == 0) return fail(SPS_ERR_INVALID, "group_concat: no features and use_xyz == 0");
+    if ((long long)m * nsample > 0x7FFFFFFFLL) return fail(SPS_ERR_INVALID, "group_concat: m*nsample overflows int");
+    if (b == 0 || m == 0 || nsample == 0) return SPS_OK;
+    if (!xyz || !new_xyz || !idx || !out || (c > 0 && !features))
+        return fail(SPS_ERR_INVALID, "group_concat: null pointer");
+    if (b > 65535) return fail(SPS_ERR_INVALID, "group_concat: batch too large for the launch grid");
+    hipStream_t st = as_stream(stream);
     const int cols = m * nsample;
     const int zchunks = c > 0 ? divup(c, QG_CCHUNK) : 1;
     hipLaunchKernelGGL(group_concat_kernel, dim3(divup(cols, QG_THREADS), b, zchunks), dim3(QG_THREADS), 0, st, n,

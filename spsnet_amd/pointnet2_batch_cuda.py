@@ -556,3 +556,24 @@ def query_and_group(radius, nsample, xyz, new_xyz, features=None, use_xyz=True):
         _lib.check(_L.sps_query_and_group(B, N, M, C, radius, nsample, 1 if use_xyz else 0, p, q, f,
                                           idx.data_ptr(), out.data_ptr(), _stream(xyz)), "query_and_group")
     return out, idx
+
+
+def group_concat(xyz, new_xyz, features, idx, use_xyz=True):
+    """The grouping half of query_and_group on neighbour indices the caller already holds (pointnet2_utils.py:312-320)
+    -> (B, 3+C, M, nsample), or (B, C, M, nsample) without use_xyz."""
+    p, q = _ptr(xyz, F32, "xyz"), _ptr(new_xyz, F32, "new_xyz")
+    B, N, _ = xyz.shape
+    M, nsample = idx.shape[1], idx.shape[2]
+    _need(idx, B * M * nsample, "idx")
+    C = 0
+    f = 0
+    if features is not None:
+        f = _ptr(features, F32, "features")
+        C = features.shape[1]
+        _need(features, B * C * N, "features")
+    out = torch.empty((B, C + (3 if use_xyz else 0), M, nsample), dtype=F32, device=xyz.device)
+    with _on(xyz):
+        _lib.check(_L.sps_group_concat(B, N, M, C, nsample, 1 if use_xyz else 0, p, q, f, _ptr(idx, I32, "idx"),
+                                       out.data_ptr(), _stream(xyz)), "group_concat")
+    return out
+

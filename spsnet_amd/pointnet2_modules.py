@@ -233,10 +233,27 @@ class _PointnetSAModuleBase(nn.Module):
             raise NotImplementedError("fp16 feature tensors are served by the fused inference path only (eval mode, no "
                                       "gradients, max pooling, IA-SSD layer widths); cast to float32 for anything else")
         scales = []
-        for grouper, mlp in zip(self.groupers, self.mlps):
-            grouped = grouper(xyz, new_xyz, features)      # (B, C, M, ns)
+        idxs = self._neighbour_indices(xyz, new_xyz)
+        for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
+            if idxs is not None:
+                grouped = pointnet2_utils.group_with_index(xyz, new_xyz, features, idxs[k], grouper.use_xyz)
+            else:
+                grouped = grouper(xyz, new_xyz, features)      # (B, C, M, ns)
             scales.append(_pool_over_samples(_shared_mlp(mlp, grouped), self.pool_method))
         return torch.cat(scales, dim=1)
+
+    def _neighbour_indices(self, xyz, new_xyz):
+        """Ball-query rows of both scales of a two-radius layer on the op-by-op (training) path, or None: the rows
+        sa_stack.run_sa_layers queried while this layer's FPS was still running (`_preball`), else ONE scan of the cloud for
+        both radii instead of one per scale (same rows: every row written, zeros for empty balls)."""
+        pre, self._preball = getattr(self, "_preball", None), None
+        if pre is not None and pre[0] is new_xyz:
+            return pre[1]
+        if not (xyz.is_cuda and len(self.groupers) == 2 and xyz.dtype == torch.float32 and xyz.is_contiguous()
+                and all(type(g) is pointnet2_utils.QueryAndGroup for g in self.groupers)):
+            return None
+        ga, gb = self.groupers
+        return _ext.ball_query_full2(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz, new_xyz.detach().contiguous())
 
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, new_xyz=None):
         """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3), new_features (B,sum C_out,npoint)."""
@@ -333,11 +350,14 @@ def _sample_dfps(mod, ctx):
     pre = getattr(mod, "_presampled", None)
     if pre is not None:
         mod._presampled = None
-        idx, done, src = pre
+        idx, done, src = pre[:3]
         if src is ctx.xyz and idx.shape[1] == ctx.npoint:
             main = torch.cuda.current_stream(idx.device)
-            main.wait_event(done)
-            idx.record_stream(main)
+            if done is not None:
+                main.wait_event(done)
+                idx.record_stream(main)
+            if len(pre) > 3 and ctx.whole:
+                ctx.new_xyz = pre[3]          # the streamed queries gathered the centroids already
             if ctx.stds is not None:
                 _thin_stds(ctx, idx)
             return idx

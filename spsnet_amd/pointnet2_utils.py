@@ -261,6 +261,18 @@ def _group_with_index(xyz, new_xyz, features, idx, use_xyz):
     return torch.cat([rel, grouped], dim=1) if use_xyz else grouped
 
 
+def group_with_index(xyz, new_xyz, features, idx, use_xyz=True):
+    """QueryAndGroup.forward behind its ball query (reference :312-320) for neighbour indices that exist already -- both
+    radii of a layer from one scan, or queries that ran while the layer's FPS was still sampling: one launch when no
+    gradient is wanted, the differentiable op sequence otherwise."""
+    if features is None:
+        assert use_xyz, "Cannot have not features and not use xyz as a feature!"
+    if xyz.is_cuda and not _needs_grad(xyz, new_xyz, features):
+        feats = features.contiguous() if features is not None else None
+        return _ext.group_concat(xyz.contiguous(), new_xyz.contiguous(), feats, idx, use_xyz)
+    return _group_with_index(xyz, new_xyz, features, idx, use_xyz)
+
+
 class QueryAndGroup(nn.Module):
     """Ball query + grouping: (xyz (B,N,3), new_xyz (B,M,3), features (B,C,N)) -> (B,3+C,M,ns)
     (or (B,C,M,ns) without use_xyz).  Reference :289-322."""

@@ -73,6 +73,8 @@ def build_sa_layers(modules_pkg, cfg=IASSD_KITTI, input_channels=4, num_class=3,
 
 HYBRID = False          # see _streamed_first_layer
 FUSE_GATHER = os.environ.get("SPS_FUSE_GATHER", "1") != "0"   # streamed chunks: the ball query gathers its own centroids
+# training passes: layer 0's ball queries consume the publishing FPS while it samples (_streamed_first_layer_queries)
+STREAM_TRAINING_QUERIES = os.environ.get("SPS_STREAM_TRAINING_QUERIES", "1") != "0"
 _SIDE_STREAMS = {}
 _FENCES = {}          # (device index, main stream handle) -> CuFence
 
@@ -369,6 +371,56 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
     return new_xyz, new_features, cls, idx, stds
 
 
+def _streamed_first_layer_queries(layer, xyz):
+    """TRAINING counterpart of _streamed_first_layer: the layer runs op by op (BatchNorm needs the statistics of ALL its grouped
+    points before anything behind the first convolution can start), but its ball queries need the picks only -- they consume
+    the publishing FPS chunk by chunk while it samples (1.8 ms on one CU per scene at 8 x 16384 -> 4096, with the other 248
+    CUs idle), so that what is left behind the last pick is the last chunk's query.  Hands the picks, the gathered centroids
+    and both scales' neighbour rows to the layer (`_presampled` / `_preball`); same kernels as the inference schedule, same
+    rows as the layer's own ball queries, correct or redo (the last chunk widens to the whole layer when a bounded wait gave
+    up).  Returns False when the layer does not qualify."""
+    from . import pointnet2_batch_cuda as _ext
+    from . import pointnet2_utils
+    B, N, _ = xyz.shape
+    M = layer.npoint_list[0] if getattr(layer, "npoint_list", None) else 0
+    if not (xyz.is_cuda and xyz.dtype == torch.float32 and xyz.is_contiguous() and not xyz.requires_grad
+            and _is_plain_dfps(layer, N) and _ext.fps_can_publish(B, N) and M % (64 * 16) == 0
+            and len(layer.groupers) == 2 and all(type(g) is pointnet2_utils.QueryAndGroup for g in layer.groupers)):
+        return False
+    ga, gb = layer.groupers
+    if max(ga.nsample, gb.nsample) > 32:
+        return False
+    dev = xyz.device
+    bounds = list(zip([0] + [M * e // 16 for e in _CHUNK_ENDS_16[:-1]], [M * e // 16 for e in _CHUNK_ENDS_16]))
+    if not (N >= 256 and all((j1 - j0) % 4 == 0 and B * (j1 - j0) <= 8192 for j0, j1 in bounds)):
+        return False      # (the range query that gathers its own centroids serves these chunk shapes)
+    main = torch.cuda.current_stream(dev)
+    producer = _helper_stream(dev, "producer")
+    idx = torch.empty((B, M), dtype=torch.int32, device=dev)
+    new_xyz = torch.empty((B, M, 3), dtype=torch.float32, device=dev)
+    idx_a = torch.empty((B, M, ga.nsample), dtype=torch.int32, device=dev)
+    idx_b = torch.empty((B, M, gb.nsample), dtype=torch.int32, device=dev)
+    zeros = _zeroed_ints(dev, 2 * B)
+    progress, timed_out = zeros[:B], zeros[B:]
+    _TIMEOUT_FLAGS.append(timed_out)
+    del _TIMEOUT_FLAGS[:-64]
+    start = torch.cuda.Event()
+    start.record(main)
+    producer.wait_event(start)
+    with torch.cuda.stream(producer), torch.no_grad():
+        work = _ext.fps_publish(xyz, None, idx, progress, presort=True)
+    for t in (xyz, idx, progress) + (() if work is None else (work,)):
+        t.record_stream(producer)
+    with torch.no_grad():
+        for j0, j1 in bounds:
+            _ext.wait_progress(progress, j1, timed_out, patient=(j1 == M))
+            _ext.ball_query_full2_range(ga.radius, gb.radius, xyz, new_xyz, idx_a, idx_b, j0, j1 - j0,
+                                        full_range_if=timed_out if j1 == M else None, gather_idx=idx)
+    layer._presampled = (idx, None, xyz, new_xyz)
+    layer._preball = (new_xyz, (idx_a, idx_b))
+    return True
+
+
 _ZERO_POOL = {}
 
 
@@ -429,6 +481,9 @@ def run_sa_layers(layers, xyz, features, stds=None, overlap=True, stream_first_l
                 xyz, features, cls_pred, idx, stds = res
                 outs.append((xyz, features, cls_pred, idx))
                 continue
+        if (k == 0 and stream_first_layer and prefetch and not use_overlap and cls_pred is None
+                and STREAM_TRAINING_QUERIES and layer.training):
+            _streamed_first_layer_queries(layer, xyz)
         if prefetch and nxt is not None and _can_prefetch(layer, nxt):
             ordered = _is_plain_dfps(layer, xyz.shape[1])
             layer._on_new_xyz = lambda nx, _n=nxt, _o=ordered: _prefetch_dfps(_n, nx, _o)
@@ -437,6 +492,8 @@ def run_sa_layers(layers, xyz, features, stds=None, overlap=True, stream_first_l
             xyz, features, cls_pred, idx, stds = layer(xyz, features, cls_pred, **kw)
         finally:
             layer._on_new_xyz = None
+            if k == 0:
+                layer._preball = None     # (consumed by the layer; dropped here if it declined or raised)
         outs.append((xyz, features, cls_pred, idx))
     return outs
 

@@ -2200,3 +2200,64 @@ def test_streamed_first_layer_repairs_timed_out_waits(G, dev, npts, ns, half):
         for la, lb in zip(got, want):
             for ta, tb in zip(la, lb):
                 assert (ta is None and tb is None) or torch.equal(ta, tb)
+
+
+# ------------------------------------------------------------------ training: layer 0's ball queries beside its FPS
+@pytest.mark.parametrize("force_timeouts", [False, True])
+def test_training_streamed_queries_equal_unstreamed(G, dev, force_timeouts, monkeypatch):
+    """A TRAINING pass (BatchNorm on batch statistics, gradients) with layer 0's ball queries consuming the publishing FPS
+    chunk by chunk (sa_stack._streamed_first_layer_queries) against the same pass with every query behind the FPS: every
+    output and every running statistic bit-identical, every parameter gradient within 1e-5 -- also when each bounded progress
+    wait is forced to give up (the last chunk's query then repairs the whole layer)."""
+    import copy
+    from spsnet_amd import _lib, pointnet2_modules as M, sa_stack, scenes
+    L = _lib.load()
+    base = sa_stack.build_sa_layers(M, sa_stack.scaled_config(npoints=[1024, 256, 128]), seed=9).to(dev).train()
+    xyz, feats = scenes.make_batch("kitti-lidar-v1", 2, 8192, seed0=77, dup_fraction=0.01)
+    x, f = G.t(xyz), G.t(feats)
+
+    def run(layers, streamed):
+        monkeypatch.setattr(sa_stack, "STREAM_TRAINING_QUERIES", streamed)
+        outs = sa_stack.run_sa_layers(layers, x, f)
+        loss = sum(o[1].square().mean() for o in outs) + sum(o[2].square().mean() for o in outs if o[2] is not None)
+        loss.backward()
+        torch.cuda.synchronize()
+        return outs
+
+    ref_layers, got_layers = copy.deepcopy(base), copy.deepcopy(base)
+    want = run(ref_layers, False)
+    sa_stack.check_timeouts()
+    old = L.sps_debug_set_wait_spins(1) if force_timeouts else None
+    try:
+        calls = []
+        orig = sa_stack._streamed_first_layer_queries
+        monkeypatch.setattr(sa_stack, "_streamed_first_layer_queries", lambda *a: calls.append(orig(*a)) or calls[-1])
+        got = run(got_layers, True)
+        assert calls == [True], "layer 0 was supposed to qualify for the streamed queries"
+        assert bool(sa_stack.check_timeouts()) == force_timeouts
+    finally:
+        if old is not None:
+            L.sps_debug_set_wait_spins(old)
+    for k, (la, lb) in enumerate(zip(got, want)):
+        for ta, tb in zip(la, lb):
+            assert (ta is None and tb is None) or torch.equal(ta, tb), f"layer {k}"
+    # (gradients: the grouping backward adds with LDS atomics, whose order is not fixed from run to run)
+    for (name, pa), (_, pb) in zip(got_layers.named_parameters(), ref_layers.named_parameters()):
+        if pa.grad is None and pb.grad is None:
+            continue
+        err = float((pa.grad - pb.grad).abs().max())
+        assert err <= 1e-5 * max(1.0, float(pb.grad.abs().max())), (name, err)
+    for (name, ba), (_, bb) in zip(got_layers.named_buffers(), ref_layers.named_buffers()):
+        assert torch.equal(ba, bb), name
+
+
+@pytest.mark.parametrize("C,use_xyz", [(0, True), (5, True), (20, False)])
+def test_group_concat_matches_query_and_group(ext, G, C, use_xyz):
+    """sps_group_concat on the rows of a ball query == the fused sps_query_and_group (which is pinned to the oracle)."""
+    rng = np.random.default_rng(C)
+    xyz = rng.uniform(-2, 2, (2, 3000, 3)).astype(np.float32)
+    new_xyz = xyz[:, rng.integers(0, 3000, 200)].copy()
+    feats = rng.normal(size=(2, C, 3000)).astype(np.float32) if C else None
+    want, idx = ext.query_and_group(0.7, 16, G.t(xyz), G.t(new_xyz), None if feats is None else G.t(feats), use_xyz)
+    got = ext.group_concat(G.t(xyz), G.t(new_xyz), None if feats is None else G.t(feats), idx, use_xyz)
+    assert torch.equal(got, want)

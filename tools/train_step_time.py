@@ -1,7 +1,8 @@
 """Time a TRAINING step (forward + backward, BatchNorm on batch statistics) of the IA-SSD SA layers 0-2 through the
-op-by-op path (HIP sampling / query / group kernels + torch Conv/BN), and print the top kernels.
-usage: python tools/train_step_time.py [B] [N] [reps]"""
-import os, sys, time
+op-by-op path (HIP sampling / query / group kernels + the train-mode conv / BatchNorm kernels).
+usage: python tools/train_step_time.py [B] [N] [reps] [ab]
+  ab: alternate sa_stack.STREAM_TRAINING_QUERIES on / off inside one process (three rounds each) and print the medians"""
+import os, sys, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from spsnet_amd import pointnet2_modules as M, sa_stack, scenes
@@ -9,6 +10,7 @@ from spsnet_amd import pointnet2_modules as M, sa_stack, scenes
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+ab = len(sys.argv) > 4 and sys.argv[4] == "ab"
 dev = torch.device("cuda:0")
 layers = sa_stack.build_sa_layers(M, sa_stack.IASSD_KITTI, seed=3).to(dev).train()
 xyz, feats = scenes.make_batch("kitti-lidar-v1", B, N, seed0=1)
@@ -24,12 +26,27 @@ def step():
     loss.backward()
 
 
-for _ in range(2):
+def timed(n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / n
+
+
+for _ in range(3):
     step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(reps):
-    step()
-torch.cuda.synchronize()
-ms = 1e3 * (time.perf_counter() - t0) / reps
-print(f"training step (SA L0-L2, fwd+bwd) {B}x{N}: {ms:.2f} ms ({B * N / ms / 1e3:.2f} M points/s)", flush=True)
+if ab:
+    res = {True: [], False: []}
+    for rnd in range(3):
+        for flag in (True, False):
+            sa_stack.STREAM_TRAINING_QUERIES = flag
+            step()
+            res[flag].append(timed(reps))
+    for flag in (True, False):
+        print(f"STREAM_TRAINING_QUERIES={flag}: " + " ".join(f"{v:.2f}" for v in res[flag]) +
+              f"  median {statistics.median(res[flag]):.2f} ms", flush=True)
+else:
+    ms = timed(reps)
+    print(f"training step (SA L0-L2, fwd+bwd) {B}x{N}: {ms:.2f} ms ({B * N / ms / 1e3:.2f} M points/s)", flush=True)
