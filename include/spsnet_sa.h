@@ -478,6 +478,57 @@ long long sps_conv1x1_wgrad_workspace_floats(int b, int ci, int co, long long l)
 int sps_conv1x1_wgrad(int b, int ci, int co, long long l, const float *x, const float *dy, float *dw, float *work,
                       sps_stream_t stream);
 
+
+/* The grouped MLP of an SA layer in TRAINING mode ([Conv2d 1x1, BatchNorm2d on batch statistics, ReLU] x n + max-pool,
+ * pointnet2_modules.py:203-211, 432-444), fused along its memory passes (csrc/mlp_train.hip): only the pre-BatchNorm
+ * convolution outputs Y_l and the gradients dA_l w.r.t. the post-ReLU activations exist in memory; BatchNorm, ReLU, the pool's
+ * gradient routing and the BatchNorm backward are applied where their operands are loaded.  All tensors (b, c, l) fp32
+ * channel-major, l = M * nsample a multiple of 64; split-fp16 MFMA arithmetic with fp32 accumulation (operands beyond +-65504
+ * or NaN / Inf poison the affected outputs with NaN and raise *overflow; never clamped silently).
+ *
+ * params: one block of 8 floats per channel {mean, invstd, scale = gamma invstd, shift = beta - mean scale, gamma, beta,
+ * c1 = mean(dZ), c2 = mean(dZ xhat)}; sps_tbn_finalize writes the first six from the statistics, sps_tbn_bwd_finalize the last
+ * two (plus d gamma, d beta).
+ *
+ * sps_tconv: out (b, co, l) = A . T(in), A[o][i] = trans ? w[i co + o] : w[o ci + i], ci <= 256.
+ *   in_mode 0: T = identity                     1: T = relu(fma(in, scale, shift))   (pin = params of the input rows)
+ *           2: T = scale (dZ - c1 - xhat c2), dZ = in [fma(in2, scale, shift) > 0], xhat = (in2 - mean) invstd
+ *           3: as 2 with `in` = the pooled gradient gout (b, ci, m) routed by arg (b, ci, m) u8 (nsample % 4 == 0)
+ *   epi_mode 0: none   1: per-channel sum / sum of squares of out -> partial   2: sums of dZ' and dZ' xhat' of the OUTPUT rows,
+ *           dZ' = out [fma(epi_y, scale', shift') > 0] (pout = params of the output rows) -> partial
+ *   partial: [sps_tconv_parts(b, l)][co][2] doubles, summed in a fixed order by the finalize calls.
+ * Operand scaling: every operand tensor is multiplied by an exact power of two that brings its largest magnitude near 2^10
+ * before it is split into fp16 halves (gradients are routinely 1e-5 and smaller; unscaled, their low halves would be fp16
+ * denormals), and the accumulators by the inverse.  amax_in (device scalar, in_mode >= 2): the largest magnitude of the
+ * incoming gradient tensor; amax_out (device scalar the caller zeroed, epi_mode 2): receives the atomic maximum of |out|.
+ * sps_tpool_bwd_stats produces it for the pooled gradient, sps_twgrad consumes it. */
+int sps_tconv_parts(int b, long long l);
+int sps_tconv(int b, int ci, int co, long long l, int in_mode, int epi_mode, int trans, const float *w, const float *in,
+              const float *in2, const float *gout, const unsigned char *arg, int nsample, int m, const float *pin, float *out,
+              const float *epi_y, const float *pout, double *partial, const float *amax_in, float *amax_out, int *overflow,
+              sps_stream_t stream);
+/* torch semantics: biased variance to normalise, unbiased for running_var, running = (1 - momentum) running + momentum batch;
+ * gamma / beta / running_* may be NULL; count = b * l. */
+int sps_tbn_finalize(int c, int nparts, double count, const double *partial, const float *gamma, const float *beta, float eps,
+                     float momentum, float *running_mean, float *running_var, float *params, sps_stream_t stream);
+int sps_tbn_bwd_finalize(int c, int nparts, double count, const double *partial, float *params, float *dgamma, float *dbeta,
+                         sps_stream_t stream);
+/* out (b, c, m) = max over the nsample columns of relu(fma(y, scale, shift)), arg = position of the FIRST maximum (a NaN wins
+ * and propagates: torch's max_pool2d), yarg = y at that position; nsample in {4, 8, 16, 32, 64}. */
+int sps_tpool_fwd(int b, int c, int m, int nsample, const float *y, const float *params, float *out, unsigned char *arg,
+                  float *yarg, sps_stream_t stream);
+/* the BatchNorm-backward sums of the LAST layer from the pooled gradient: partial (b, c, 2) doubles = b parts; amax_out
+ * (zeroed device scalar, may be NULL) receives max |gout| */
+int sps_tpool_bwd_stats(int b, int c, int m, const float *yarg, const float *gout, const float *params, double *partial,
+                        float *amax_out, sps_stream_t stream);
+/* dw (co, ci) = sum over all columns of dY (x) T(x): dY from (dA, y, pd) as in_mode 2 / 3 of sps_tconv (dmode), T = identity
+ * (xmode 0) or relu(fma(x, scale, shift)) with px (xmode 1); co, ci <= 256, l a multiple of 32; work =
+ * sps_twgrad_workspace_floats floats. */
+long long sps_twgrad_workspace_floats(int b, int co, int ci, long long l);
+int sps_twgrad(int b, int co, int ci, long long l, int dmode, int xmode, const float *dA, const float *y, const float *gout,
+               const unsigned char *arg, int nsample, int m, const float *pd, const float *x, const float *px,
+               const float *amax_in, float *dw, float *work, int *overflow, sps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

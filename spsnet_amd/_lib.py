@@ -67,6 +67,14 @@ _PROTOS = {
     "sps_three_nn_kernel_launcher_stack": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_three_interpolate_kernel_launcher_stack": [_i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_three_interpolate_grad_kernel_launcher_stack": [_i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sps_tconv_parts": [_i, ctypes.c_longlong],
+    "sps_tconv": [_i, _i, _i, ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                  _vp],
+    "sps_tbn_finalize": [_i, _i, ctypes.c_double, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp],
+    "sps_tbn_bwd_finalize": [_i, _i, ctypes.c_double, _vp, _vp, _vp, _vp, _vp],
+    "sps_tpool_fwd": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_tpool_bwd_stats": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_twgrad": [_i, _i, _i, ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_pool_max_fwd": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
     "sps_pool_max_bwd": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
     "sps_bn_relu_train_fwd": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -101,7 +109,7 @@ _PROTOS = {
 }
 EXPORTS = ["sps_abi_version", "sps_last_error", "sps_opt_n_threads", "sps_fps_workspace_floats",
            "sps_index_add_workspace_ints", "sps_ball_query_grid_workspace_ints", "sps_bn_train_workspace_doubles", "sps_conv1x1_wgrad_workspace_floats",
-           "sps_pack_columns_capacity", "sps_debug_set_wait_spins"] + list(_PROTOS)
+           "sps_pack_columns_capacity", "sps_debug_set_wait_spins", "sps_twgrad_workspace_floats"] + list(_PROTOS)
 
 _lib = None
 
@@ -138,6 +146,8 @@ def load():
     lib.sps_index_add_workspace_ints.argtypes = [_i, _i, _i]
     lib.sps_debug_set_wait_spins.argtypes = [ctypes.c_uint]
     lib.sps_debug_set_wait_spins.restype = ctypes.c_uint
+    lib.sps_twgrad_workspace_floats.argtypes = [_i, _i, _i, ctypes.c_longlong]
+    lib.sps_twgrad_workspace_floats.restype = ctypes.c_longlong
     lib.sps_pack_columns_capacity.argtypes = [_i, _i, _i]
     lib.sps_pack_columns_capacity.restype = ctypes.c_longlong
     for name, args in _PROTOS.items():

@@ -1,0 +1,826 @@
+// mlp_train.hip -- the grouped MLP of an SA layer in TRAINING mode, fused along its memory passes.
+//
+// pointnet2_modules.py:203-211 / :432-444 of the reference run, per scale, [Conv2d 1x1 -> BatchNorm2d (batch statistics) ->
+// ReLU] x 3 and a max-pool on (B, C, M, nsample) activations.  BatchNorm needs the statistics of ALL grouped points before the
+// next convolution can start, so the layers cannot be chained in registers as in inference; what can be removed are the
+// elementwise passes between the convolutions.  Op by op (conv, statistics, normalise + ReLU, pool; backward: pool, BatchNorm
+// reduce, BatchNorm apply, data gradient, weight gradient) every pre-activation tensor crosses HBM ~5 times forward and ~10
+// times backward, and those passes already ran at 5-6 TB/s (bn_relu_train.hip), i.e. only fusion removes them.  Here the ONLY
+// tensors that exist are the pre-BatchNorm convolution outputs Y_l (forward) and the gradients dA_l w.r.t. the post-ReLU
+// activations (backward); everything else is recomputed where it is consumed:
+//
+//   forward   Y_l = W_l . T(Y_{l-1})        T = relu(fma(y, scale, shift)) applied while the operand is loaded; the epilogue
+//                                           accumulates sum / sum of squares of Y_l per channel (tconv_kernel, TEPI_STATS)
+//             pooled = max_s T(Y_3)         BatchNorm + ReLU + max-pool + arg-max in one pass (tpool_fwd_kernel)
+//   backward  dY_l = scale (dZ - c1 - xhat c2), dZ = dA_l [z > 0]   recomputed from (dA_l, Y_l) in the operand load of BOTH
+//             dA_{l-1} = W_l^T . dY_l       gradient kernels; for the last layer dA_3 is never materialised either: it is the
+//             dW_l = dY_l . T(Y_{l-1})^T    pooled gradient routed by the arg-max (TIN_BNBWD_POOL).  The data-gradient
+//                                           kernel's epilogue accumulates the two BatchNorm-backward sums of layer l-1.
+//
+// Arithmetic: split-fp16 on v_mfma_f32_16x16x32_f16 (every fp32 operand as hi + lo halves, three products, fp32 accumulate:
+// ~22 significant bits, the same scheme as the inference kernels of sa_mlp_f16.hip) -- at 8 TB/s these GEMMs (64-256 channels
+// on either side) need ~500 TFLOP/s of issued matrix work to stay memory-bound, three times what the fp32 MFMA pipe has.
+// Operands beyond +-65504 or NaN / Inf are never clamped silently: the affected output columns (or the whole weight
+// gradient) are written as NaN and the overflow flag is raised.  Statistics are accumulated per lane in fp32 over a
+// workgroup's columns, then in fp64 in a fixed order (bit-reproducible from run to run).
+#include "sps_common.h"
+
+namespace sps {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr int TP = 8;   // floats per channel of a parameter block: mean, invstd, scale, shift, gamma, beta, c1, c2
+enum { TIN_RAW = 0, TIN_BNRELU = 1, TIN_BNBWD = 2, TIN_BNBWD_POOL = 3 };
+enum { TEPI_NONE = 0, TEPI_STATS = 1, TEPI_BWD = 2 };
+
+__device__ __forceinline__ f32x4 tmfma(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// relu that keeps a NaN (torch's clamp_min does)
+__device__ __forceinline__ float trelu(float z) { return (z > 0.f || z != z) ? z : 0.f; }
+
+// hi / lo halves of a value clamped into the fp16 range (the caller tracks range violations separately)
+__device__ __forceinline__ void tsplit(float v, _Float16 &hi, _Float16 &lo) {
+    const float c = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+    hi = (_Float16)c;
+    lo = (_Float16)(c - (float)hi);
+}
+// largest magnitude seen so far, +Inf once a NaN / Inf passed (0 * v is NaN exactly then)
+__device__ __forceinline__ float ttrack(float mx, const f32x4 v) {
+    const float z = __builtin_fmaf(v[0], 0.f, __builtin_fmaf(v[1], 0.f, __builtin_fmaf(v[2], 0.f, v[3] * 0.f)));
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    return (z == 0.f) ? mx : INFINITY;
+}
+
+// Exact power-of-two scaling in front of the split: fp16 keeps 11 bits per half only for |v| >= 2^-14, and the low half of a
+// value below ~0.06 is already a half denormal (absolute error 3e-8, not 2^-22 relative).  Gradients are routinely 1e-5 and
+// smaller, so every operand tensor is multiplied by 2^k with the tensor's largest magnitude brought near 2^10 (weights: near
+// 2^8), and the accumulators are multiplied by the inverse afterwards -- both exact.  The largest magnitude of a gradient
+// tensor is tracked by the kernel that produces it (atomic max on the float's bits: order-independent, reproducible).
+__device__ __forceinline__ float tpow2_scale(float target, float amax) {
+    if (!(amax > 0.f) || !(amax < INFINITY)) return 1.f;
+    int e = (int)floorf(log2f(target / amax));
+    e = e < -60 ? -60 : (e > 60 ? 60 : e);
+    return ldexpf(1.f, e);
+}
+// max over the workgroup (all threads get it); `scratch` = 8 floats of LDS
+__device__ __forceinline__ float tblock_max(float v, float *scratch, int nwaves) {
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = scratch[0];
+    for (int w = 1; w < nwaves; ++w) r = fmaxf(r, scratch[w]);
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ void tatomic_amax(float *dst, float v) {   // v >= 0 (or NaN, which then sticks)
+    atomicMax(reinterpret_cast<unsigned int *>(dst), __float_as_uint(v));
+}
+
+struct TConvArgs {
+    int b, ci, co, S;            // scenes, input rows, output rows, k-steps of 32 input rows
+    long long l;                 // columns per scene (multiple of 64)
+    int trans;                   // A[o][i] = trans ? w[i * co + o] : w[o * ci + i]
+    const float *w;
+    const float *in, *in2;       // RAW / BNRELU: in = the operand; BNBWD: in = dA, in2 = Y; BNBWD_POOL: in2 = Y
+    const float *gout;           // BNBWD_POOL: pooled gradient (b, ci, m) ...
+    const unsigned char *arg;    // ... and the arg-max of the pool (b, ci, m)
+    int ns, m;
+    const float *pin;            // (ci, 8) parameter block of the input rows
+    float *out;                  // (b, co, l)
+    const float *epi_y;          // TEPI_BWD: Y of the OUTPUT rows (b, co, l)
+    const float *pout;           // TEPI_BWD: (co, 8) parameter block of the output rows
+    double *partial;             // [gridDim.x][co][2]
+    const float *amax_in;        // BNBWD modes: largest |incoming gradient| (device scalar)
+    float *amax_out;             // TEPI_BWD: atomic max of |out| (device scalar, zeroed by the caller)
+    int *overflow;
+};
+
+// One 64-column block per wave at a time; the 16 RT output rows of blockIdx.z against all input rows.  Four waves per
+// workgroup, ONE workgroup per CU at the wide shapes: what keeps HBM busy is not occupancy but the loads each wave has in
+// flight -- the operand rows of a k-step (8 KiB per wave and tensor) are requested TWO k-steps ahead of their use, across
+// block boundaries, from a three-deep ring of register buffers.
+//   B operand (activations): lane (q, c) loads rows 32 s + 8 q + e, e = 0..7, as float4 = columns 4c..4c+3; element j of the
+//   float4 feeds column tile j, so loads and stores stay 16 bytes per lane and 256 contiguous bytes per row.
+//   A operand (weights): scaled and split once per workgroup into LDS as [tile][k-step][hi | lo][lane][8 halves].
+template <int RT, int IN, int EPI>
+__global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool GRAD = (IN == TIN_BNBWD || IN == TIN_BNBWD_POOL);
+    const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
+    const int wave = threadIdx.x >> 6;
+    const int S = a.S, cip = 32 * S;
+    const int rows_wg = 16 * RT;
+    const int row0 = blockIdx.z * rows_wg;
+    char *wl = smem;
+    float *pin_l = reinterpret_cast<float *>(smem + (size_t)RT * S * 2048);
+    float *pout_l = pin_l + (IN != TIN_RAW ? cip * TP : 0);
+    double *red = reinterpret_cast<double *>(pout_l + (EPI == TEPI_BWD ? rows_wg * TP : 0));
+    float *scratch = reinterpret_cast<float *>(red + (EPI != TEPI_NONE ? (size_t)4 * 16 * RT * 2 : 0));
+
+    auto wval = [&](int o, int k) -> float {
+        const int row = row0 + o;
+        if (row < a.co && k < a.ci) return a.trans ? a.w[(size_t)k * a.co + row] : a.w[(size_t)row * a.ci + k];
+        return 0.f;
+    };
+    float wmax = 0.f;
+    for (int idx = threadIdx.x; idx < rows_wg * cip; idx += 256) wmax = fmaxf(wmax, fabsf(wval(idx / cip, idx % cip)));
+    const float sw = tpow2_scale(256.f, tblock_max(wmax, scratch, 4));
+    for (int idx = threadIdx.x; idx < rows_wg * cip; idx += 256) {
+        const int o = idx / cip, k = idx - o * cip;
+        _Float16 hi, lo;
+        tsplit(wval(o, k) * sw, hi, lo);
+        const int t = o >> 4, i = o & 15, s = k >> 5, qq = (k & 31) >> 3, e = k & 7;
+        char *dst = wl + ((size_t)(t * S + s) * 2) * 1024 + (qq * 16 + i) * 16 + e * 2;
+        *reinterpret_cast<_Float16 *>(dst) = hi;
+        *reinterpret_cast<_Float16 *>(dst + 1024) = lo;
+    }
+    float sx = 1.f;
+    if (IN != TIN_RAW) {
+        float smax = 0.f;
+        for (int idx = threadIdx.x; idx < cip * TP; idx += 256) {
+            const float v = (idx / TP < a.ci) ? a.pin[idx] : 0.f;
+            pin_l[idx] = v;
+            if ((idx & (TP - 1)) == 2) smax = fmaxf(smax, fabsf(v));
+        }
+        if (GRAD) sx = tpow2_scale(1024.f, tblock_max(smax, scratch, 4) * (*a.amax_in));
+    }
+    if (EPI == TEPI_BWD)
+        for (int idx = threadIdx.x; idx < rows_wg * TP; idx += 256)
+            pout_l[idx] = (row0 + idx / TP < a.co) ? a.pout[(size_t)row0 * TP + idx] : 0.f;
+    __syncthreads();
+    const float inv = 1.f / (sx * sw);                                  // powers of two: exact
+
+    float st1[RT][4], st2[RT][4];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st1[t][r] = 0.f; st2[t][r] = 0.f; }
+    bool any_bad = false;
+    float omax = 0.f;
+
+    // this wave's blocks: id = (blockIdx.x + i gridDim.x) 4 + wave, i = 0 .. nblk - 1; its pieces: (block, k-step), in order
+    const long long nb64 = a.l >> 6;
+    const long long total = (long long)a.b * nb64;
+    const long long first = (long long)blockIdx.x * 4 + wave, stride = (long long)gridDim.x * 4;
+    const long long nblk = first < total ? (total - first + stride - 1) / stride : 0;
+    const long long npieces = nblk * S;
+
+    struct Piece { f32x4 xa[8], xb[GRAD ? 8 : 1]; };
+    auto load = [&](long long piece, Piece &pc) {
+        const long long i = piece / S;
+        const int s = (int)(piece - i * S);
+        const long long id = first + i * stride;
+        const int scene = (int)(id / nb64);
+        const long long col0 = (id - (long long)scene * nb64) * 64 + 4 * c;
+        const float *src = a.in + (size_t)scene * a.ci * a.l + col0;
+        const float *src2 = a.in2 + (size_t)scene * a.ci * a.l + col0;
+        const long long cen = (IN == TIN_BNBWD_POOL) ? col0 / a.ns : 0;     // the four columns belong to ONE centroid
+        const size_t pool_base = (size_t)scene * a.ci * a.m + cen;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int row = 32 * s + 8 * q + e;
+            pc.xa[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (GRAD) pc.xb[e] = pc.xa[e];
+            if (row < a.ci) {
+                if (IN == TIN_BNBWD_POOL) {
+                    pc.xa[e][0] = a.gout[pool_base + (size_t)row * a.m];
+                    pc.xa[e][1] = (float)((int)a.arg[pool_base + (size_t)row * a.m] - (int)(col0 - cen * a.ns));
+                } else {
+                    pc.xa[e] = *reinterpret_cast<const f32x4 *>(src + (size_t)row * a.l);
+                }
+                if (GRAD) pc.xb[e] = *reinterpret_cast<const f32x4 *>(src2 + (size_t)row * a.l);
+            }
+        }
+    };
+    // (the gradient modes at 128 rows: one k-step ahead only -- two tensors per piece, and 192 accumulator / statistics registers)
+    constexpr int DEPTH = (GRAD && RT == 8) ? 1 : 2;
+    Piece b0, b1, b2;
+    if (npieces > 0) load(0, b0);
+    if (DEPTH == 2 && npieces > 1) load(1, b1);
+
+    f32x4 acc[RT][4];
+    float mx = 0.f;
+    int s = 0;
+    long long blk = 0;
+    for (long long piece = 0; piece < npieces; ++piece) {
+        if (DEPTH == 2) {
+            if (piece + 2 < npieces) load(piece + 2, b2);
+        } else if (piece + 1 < npieces) {
+            load(piece + 1, b1);
+        }
+        if (s == 0) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            mx = 0.f;
+        }
+        h8 bh[4], bl[4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float *P = pin_l + (32 * s + 8 * q + e) * TP;
+            f32x4 v;
+            if (IN == TIN_RAW) {
+                v = b0.xa[e];
+            } else if (IN == TIN_BNRELU) {
+                const f32x4 p0 = *reinterpret_cast<const f32x4 *>(P);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = trelu(__builtin_fmaf(b0.xa[e][j], p0[2], p0[3]));
+            } else {
+                const f32x4 p0 = *reinterpret_cast<const f32x4 *>(P), p1 = *reinterpret_cast<const f32x4 *>(P + 4);
+                f32x4 g = b0.xa[e];
+                if (IN == TIN_BNBWD_POOL) {
+                    const int am = (int)b0.xa[e][1];
+                    const float gg = b0.xa[e][0];
+                    g = (f32x4){am == 0 ? gg : 0.f, am == 1 ? gg : 0.f, am == 2 ? gg : 0.f, am == 3 ? gg : 0.f};
+                }
+                const float ks = p0[2] * sx;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float y = b0.xb[GRAD ? e : 0][j];
+                    const float z = __builtin_fmaf(y, p0[2], p0[3]);
+                    const float xh = (y - p0[0]) * p0[1];
+                    const float dz = z > 0.f ? g[j] : 0.f;
+                    v[j] = ks * (dz - p1[2] - xh * p1[3]);
+                }
+            }
+            mx = ttrack(mx, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                _Float16 hi, lo;
+                tsplit(v[j], hi, lo);
+                bh[j][e] = hi;
+                bl[j][e] = lo;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const char *fr = wl + ((size_t)(t * S + s) * 2) * 1024 + lane * 16;
+            const h8 ah = *reinterpret_cast<const h8 *>(fr), al = *reinterpret_cast<const h8 *>(fr + 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[t][j] = tmfma(ah, bh[j], acc[t][j]);
+                acc[t][j] = tmfma(ah, bl[j], acc[t][j]);
+                acc[t][j] = tmfma(al, bh[j], acc[t][j]);
+            }
+        }
+        b0 = b1;
+        if (DEPTH == 2) b1 = b2;
+        if (++s < S) continue;
+        // ---- the block is complete: rows 16 t + 4 q + r, columns col0 .. col0 + 3 ----
+        s = 0;
+        const long long id = first + blk * stride;
+        ++blk;
+        const int scene = (int)(id / nb64);
+        const long long col0 = (id - (long long)scene * nb64) * 64 + 4 * c;
+        const bool poison = __builtin_amdgcn_ballot_w64(mx > 65504.f) != 0ull;   // an unrepresentable operand: NaN, never clamped
+        any_bad |= poison;
+        const float nanv = __int_as_float(0x7fc00000);
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int orow = 16 * t + 4 * q + r, row = row0 + orow;
+                if (row >= a.co) continue;
+                f32x4 o = (f32x4){acc[t][0][r] * inv, acc[t][1][r] * inv, acc[t][2][r] * inv, acc[t][3][r] * inv};
+                if (poison) o = (f32x4){nanv, nanv, nanv, nanv};
+                const size_t at = ((size_t)scene * a.co + row) * a.l + col0;
+                *reinterpret_cast<f32x4 *>(a.out + at) = o;
+                if (EPI == TEPI_STATS) {
+                    st1[t][r] += (o[0] + o[1]) + (o[2] + o[3]);
+                    st2[t][r] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+                } else if (EPI == TEPI_BWD) {
+                    const f32x4 yp = *reinterpret_cast<const f32x4 *>(a.epi_y + at);
+                    const f32x4 p0 = *reinterpret_cast<const f32x4 *>(pout_l + orow * TP);
+                    omax = fmaxf(omax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float z = __builtin_fmaf(yp[j], p0[2], p0[3]);
+                        const float dz = z > 0.f ? o[j] : 0.f;
+                        st1[t][r] += dz;
+                        st2[t][r] += dz * ((yp[j] - p0[0]) * p0[1]);
+                    }
+                }
+            }
+    }
+    if (any_bad && a.overflow) *a.overflow = 1;
+    if (EPI == TEPI_BWD && a.amax_out) {
+        for (int off = 32; off > 0; off >>= 1) omax = fmaxf(omax, __shfl_xor(omax, off));
+        if (lane == 0) tatomic_amax(a.amax_out, any_bad ? INFINITY : omax);
+    }
+    if (EPI != TEPI_NONE) {
+        // per-lane fp32 partials -> fp64, the 16 lanes of a row meet in a butterfly, the four waves in LDS (fixed order)
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double d1 = st1[t][r], d2 = st2[t][r];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) { d1 += __shfl_xor(d1, off); d2 += __shfl_xor(d2, off); }
+                if (c == 0) {
+                    double *o = red + ((size_t)wave * 16 * RT + 16 * t + 4 * q + r) * 2;
+                    o[0] = d1; o[1] = d2;
+                }
+            }
+        __syncthreads();
+        for (int o = threadIdx.x; o < rows_wg; o += 256) {
+            if (row0 + o >= a.co) continue;
+            double d1 = 0.0, d2 = 0.0;
+            for (int w = 0; w < 4; ++w) { d1 += red[((size_t)w * 16 * RT + o) * 2]; d2 += red[((size_t)w * 16 * RT + o) * 2 + 1]; }
+            double *dst = a.partial + ((size_t)blockIdx.x * a.co + row0 + o) * 2;
+            dst[0] = d1; dst[1] = d2;
+        }
+    }
+}
+
+// ---- weight gradient: dW (co x ci) = sum over all columns of dY (x) T(X) -------------------------------------------------
+struct TWgradArgs {
+    int b, co, ci;
+    long long l;                 // columns per scene (multiple of 32 NK)
+    int dmode, xmode;            // TIN_BNBWD / TIN_BNBWD_POOL for dY; TIN_RAW / TIN_BNRELU for the other operand
+    const float *dA, *y;         // (b, co, l)
+    const float *gout;
+    const unsigned char *arg;
+    int ns, m;
+    const float *pd;             // (co, 8)
+    const float *x;              // (b, ci, l)
+    const float *px;             // (ci, 8)
+    float *partial;              // [gridDim.x][cop][cip]  (cop, cip = co, ci rounded up to 16)
+    const float *amax_in;        // largest |incoming gradient|
+    int *overflow;
+};
+
+// 8 waves; a stage = 32 NK columns of every row of both operands, transformed and split ONCE into LDS (rows 64 NK + 16 bytes
+// apart: the 16 rows of a fragment start 16 bytes apart modulo 256, no bank conflicts), then each wave multiplies its output
+// tiles (t = wt, wt + 4, ..; u = wu, wu + 2, ..).  The next stage's global loads are in flight during the MFMAs.  NK widens
+// the stage for narrow layers (4 passes of 512 / (8 NK) rows cover 64 NK... rows): a stage then moves enough bytes to hide its
+// two barriers.
+template <int NK>
+__global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RS = 64 * NK + 16;            // LDS bytes per operand row
+    constexpr int CG = 8 * NK, RR = 512 / CG;   // float4 groups per row of a stage, rows per pass
+    const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, c = lane & 15, wave = tid >> 6;
+    const int wt = wave >> 1, wu = wave & 1;
+    const int T = (a.co + 15) >> 4, U = (a.ci + 15) >> 4;
+    const int cop = 16 * T, cip = 16 * U;
+    char *ahi = smem, *alo = ahi + (size_t)cop * RS, *bhi = alo + (size_t)cop * RS, *blo = bhi + (size_t)cip * RS;
+    float *pd_l = reinterpret_cast<float *>(blo + (size_t)cip * RS);
+    float *px_l = pd_l + cop * TP;
+    float *scratch = px_l + cip * TP;           // 8 floats + the poison flag
+    float smax = 0.f;
+    for (int i = tid; i < cop * TP; i += 512) {
+        const float v = (i / TP < a.co) ? a.pd[i] : 0.f;
+        pd_l[i] = v;
+        if ((i & (TP - 1)) == 2) smax = fmaxf(smax, fabsf(v));
+    }
+    for (int i = tid; i < cip * TP; i += 512) px_l[i] = (a.xmode != TIN_RAW && i / TP < a.ci) ? a.px[i] : 0.f;
+    const float sx = tpow2_scale(1024.f, tblock_max(smax, scratch, 8) * (*a.amax_in));   // (ends with a barrier: LDS is ready)
+
+    const int cg = tid % CG, rr = tid / CG;                      // float4 group within the stage, row within a pass
+    const long long per_scene = a.l / (32 * NK);
+    const long long total = (long long)a.b * per_scene;
+    const long long s0 = total * blockIdx.x / gridDim.x, s1 = total * (blockIdx.x + 1) / gridDim.x;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mx = 0.f;
+
+    f32x4 pa[4], pb[4], pxv[4];
+    auto prefetch = [&](long long st) {
+        const int scene = (int)(st / per_scene);
+        const long long col = (st - (long long)scene * per_scene) * (32 * NK) + 4 * cg;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = rr + RR * p;
+            pa[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            pb[p] = pa[p];
+            pxv[p] = pa[p];
+            if (row < a.co) {
+                const size_t at = ((size_t)scene * a.co + row) * a.l + col;
+                if (a.dmode == TIN_BNBWD_POOL) {
+                    const long long cen = col / a.ns;
+                    const size_t pat = ((size_t)scene * a.co + row) * a.m + cen;
+                    pa[p][0] = a.gout[pat];
+                    pa[p][1] = (float)((int)a.arg[pat] - (int)(col - cen * a.ns));
+                } else {
+                    pa[p] = *reinterpret_cast<const f32x4 *>(a.dA + at);
+                }
+                pb[p] = *reinterpret_cast<const f32x4 *>(a.y + at);
+            }
+            if (row < a.ci) pxv[p] = *reinterpret_cast<const f32x4 *>(a.x + ((size_t)scene * a.ci + row) * a.l + col);
+        }
+    };
+    auto put = [&](char *hi_base, char *lo_base, int row, const f32x4 v) {
+        h4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            _Float16 hh, l2;
+            tsplit(v[j], hh, l2);
+            hi[j] = hh;
+            lo[j] = l2;
+        }
+        *reinterpret_cast<h4 *>(hi_base + (size_t)row * RS + cg * 8) = hi;
+        *reinterpret_cast<h4 *>(lo_base + (size_t)row * RS + cg * 8) = lo;
+    };
+    if (s0 < s1) prefetch(s0);
+    for (long long st = s0; st < s1; ++st) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = rr + RR * p;
+            if (row < cop) {
+                const f32x4 p0 = *reinterpret_cast<const f32x4 *>(pd_l + row * TP), p1 = *reinterpret_cast<const f32x4 *>(pd_l + row * TP + 4);
+                f32x4 g = pa[p], v;
+                if (a.dmode == TIN_BNBWD_POOL) {
+                    const int am = (int)pa[p][1];
+                    const float gg = pa[p][0];
+                    g = (f32x4){am == 0 ? gg : 0.f, am == 1 ? gg : 0.f, am == 2 ? gg : 0.f, am == 3 ? gg : 0.f};
+                }
+                const float ks = p0[2] * sx;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float y = pb[p][j];
+                    const float z = __builtin_fmaf(y, p0[2], p0[3]);
+                    const float xh = (y - p0[0]) * p0[1];
+                    const float dz = z > 0.f ? g[j] : 0.f;
+                    v[j] = ks * (dz - p1[2] - xh * p1[3]);
+                }
+                mx = ttrack(mx, v);
+                put(ahi, alo, row, v);
+            }
+            if (row < cip) {
+                f32x4 v = pxv[p];
+                if (a.xmode == TIN_BNRELU) {
+                    const f32x4 p0 = *reinterpret_cast<const f32x4 *>(px_l + row * TP);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = trelu(__builtin_fmaf(v[j], p0[2], p0[3]));
+                }
+                mx = ttrack(mx, v);
+                put(bhi, blo, row, v);
+            }
+        }
+        __syncthreads();
+        if (st + 1 < s1) prefetch(st + 1);
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = wt + 4 * i;
+                if (t >= T) continue;
+                const h8 fah = *reinterpret_cast<const h8 *>(ahi + (size_t)(16 * t + c) * RS + kk * 64 + q * 16);
+                const h8 fal = *reinterpret_cast<const h8 *>(alo + (size_t)(16 * t + c) * RS + kk * 64 + q * 16);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int u = wu + 2 * j;
+                    if (u >= U) continue;
+                    const h8 fbh = *reinterpret_cast<const h8 *>(bhi + (size_t)(16 * u + c) * RS + kk * 64 + q * 16);
+                    const h8 fbl = *reinterpret_cast<const h8 *>(blo + (size_t)(16 * u + c) * RS + kk * 64 + q * 16);
+                    acc[i][j] = tmfma(fah, fbh, acc[i][j]);
+                    acc[i][j] = tmfma(fah, fbl, acc[i][j]);
+                    acc[i][j] = tmfma(fal, fbh, acc[i][j]);
+                }
+            }
+        __syncthreads();
+    }
+    // an unrepresentable operand anywhere in this workgroup's columns: its whole partial is NaN
+    const bool poison = tblock_max(mx, scratch, 8) > 65504.f;
+    if (poison && tid == 0 && a.overflow) *a.overflow = 1;
+    const float nanv = __int_as_float(0x7fc00000), inv = 1.f / sx;
+    float *dst = a.partial + (size_t)blockIdx.x * cop * cip;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = wt + 4 * i;
+        if (t >= T) continue;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int u = wu + 2 * j;
+            if (u >= U) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(size_t)(16 * t + 4 * q + r) * cip + 16 * u + c] = poison ? nanv : acc[i][j][r] * inv;
+        }
+    }
+}
+
+// dw[o][i] = sum over the workgroup partials, in launch order (eight loads in flight per thread)
+__global__ __launch_bounds__(256) void twgrad_reduce_kernel(int co, int ci, int cip, int cop, int nparts, const float *__restrict__ partial,
+                                                            float *__restrict__ dw) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= co * ci) return;
+    const int o = e / ci, i = e - o * ci;
+    const float *p = partial + (size_t)o * cip + i;
+    const size_t stride = (size_t)cop * cip;
+    float s = 0.f;
+    int k = 0;
+    for (; k + 8 <= nparts; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nparts; ++k) s += p[(size_t)k * stride];
+    dw[e] = s;
+}
+
+// ---- statistics -> parameter blocks -----------------------------------------------------------------------------------------
+// one wave per channel: lane l adds parts l, l + 64, ..., the lane sums meet in a butterfly (a fixed order)
+__device__ __forceinline__ void tsum_parts(const double *partial, int c, int ch, int nparts, double &s1, double &s2) {
+    const int lane = threadIdx.x & 63;
+    double d1 = 0.0, d2 = 0.0;
+    for (int k = lane; k < nparts; k += 64) {
+        d1 += partial[((size_t)k * c + ch) * 2];
+        d2 += partial[((size_t)k * c + ch) * 2 + 1];
+    }
+    for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_xor(d1, off); d2 += __shfl_xor(d2, off); }
+    s1 = d1; s2 = d2;
+}
+
+__global__ __launch_bounds__(256) void tbn_finalize_kernel(int c, int nparts, double count, const double *__restrict__ partial,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                           float momentum, float *__restrict__ running_mean,
+                                                           float *__restrict__ running_var, float *__restrict__ P) {
+    const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ch >= c) return;
+    double s1, s2;
+    tsum_parts(partial, c, ch, nparts, s1, s2);
+    if ((threadIdx.x & 63) != 0) return;
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)m, invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[ch] : 1.f, bt = beta ? beta[ch] : 0.f;
+    const float scale = g * invstd;
+    float *p = P + (size_t)ch * TP;
+    p[0] = mean; p[1] = invstd; p[2] = scale; p[3] = bt - mean * scale; p[4] = g; p[5] = bt; p[6] = 0.f; p[7] = 0.f;
+    if (running_mean) running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * mean;
+    if (running_var) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+    }
+}
+
+__global__ __launch_bounds__(256) void tbn_bwd_finalize_kernel(int c, int nparts, double inv_count, const double *__restrict__ partial,
+                                                               float *__restrict__ P, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ch >= c) return;
+    double s1, s2;
+    tsum_parts(partial, c, ch, nparts, s1, s2);
+    if ((threadIdx.x & 63) != 0) return;
+    P[(size_t)ch * TP + 6] = (float)(s1 * inv_count);
+    P[(size_t)ch * TP + 7] = (float)(s2 * inv_count);
+    if (dbeta) dbeta[ch] = (float)s1;
+    if (dgamma) dgamma[ch] = (float)s2;
+}
+
+// ---- BatchNorm + ReLU + max over the samples (+ arg-max), one pass over Y_3 ------------------------------------------------
+// the FIRST maximum wins; a NaN wins and of several NaNs the last keeps the index (torch's max_pool2d; group_gather.hip)
+__device__ __forceinline__ bool tpool_takes(float b, int bi, float a, int ai) {
+    const bool an = a != a, bn = b != b;
+    if (an || bn) return bn && (!an || bi > ai);
+    return b > a || (b == a && bi < ai);
+}
+// G = nsample / 4 lanes share a row of nsample values (16 bytes each).  yarg = the pre-BatchNorm value at the arg-max: what
+// the backward needs of Y for the BatchNorm sums of the last layer, so that it does not have to gather it again.
+template <int G>
+__global__ __launch_bounds__(256) void tpool_fwd_kernel(long long rows, int c, int m, const float *__restrict__ y,
+                                                        const float *__restrict__ P, float *__restrict__ out,
+                                                        unsigned char *__restrict__ arg, float *__restrict__ yarg) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long r = e / G;
+    const int sub = (int)(e - r * G);
+    const bool live = r < rows;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    float sc = 0.f, sh = 0.f;
+    if (live) {
+        v = *reinterpret_cast<const f32x4 *>(y + e * 4);
+        const int ch = (int)((r / m) % c);
+        sc = P[(size_t)ch * TP + 2];
+        sh = P[(size_t)ch * TP + 3];
+    }
+    float best = trelu(__builtin_fmaf(v[0], sc, sh)), by = v[0];
+    int bi = sub * 4;
+#pragma unroll
+    for (int u = 1; u < 4; ++u) {
+        const float z = trelu(__builtin_fmaf(v[u], sc, sh));
+        if (z > best || z != z) { best = z; bi = sub * 4 + u; by = v[u]; }
+    }
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1) {
+        const float ob = __shfl_xor(best, off), oy = __shfl_xor(by, off);
+        const int oi = __shfl_xor(bi, off);
+        if (tpool_takes(ob, oi, best, bi)) { best = ob; bi = oi; by = oy; }
+    }
+    if (live && sub == 0) { out[r] = best; arg[r] = (unsigned char)bi; yarg[r] = by; }
+}
+
+// The two BatchNorm-backward sums of the LAST layer from the pooled gradient alone: dZ_3 is gout at the arg-max (where the
+// pooled value is positive) and zero elsewhere.  One workgroup per (channel, scene); partial[(scene * c + ch) * 2].
+__global__ __launch_bounds__(256) void tpool_bwd_stats_kernel(int c, int m, const float *__restrict__ yarg,
+                                                              const float *__restrict__ gout, const float *__restrict__ P,
+                                                              double *__restrict__ partial, float *__restrict__ amax_out) {
+    __shared__ double sh1[4], sh2[4];
+    const int ch = blockIdx.x, scene = blockIdx.y;
+    const f32x4 p0 = *reinterpret_cast<const f32x4 *>(P + (size_t)ch * TP);
+    const size_t base = ((size_t)scene * c + ch) * m;
+    double d1 = 0.0, d2 = 0.0;
+    float gm = 0.f;
+    for (int j = threadIdx.x; j < m; j += 256) {
+        const float g = gout[base + j];
+        const float yy = yarg[base + j];
+        const float z = __builtin_fmaf(yy, p0[2], p0[3]);
+        const float dz = z > 0.f ? g : 0.f;
+        d1 += dz;
+        d2 += (double)dz * ((yy - p0[0]) * p0[1]);
+        gm = (g != g) ? INFINITY : fmaxf(gm, fabsf(g));
+    }
+    for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_xor(d1, off); d2 += __shfl_xor(d2, off); gm = fmaxf(gm, __shfl_xor(gm, off)); }
+    if (amax_out && (threadIdx.x & 63) == 0) tatomic_amax(amax_out, gm);
+    if ((threadIdx.x & 63) == 0) { sh1[threadIdx.x >> 6] = d1; sh2[threadIdx.x >> 6] = d2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double *o = partial + ((size_t)scene * c + ch) * 2;
+        o[0] = (sh1[0] + sh1[1]) + (sh1[2] + sh1[3]);
+        o[1] = (sh2[0] + sh2[1]) + (sh2[2] + sh2[3]);
+    }
+}
+
+int tconv_grid_x(int b, long long l) {
+    const long long groups = ((long long)b * (l >> 6) + 3) / 4;
+    return (int)(groups < 512 ? groups : 512);
+}
+
+template <int RT, int IN>
+int tconv_launch_epi(const TConvArgs &a, int epi, hipStream_t st) {
+    const int cip = 32 * a.S, rows_wg = 16 * RT;
+    const size_t lds = (size_t)RT * a.S * 2048 + (IN != TIN_RAW ? cip * TP * 4 : 0) + (epi == TEPI_BWD ? rows_wg * TP * 4 : 0) +
+                       (epi != TEPI_NONE ? (size_t)4 * 16 * RT * 2 * 8 : 0) + 64;
+    if (lds > 156 * 1024) return fail(SPS_ERR_INVALID, "tconv: %zu bytes of LDS (ci = %d)", lds, a.ci);
+    const dim3 grid(tconv_grid_x(a.b, a.l), 1, divup(a.co, rows_wg));
+#define SPS_TCONV_GO(EPI)                                                                                               \
+    {                                                                                                                   \
+        static LdsLimitOnce raised;                                                                                     \
+        if (lds > 64 * 1024) {                                                                                          \
+            const int rc = raise_lds_limit((const void *)tconv_kernel<RT, IN, EPI>, 156 * 1024, raised, "tconv");      \
+            if (rc != SPS_OK) return rc;                                                                                \
+        }                                                                                                               \
+        hipLaunchKernelGGL((tconv_kernel<RT, IN, EPI>), grid, dim3(256), lds, st, a);                                   \
+    }
+    if (epi == TEPI_NONE) SPS_TCONV_GO(TEPI_NONE)
+    else if (epi == TEPI_STATS) SPS_TCONV_GO(TEPI_STATS)
+    else SPS_TCONV_GO(TEPI_BWD)
+#undef SPS_TCONV_GO
+    return check_launch("tconv_kernel");
+}
+
+template <int RT>
+int tconv_launch_in(const TConvArgs &a, int in_mode, int epi, hipStream_t st) {
+    switch (in_mode) {
+        case TIN_RAW: return tconv_launch_epi<RT, TIN_RAW>(a, epi, st);
+        case TIN_BNRELU: return tconv_launch_epi<RT, TIN_BNRELU>(a, epi, st);
+        case TIN_BNBWD: return tconv_launch_epi<RT, TIN_BNBWD>(a, epi, st);
+        default: return tconv_launch_epi<RT, TIN_BNBWD_POOL>(a, epi, st);
+    }
+}
+
+template <int NK>
+int twgrad_launch(const TWgradArgs &a, int parts, size_t lds, hipStream_t st) {
+    static LdsLimitOnce raised;
+    if (lds > 64 * 1024) {
+        const int rc = raise_lds_limit((const void *)twgrad_kernel<NK>, 128 * 1024, raised, "twgrad");
+        if (rc != SPS_OK) return rc;
+    }
+    hipLaunchKernelGGL(twgrad_kernel<NK>, dim3(parts), dim3(512), lds, st, a);
+    return SPS_OK;
+}
+
+}  // namespace
+}  // namespace sps
+
+using namespace sps;
+
+// Workgroups along the columns of sps_tconv = first dimension of its `partial` output ([parts][co][2] doubles).
+extern "C" int sps_tconv_parts(int b, long long l) {
+    if (b <= 0 || l <= 0) return 0;
+    return tconv_grid_x(b, l);
+}
+
+extern "C" int sps_tconv(int b, int ci, int co, long long l, int in_mode, int epi_mode, int trans, const float *w, const float *in,
+                         const float *in2, const float *gout, const unsigned char *arg, int nsample, int m, const float *pin,
+                         float *out, const float *epi_y, const float *pout, double *partial, const float *amax_in,
+                         float *amax_out, int *overflow, sps_stream_t stream) {
+    if (b < 0 || ci <= 0 || co <= 0 || l < 0 || ci > 256) return fail(SPS_ERR_INVALID, "tconv: bad shape b=%d ci=%d co=%d l=%lld", b, ci, co, l);
+    if (b == 0 || l == 0) return SPS_OK;
+    if (l % 64) return fail(SPS_ERR_INVALID, "tconv: l = %lld must be a multiple of 64", l);
+    if (in_mode < TIN_RAW || in_mode > TIN_BNBWD_POOL || epi_mode < TEPI_NONE || epi_mode > TEPI_BWD)
+        return fail(SPS_ERR_INVALID, "tconv: unknown mode");
+    if (!w || !out || (in_mode != TIN_BNBWD_POOL && !in) || (in_mode != TIN_RAW && !pin) || (in_mode >= TIN_BNBWD && !in2) ||
+        (epi_mode != TEPI_NONE && !partial) || (epi_mode == TEPI_BWD && (!epi_y || !pout)) || (in_mode >= TIN_BNBWD && !amax_in))
+        return fail(SPS_ERR_INVALID, "tconv: null pointer");
+    if (in_mode == TIN_BNBWD_POOL && (!gout || !arg || nsample <= 0 || (nsample % 4) || m <= 0 || (long long)m * nsample != l))
+        return fail(SPS_ERR_INVALID, "tconv: the pooled-gradient operand needs gout, arg, nsample %% 4 == 0 and m * nsample == l");
+    TConvArgs a;
+    a.b = b; a.ci = ci; a.co = co; a.S = (ci + 31) / 32; a.l = l; a.trans = trans ? 1 : 0; a.w = w;
+    a.in = in ? in : in2; a.in2 = in2 ? in2 : in; a.gout = gout; a.arg = arg; a.ns = nsample > 0 ? nsample : 4; a.m = m;
+    a.pin = pin; a.out = out; a.epi_y = epi_y; a.pout = pout; a.partial = partial; a.amax_in = amax_in; a.amax_out = amax_out;
+    a.overflow = overflow;
+    hipStream_t st = as_stream(stream);
+    if (co <= 16) return tconv_launch_in<1>(a, in_mode, epi_mode, st);
+    if (co <= 32) return tconv_launch_in<2>(a, in_mode, epi_mode, st);
+    if (co <= 64) return tconv_launch_in<4>(a, in_mode, epi_mode, st);
+    return tconv_launch_in<8>(a, in_mode, epi_mode, st);        // 128 rows per workgroup (blockIdx.z walks the rest)
+}
+
+extern "C" int sps_tbn_finalize(int c, int nparts, double count, const double *partial, const float *gamma, const float *beta,
+                                float eps, float momentum, float *running_mean, float *running_var, float *params,
+                                sps_stream_t stream) {
+    if (c <= 0 || nparts <= 0 || count <= 0.0 || !partial || !params) return fail(SPS_ERR_INVALID, "tbn_finalize: bad arguments");
+    hipLaunchKernelGGL(tbn_finalize_kernel, dim3(divup(c, 4)), dim3(256), 0, as_stream(stream), c, nparts, count, partial, gamma, beta,
+                       eps, momentum, running_mean, running_var, params);
+    return check_launch("tbn_finalize_kernel");
+}
+
+extern "C" int sps_tbn_bwd_finalize(int c, int nparts, double count, const double *partial, float *params, float *dgamma,
+                                    float *dbeta, sps_stream_t stream) {
+    if (c <= 0 || nparts <= 0 || count <= 0.0 || !partial || !params) return fail(SPS_ERR_INVALID, "tbn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(tbn_bwd_finalize_kernel, dim3(divup(c, 4)), dim3(256), 0, as_stream(stream), c, nparts, 1.0 / count, partial,
+                       params, dgamma, dbeta);
+    return check_launch("tbn_bwd_finalize_kernel");
+}
+
+extern "C" int sps_tpool_fwd(int b, int c, int m, int nsample, const float *y, const float *params, float *out,
+                             unsigned char *arg, float *yarg, sps_stream_t stream) {
+    if (b < 0 || c <= 0 || m < 0 || nsample <= 0) return fail(SPS_ERR_INVALID, "tpool_fwd: bad shape");
+    if (b == 0 || m == 0) return SPS_OK;
+    if (nsample != 4 && nsample != 8 && nsample != 16 && nsample != 32 && nsample != 64)
+        return fail(SPS_ERR_INVALID, "tpool_fwd: nsample %d not in {4, 8, 16, 32, 64}", nsample);
+    if (!y || !params || !out || !arg || !yarg) return fail(SPS_ERR_INVALID, "tpool_fwd: null pointer");
+    const long long rows = (long long)b * c * m;
+    const int G = nsample / 4;
+    const long long g = (rows * G + 255) / 256;
+    if (g > 0x7fffffffLL) return fail(SPS_ERR_INVALID, "tpool_fwd: too many rows");
+    hipStream_t st = as_stream(stream);
+#define SPS_TPOOL(GG) hipLaunchKernelGGL(tpool_fwd_kernel<GG>, dim3((unsigned)g), dim3(256), 0, st, rows, c, m, y, params, out, arg, yarg)
+    if (G == 1) SPS_TPOOL(1);
+    else if (G == 2) SPS_TPOOL(2);
+    else if (G == 4) SPS_TPOOL(4);
+    else if (G == 8) SPS_TPOOL(8);
+    else SPS_TPOOL(16);
+#undef SPS_TPOOL
+    return check_launch("tpool_fwd_kernel");
+}
+
+// partial: (b, c, 2) doubles = `b` parts for sps_tbn_bwd_finalize
+extern "C" int sps_tpool_bwd_stats(int b, int c, int m, const float *yarg, const float *gout, const float *params, double *partial,
+                                   float *amax_out, sps_stream_t stream) {
+    if (b <= 0 || c <= 0 || m <= 0 || b > 65535) return fail(SPS_ERR_INVALID, "tpool_bwd_stats: bad shape");
+    if (!yarg || !gout || !params || !partial) return fail(SPS_ERR_INVALID, "tpool_bwd_stats: null pointer");
+    hipLaunchKernelGGL(tpool_bwd_stats_kernel, dim3(c, b), dim3(256), 0, as_stream(stream), c, m, yarg, gout, params, partial, amax_out);
+    return check_launch("tpool_bwd_stats_kernel");
+}
+
+static int twgrad_nk(int co, int ci, long long l) {
+    const int rows = 16 * divup(co > ci ? co : ci, 16);
+    if (rows <= 64 && l % 128 == 0) return 4;
+    if (rows <= 128 && l % 64 == 0) return 2;
+    return 1;
+}
+static int twgrad_parts(int b, int co, int ci, long long l) {
+    const long long stages = (long long)b * (l / (32 * twgrad_nk(co, ci, l)));
+    return (int)(stages < 256 ? stages : 256);
+}
+
+extern "C" long long sps_twgrad_workspace_floats(int b, int co, int ci, long long l) {
+    if (b <= 0 || co <= 0 || ci <= 0 || l <= 0) return 0;
+    return (long long)twgrad_parts(b, co, ci, l) * (16 * divup(co, 16)) * (16 * divup(ci, 16));
+}
+
+extern "C" int sps_twgrad(int b, int co, int ci, long long l, int dmode, int xmode, const float *dA, const float *y,
+                          const float *gout, const unsigned char *arg, int nsample, int m, const float *pd, const float *x,
+                          const float *px, const float *amax_in, float *dw, float *work, int *overflow, sps_stream_t stream) {
+    if (b <= 0 || co <= 0 || ci <= 0 || l <= 0 || co > 256 || ci > 256)
+        return fail(SPS_ERR_INVALID, "twgrad: bad shape b=%d co=%d ci=%d l=%lld", b, co, ci, l);
+    if (l % 32) return fail(SPS_ERR_INVALID, "twgrad: l = %lld must be a multiple of 32", l);
+    if ((dmode != TIN_BNBWD && dmode != TIN_BNBWD_POOL) || (xmode != TIN_RAW && xmode != TIN_BNRELU))
+        return fail(SPS_ERR_INVALID, "twgrad: unknown mode");
+    if (!y || !pd || !x || !dw || !work || !amax_in || (dmode == TIN_BNBWD && !dA) || (xmode == TIN_BNRELU && !px))
+        return fail(SPS_ERR_INVALID, "twgrad: null pointer");
+    if (dmode == TIN_BNBWD_POOL && (!gout || !arg || nsample <= 0 || (nsample % 4) || m <= 0 || (long long)m * nsample != l))
+        return fail(SPS_ERR_INVALID, "twgrad: the pooled-gradient operand needs gout, arg, nsample %% 4 == 0 and m * nsample == l");
+    TWgradArgs a;
+    a.b = b; a.co = co; a.ci = ci; a.l = l; a.dmode = dmode; a.xmode = xmode; a.dA = dA; a.y = y; a.gout = gout; a.arg = arg;
+    a.ns = nsample > 0 ? nsample : 4; a.m = m; a.pd = pd; a.x = x; a.px = px; a.partial = work; a.amax_in = amax_in; a.overflow = overflow;
+    const int cop = 16 * divup(co, 16), cip = 16 * divup(ci, 16), nk = twgrad_nk(co, ci, l), parts = twgrad_parts(b, co, ci, l);
+    const size_t lds = (size_t)(cop + cip) * 2 * (64 * nk + 16) + (size_t)(cop + cip) * TP * 4 + 64;
+    hipStream_t st = as_stream(stream);
+    const int rc = nk == 4 ? twgrad_launch<4>(a, parts, lds, st) : (nk == 2 ? twgrad_launch<2>(a, parts, lds, st) : twgrad_launch<1>(a, parts, lds, st));
+    if (rc != SPS_OK) return rc;
+    hipLaunchKernelGGL(twgrad_reduce_kernel, dim3(divup(co * ci, 256)), dim3(256), 0, st, co, ci, cip, cop, parts, work, dw);
+    return check_launch("twgrad_kernel");
+}

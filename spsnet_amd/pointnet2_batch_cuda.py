@@ -577,3 +577,98 @@ def group_concat(xyz, new_xyz, features, idx, use_xyz=True):
                                        out.data_ptr(), _stream(xyz)), "group_concat")
     return out
 
+
+
+# ---- the fused train-mode grouped MLP (csrc/mlp_train.hip) ----------------------------------------------------------------
+TIN_RAW, TIN_BNRELU, TIN_BNBWD, TIN_BNBWD_POOL = 0, 1, 2, 3
+TEPI_NONE, TEPI_STATS, TEPI_BWD = 0, 1, 2
+TRAIN_PARAMS = 8     # floats per channel of a parameter block: mean, invstd, scale, shift, gamma, beta, c1, c2
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def tconv_parts(b, l):
+    return int(_L.sps_tconv_parts(b, l))
+
+
+def tconv(w, in_mode, epi_mode, out, operand=None, y=None, gout=None, arg=None, nsample=0, pin=None, epi_y=None, pout=None,
+          transposed=False, overflow=None, amax_in=None, amax_out=None):
+    """out (b, co, l) = A . T(operand): one convolution (or data-gradient) launch of the fused train-mode grouped MLP, see
+    include/spsnet_sa.h sps_tconv.  -> the per-workgroup statistics (parts, co, 2) float64 for epi_mode != TEPI_NONE."""
+    b, co = out.shape[0], out.shape[1]
+    l = out.numel() // max(1, b * co)
+    ref = y if y is not None else operand
+    ci = ref.shape[1]
+    for t in (operand, y, epi_y, out):
+        if t is not None:
+            _ptr(t, F32, "tconv tensor")
+    m = gout.shape[2] if gout is not None else 0
+    partial = None
+    if epi_mode != TEPI_NONE:
+        partial = torch.empty((tconv_parts(b, l), co, 2), dtype=torch.float64, device=out.device)
+    with _on(out):
+        _lib.check(_L.sps_tconv(b, ci, co, l, in_mode, epi_mode, 1 if transposed else 0, _ptr(w, F32, "w"), _p(operand), _p(y),
+                                _p(gout), _p(arg), nsample, m, _p(pin), out.data_ptr(), _p(epi_y), _p(pout), _p(partial),
+                                _p(amax_in), _p(amax_out), _p(overflow), _stream(out)), "tconv")
+    return partial
+
+
+def tbn_finalize(partial, count, bn, params):
+    """statistics -> params[:, 0:6] (+ the module's running statistics, torch semantics)"""
+    parts, c = partial.shape[0], partial.shape[1]
+    with _on(params):
+        _lib.check(_L.sps_tbn_finalize(c, parts, float(count), partial.data_ptr(), _p(bn.weight), _p(bn.bias), float(bn.eps),
+                                       float(bn.momentum), _p(bn.running_mean), _p(bn.running_var), params.data_ptr(),
+                                       _stream(params)), "tbn_finalize")
+
+
+def tbn_bwd_finalize(partial, count, params):
+    """BatchNorm-backward sums -> params[:, 6:8]; returns (d gamma, d beta)"""
+    parts, c = partial.shape[0], partial.shape[1]
+    dg = torch.empty((c,), dtype=F32, device=params.device)
+    db = torch.empty((c,), dtype=F32, device=params.device)
+    with _on(params):
+        _lib.check(_L.sps_tbn_bwd_finalize(c, parts, float(count), partial.data_ptr(), params.data_ptr(), dg.data_ptr(),
+                                           db.data_ptr(), _stream(params)), "tbn_bwd_finalize")
+    return dg, db
+
+
+def tpool_fwd(y, params):
+    """(B, C, M, ns) pre-BatchNorm outputs -> (pooled (B, C, M), arg (B, C, M) u8, y at the arg-max (B, C, M))"""
+    B, C, M, ns = y.shape
+    out = torch.empty((B, C, M), dtype=F32, device=y.device)
+    yarg = torch.empty((B, C, M), dtype=F32, device=y.device)
+    arg = torch.empty((B, C, M), dtype=torch.uint8, device=y.device)
+    with _on(y):
+        _lib.check(_L.sps_tpool_fwd(B, C, M, ns, _ptr(y, F32, "y"), params.data_ptr(), out.data_ptr(), arg.data_ptr(),
+                                    yarg.data_ptr(), _stream(y)), "tpool_fwd")
+    return out, arg, yarg
+
+
+def tpool_bwd_stats(yarg, gout, params, amax_out=None):
+    """-> the last layer's BatchNorm-backward sums (B, C, 2) float64; amax_out (zeroed scalar) receives max |gout|"""
+    B, C, M = yarg.shape
+    partial = torch.empty((B, C, 2), dtype=torch.float64, device=yarg.device)
+    with _on(yarg):
+        _lib.check(_L.sps_tpool_bwd_stats(B, C, M, _ptr(yarg, F32, "yarg"), _ptr(gout, F32, "gout"), params.data_ptr(),
+                                          partial.data_ptr(), _p(amax_out), _stream(yarg)), "tpool_bwd_stats")
+    return partial
+
+
+def twgrad(y, pd, x, px, amax_in, dA=None, gout=None, arg=None, nsample=0, overflow=None):
+    """dW (co, ci) of one layer: dY recomputed from (dA | pooled gradient, y, pd), the other operand x raw (px None) or
+    through BatchNorm + ReLU (px)."""
+    b, co, ci = y.shape[0], y.shape[1], x.shape[1]
+    l = y.numel() // max(1, b * co)
+    m = gout.shape[2] if gout is not None else 0
+    dw = torch.empty((co, ci), dtype=F32, device=y.device)
+    work = torch.empty((int(_L.sps_twgrad_workspace_floats(b, co, ci, l)),), dtype=F32, device=y.device)
+    with _on(y):
+        _lib.check(_L.sps_twgrad(b, co, ci, l, TIN_BNBWD if dA is not None else TIN_BNBWD_POOL,
+                                 TIN_BNRELU if px is not None else TIN_RAW, _p(dA), _ptr(y, F32, "y"), _p(gout), _p(arg), nsample,
+                                 m, pd.data_ptr(), _ptr(x, F32, "x"), _p(px), amax_in.data_ptr(), dw.data_ptr(), work.data_ptr(),
+                                 _p(overflow),
+                                 _stream(y)), "twgrad")
+    return dw

@@ -10,6 +10,7 @@ builders, the sampling strategies live in a dispatch table (`_SAMPLERS`, same pr
 reference's if/elif chain at :284-419), score-based sampling is one fused kernel
 (`sps_score_topk`) and grouping uses the fused query+group kernel when no gradient is needed.
 """
+import os
 from typing import Callable, List, Optional
 
 import torch
@@ -120,6 +121,100 @@ class _Conv1x1Train(torch.autograd.Function):
 
 
 FUSED_CONV_TRAINING = True
+# [Conv2d 1x1, BatchNorm2d(batch statistics), ReLU] x n + max-pool as the fused kernels of csrc/mlp_train.hip (split-fp16
+# MFMA arithmetic: active unless fused.set_precision("fp32") asks for the exact op-by-op path)
+FUSED_MLP_TRAINING = os.environ.get("SPS_FUSED_MLP_TRAINING", "0") != "0"
+
+
+class _GroupedMLPPoolTrain(torch.autograd.Function):
+    """max_s relu(bn_n(conv_n(... relu(bn_1(conv_1(x)))))) for a (B, C0, M, ns) grouped tensor in train() mode -> (B, Cn, M),
+    forward and backward on csrc/mlp_train.hip: only the pre-BatchNorm convolution outputs (forward) and the gradients
+    w.r.t. the post-ReLU activations (backward) are materialised; BatchNorm / ReLU / the pool's gradient routing / the
+    BatchNorm backward are applied where the operands are loaded, the batch statistics come out of the convolutions'
+    epilogues.  Updates the running statistics like nn.BatchNorm2d.forward.  Reference op sequence:
+    pointnet2_modules.py:432-444."""
+
+    @staticmethod
+    def forward(ctx, bns, x, *wgb):
+        n = len(bns)
+        x = x.contiguous()
+        B, _, M, ns = x.shape
+        count = B * M * ns
+        flag = _fused._overflow_flag(x.device)
+        ys, ps, ws = [], [], []
+        operand, pin, mode = x, None, _ext.TIN_RAW
+        for k, bn in enumerate(bns):
+            w = wgb[3 * k].detach()
+            w = w.reshape(w.shape[0], w.shape[1]).contiguous()
+            y = torch.empty((B, w.shape[0], M, ns), dtype=torch.float32, device=x.device)
+            partial = _ext.tconv(w, mode, _ext.TEPI_STATS, y, operand=operand, pin=pin, overflow=flag)
+            params = torch.empty((w.shape[0], _ext.TRAIN_PARAMS), dtype=torch.float32, device=x.device)
+            _ext.tbn_finalize(partial, count, bn, params)
+            bn.num_batches_tracked.add_(1)
+            ys.append(y); ps.append(params); ws.append(w)
+            operand, pin, mode = y, params, _ext.TIN_BNRELU
+        out, arg, yarg = _ext.tpool_fwd(ys[-1], ps[-1])
+        ctx.n, ctx.ns, ctx.count = n, ns, count
+        ctx.save_for_backward(x, arg, yarg, *ys, *ps, *ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        n, ns, count = ctx.n, ctx.ns, ctx.count
+        saved = ctx.saved_tensors
+        x, arg, yarg = saved[0], saved[1], saved[2]
+        ys, ps, ws = saved[3:3 + n], saved[3 + n:3 + 2 * n], saved[3 + 2 * n:3 + 3 * n]
+        gout = gout.contiguous()
+        flag = _fused._overflow_flag(x.device)
+        grads = [None] * (3 * n)
+        # BatchNorm-backward sums of the last layer from the pooled gradient; its dA is never materialised
+        # amax[k]: largest magnitude of the gradient that enters layer k's BatchNorm backward (the kernels scale their fp16
+        # operands by an exact power of two derived from it: csrc/mlp_train.hip)
+        amax = torch.zeros((n,), dtype=torch.float32, device=x.device)
+        grads[3 * n - 2], grads[3 * n - 1] = _ext.tbn_bwd_finalize(
+            _ext.tpool_bwd_stats(yarg, gout, ps[-1], amax_out=amax[n - 1:]), count, ps[-1])
+        dA, dx = None, None
+        for k in range(n - 1, -1, -1):
+            pool = dict(gout=gout, arg=arg, nsample=ns) if k == n - 1 else dict(dA=dA)
+            if ctx.needs_input_grad[2 + 3 * k]:
+                dw = _ext.twgrad(ys[k], ps[k], ys[k - 1] if k else x, ps[k - 1] if k else None, amax[k:], overflow=flag, **pool)
+                grads[3 * k] = dw.view(dw.shape[0], dw.shape[1], 1, 1)
+            din = dict(operand=dA) if k < n - 1 else dict(gout=gout, arg=arg, nsample=ns)
+            mode = _ext.TIN_BNBWD if k < n - 1 else _ext.TIN_BNBWD_POOL
+            if k > 0:
+                prev = torch.empty_like(ys[k - 1])
+                partial = _ext.tconv(ws[k], mode, _ext.TEPI_BWD, prev, y=ys[k], pin=ps[k], epi_y=ys[k - 1], pout=ps[k - 1],
+                                     transposed=True, overflow=flag, amax_in=amax[k:], amax_out=amax[k - 1:], **din)
+                grads[3 * k - 2], grads[3 * k - 1] = _ext.tbn_bwd_finalize(partial, count, ps[k - 1])
+                dA = prev
+            elif ctx.needs_input_grad[1]:
+                dx = torch.empty_like(x)
+                _ext.tconv(ws[0], mode, _ext.TEPI_NONE, dx, y=ys[0], pin=ps[0], transposed=True, overflow=flag, amax_in=amax[0:],
+                           **din)
+        return (None, dx) + tuple(grads)
+
+
+def _fused_mlp_pool_train(mlp: nn.Sequential, x: torch.Tensor, pool_method: str):
+    """-> pooled (B, C, M) through _GroupedMLPPoolTrain, or None when the stack / shapes do not qualify."""
+    if not (FUSED_MLP_TRAINING and _fused.PRECISION != "fp32" and pool_method == 'max_pool' and mlp.training and x.is_cuda
+            and x.dtype == torch.float32 and x.dim() == 4 and torch.is_grad_enabled()):
+        return None
+    mods = list(mlp)
+    if len(mods) % 3 or not mods:
+        return None
+    B, c0, M, ns = x.shape
+    if ns not in (4, 8, 16, 32, 64) or (M * ns) % 64 or c0 > 256 or B * M * ns == 0:
+        return None
+    bns, wgb = [], []
+    for conv, bn, act in zip(mods[0::3], mods[1::3], mods[2::3]):
+        if not (isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and isinstance(act, nn.ReLU) and bn.affine
+                and bn.track_running_stats and bn.momentum is not None and bn.training and conv.kernel_size == (1, 1)
+                and conv.stride == (1, 1) and conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.float32
+                and bn.weight.dtype == torch.float32 and max(conv.weight.shape[:2]) <= 256):
+            return None
+        bns.append(bn)
+        wgb += [conv.weight, bn.weight, bn.bias]
+    return _GroupedMLPPoolTrain.apply(tuple(bns), x, *wgb)
 
 
 def _shared_mlp(mlp: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
@@ -239,7 +334,8 @@ class _PointnetSAModuleBase(nn.Module):
                 grouped = pointnet2_utils.group_with_index(xyz, new_xyz, features, idxs[k], grouper.use_xyz)
             else:
                 grouped = grouper(xyz, new_xyz, features)      # (B, C, M, ns)
-            scales.append(_pool_over_samples(_shared_mlp(mlp, grouped), self.pool_method))
+            pooled = _fused_mlp_pool_train(mlp, grouped, self.pool_method)
+            scales.append(pooled if pooled is not None else _pool_over_samples(_shared_mlp(mlp, grouped), self.pool_method))
         return torch.cat(scales, dim=1)
 
     def _neighbour_indices(self, xyz, new_xyz):

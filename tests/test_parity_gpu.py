@@ -2261,3 +2261,79 @@ def test_group_concat_matches_query_and_group(ext, G, C, use_xyz):
     want, idx = ext.query_and_group(0.7, 16, G.t(xyz), G.t(new_xyz), None if feats is None else G.t(feats), use_xyz)
     got = ext.group_concat(G.t(xyz), G.t(new_xyz), None if feats is None else G.t(feats), idx, use_xyz)
     assert torch.equal(got, want)
+
+
+# ------------------------------------------------------------------ the fused train-mode grouped MLP (csrc/mlp_train.hip)
+@pytest.mark.parametrize("B,M,ns,widths", [(2, 128, 16, [7, 24, 40, 72]), (2, 64, 32, [131, 128, 256, 256]),
+                                           (3, 40, 8, [4, 16, 32]), (1, 16, 4, [19]), (2, 32, 64, [67, 64, 96, 128]),
+                                           (2, 48, 16, [259, 256, 200])])
+def test_fused_train_mode_mlp_matches_torch(dev, B, M, ns, widths, monkeypatch):
+    """_GroupedMLPPoolTrain (conv + batch statistics in the epilogue, BatchNorm / ReLU / pool routing / BatchNorm backward
+    in the operand loads, split-fp16 MFMA) against the plain torch op sequence of the reference (pointnet2_modules.py:432-444)
+    in float64 on the CPU: pooled output, running statistics, and the gradients w.r.t. the grouped input and every
+    parameter, at 2e-4 of the largest reference magnitude (the op-by-op GPU path is held to the same bar).  Shapes cover
+    channel counts that are not multiples of 16 / 32, more than 128 output rows (two row chunks), one to three layers,
+    every supported nsample, and a first width beyond 256 (declined: falls back to the op-by-op path)."""
+    import copy
+    from spsnet_amd import fused, pointnet2_modules as PM
+    torch.manual_seed(B * 1000 + M + ns)
+    c0 = widths[0] if len(widths) > 1 else 5
+    chain = widths if len(widths) > 1 else [5] + widths
+    mlp = PM._conv_bn_relu_stack(list(chain), torch.nn.Conv2d, torch.nn.BatchNorm2d)
+    for mod in mlp:
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.weight.data.uniform_(0.5, 1.5).mul_(torch.where(torch.rand_like(mod.weight) < 0.2, -1.0, 1.0))
+            mod.bias.data.normal_(0, 0.3)
+            mod.running_mean.normal_()
+            mod.running_var.uniform_(0.5, 2.0)
+    ref = copy.deepcopy(mlp).double().train()
+    mlp = mlp.to(dev).train()
+    x0 = torch.randn(B, c0, M, ns)
+    wout = torch.randn(B, chain[-1], M)
+
+    xr = x0.double().requires_grad_(True)
+    out_r = ref(xr).max(dim=3)[0]
+    (out_r * wout.double()).sum().backward()
+
+    xg = x0.to(dev).requires_grad_(True)
+    monkeypatch.setattr(PM, "FUSED_MLP_TRAINING", True)
+    got = PM._fused_mlp_pool_train(mlp, xg, 'max_pool')
+    if max(chain) > 256:
+        assert got is None
+        return
+    assert got is not None, "the stack was supposed to qualify"
+    (got * wout.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert not fused.check_overflow()
+
+    def close(a, b, what, tol=2e-4):
+        a, b = a.detach().cpu().double(), b.detach()
+        assert a.shape == b.shape, what
+        err = float((a - b).abs().max())
+        assert err <= tol * max(1.0, float(b.abs().max())), (what, err, float(b.abs().max()))
+
+    close(got, out_r, "pooled")
+    close(xg.grad, xr.grad, "d/d input")
+    for (name, pg), (_, pr) in zip(mlp.named_parameters(), ref.named_parameters()):
+        close(pg.grad, pr.grad, "d/d " + name)
+    for (name, bg), (_, br) in zip(mlp.named_buffers(), ref.named_buffers()):
+        if bg.dtype.is_floating_point:
+            close(bg, br, "buffer " + name)
+        else:
+            assert int(bg) == int(br), name
+
+
+def test_fused_train_mode_mlp_poisons_unrepresentable_operands(dev, monkeypatch):
+    """An operand beyond the split-fp16 range is never clamped silently: the outputs that depend on it are NaN and the overflow
+    flag is raised."""
+    from spsnet_amd import fused, pointnet2_modules as PM
+    torch.manual_seed(0)
+    mlp = PM._conv_bn_relu_stack([4, 16, 32], torch.nn.Conv2d, torch.nn.BatchNorm2d).to(dev).train()
+    x = torch.randn(2, 4, 32, 16, device=dev)
+    x[1, 2, 5, 3] = 1e6
+    monkeypatch.setattr(PM, "FUSED_MLP_TRAINING", True)
+    fused.check_overflow()
+    out = PM._fused_mlp_pool_train(mlp, x.requires_grad_(True), 'max_pool')
+    torch.cuda.synchronize()
+    assert out is not None and bool(torch.isnan(out).any())
+    assert fused.check_overflow()

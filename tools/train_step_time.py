@@ -1,7 +1,8 @@
 """Time a TRAINING step (forward + backward, BatchNorm on batch statistics) of the IA-SSD SA layers 0-2 through the
 op-by-op path (HIP sampling / query / group kernels + the train-mode conv / BatchNorm kernels).
 usage: python tools/train_step_time.py [B] [N] [reps] [ab]
-  ab: alternate sa_stack.STREAM_TRAINING_QUERIES on / off inside one process (three rounds each) and print the medians"""
+  ab: alternate sa_stack.STREAM_TRAINING_QUERIES on / off inside one process (three rounds each) and print the medians
+  abf: the same for pointnet2_modules.FUSED_MLP_TRAINING (csrc/mlp_train.hip against the op-by-op kernels)"""
 import os, sys, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +11,7 @@ from spsnet_amd import pointnet2_modules as M, sa_stack, scenes
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-ab = len(sys.argv) > 4 and sys.argv[4] == "ab"
+ab = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] in ("ab", "abf") else ""
 dev = torch.device("cuda:0")
 layers = sa_stack.build_sa_layers(M, sa_stack.IASSD_KITTI, seed=3).to(dev).train()
 xyz, feats = scenes.make_batch("kitti-lidar-v1", B, N, seed0=1)
@@ -41,11 +42,14 @@ if ab:
     res = {True: [], False: []}
     for rnd in range(3):
         for flag in (True, False):
-            sa_stack.STREAM_TRAINING_QUERIES = flag
+            if ab == "ab":
+                sa_stack.STREAM_TRAINING_QUERIES = flag
+            else:
+                M.FUSED_MLP_TRAINING = flag
             step()
             res[flag].append(timed(reps))
     for flag in (True, False):
-        print(f"STREAM_TRAINING_QUERIES={flag}: " + " ".join(f"{v:.2f}" for v in res[flag]) +
+        print(("STREAM_TRAINING_QUERIES" if ab == "ab" else "FUSED_MLP_TRAINING") + f"={flag}: " + " ".join(f"{v:.2f}" for v in res[flag]) +
               f"  median {statistics.median(res[flag]):.2f} ms", flush=True)
 else:
     ms = timed(reps)
