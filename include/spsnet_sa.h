@@ -496,17 +496,18 @@ int sps_conv1x1_wgrad(int b, int ci, int co, long long l, const float *x, const 
  *           3: as 2 with `in` = the pooled gradient gout (b, ci, m) routed by arg (b, ci, m) u8 (nsample % 4 == 0)
  *   epi_mode 0: none   1: per-channel sum / sum of squares of out -> partial   2: sums of dZ' and dZ' xhat' of the OUTPUT rows,
  *           dZ' = out [fma(epi_y, scale', shift') > 0] (pout = params of the output rows) -> partial
- *   partial: [sps_tconv_parts(b, l)][co][2] doubles, summed in a fixed order by the finalize calls.
+ *   partial: [sps_tconv_parts(b, l, co)][co][2] doubles, summed in a fixed order by the finalize calls.
+ *   wamax: device scalar, the largest |w| (the weights are scaled by a power of two before they are split as well).
  * Operand scaling: every operand tensor is multiplied by an exact power of two that brings its largest magnitude near 2^10
  * before it is split into fp16 halves (gradients are routinely 1e-5 and smaller; unscaled, their low halves would be fp16
  * denormals), and the accumulators by the inverse.  amax_in (device scalar, in_mode >= 2): the largest magnitude of the
  * incoming gradient tensor; amax_out (device scalar the caller zeroed, epi_mode 2): receives the atomic maximum of |out|.
  * sps_tpool_bwd_stats produces it for the pooled gradient, sps_twgrad consumes it. */
-int sps_tconv_parts(int b, long long l);
+int sps_tconv_parts(int b, long long l, int co);
 int sps_tconv(int b, int ci, int co, long long l, int in_mode, int epi_mode, int trans, const float *w, const float *in,
               const float *in2, const float *gout, const unsigned char *arg, int nsample, int m, const float *pin, float *out,
-              const float *epi_y, const float *pout, double *partial, const float *amax_in, float *amax_out, int *overflow,
-              sps_stream_t stream);
+              const float *epi_y, const float *pout, double *partial, const float *amax_in, float *amax_out,
+              const float *wamax, int *overflow, sps_stream_t stream);
 /* torch semantics: biased variance to normalise, unbiased for running_var, running = (1 - momentum) running + momentum batch;
  * gamma / beta / running_* may be NULL; count = b * l. */
 int sps_tbn_finalize(int c, int nparts, double count, const double *partial, const float *gamma, const float *beta, float eps,

@@ -67,9 +67,9 @@ _PROTOS = {
     "sps_three_nn_kernel_launcher_stack": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_three_interpolate_kernel_launcher_stack": [_i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_three_interpolate_grad_kernel_launcher_stack": [_i, _i, _vp, _vp, _vp, _vp, _vp],
-    "sps_tconv_parts": [_i, ctypes.c_longlong],
+    "sps_tconv_parts": [_i, ctypes.c_longlong, _i],
     "sps_tconv": [_i, _i, _i, ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                  _vp],
+                  _vp, _vp],
     "sps_tbn_finalize": [_i, _i, ctypes.c_double, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp],
     "sps_tbn_bwd_finalize": [_i, _i, ctypes.c_double, _vp, _vp, _vp, _vp, _vp],
     "sps_tpool_fwd": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -77,7 +77,10 @@ __device__ __forceinline__ float tblock_max(float v, float *scratch, int nwaves)
     return r;
 }
 __device__ __forceinline__ void tatomic_amax(float *dst, float v) {   // v >= 0 (or NaN, which then sticks)
-    atomicMax(reinterpret_cast<unsigned int *>(dst), __float_as_uint(v));
+    // (thousands of waves on one address: the value only grows, so whoever cannot raise it need not queue up for the atomic)
+    const unsigned int bits = __float_as_uint(v);
+    if (bits > __atomic_load_n(reinterpret_cast<unsigned int *>(dst), __ATOMIC_RELAXED))
+        atomicMax(reinterpret_cast<unsigned int *>(dst), bits);
 }
 
 struct TConvArgs {
@@ -96,6 +99,7 @@ struct TConvArgs {
     double *partial;             // [gridDim.x][co][2]
     const float *amax_in;        // BNBWD modes: largest |incoming gradient| (device scalar)
     float *amax_out;             // TEPI_BWD: atomic max of |out| (device scalar, zeroed by the caller)
+    const float *wamax;          // largest |w| (device scalar)
     int *overflow;
 };
 
@@ -120,47 +124,6 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
     float *pout_l = pin_l + (IN != TIN_RAW ? cip * TP : 0);
     double *red = reinterpret_cast<double *>(pout_l + (EPI == TEPI_BWD ? rows_wg * TP : 0));
     float *scratch = reinterpret_cast<float *>(red + (EPI != TEPI_NONE ? (size_t)4 * 16 * RT * 2 : 0));
-
-    auto wval = [&](int o, int k) -> float {
-        const int row = row0 + o;
-        if (row < a.co && k < a.ci) return a.trans ? a.w[(size_t)k * a.co + row] : a.w[(size_t)row * a.ci + k];
-        return 0.f;
-    };
-    float wmax = 0.f;
-    for (int idx = threadIdx.x; idx < rows_wg * cip; idx += 256) wmax = fmaxf(wmax, fabsf(wval(idx / cip, idx % cip)));
-    const float sw = tpow2_scale(256.f, tblock_max(wmax, scratch, 4));
-    for (int idx = threadIdx.x; idx < rows_wg * cip; idx += 256) {
-        const int o = idx / cip, k = idx - o * cip;
-        _Float16 hi, lo;
-        tsplit(wval(o, k) * sw, hi, lo);
-        const int t = o >> 4, i = o & 15, s = k >> 5, qq = (k & 31) >> 3, e = k & 7;
-        char *dst = wl + ((size_t)(t * S + s) * 2) * 1024 + (qq * 16 + i) * 16 + e * 2;
-        *reinterpret_cast<_Float16 *>(dst) = hi;
-        *reinterpret_cast<_Float16 *>(dst + 1024) = lo;
-    }
-    float sx = 1.f;
-    if (IN != TIN_RAW) {
-        float smax = 0.f;
-        for (int idx = threadIdx.x; idx < cip * TP; idx += 256) {
-            const float v = (idx / TP < a.ci) ? a.pin[idx] : 0.f;
-            pin_l[idx] = v;
-            if ((idx & (TP - 1)) == 2) smax = fmaxf(smax, fabsf(v));
-        }
-        if (GRAD) sx = tpow2_scale(1024.f, tblock_max(smax, scratch, 4) * (*a.amax_in));
-    }
-    if (EPI == TEPI_BWD)
-        for (int idx = threadIdx.x; idx < rows_wg * TP; idx += 256)
-            pout_l[idx] = (row0 + idx / TP < a.co) ? a.pout[(size_t)row0 * TP + idx] : 0.f;
-    __syncthreads();
-    const float inv = 1.f / (sx * sw);                                  // powers of two: exact
-
-    float st1[RT][4], st2[RT][4];
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { st1[t][r] = 0.f; st2[t][r] = 0.f; }
-    bool any_bad = false;
-    float omax = 0.f;
 
     // this wave's blocks: id = (blockIdx.x + i gridDim.x) 4 + wave, i = 0 .. nblk - 1; its pieces: (block, k-step), in order
     const long long nb64 = a.l >> 6;
@@ -199,8 +162,63 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
     // (the gradient modes at 128 rows: one k-step ahead only -- two tensors per piece, and 192 accumulator / statistics registers)
     constexpr int DEPTH = (GRAD && RT == 8) ? 1 : 2;
     Piece b0, b1, b2;
-    if (npieces > 0) load(0, b0);
+    if (npieces > 0) load(0, b0);            // (in flight while the weights are staged)
     if (DEPTH == 2 && npieces > 1) load(1, b1);
+
+    // Weights -> LDS: 16 independent loads per thread and trip (a plain loop waits for every load: 128 round trips to L2 per
+    // workgroup at the widest shapes, longer than the workgroup's whole column range took); the transposed operand walks
+    // the rows fastest so that consecutive lanes still read consecutive floats.
+    const float sw = tpow2_scale(256.f, *a.wamax);
+    {
+        constexpr int WB = 16;
+        const int nel = rows_wg * cip;
+        for (int base = 0; base < nel; base += 256 * WB) {
+            float wv[WB];
+#pragma unroll
+            for (int u = 0; u < WB; ++u) {
+                const int idx = base + u * 256 + (int)threadIdx.x;
+                const int o = a.trans ? idx % rows_wg : idx / cip, k = a.trans ? idx / rows_wg : idx % cip;
+                const int row = row0 + o;
+                wv[u] = 0.f;
+                if (idx < nel && row < a.co && k < a.ci) wv[u] = a.trans ? a.w[(size_t)k * a.co + row] : a.w[(size_t)row * a.ci + k];
+            }
+#pragma unroll
+            for (int u = 0; u < WB; ++u) {
+                const int idx = base + u * 256 + (int)threadIdx.x;
+                if (idx >= nel) continue;
+                const int o = a.trans ? idx % rows_wg : idx / cip, k = a.trans ? idx / rows_wg : idx % cip;
+                _Float16 hi, lo;
+                tsplit(wv[u] * sw, hi, lo);
+                const int t = o >> 4, i = o & 15, ss = k >> 5, qq = (k & 31) >> 3, e = k & 7;
+                char *dst = wl + ((size_t)(t * S + ss) * 2) * 1024 + (qq * 16 + i) * 16 + e * 2;
+                *reinterpret_cast<_Float16 *>(dst) = hi;
+                *reinterpret_cast<_Float16 *>(dst + 1024) = lo;
+            }
+        }
+    }
+    float sx = 1.f;
+    if (IN != TIN_RAW) {
+        float smax = 0.f;
+        for (int idx = threadIdx.x; idx < cip * TP; idx += 256) {
+            const float v = (idx / TP < a.ci) ? a.pin[idx] : 0.f;
+            pin_l[idx] = v;
+            if ((idx & (TP - 1)) == 2) smax = fmaxf(smax, fabsf(v));
+        }
+        if (GRAD) sx = tpow2_scale(1024.f, tblock_max(smax, scratch, 4) * (*a.amax_in));
+    }
+    if (EPI == TEPI_BWD)
+        for (int idx = threadIdx.x; idx < rows_wg * TP; idx += 256)
+            pout_l[idx] = (row0 + idx / TP < a.co) ? a.pout[(size_t)row0 * TP + idx] : 0.f;
+    __syncthreads();
+    const float inv = 1.f / (sx * sw);                                  // powers of two: exact
+
+    float st1[RT][4], st2[RT][4];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st1[t][r] = 0.f; st2[t][r] = 0.f; }
+    bool any_bad = false;
+    float omax = 0.f;
 
     f32x4 acc[RT][4];
     float mx = 0.f;
@@ -651,9 +669,12 @@ __global__ __launch_bounds__(256) void tpool_bwd_stats_kernel(int c, int m, cons
     }
 }
 
-int tconv_grid_x(int b, long long l) {
+// workgroups along the columns: as many as stay resident (one per CU at 128 rows per workgroup -- the weights then fill the
+// LDS and a wave holds ~400 registers --, two otherwise), each walking its share of the 64-column blocks
+int tconv_grid_x(int b, long long l, int co) {
     const long long groups = ((long long)b * (l >> 6) + 3) / 4;
-    return (int)(groups < 512 ? groups : 512);
+    const long long cap = co > 64 ? 256 : 512;
+    return (int)(groups < cap ? groups : cap);
 }
 
 template <int RT, int IN>
@@ -662,7 +683,7 @@ int tconv_launch_epi(const TConvArgs &a, int epi, hipStream_t st) {
     const size_t lds = (size_t)RT * a.S * 2048 + (IN != TIN_RAW ? cip * TP * 4 : 0) + (epi == TEPI_BWD ? rows_wg * TP * 4 : 0) +
                        (epi != TEPI_NONE ? (size_t)4 * 16 * RT * 2 * 8 : 0) + 64;
     if (lds > 156 * 1024) return fail(SPS_ERR_INVALID, "tconv: %zu bytes of LDS (ci = %d)", lds, a.ci);
-    const dim3 grid(tconv_grid_x(a.b, a.l), 1, divup(a.co, rows_wg));
+    const dim3 grid(tconv_grid_x(a.b, a.l, a.co), 1, divup(a.co, rows_wg));
 #define SPS_TCONV_GO(EPI)                                                                                               \
     {                                                                                                                   \
         static LdsLimitOnce raised;                                                                                     \
@@ -706,21 +727,21 @@ int twgrad_launch(const TWgradArgs &a, int parts, size_t lds, hipStream_t st) {
 using namespace sps;
 
 // Workgroups along the columns of sps_tconv = first dimension of its `partial` output ([parts][co][2] doubles).
-extern "C" int sps_tconv_parts(int b, long long l) {
-    if (b <= 0 || l <= 0) return 0;
-    return tconv_grid_x(b, l);
+extern "C" int sps_tconv_parts(int b, long long l, int co) {
+    if (b <= 0 || l <= 0 || co <= 0) return 0;
+    return tconv_grid_x(b, l, co);
 }
 
 extern "C" int sps_tconv(int b, int ci, int co, long long l, int in_mode, int epi_mode, int trans, const float *w, const float *in,
                          const float *in2, const float *gout, const unsigned char *arg, int nsample, int m, const float *pin,
                          float *out, const float *epi_y, const float *pout, double *partial, const float *amax_in,
-                         float *amax_out, int *overflow, sps_stream_t stream) {
+                         float *amax_out, const float *wamax, int *overflow, sps_stream_t stream) {
     if (b < 0 || ci <= 0 || co <= 0 || l < 0 || ci > 256) return fail(SPS_ERR_INVALID, "tconv: bad shape b=%d ci=%d co=%d l=%lld", b, ci, co, l);
     if (b == 0 || l == 0) return SPS_OK;
     if (l % 64) return fail(SPS_ERR_INVALID, "tconv: l = %lld must be a multiple of 64", l);
     if (in_mode < TIN_RAW || in_mode > TIN_BNBWD_POOL || epi_mode < TEPI_NONE || epi_mode > TEPI_BWD)
         return fail(SPS_ERR_INVALID, "tconv: unknown mode");
-    if (!w || !out || (in_mode != TIN_BNBWD_POOL && !in) || (in_mode != TIN_RAW && !pin) || (in_mode >= TIN_BNBWD && !in2) ||
+    if (!w || !wamax || !out || (in_mode != TIN_BNBWD_POOL && !in) || (in_mode != TIN_RAW && !pin) || (in_mode >= TIN_BNBWD && !in2) ||
         (epi_mode != TEPI_NONE && !partial) || (epi_mode == TEPI_BWD && (!epi_y || !pout)) || (in_mode >= TIN_BNBWD && !amax_in))
         return fail(SPS_ERR_INVALID, "tconv: null pointer");
     if (in_mode == TIN_BNBWD_POOL && (!gout || !arg || nsample <= 0 || (nsample % 4) || m <= 0 || (long long)m * nsample != l))
@@ -729,7 +750,7 @@ extern "C" int sps_tconv(int b, int ci, int co, long long l, int in_mode, int ep
     a.b = b; a.ci = ci; a.co = co; a.S = (ci + 31) / 32; a.l = l; a.trans = trans ? 1 : 0; a.w = w;
     a.in = in ? in : in2; a.in2 = in2 ? in2 : in; a.gout = gout; a.arg = arg; a.ns = nsample > 0 ? nsample : 4; a.m = m;
     a.pin = pin; a.out = out; a.epi_y = epi_y; a.pout = pout; a.partial = partial; a.amax_in = amax_in; a.amax_out = amax_out;
-    a.overflow = overflow;
+    a.wamax = wamax; a.overflow = overflow;
     hipStream_t st = as_stream(stream);
     if (co <= 16) return tconv_launch_in<1>(a, in_mode, epi_mode, st);
     if (co <= 32) return tconv_launch_in<2>(a, in_mode, epi_mode, st);

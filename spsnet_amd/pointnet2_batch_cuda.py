@@ -589,11 +589,11 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
-def tconv_parts(b, l):
-    return int(_L.sps_tconv_parts(b, l))
+def tconv_parts(b, l, co):
+    return int(_L.sps_tconv_parts(b, l, co))
 
 
-def tconv(w, in_mode, epi_mode, out, operand=None, y=None, gout=None, arg=None, nsample=0, pin=None, epi_y=None, pout=None,
+def tconv(w, wamax, in_mode, epi_mode, out, operand=None, y=None, gout=None, arg=None, nsample=0, pin=None, epi_y=None, pout=None,
           transposed=False, overflow=None, amax_in=None, amax_out=None):
     """out (b, co, l) = A . T(operand): one convolution (or data-gradient) launch of the fused train-mode grouped MLP, see
     include/spsnet_sa.h sps_tconv.  -> the per-workgroup statistics (parts, co, 2) float64 for epi_mode != TEPI_NONE."""
@@ -607,11 +607,11 @@ def tconv(w, in_mode, epi_mode, out, operand=None, y=None, gout=None, arg=None, 
     m = gout.shape[2] if gout is not None else 0
     partial = None
     if epi_mode != TEPI_NONE:
-        partial = torch.empty((tconv_parts(b, l), co, 2), dtype=torch.float64, device=out.device)
+        partial = torch.empty((tconv_parts(b, l, co), co, 2), dtype=torch.float64, device=out.device)
     with _on(out):
         _lib.check(_L.sps_tconv(b, ci, co, l, in_mode, epi_mode, 1 if transposed else 0, _ptr(w, F32, "w"), _p(operand), _p(y),
                                 _p(gout), _p(arg), nsample, m, _p(pin), out.data_ptr(), _p(epi_y), _p(pout), _p(partial),
-                                _p(amax_in), _p(amax_out), _p(overflow), _stream(out)), "tconv")
+                                _p(amax_in), _p(amax_out), wamax.data_ptr(), _p(overflow), _stream(out)), "tconv")
     return partial
 
 

@@ -123,7 +123,7 @@ class _Conv1x1Train(torch.autograd.Function):
 FUSED_CONV_TRAINING = True
 # [Conv2d 1x1, BatchNorm2d(batch statistics), ReLU] x n + max-pool as the fused kernels of csrc/mlp_train.hip (split-fp16
 # MFMA arithmetic: active unless fused.set_precision("fp32") asks for the exact op-by-op path)
-FUSED_MLP_TRAINING = os.environ.get("SPS_FUSED_MLP_TRAINING", "0") != "0"
+FUSED_MLP_TRAINING = os.environ.get("SPS_FUSED_MLP_TRAINING", "1") != "0"
 
 
 class _GroupedMLPPoolTrain(torch.autograd.Function):
@@ -141,21 +141,22 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
         B, _, M, ns = x.shape
         count = B * M * ns
         flag = _fused._overflow_flag(x.device)
-        ys, ps, ws = [], [], []
+        ys, ps, ws, was = [], [], [], []
         operand, pin, mode = x, None, _ext.TIN_RAW
         for k, bn in enumerate(bns):
             w = wgb[3 * k].detach()
             w = w.reshape(w.shape[0], w.shape[1]).contiguous()
             y = torch.empty((B, w.shape[0], M, ns), dtype=torch.float32, device=x.device)
-            partial = _ext.tconv(w, mode, _ext.TEPI_STATS, y, operand=operand, pin=pin, overflow=flag)
+            wa = w.abs().amax().reshape(1)     # (the kernels scale the weights by a power of two derived from it)
+            partial = _ext.tconv(w, wa, mode, _ext.TEPI_STATS, y, operand=operand, pin=pin, overflow=flag)
             params = torch.empty((w.shape[0], _ext.TRAIN_PARAMS), dtype=torch.float32, device=x.device)
             _ext.tbn_finalize(partial, count, bn, params)
             bn.num_batches_tracked.add_(1)
-            ys.append(y); ps.append(params); ws.append(w)
+            ys.append(y); ps.append(params); ws.append(w); was.append(wa)
             operand, pin, mode = y, params, _ext.TIN_BNRELU
         out, arg, yarg = _ext.tpool_fwd(ys[-1], ps[-1])
         ctx.n, ctx.ns, ctx.count = n, ns, count
-        ctx.save_for_backward(x, arg, yarg, *ys, *ps, *ws)
+        ctx.save_for_backward(x, arg, yarg, *ys, *ps, *ws, *was)
         return out
 
     @staticmethod
@@ -163,7 +164,7 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
         n, ns, count = ctx.n, ctx.ns, ctx.count
         saved = ctx.saved_tensors
         x, arg, yarg = saved[0], saved[1], saved[2]
-        ys, ps, ws = saved[3:3 + n], saved[3 + n:3 + 2 * n], saved[3 + 2 * n:3 + 3 * n]
+        ys, ps, ws, was = saved[3:3 + n], saved[3 + n:3 + 2 * n], saved[3 + 2 * n:3 + 3 * n], saved[3 + 3 * n:3 + 4 * n]
         gout = gout.contiguous()
         flag = _fused._overflow_flag(x.device)
         grads = [None] * (3 * n)
@@ -183,13 +184,13 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
             mode = _ext.TIN_BNBWD if k < n - 1 else _ext.TIN_BNBWD_POOL
             if k > 0:
                 prev = torch.empty_like(ys[k - 1])
-                partial = _ext.tconv(ws[k], mode, _ext.TEPI_BWD, prev, y=ys[k], pin=ps[k], epi_y=ys[k - 1], pout=ps[k - 1],
+                partial = _ext.tconv(ws[k], was[k], mode, _ext.TEPI_BWD, prev, y=ys[k], pin=ps[k], epi_y=ys[k - 1], pout=ps[k - 1],
                                      transposed=True, overflow=flag, amax_in=amax[k:], amax_out=amax[k - 1:], **din)
                 grads[3 * k - 2], grads[3 * k - 1] = _ext.tbn_bwd_finalize(partial, count, ps[k - 1])
                 dA = prev
             elif ctx.needs_input_grad[1]:
                 dx = torch.empty_like(x)
-                _ext.tconv(ws[0], mode, _ext.TEPI_NONE, dx, y=ys[0], pin=ps[0], transposed=True, overflow=flag, amax_in=amax[0:],
+                _ext.tconv(ws[0], was[0], mode, _ext.TEPI_NONE, dx, y=ys[0], pin=ps[0], transposed=True, overflow=flag, amax_in=amax[0:],
                            **din)
         return (None, dx) + tuple(grads)
 

@@ -29,17 +29,18 @@ m2 = copy.deepcopy(mlp).to(dev).train()
 x = x0.to(dev)
 count = B * M * ns
 flag = fused._overflow_flag(dev)
-ys, ps, ws = [], [], []
+ys, ps, ws, was = [], [], [], []
 operand, pin, mode = x, None, ext.TIN_RAW
 convs = [m2[3 * k] for k in range(n)]; bns = [m2[3 * k + 1] for k in range(n)]
 for k in range(n):
     w = convs[k].weight.detach().reshape(chain[k + 1], chain[k]).contiguous()
     y = torch.empty((B, chain[k + 1], M, ns), device=dev)
-    partial = ext.tconv(w, mode, ext.TEPI_STATS, y, operand=operand, pin=pin, overflow=flag)
+    wa = w.abs().amax().reshape(1)
+    partial = ext.tconv(w, wa, mode, ext.TEPI_STATS, y, operand=operand, pin=pin, overflow=flag)
     P = torch.empty((chain[k + 1], 8), device=dev)
     ext.tbn_finalize(partial, count, bns[k], P)
     print(f"Y{k+1} {rel(y, Yr[k].detach()):.1e}", end="  ")
-    ys.append(y); ps.append(P); ws.append(w)
+    ys.append(y); ps.append(P); ws.append(w); was.append(wa)
     operand, pin, mode = y, P, ext.TIN_BNRELU
 out, arg, yarg = ext.tpool_fwd(ys[-1], ps[-1])
 print(f"out {rel(out, Ar[-1].detach().max(dim=3)[0]):.1e}")
@@ -56,7 +57,7 @@ for k in range(n - 1, -1, -1):
     md = ext.TIN_BNBWD if k < n - 1 else ext.TIN_BNBWD_POOL
     if k > 0:
         prev = torch.empty_like(ys[k - 1])
-        partial = ext.tconv(ws[k], md, ext.TEPI_BWD, prev, y=ys[k], pin=ps[k], epi_y=ys[k - 1], pout=ps[k - 1], transposed=True, overflow=flag, amax_in=amax[k:], amax_out=amax[k - 1:], **din)
+        partial = ext.tconv(ws[k], was[k], md, ext.TEPI_BWD, prev, y=ys[k], pin=ps[k], epi_y=ys[k - 1], pout=ps[k - 1], transposed=True, overflow=flag, amax_in=amax[k:], amax_out=amax[k - 1:], **din)
         dg, db = ext.tbn_bwd_finalize(partial, count, ps[k - 1])
         print(f"dA{k} {rel(prev, Ar[k-1].grad):.1e} dgamma{k} {rel(dg, ref[3*k-2].weight.grad):.1e} dbeta{k} {rel(db, ref[3*k-2].bias.grad):.1e}")
         # where is dA wrong?
@@ -69,7 +70,7 @@ for k in range(n - 1, -1, -1):
         dA = prev
     else:
         dx = torch.empty_like(x)
-        ext.tconv(ws[0], md, ext.TEPI_NONE, dx, y=ys[0], pin=ps[0], transposed=True, overflow=flag, amax_in=amax[0:], **din)
+        ext.tconv(ws[0], was[0], md, ext.TEPI_NONE, dx, y=ys[0], pin=ps[0], transposed=True, overflow=flag, amax_in=amax[0:], **din)
         print(f"dx {rel(dx, xin.grad):.1e}")
 torch.cuda.synchronize()
 print("overflow", fused.check_overflow())
