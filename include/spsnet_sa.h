@@ -511,7 +511,11 @@ int sps_tconv(int b, int ci, int co, long long l, int in_mode, int epi_mode, int
 /* torch semantics: biased variance to normalise, unbiased for running_var, running = (1 - momentum) running + momentum batch;
  * gamma / beta / running_* may be NULL; count = b * l. */
 int sps_tbn_finalize(int c, int nparts, double count, const double *partial, const float *gamma, const float *beta, float eps,
-                     float momentum, float *running_mean, float *running_var, float *params, sps_stream_t stream);
+                     float momentum, float *running_mean, float *running_var, float *params, long long *num_batches_tracked,
+                     sps_stream_t stream);   /* num_batches_tracked (int64 device scalar, may be NULL) += 1 */
+/* out[k] = max |p_k[0 .. n_k)| for `count` <= 4 arrays in one launch (the `wamax` scalars of a grouped MLP's layers) */
+int sps_tamax4(int count, const float *p0, long long n0, const float *p1, long long n1, const float *p2, long long n2,
+               const float *p3, long long n3, float *out, sps_stream_t stream);
 int sps_tbn_bwd_finalize(int c, int nparts, double count, const double *partial, float *params, float *dgamma, float *dbeta,
                          sps_stream_t stream);
 /* out (b, c, m) = max over the nsample columns of relu(fma(y, scale, shift)), arg = position of the FIRST maximum (a NaN wins

@@ -47,13 +47,43 @@ __device__ __forceinline__ void tsplit(float v, _Float16 &hi, _Float16 &lo) {
     hi = (_Float16)c;
     lo = (_Float16)(c - (float)hi);
 }
-// largest magnitude seen so far, +Inf once a NaN / Inf passed (0 * v is NaN exactly then)
-__device__ __forceinline__ float ttrack(float mx, const f32x4 v) {
-    const float z = __builtin_fmaf(v[0], 0.f, __builtin_fmaf(v[1], 0.f, __builtin_fmaf(v[2], 0.f, v[3] * 0.f)));
-    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-    return (z == 0.f) ? mx : INFINITY;
+// The VALU, not the matrix pipe, is what these memory-bound kernels keep busy, so the per-element work is kept short:
+//   * two values -> packed halves with ONE v_cvt_pkrtz_f16_f32 (round toward zero: hi + lo still carries 22 bits, the low half
+//     takes what the high half dropped); round-toward-zero saturates at 65504 instead of producing Inf, so the range check
+//     stays explicit: one v_max3_f32 (|a|, |b| as input modifiers) per pair.  A NaN passes through the conversion and the
+//     matrix pipe and is caught on the accumulators.
+//   * ReLU as an integer max (keeps +NaN like torch's clamp_min, one instruction).
+typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void tsplit2(float a, float b, unsigned int &hi, unsigned int &lo, float &mx) {
+    mx = fmaxf(fmaxf(mx, fabsf(a)), fabsf(b));
+    const hp2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const hp2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
+    hi = __builtin_bit_cast(unsigned int, h);
+    lo = __builtin_bit_cast(unsigned int, l);
 }
-
+__device__ __forceinline__ float trelu_i(float z) {
+    const int b = __float_as_int(z);
+    return __int_as_float(b > 0 ? b : 0);
+}
+union TFrag { h8 v; unsigned int u[4]; };
+// per-row constants of the BatchNorm backward: dY = ks dZ + ka y + kb  with  ks = scale sx, ka = -ks c2 invstd,
+// kb = ks (c2 invstd mean - c1)   (= ks (dZ - c1 - xhat c2), xhat = (y - mean) invstd)
+struct TBwdRow { float sc, sh, ks, ka, kb; };
+__device__ __forceinline__ TBwdRow tbwd_row(const float *P, float sx) {
+    const f32x4 p0 = *reinterpret_cast<const f32x4 *>(P), p1 = *reinterpret_cast<const f32x4 *>(P + 4);
+    TBwdRow r;
+    r.sc = p0[2]; r.sh = p0[3];
+    r.ks = p0[2] * sx;
+    const float t = r.ks * p1[3] * p0[1];
+    r.ka = -t;
+    r.kb = __builtin_fmaf(t, p0[0], -r.ks * p1[2]);
+    return r;
+}
+__device__ __forceinline__ float tbwd_apply(const TBwdRow &r, float g, float y) {
+    const float z = __builtin_fmaf(y, r.sc, r.sh);
+    const float dz = z > 0.f ? g : 0.f;
+    return __builtin_fmaf(r.ks, dz, __builtin_fmaf(r.ka, y, r.kb));
+}
 // Exact power-of-two scaling in front of the split: fp16 keeps 11 bits per half only for |v| >= 2^-14, and the low half of a
 // value below ~0.06 is already a half denormal (absolute error 3e-8, not 2^-22 relative).  Gradients are routinely 1e-5 and
 // smaller, so every operand tensor is multiplied by 2^k with the tensor's largest magnitude brought near 2^10 (weights: near
@@ -217,7 +247,7 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
     for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { st1[t][r] = 0.f; st2[t][r] = 0.f; }
-    bool any_bad = false;
+    bool any_bad = false, nonfinite = false;
     float omax = 0.f;
 
     f32x4 acc[RT][4];
@@ -237,43 +267,34 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
                 for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             mx = 0.f;
         }
-        h8 bh[4], bl[4];
+        TFrag bh[4], bl[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float *P = pin_l + (32 * s + 8 * q + e) * TP;
-            f32x4 v;
-            if (IN == TIN_RAW) {
-                v = b0.xa[e];
-            } else if (IN == TIN_BNRELU) {
-                const f32x4 p0 = *reinterpret_cast<const f32x4 *>(P);
+        for (int e2 = 0; e2 < 4; ++e2) {
+            f32x4 v[2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = trelu(__builtin_fmaf(b0.xa[e][j], p0[2], p0[3]));
-            } else {
-                const f32x4 p0 = *reinterpret_cast<const f32x4 *>(P), p1 = *reinterpret_cast<const f32x4 *>(P + 4);
-                f32x4 g = b0.xa[e];
-                if (IN == TIN_BNBWD_POOL) {
-                    const int am = (int)b0.xa[e][1];
-                    const float gg = b0.xa[e][0];
-                    g = (f32x4){am == 0 ? gg : 0.f, am == 1 ? gg : 0.f, am == 2 ? gg : 0.f, am == 3 ? gg : 0.f};
-                }
-                const float ks = p0[2] * sx;
+            for (int h = 0; h < 2; ++h) {
+                const int e = 2 * e2 + h;
+                const float *P = pin_l + (32 * s + 8 * q + e) * TP;
+                if (IN == TIN_RAW) {
+                    v[h] = b0.xa[e];
+                } else if (IN == TIN_BNRELU) {
+                    const f32x4 p0 = *reinterpret_cast<const f32x4 *>(P);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float y = b0.xb[GRAD ? e : 0][j];
-                    const float z = __builtin_fmaf(y, p0[2], p0[3]);
-                    const float xh = (y - p0[0]) * p0[1];
-                    const float dz = z > 0.f ? g[j] : 0.f;
-                    v[j] = ks * (dz - p1[2] - xh * p1[3]);
+                    for (int j = 0; j < 4; ++j) v[h][j] = trelu_i(__builtin_fmaf(b0.xa[e][j], p0[2], p0[3]));
+                } else {
+                    const TBwdRow rw = tbwd_row(P, sx);
+                    f32x4 g = b0.xa[e];
+                    if (IN == TIN_BNBWD_POOL) {
+                        const int am = (int)b0.xa[e][1];
+                        const float gg = b0.xa[e][0];
+                        g = (f32x4){am == 0 ? gg : 0.f, am == 1 ? gg : 0.f, am == 2 ? gg : 0.f, am == 3 ? gg : 0.f};
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[h][j] = tbwd_apply(rw, g[j], b0.xb[GRAD ? e : 0][j]);
                 }
             }
-            mx = ttrack(mx, v);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                _Float16 hi, lo;
-                tsplit(v[j], hi, lo);
-                bh[j][e] = hi;
-                bl[j][e] = lo;
-            }
+            for (int j = 0; j < 4; ++j) tsplit2(v[0][j], v[1][j], bh[j].u[e2], bl[j].u[e2], mx);
         }
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
@@ -281,9 +302,9 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
             const h8 ah = *reinterpret_cast<const h8 *>(fr), al = *reinterpret_cast<const h8 *>(fr + 1024);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc[t][j] = tmfma(ah, bh[j], acc[t][j]);
-                acc[t][j] = tmfma(ah, bl[j], acc[t][j]);
-                acc[t][j] = tmfma(al, bh[j], acc[t][j]);
+                acc[t][j] = tmfma(ah, bh[j].v, acc[t][j]);
+                acc[t][j] = tmfma(ah, bl[j].v, acc[t][j]);
+                acc[t][j] = tmfma(al, bh[j].v, acc[t][j]);
             }
         }
         b0 = b1;
@@ -305,7 +326,9 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
                 const int orow = 16 * t + 4 * q + r, row = row0 + orow;
                 if (row >= a.co) continue;
                 f32x4 o = (f32x4){acc[t][0][r] * inv, acc[t][1][r] * inv, acc[t][2][r] * inv, acc[t][3][r] * inv};
-                if (poison) o = (f32x4){nanv, nanv, nanv, nanv};
+                const bool finite = (fabsf(o[0]) + fabsf(o[1])) + (fabsf(o[2]) + fabsf(o[3])) < INFINITY;   // (false for a NaN too)
+                nonfinite |= !finite;
+                if (poison || !finite) o = (f32x4){nanv, nanv, nanv, nanv};
                 const size_t at = ((size_t)scene * a.co + row) * a.l + col0;
                 *reinterpret_cast<f32x4 *>(a.out + at) = o;
                 if (EPI == TEPI_STATS) {
@@ -325,10 +348,11 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
                 }
             }
     }
+    any_bad |= __builtin_amdgcn_ballot_w64(nonfinite) != 0ull;
     if (any_bad && a.overflow) *a.overflow = 1;
     if (EPI == TEPI_BWD && a.amax_out) {
-        for (int off = 32; off > 0; off >>= 1) omax = fmaxf(omax, __shfl_xor(omax, off));
-        if (lane == 0) tatomic_amax(a.amax_out, any_bad ? INFINITY : omax);
+        const float wgmax = tblock_max(any_bad ? INFINITY : omax, scratch, 4);
+        if (threadIdx.x == 0) tatomic_amax(a.amax_out, wgmax);
     }
     if (EPI != TEPI_NONE) {
         // per-lane fp32 partials -> fp64, the 16 lanes of a row meet in a butterfly, the four waves in LDS (fixed order)
@@ -437,16 +461,11 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
         }
     };
     auto put = [&](char *hi_base, char *lo_base, int row, const f32x4 v) {
-        h4 hi, lo;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            _Float16 hh, l2;
-            tsplit(v[j], hh, l2);
-            hi[j] = hh;
-            lo[j] = l2;
-        }
-        *reinterpret_cast<h4 *>(hi_base + (size_t)row * RS + cg * 8) = hi;
-        *reinterpret_cast<h4 *>(lo_base + (size_t)row * RS + cg * 8) = lo;
+        uint2 hi, lo;
+        tsplit2(v[0], v[1], hi.x, lo.x, mx);
+        tsplit2(v[2], v[3], hi.y, lo.y, mx);
+        *reinterpret_cast<uint2 *>(hi_base + (size_t)row * RS + cg * 8) = hi;
+        *reinterpret_cast<uint2 *>(lo_base + (size_t)row * RS + cg * 8) = lo;
     };
     if (s0 < s1) prefetch(s0);
     for (long long st = s0; st < s1; ++st) {
@@ -454,23 +473,15 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
         for (int p = 0; p < 4; ++p) {
             const int row = rr + RR * p;
             if (row < cop) {
-                const f32x4 p0 = *reinterpret_cast<const f32x4 *>(pd_l + row * TP), p1 = *reinterpret_cast<const f32x4 *>(pd_l + row * TP + 4);
+                const TBwdRow rw = tbwd_row(pd_l + row * TP, sx);
                 f32x4 g = pa[p], v;
                 if (a.dmode == TIN_BNBWD_POOL) {
                     const int am = (int)pa[p][1];
                     const float gg = pa[p][0];
                     g = (f32x4){am == 0 ? gg : 0.f, am == 1 ? gg : 0.f, am == 2 ? gg : 0.f, am == 3 ? gg : 0.f};
                 }
-                const float ks = p0[2] * sx;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float y = pb[p][j];
-                    const float z = __builtin_fmaf(y, p0[2], p0[3]);
-                    const float xh = (y - p0[0]) * p0[1];
-                    const float dz = z > 0.f ? g[j] : 0.f;
-                    v[j] = ks * (dz - p1[2] - xh * p1[3]);
-                }
-                mx = ttrack(mx, v);
+                for (int j = 0; j < 4; ++j) v[j] = tbwd_apply(rw, g[j], pb[p][j]);
                 put(ahi, alo, row, v);
             }
             if (row < cip) {
@@ -478,9 +489,8 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
                 if (a.xmode == TIN_BNRELU) {
                     const f32x4 p0 = *reinterpret_cast<const f32x4 *>(px_l + row * TP);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = trelu(__builtin_fmaf(v[j], p0[2], p0[3]));
+                    for (int j = 0; j < 4; ++j) v[j] = trelu_i(__builtin_fmaf(v[j], p0[2], p0[3]));
                 }
-                mx = ttrack(mx, v);
                 put(bhi, blo, row, v);
             }
         }
@@ -508,7 +518,13 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
         __syncthreads();
     }
     // an unrepresentable operand anywhere in this workgroup's columns: its whole partial is NaN
-    const bool poison = tblock_max(mx, scratch, 8) > 65504.f;
+    float accbad = 0.f;     // a NaN operand went through the conversion and the matrix pipe: it shows on the accumulators
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (!((fabsf(acc[i][j][0]) + fabsf(acc[i][j][1])) + (fabsf(acc[i][j][2]) + fabsf(acc[i][j][3])) < INFINITY)) accbad = INFINITY;
+    const bool poison = tblock_max(fmaxf(mx, accbad), scratch, 8) > 65504.f;
     if (poison && tid == 0 && a.overflow) *a.overflow = 1;
     const float nanv = __int_as_float(0x7fc00000), inv = 1.f / sx;
     float *dst = a.partial + (size_t)blockIdx.x * cop * cip;
@@ -563,9 +579,11 @@ __device__ __forceinline__ void tsum_parts(const double *partial, int c, int ch,
 __global__ __launch_bounds__(256) void tbn_finalize_kernel(int c, int nparts, double count, const double *__restrict__ partial,
                                                            const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                            float momentum, float *__restrict__ running_mean,
-                                                           float *__restrict__ running_var, float *__restrict__ P) {
+                                                           float *__restrict__ running_var, float *__restrict__ P,
+                                                           long long *__restrict__ num_batches_tracked) {
     const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ch >= c) return;
+    if (ch == 0 && (threadIdx.x & 63) == 0 && num_batches_tracked) *num_batches_tracked += 1;   // nn.BatchNorm2d.forward's counter
     double s1, s2;
     tsum_parts(partial, c, ch, nparts, s1, s2);
     if ((threadIdx.x & 63) != 0) return;
@@ -658,14 +676,15 @@ __global__ __launch_bounds__(256) void tpool_bwd_stats_kernel(int c, int m, cons
         d2 += (double)dz * ((yy - p0[0]) * p0[1]);
         gm = (g != g) ? INFINITY : fmaxf(gm, fabsf(g));
     }
+    __shared__ float shm[4];
     for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_xor(d1, off); d2 += __shfl_xor(d2, off); gm = fmaxf(gm, __shfl_xor(gm, off)); }
-    if (amax_out && (threadIdx.x & 63) == 0) tatomic_amax(amax_out, gm);
-    if ((threadIdx.x & 63) == 0) { sh1[threadIdx.x >> 6] = d1; sh2[threadIdx.x >> 6] = d2; }
+    if ((threadIdx.x & 63) == 0) { sh1[threadIdx.x >> 6] = d1; sh2[threadIdx.x >> 6] = d2; shm[threadIdx.x >> 6] = gm; }
     __syncthreads();
     if (threadIdx.x == 0) {
         double *o = partial + ((size_t)scene * c + ch) * 2;
         o[0] = (sh1[0] + sh1[1]) + (sh1[2] + sh1[3]);
         o[1] = (sh2[0] + sh2[1]) + (sh2[2] + sh2[3]);
+        if (amax_out) tatomic_amax(amax_out, fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3])));   // one per workgroup
     }
 }
 
@@ -758,12 +777,40 @@ extern "C" int sps_tconv(int b, int ci, int co, long long l, int in_mode, int ep
     return tconv_launch_in<8>(a, in_mode, epi_mode, st);        // 128 rows per workgroup (blockIdx.z walks the rest)
 }
 
+// out[k] = max |p_k[0 .. n_k)| for up to four arrays (the weight matrices of one grouped MLP): one launch, one workgroup each
+namespace sps { namespace {
+struct TAmaxArgs { const float *p[4]; long long n[4]; float *out; };
+__global__ __launch_bounds__(256) void tamax_kernel(TAmaxArgs a) {
+    __shared__ float scratch[8];
+    const float *p = a.p[blockIdx.x];
+    const long long n = a.n[blockIdx.x];
+    float m = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 256) {
+        const float v = p[i];
+        m = (v != v) ? INFINITY : fmaxf(m, fabsf(v));
+    }
+    m = tblock_max(m, scratch, 4);
+    if (threadIdx.x == 0) a.out[blockIdx.x] = m;
+}
+} }
+
+extern "C" int sps_tamax4(int count, const float *p0, long long n0, const float *p1, long long n1, const float *p2, long long n2,
+                          const float *p3, long long n3, float *out, sps_stream_t stream) {
+    if (count < 1 || count > 4 || !out) return fail(SPS_ERR_INVALID, "tamax4: 1..4 arrays and an output");
+    TAmaxArgs a;
+    a.p[0] = p0; a.p[1] = p1; a.p[2] = p2; a.p[3] = p3; a.n[0] = n0; a.n[1] = n1; a.n[2] = n2; a.n[3] = n3; a.out = out;
+    for (int k = 0; k < count; ++k)
+        if (!a.p[k] || a.n[k] < 0) return fail(SPS_ERR_INVALID, "tamax4: array %d", k);
+    hipLaunchKernelGGL(tamax_kernel, dim3(count), dim3(256), 0, as_stream(stream), a);
+    return check_launch("tamax_kernel");
+}
+
 extern "C" int sps_tbn_finalize(int c, int nparts, double count, const double *partial, const float *gamma, const float *beta,
                                 float eps, float momentum, float *running_mean, float *running_var, float *params,
-                                sps_stream_t stream) {
+                                long long *num_batches_tracked, sps_stream_t stream) {
     if (c <= 0 || nparts <= 0 || count <= 0.0 || !partial || !params) return fail(SPS_ERR_INVALID, "tbn_finalize: bad arguments");
     hipLaunchKernelGGL(tbn_finalize_kernel, dim3(divup(c, 4)), dim3(256), 0, as_stream(stream), c, nparts, count, partial, gamma, beta,
-                       eps, momentum, running_mean, running_var, params);
+                       eps, momentum, running_mean, running_var, params, num_batches_tracked);
     return check_launch("tbn_finalize_kernel");
 }
 

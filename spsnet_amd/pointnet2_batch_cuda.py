@@ -615,13 +615,26 @@ def tconv(w, wamax, in_mode, epi_mode, out, operand=None, y=None, gout=None, arg
     return partial
 
 
+def weights_amax(ws):
+    """-> (len(ws),) float32: the largest magnitude of each (contiguous fp32) weight matrix, one launch for up to four"""
+    out = torch.empty((len(ws),), dtype=F32, device=ws[0].device)
+    for k0 in range(0, len(ws), 4):
+        grp = list(ws[k0:k0 + 4])
+        args = []
+        for k in range(4):
+            args += [_ptr(grp[k], F32, "w"), grp[k].numel()] if k < len(grp) else [0, 0]
+        with _on(out):
+            _lib.check(_L.sps_tamax4(len(grp), *args, out[k0:].data_ptr(), _stream(out)), "tamax4")
+    return out
+
+
 def tbn_finalize(partial, count, bn, params):
-    """statistics -> params[:, 0:6] (+ the module's running statistics, torch semantics)"""
+    """statistics -> params[:, 0:6] (+ the module's running statistics and batch counter, torch semantics)"""
     parts, c = partial.shape[0], partial.shape[1]
     with _on(params):
         _lib.check(_L.sps_tbn_finalize(c, parts, float(count), partial.data_ptr(), _p(bn.weight), _p(bn.bias), float(bn.eps),
                                        float(bn.momentum), _p(bn.running_mean), _p(bn.running_var), params.data_ptr(),
-                                       _stream(params)), "tbn_finalize")
+                                       _p(bn.num_batches_tracked), _stream(params)), "tbn_finalize")
 
 
 def tbn_bwd_finalize(partial, count, params):

@@ -141,18 +141,18 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
         B, _, M, ns = x.shape
         count = B * M * ns
         flag = _fused._overflow_flag(x.device)
-        ys, ps, ws, was = [], [], [], []
+        ys, ps = [], []
+        ws = [wgb[3 * k].detach().reshape(wgb[3 * k].shape[0], wgb[3 * k].shape[1]).contiguous() for k in range(n)]
+        wamax = _ext.weights_amax(ws)          # (the kernels scale the weights by a power of two derived from it)
+        was = [wamax[k:k + 1] for k in range(n)]
         operand, pin, mode = x, None, _ext.TIN_RAW
         for k, bn in enumerate(bns):
-            w = wgb[3 * k].detach()
-            w = w.reshape(w.shape[0], w.shape[1]).contiguous()
+            w = ws[k]
             y = torch.empty((B, w.shape[0], M, ns), dtype=torch.float32, device=x.device)
-            wa = w.abs().amax().reshape(1)     # (the kernels scale the weights by a power of two derived from it)
-            partial = _ext.tconv(w, wa, mode, _ext.TEPI_STATS, y, operand=operand, pin=pin, overflow=flag)
+            partial = _ext.tconv(w, was[k], mode, _ext.TEPI_STATS, y, operand=operand, pin=pin, overflow=flag)
             params = torch.empty((w.shape[0], _ext.TRAIN_PARAMS), dtype=torch.float32, device=x.device)
-            _ext.tbn_finalize(partial, count, bn, params)
-            bn.num_batches_tracked.add_(1)
-            ys.append(y); ps.append(params); ws.append(w); was.append(wa)
+            _ext.tbn_finalize(partial, count, bn, params)      # (also counts the batch: num_batches_tracked += 1)
+            ys.append(y); ps.append(params)
             operand, pin, mode = y, params, _ext.TIN_BNRELU
         out, arg, yarg = _ext.tpool_fwd(ys[-1], ps[-1])
         ctx.n, ctx.ns, ctx.count = n, ns, count
