@@ -162,7 +162,10 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
     const long long nblk = first < total ? (total - first + stride - 1) / stride : 0;
     const long long npieces = nblk * S;
 
-    struct Piece { f32x4 xa[8], xb[GRAD ? 8 : 1]; };
+    // (POOL mode: the pooled gradient and the raw arg-max byte; NO arithmetic on loaded values in here -- it would wait for
+    //  the load, and with it for everything requested before it, where the request is issued)
+    constexpr bool POOL = (IN == TIN_BNBWD_POOL);
+    struct Piece { f32x4 xa[POOL ? 1 : 8], xb[GRAD ? 8 : 1]; float pg[POOL ? 8 : 1]; int pi[POOL ? 8 : 1]; };
     auto load = [&](long long piece, Piece &pc) {
         const long long i = piece / S;
         const int s = (int)(piece - i * S);
@@ -176,16 +179,17 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int row = 32 * s + 8 * q + e;
-            pc.xa[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (GRAD) pc.xb[e] = pc.xa[e];
+            if (!POOL) pc.xa[POOL ? 0 : e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (POOL) { pc.pg[POOL ? e : 0] = 0.f; pc.pi[POOL ? e : 0] = 255; }
+            if (GRAD) pc.xb[GRAD ? e : 0] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (row < a.ci) {
-                if (IN == TIN_BNBWD_POOL) {
-                    pc.xa[e][0] = a.gout[pool_base + (size_t)row * a.m];
-                    pc.xa[e][1] = (float)((int)a.arg[pool_base + (size_t)row * a.m] - (int)(col0 - cen * a.ns));
+                if (POOL) {
+                    pc.pg[POOL ? e : 0] = a.gout[pool_base + (size_t)row * a.m];
+                    pc.pi[POOL ? e : 0] = a.arg[pool_base + (size_t)row * a.m];
                 } else {
-                    pc.xa[e] = *reinterpret_cast<const f32x4 *>(src + (size_t)row * a.l);
+                    pc.xa[POOL ? 0 : e] = *reinterpret_cast<const f32x4 *>(src + (size_t)row * a.l);
                 }
-                if (GRAD) pc.xb[e] = *reinterpret_cast<const f32x4 *>(src2 + (size_t)row * a.l);
+                if (GRAD) pc.xb[GRAD ? e : 0] = *reinterpret_cast<const f32x4 *>(src2 + (size_t)row * a.l);
             }
         }
     };
@@ -252,6 +256,7 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
 
     f32x4 acc[RT][4];
     float mx = 0.f;
+    int sidx0 = 0;
     int s = 0;
     long long blk = 0;
     for (long long piece = 0; piece < npieces; ++piece) {
@@ -266,6 +271,11 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             mx = 0.f;
+            if (POOL) {
+                const long long id = first + blk * stride;
+                const long long col0 = (id - (id / nb64) * nb64) * 64 + 4 * c;
+                sidx0 = (int)(col0 % a.ns);
+            }
         }
         TFrag bh[4], bl[4];
 #pragma unroll
@@ -276,17 +286,17 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
                 const int e = 2 * e2 + h;
                 const float *P = pin_l + (32 * s + 8 * q + e) * TP;
                 if (IN == TIN_RAW) {
-                    v[h] = b0.xa[e];
+                    v[h] = b0.xa[POOL ? 0 : e];
                 } else if (IN == TIN_BNRELU) {
                     const f32x4 p0 = *reinterpret_cast<const f32x4 *>(P);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[h][j] = trelu_i(__builtin_fmaf(b0.xa[e][j], p0[2], p0[3]));
+                    for (int j = 0; j < 4; ++j) v[h][j] = trelu_i(__builtin_fmaf(b0.xa[POOL ? 0 : e][j], p0[2], p0[3]));
                 } else {
                     const TBwdRow rw = tbwd_row(P, sx);
-                    f32x4 g = b0.xa[e];
-                    if (IN == TIN_BNBWD_POOL) {
-                        const int am = (int)b0.xa[e][1];
-                        const float gg = b0.xa[e][0];
+                    f32x4 g = b0.xa[POOL ? 0 : e];
+                    if (POOL) {
+                        const int am = b0.pi[POOL ? e : 0] - sidx0;     // position of the arg-max relative to this lane's columns
+                        const float gg = b0.pg[POOL ? e : 0];
                         g = (f32x4){am == 0 ? gg : 0.f, am == 1 ? gg : 0.f, am == 2 ? gg : 0.f, am == 3 ? gg : 0.f};
                     }
 #pragma unroll
@@ -436,6 +446,8 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
     float mx = 0.f;
 
     f32x4 pa[4], pb[4], pxv[4];
+    float pg[4];
+    int pi[4], psub = 0;     // POOL mode: pooled gradient, raw arg-max byte (no arithmetic on loaded values while prefetching)
     auto prefetch = [&](long long st) {
         const int scene = (int)(st / per_scene);
         const long long col = (st - (long long)scene * per_scene) * (32 * NK) + 4 * cg;
@@ -445,13 +457,16 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
             pa[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
             pb[p] = pa[p];
             pxv[p] = pa[p];
+            pg[p] = 0.f;
+            pi[p] = 255;
             if (row < a.co) {
                 const size_t at = ((size_t)scene * a.co + row) * a.l + col;
                 if (a.dmode == TIN_BNBWD_POOL) {
                     const long long cen = col / a.ns;
                     const size_t pat = ((size_t)scene * a.co + row) * a.m + cen;
-                    pa[p][0] = a.gout[pat];
-                    pa[p][1] = (float)((int)a.arg[pat] - (int)(col - cen * a.ns));
+                    pg[p] = a.gout[pat];
+                    pi[p] = a.arg[pat];
+                    psub = (int)(col - cen * a.ns);
                 } else {
                     pa[p] = *reinterpret_cast<const f32x4 *>(a.dA + at);
                 }
@@ -476,8 +491,8 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
                 const TBwdRow rw = tbwd_row(pd_l + row * TP, sx);
                 f32x4 g = pa[p], v;
                 if (a.dmode == TIN_BNBWD_POOL) {
-                    const int am = (int)pa[p][1];
-                    const float gg = pa[p][0];
+                    const int am = pi[p] - psub;
+                    const float gg = pg[p];
                     g = (f32x4){am == 0 ? gg : 0.f, am == 1 ? gg : 0.f, am == 2 ? gg : 0.f, am == 3 ? gg : 0.f};
                 }
 #pragma unroll
@@ -785,10 +800,23 @@ __global__ __launch_bounds__(256) void tamax_kernel(TAmaxArgs a) {
     const float *p = a.p[blockIdx.x];
     const long long n = a.n[blockIdx.x];
     float m = 0.f;
-    for (long long i = threadIdx.x; i < n; i += 256) {
-        const float v = p[i];
-        m = (v != v) ? INFINITY : fmaxf(m, fabsf(v));
+    auto take = [&](float v) { m = (v != v) ? INFINITY : fmaxf(m, fabsf(v)); };
+    long long done = 0;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {            // eight 16-byte loads in flight per thread
+        const long long n4 = n >> 2;
+        for (long long base = 0; base < n4; base += 256 * 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long i = base + u * 256 + threadIdx.x;
+                v[u] = i < n4 ? *reinterpret_cast<const f32x4 *>(p + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { take(v[u][0]); take(v[u][1]); take(v[u][2]); take(v[u][3]); }
+        }
+        done = n4 << 2;
     }
+    for (long long i = done + threadIdx.x; i < n; i += 256) take(p[i]);
     m = tblock_max(m, scratch, 4);
     if (threadIdx.x == 0) a.out[blockIdx.x] = m;
 }

@@ -2266,14 +2266,15 @@ def test_group_concat_matches_query_and_group(ext, G, C, use_xyz):
 # ------------------------------------------------------------------ the fused train-mode grouped MLP (csrc/mlp_train.hip)
 @pytest.mark.parametrize("B,M,ns,widths", [(2, 128, 16, [7, 24, 40, 72]), (2, 64, 32, [131, 128, 256, 256]),
                                            (3, 40, 8, [4, 16, 32]), (1, 16, 4, [19]), (2, 32, 64, [67, 64, 96, 128]),
-                                           (2, 48, 16, [259, 256, 200])])
+                                           (2, 48, 16, [259, 256, 200]), (2, 24, 8, [20, 48, 40]), (1, 8, 8, [5, 16, 16, 16])])
 def test_fused_train_mode_mlp_matches_torch(dev, B, M, ns, widths, monkeypatch):
     """_GroupedMLPPoolTrain (conv + batch statistics in the epilogue, BatchNorm / ReLU / pool routing / BatchNorm backward
     in the operand loads, split-fp16 MFMA) against the plain torch op sequence of the reference (pointnet2_modules.py:432-444)
     in float64 on the CPU: pooled output, running statistics, and the gradients w.r.t. the grouped input and every
     parameter, at 2e-4 of the largest reference magnitude (the op-by-op GPU path is held to the same bar).  Shapes cover
     channel counts that are not multiples of 16 / 32, more than 128 output rows (two row chunks), one to three layers,
-    every supported nsample, and a first width beyond 256 (declined: falls back to the op-by-op path)."""
+    every supported nsample, column counts that are odd multiples of 64 (the narrower weight-gradient stage) or a single
+    64-column block, and a first width beyond 256 (declined: falls back to the op-by-op path)."""
     import copy
     from spsnet_amd import fused, pointnet2_modules as PM
     torch.manual_seed(B * 1000 + M + ns)
