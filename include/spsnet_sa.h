@@ -526,6 +526,12 @@ int sps_tpool_fwd(int b, int c, int m, int nsample, const float *y, const float 
  * (zeroed device scalar, may be NULL) receives max |gout| */
 int sps_tpool_bwd_stats(int b, int c, int m, const float *yarg, const float *gout, const float *params, double *partial,
                         float *amax_out, sps_stream_t stream);
+/* The same stack WITHOUT a pool (aggregation / confidence layers: Conv1d + BatchNorm1d + ReLU on (b, c, l) tensors,
+ * pointnet2_modules.py:213-245, 449-455): out = relu(fma(y, scale, shift)), and the last layer's BatchNorm-backward sums from a
+ * dense incoming gradient dA (partial (b, c, 2) doubles = b parts; amax_out receives max |dA|).  l a multiple of 4. */
+int sps_tbn_apply_relu(int b, int c, long long l, const float *y, const float *params, float *out, sps_stream_t stream);
+int sps_tbn_bwd_stats(int b, int c, long long l, const float *y, const float *dA, const float *params, double *partial,
+                      float *amax_out, sps_stream_t stream);
 /* dw (co, ci) = sum over all columns of dY (x) T(x): dY from (dA, y, pd) as in_mode 2 / 3 of sps_tconv (dmode), T = identity
  * (xmode 0) or relu(fma(x, scale, shift)) with px (xmode 1); co, ci <= 256, l a multiple of 32; work =
  * sps_twgrad_workspace_floats floats. */

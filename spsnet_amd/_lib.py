@@ -73,6 +73,8 @@ _PROTOS = {
     "sps_tbn_finalize": [_i, _i, ctypes.c_double, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "sps_tamax4": [_i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp],
     "sps_tbn_bwd_finalize": [_i, _i, ctypes.c_double, _vp, _vp, _vp, _vp, _vp],
+    "sps_tbn_apply_relu": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp],
+    "sps_tbn_bwd_stats": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_tpool_fwd": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_tpool_bwd_stats": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_twgrad": [_i, _i, _i, ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

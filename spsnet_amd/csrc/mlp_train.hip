@@ -705,6 +705,55 @@ __global__ __launch_bounds__(256) void tpool_bwd_stats_kernel(int c, int m, cons
 
 // workgroups along the columns: as many as stay resident (one per CU at 128 rows per workgroup -- the weights then fill the
 // LDS and a wave holds ~400 registers --, two otherwise), each walking its share of the 64-column blocks
+// ---- the same stack WITHOUT a pool (the aggregation / confidence layers: Conv1d + BatchNorm1d + ReLU on (b, c, m)) ----------
+// out = relu(fma(y, scale, shift)); one workgroup per (channel, scene) row
+__global__ __launch_bounds__(256) void tbn_apply_relu_kernel(int c, long long l, const float *__restrict__ y, const float *__restrict__ P,
+                                                             float *__restrict__ out) {
+    const int ch = blockIdx.x, scene = blockIdx.y;
+    const float sc = P[(size_t)ch * TP + 2], sh = P[(size_t)ch * TP + 3];
+    const size_t base = ((size_t)scene * c + ch) * l;
+    for (long long e = 4 * threadIdx.x; e < l; e += 4 * 256) {     // l % 4 == 0 (host)
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(y + base + e);
+        *reinterpret_cast<f32x4 *>(out + base + e) = (f32x4){trelu_i(__builtin_fmaf(v[0], sc, sh)), trelu_i(__builtin_fmaf(v[1], sc, sh)),
+                                                              trelu_i(__builtin_fmaf(v[2], sc, sh)), trelu_i(__builtin_fmaf(v[3], sc, sh))};
+    }
+}
+// the BatchNorm-backward sums of the last layer from a DENSE incoming gradient; partial[(scene * c + ch) * 2], amax of |dA|
+__global__ __launch_bounds__(256) void tbn_bwd_stats_kernel(int c, long long l, const float *__restrict__ y, const float *__restrict__ dA,
+                                                            const float *__restrict__ P, double *__restrict__ partial,
+                                                            float *__restrict__ amax_out) {
+    __shared__ double sh1[4], sh2[4];
+    __shared__ float shm[4];
+    const int ch = blockIdx.x, scene = blockIdx.y;
+    const f32x4 p0 = *reinterpret_cast<const f32x4 *>(P + (size_t)ch * TP);
+    const size_t base = ((size_t)scene * c + ch) * l;
+    double d1 = 0.0, d2 = 0.0;
+    float gm = 0.f;
+    for (long long e = 4 * threadIdx.x; e < l; e += 4 * 256) {
+        const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + base + e), gv = *reinterpret_cast<const f32x4 *>(dA + base + e);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float z = __builtin_fmaf(yv[j], p0[2], p0[3]);
+            const float dz = z > 0.f ? gv[j] : 0.f;
+            s1 += dz;
+            s2 += dz * ((yv[j] - p0[0]) * p0[1]);
+            gm = (gv[j] != gv[j]) ? INFINITY : fmaxf(gm, fabsf(gv[j]));
+        }
+        d1 += s1;
+        d2 += s2;
+    }
+    for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_xor(d1, off); d2 += __shfl_xor(d2, off); gm = fmaxf(gm, __shfl_xor(gm, off)); }
+    if ((threadIdx.x & 63) == 0) { sh1[threadIdx.x >> 6] = d1; sh2[threadIdx.x >> 6] = d2; shm[threadIdx.x >> 6] = gm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double *o = partial + ((size_t)scene * c + ch) * 2;
+        o[0] = (sh1[0] + sh1[1]) + (sh1[2] + sh1[3]);
+        o[1] = (sh2[0] + sh2[1]) + (sh2[2] + sh2[3]);
+        if (amax_out) tatomic_amax(amax_out, fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3])));
+    }
+}
+
 int tconv_grid_x(int b, long long l, int co) {
     const long long groups = ((long long)b * (l >> 6) + 3) / 4;
     const long long cap = co > 64 ? 256 : 512;
@@ -879,6 +928,23 @@ extern "C" int sps_tpool_bwd_stats(int b, int c, int m, const float *yarg, const
     if (!yarg || !gout || !params || !partial) return fail(SPS_ERR_INVALID, "tpool_bwd_stats: null pointer");
     hipLaunchKernelGGL(tpool_bwd_stats_kernel, dim3(c, b), dim3(256), 0, as_stream(stream), c, m, yarg, gout, params, partial, amax_out);
     return check_launch("tpool_bwd_stats_kernel");
+}
+
+extern "C" int sps_tbn_apply_relu(int b, int c, long long l, const float *y, const float *params, float *out, sps_stream_t stream) {
+    if (b < 0 || c <= 0 || l < 0 || (l % 4) || b > 65535) return fail(SPS_ERR_INVALID, "tbn_apply_relu: bad shape b=%d c=%d l=%lld", b, c, l);
+    if (b == 0 || l == 0) return SPS_OK;
+    if (!y || !params || !out) return fail(SPS_ERR_INVALID, "tbn_apply_relu: null pointer");
+    hipLaunchKernelGGL(tbn_apply_relu_kernel, dim3(c, b), dim3(256), 0, as_stream(stream), c, l, y, params, out);
+    return check_launch("tbn_apply_relu_kernel");
+}
+
+// partial: (b, c, 2) doubles = `b` parts for sps_tbn_bwd_finalize
+extern "C" int sps_tbn_bwd_stats(int b, int c, long long l, const float *y, const float *dA, const float *params, double *partial,
+                                 float *amax_out, sps_stream_t stream) {
+    if (b <= 0 || c <= 0 || l <= 0 || (l % 4) || b > 65535) return fail(SPS_ERR_INVALID, "tbn_bwd_stats: bad shape b=%d c=%d l=%lld", b, c, l);
+    if (!y || !dA || !params || !partial) return fail(SPS_ERR_INVALID, "tbn_bwd_stats: null pointer");
+    hipLaunchKernelGGL(tbn_bwd_stats_kernel, dim3(c, b), dim3(256), 0, as_stream(stream), c, l, y, dA, params, partial, amax_out);
+    return check_launch("tbn_bwd_stats_kernel");
 }
 
 static int twgrad_nk(int co, int ci, long long l) {

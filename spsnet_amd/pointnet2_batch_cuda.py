@@ -670,6 +670,26 @@ def tpool_bwd_stats(yarg, gout, params, amax_out=None):
     return partial
 
 
+def tbn_apply_relu(y, params):
+    """relu(batch_norm(y)) from the parameter block: the output of a stack that has no pool behind it"""
+    b, c = y.shape[0], y.shape[1]
+    out = torch.empty_like(y)
+    with _on(y):
+        _lib.check(_L.sps_tbn_apply_relu(b, c, y.numel() // max(1, b * c), _ptr(y, F32, "y"), params.data_ptr(), out.data_ptr(),
+                                         _stream(y)), "tbn_apply_relu")
+    return out
+
+
+def tbn_bwd_stats(y, dA, params, amax_out=None):
+    """-> the last layer's BatchNorm-backward sums (B, C, 2) float64 from a dense incoming gradient"""
+    b, c = y.shape[0], y.shape[1]
+    partial = torch.empty((b, c, 2), dtype=torch.float64, device=y.device)
+    with _on(y):
+        _lib.check(_L.sps_tbn_bwd_stats(b, c, y.numel() // max(1, b * c), _ptr(y, F32, "y"), _ptr(dA, F32, "dA"), params.data_ptr(),
+                                        partial.data_ptr(), _p(amax_out), _stream(y)), "tbn_bwd_stats")
+    return partial
+
+
 def twgrad(y, pd, x, px, amax_in, dA=None, gout=None, arg=None, nsample=0, overflow=None):
     """dW (co, ci) of one layer: dY recomputed from (dA | pooled gradient, y, pd), the other operand x raw (px None) or
     through BatchNorm + ReLU (px)."""

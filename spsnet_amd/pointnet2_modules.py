@@ -124,22 +124,28 @@ FUSED_CONV_TRAINING = True
 # [Conv2d 1x1, BatchNorm2d(batch statistics), ReLU] x n + max-pool as the fused kernels of csrc/mlp_train.hip (split-fp16
 # MFMA arithmetic: active unless fused.set_precision("fp32") asks for the exact op-by-op path)
 FUSED_MLP_TRAINING = os.environ.get("SPS_FUSED_MLP_TRAINING", "1") != "0"
+# the aggregation / confidence stacks ([Conv1d, BatchNorm1d, ReLU] on (B, C, M)) through the same kernels: built, tested, and
+# measured NOT to pay at the IA-SSD shapes -- these tensors are 2-8 MB, the stack is launch-bound either way, and the fused
+# form needs more launches than torch's (8.46 vs 8.31 ms per training step of SA layers 0-2).  Opt-in.
+FUSED_POINTWISE_TRAINING = os.environ.get("SPS_FUSED_POINTWISE_TRAINING", "0") != "0"
 
 
 class _GroupedMLPPoolTrain(torch.autograd.Function):
-    """max_s relu(bn_n(conv_n(... relu(bn_1(conv_1(x)))))) for a (B, C0, M, ns) grouped tensor in train() mode -> (B, Cn, M),
-    forward and backward on csrc/mlp_train.hip: only the pre-BatchNorm convolution outputs (forward) and the gradients
-    w.r.t. the post-ReLU activations (backward) are materialised; BatchNorm / ReLU / the pool's gradient routing / the
-    BatchNorm backward are applied where the operands are loaded, the batch statistics come out of the convolutions'
-    epilogues.  Updates the running statistics like nn.BatchNorm2d.forward.  Reference op sequence:
-    pointnet2_modules.py:432-444."""
+    """pool=True: max_s relu(bn_n(conv_n(... relu(bn_1(conv_1(x)))))) for a (B, C0, M, ns) grouped tensor in train() mode ->
+    (B, Cn, M); pool=False: the same stack without the pool on a (B, C0, L) tensor -> (B, Cn, L) (the aggregation /
+    confidence layers).  Forward and backward on csrc/mlp_train.hip: only the pre-BatchNorm convolution outputs (forward)
+    and the gradients w.r.t. the post-ReLU activations (backward) are materialised; BatchNorm / ReLU / the pool's gradient
+    routing / the BatchNorm backward are applied where the operands are loaded, the batch statistics come out of the
+    convolutions' epilogues.  Updates the running statistics like nn.BatchNorm.forward.  Reference op sequence:
+    pointnet2_modules.py:432-444 (grouped MLP + pool), :449-455 (aggregation / confidence)."""
 
     @staticmethod
-    def forward(ctx, bns, x, *wgb):
+    def forward(ctx, bns, pool, x, *wgb):
         n = len(bns)
         x = x.contiguous()
-        B, _, M, ns = x.shape
-        count = B * M * ns
+        B, tail = x.shape[0], tuple(x.shape[2:])
+        ns = tail[1] if pool else 1
+        count = x.numel() // x.shape[1]
         flag = _fused._overflow_flag(x.device)
         ys, ps = [], []
         ws = [wgb[3 * k].detach().reshape(wgb[3 * k].shape[0], wgb[3 * k].shape[1]).contiguous() for k in range(n)]
@@ -148,74 +154,94 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
         operand, pin, mode = x, None, _ext.TIN_RAW
         for k, bn in enumerate(bns):
             w = ws[k]
-            y = torch.empty((B, w.shape[0], M, ns), dtype=torch.float32, device=x.device)
+            y = torch.empty((B, w.shape[0]) + tail, dtype=torch.float32, device=x.device)
             partial = _ext.tconv(w, was[k], mode, _ext.TEPI_STATS, y, operand=operand, pin=pin, overflow=flag)
             params = torch.empty((w.shape[0], _ext.TRAIN_PARAMS), dtype=torch.float32, device=x.device)
             _ext.tbn_finalize(partial, count, bn, params)      # (also counts the batch: num_batches_tracked += 1)
             ys.append(y); ps.append(params)
             operand, pin, mode = y, params, _ext.TIN_BNRELU
-        out, arg, yarg = _ext.tpool_fwd(ys[-1], ps[-1])
-        ctx.n, ctx.ns, ctx.count = n, ns, count
+        if pool:
+            out, arg, yarg = _ext.tpool_fwd(ys[-1], ps[-1])
+        else:
+            out = _ext.tbn_apply_relu(ys[-1], ps[-1])
+            arg = yarg = out.new_empty((0,))
+        ctx.n, ctx.ns, ctx.count, ctx.pool = n, ns, count, pool
         ctx.save_for_backward(x, arg, yarg, *ys, *ps, *ws, *was)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        n, ns, count = ctx.n, ctx.ns, ctx.count
+        n, ns, count, pool = ctx.n, ctx.ns, ctx.count, ctx.pool
         saved = ctx.saved_tensors
         x, arg, yarg = saved[0], saved[1], saved[2]
         ys, ps, ws, was = saved[3:3 + n], saved[3 + n:3 + 2 * n], saved[3 + 2 * n:3 + 3 * n], saved[3 + 3 * n:3 + 4 * n]
         gout = gout.contiguous()
         flag = _fused._overflow_flag(x.device)
         grads = [None] * (3 * n)
-        # BatchNorm-backward sums of the last layer from the pooled gradient; its dA is never materialised
         # amax[k]: largest magnitude of the gradient that enters layer k's BatchNorm backward (the kernels scale their fp16
         # operands by an exact power of two derived from it: csrc/mlp_train.hip)
         amax = torch.zeros((n,), dtype=torch.float32, device=x.device)
-        grads[3 * n - 2], grads[3 * n - 1] = _ext.tbn_bwd_finalize(
-            _ext.tpool_bwd_stats(yarg, gout, ps[-1], amax_out=amax[n - 1:]), count, ps[-1])
-        dA, dx = None, None
+        # BatchNorm-backward sums of the last layer: from the pooled gradient alone (its dA is never materialised), or from
+        # the dense incoming gradient of a stack without a pool
+        last = (_ext.tpool_bwd_stats(yarg, gout, ps[-1], amax_out=amax[n - 1:]) if pool
+                else _ext.tbn_bwd_stats(ys[-1], gout, ps[-1], amax_out=amax[n - 1:]))
+        grads[3 * n - 2], grads[3 * n - 1] = _ext.tbn_bwd_finalize(last, count, ps[-1])
+        dA, dx = (None if pool else gout), None
         for k in range(n - 1, -1, -1):
-            pool = dict(gout=gout, arg=arg, nsample=ns) if k == n - 1 else dict(dA=dA)
-            if ctx.needs_input_grad[2 + 3 * k]:
-                dw = _ext.twgrad(ys[k], ps[k], ys[k - 1] if k else x, ps[k - 1] if k else None, amax[k:], overflow=flag, **pool)
-                grads[3 * k] = dw.view(dw.shape[0], dw.shape[1], 1, 1)
-            din = dict(operand=dA) if k < n - 1 else dict(gout=gout, arg=arg, nsample=ns)
-            mode = _ext.TIN_BNBWD if k < n - 1 else _ext.TIN_BNBWD_POOL
+            routed = pool and k == n - 1            # the incoming gradient is the pooled one, routed by the arg-max in the load
+            if ctx.needs_input_grad[3 + 3 * k]:
+                src = dict(gout=gout, arg=arg, nsample=ns) if routed else dict(dA=dA)
+                dw = _ext.twgrad(ys[k], ps[k], ys[k - 1] if k else x, ps[k - 1] if k else None, amax[k:], overflow=flag, **src)
+                grads[3 * k] = dw.view(wgb_shape(ctx, k, dw))
+            din = dict(gout=gout, arg=arg, nsample=ns) if routed else dict(operand=dA)
+            mode = _ext.TIN_BNBWD_POOL if routed else _ext.TIN_BNBWD
             if k > 0:
                 prev = torch.empty_like(ys[k - 1])
                 partial = _ext.tconv(ws[k], was[k], mode, _ext.TEPI_BWD, prev, y=ys[k], pin=ps[k], epi_y=ys[k - 1], pout=ps[k - 1],
                                      transposed=True, overflow=flag, amax_in=amax[k:], amax_out=amax[k - 1:], **din)
                 grads[3 * k - 2], grads[3 * k - 1] = _ext.tbn_bwd_finalize(partial, count, ps[k - 1])
                 dA = prev
-            elif ctx.needs_input_grad[1]:
+            elif ctx.needs_input_grad[2]:
                 dx = torch.empty_like(x)
                 _ext.tconv(ws[0], was[0], mode, _ext.TEPI_NONE, dx, y=ys[0], pin=ps[0], transposed=True, overflow=flag, amax_in=amax[0:],
                            **din)
-        return (None, dx) + tuple(grads)
+        return (None, None, dx) + tuple(grads)
+
+
+def wgb_shape(ctx, k, dw):
+    """(co, ci) -> the convolution weight's own shape: (co, ci, 1, 1) for Conv2d, (co, ci, 1) for Conv1d"""
+    return (dw.shape[0], dw.shape[1], 1, 1) if ctx.pool else (dw.shape[0], dw.shape[1], 1)
+
+
+def _fused_stack_train(mods, x, pool: bool):
+    """[conv 1x1 (no bias), BatchNorm on batch statistics, ReLU] x n (+ max over the last axis when pool) through
+    _GroupedMLPPoolTrain, or None when the modules / shapes do not qualify.  mods: the flat module list."""
+    conv_t, bn_t = (nn.Conv2d, nn.BatchNorm2d) if pool else (nn.Conv1d, nn.BatchNorm1d)
+    if not (FUSED_MLP_TRAINING and _fused.PRECISION != "fp32" and x.is_cuda and x.dtype == torch.float32
+            and x.dim() == (4 if pool else 3) and torch.is_grad_enabled()):
+        return None
+    if len(mods) % 3 or not mods:
+        return None
+    cols = x.shape[2] * (x.shape[3] if pool else 1)
+    if (pool and x.shape[3] not in (4, 8, 16, 32, 64)) or cols % 64 or x.shape[1] > 256 or x.numel() == 0:
+        return None
+    bns, wgb = [], []
+    for conv, bn, act in zip(mods[0::3], mods[1::3], mods[2::3]):
+        if not (isinstance(conv, conv_t) and isinstance(bn, bn_t) and isinstance(act, nn.ReLU) and bn.affine
+                and bn.track_running_stats and bn.momentum is not None and bn.training and all(k == 1 for k in conv.kernel_size)
+                and all(v == 1 for v in conv.stride) and conv.groups == 1 and conv.bias is None
+                and conv.weight.dtype == torch.float32 and bn.weight.dtype == torch.float32 and max(conv.weight.shape[:2]) <= 256):
+            return None
+        bns.append(bn)
+        wgb += [conv.weight, bn.weight, bn.bias]
+    return _GroupedMLPPoolTrain.apply(tuple(bns), pool, x, *wgb)
 
 
 def _fused_mlp_pool_train(mlp: nn.Sequential, x: torch.Tensor, pool_method: str):
     """-> pooled (B, C, M) through _GroupedMLPPoolTrain, or None when the stack / shapes do not qualify."""
-    if not (FUSED_MLP_TRAINING and _fused.PRECISION != "fp32" and pool_method == 'max_pool' and mlp.training and x.is_cuda
-            and x.dtype == torch.float32 and x.dim() == 4 and torch.is_grad_enabled()):
+    if pool_method != 'max_pool' or not mlp.training:
         return None
-    mods = list(mlp)
-    if len(mods) % 3 or not mods:
-        return None
-    B, c0, M, ns = x.shape
-    if ns not in (4, 8, 16, 32, 64) or (M * ns) % 64 or c0 > 256 or B * M * ns == 0:
-        return None
-    bns, wgb = [], []
-    for conv, bn, act in zip(mods[0::3], mods[1::3], mods[2::3]):
-        if not (isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and isinstance(act, nn.ReLU) and bn.affine
-                and bn.track_running_stats and bn.momentum is not None and bn.training and conv.kernel_size == (1, 1)
-                and conv.stride == (1, 1) and conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.float32
-                and bn.weight.dtype == torch.float32 and max(conv.weight.shape[:2]) <= 256):
-            return None
-        bns.append(bn)
-        wgb += [conv.weight, bn.weight, bn.bias]
-    return _GroupedMLPPoolTrain.apply(tuple(bns), x, *wgb)
+    return _fused_stack_train(list(mlp), x, True)
 
 
 def _shared_mlp(mlp: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
@@ -240,6 +266,24 @@ def _shared_mlp(mlp: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
             z = conv(x)
         x = _BatchNormReLUTrain.apply(z, bn.weight, bn.bias, bn)
     return x
+
+
+def _pointwise_stack(stack: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """stack(x) for an aggregation / confidence stack on (B, C, M) (reference :213-245): in training its leading
+    [Conv1d, BatchNorm1d, ReLU] triples run on the fused kernels of csrc/mlp_train.hip, whatever follows (the class-score
+    convolution with its bias) through torch."""
+    mods = list(stack)
+    lead = 0
+    while (lead + 3 <= len(mods) and isinstance(mods[lead], nn.Conv1d) and isinstance(mods[lead + 1], nn.BatchNorm1d)
+           and isinstance(mods[lead + 2], nn.ReLU)):
+        lead += 3
+    if lead and stack.training and FUSED_POINTWISE_TRAINING:
+        y = _fused_stack_train(mods[:lead], x, False)
+        if y is not None:
+            for mod in mods[lead:]:
+                y = mod(y)
+            return y
+    return stack(x)
 
 
 def _pool_over_samples(grouped: torch.Tensor, method: str) -> torch.Tensor:
@@ -648,13 +692,13 @@ class _SamplingSAModule(_PointnetSAModuleBase):
                 pooled = pooled.transpose(1, 2).contiguous()
             if half_out:
                 raise NotImplementedError("fp16 feature tensors need the fused aggregation kernel (widths multiples of 16)")
-            pooled = self.aggregation_layer(pooled)
+            pooled = _pointwise_stack(self.aggregation_layer, pooled)
         else:
             if x_pm:
                 pooled = pooled.transpose(1, 2).contiguous()
             if half_out:
                 pooled = pooled.half()
-        cls = head(pooled).transpose(1, 2) if head is not None else None
+        cls = _pointwise_stack(head, pooled).transpose(1, 2) if head is not None else None
         return pooled, cls
 
     def _abstract(self, xyz, new_xyz, features, sampled_idx):

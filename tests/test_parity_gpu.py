@@ -2338,3 +2338,56 @@ def test_fused_train_mode_mlp_poisons_unrepresentable_operands(dev, monkeypatch)
     torch.cuda.synchronize()
     assert out is not None and bool(torch.isnan(out).any())
     assert fused.check_overflow()
+
+
+@pytest.mark.parametrize("B,M,widths,tailconv", [(2, 256, [96, 64], False), (3, 128, [256, 128, 128], True), (2, 64, [40, 24], True)])
+def test_fused_train_mode_pointwise_stack_matches_torch(dev, B, M, widths, tailconv, monkeypatch):
+    """The aggregation / confidence stacks ([Conv1d, BatchNorm1d, ReLU] x n, optionally a class-score Conv1d with bias behind
+    them) in train() mode through _pointwise_stack (fused kernels, no pool) against float64 torch: output, running statistics
+    and every gradient."""
+    import copy
+    from spsnet_amd import fused, pointnet2_modules as PM
+    torch.manual_seed(M + len(widths))
+    mods = list(PM._conv_bn_relu_stack(list(widths), torch.nn.Conv1d, torch.nn.BatchNorm1d))
+    if tailconv:
+        mods.append(torch.nn.Conv1d(widths[-1], 3, kernel_size=1, bias=True))
+    stack = torch.nn.Sequential(*mods)
+    for mod in stack:
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.3)
+    ref = copy.deepcopy(stack).double().train()
+    stack = stack.to(dev).train()
+    x0 = torch.randn(B, widths[0], M).abs() * 2 + 0.1          # post-ReLU-like inputs
+    cout = 3 if tailconv else widths[-1]
+    wout = torch.randn(B, cout, M) * 1e-4                       # small gradients, as a mean-reduced loss produces them
+    xr = x0.double().requires_grad_(True)
+    out_r = ref(xr)
+    (out_r * wout.double()).sum().backward()
+    xg = x0.to(dev).requires_grad_(True)
+    monkeypatch.setattr(PM, "FUSED_MLP_TRAINING", True)
+    monkeypatch.setattr(PM, "FUSED_POINTWISE_TRAINING", True)
+    calls = []
+    orig = PM._fused_stack_train
+    monkeypatch.setattr(PM, "_fused_stack_train", lambda *a: calls.append(orig(*a)) or calls[-1])
+    got = PM._pointwise_stack(stack, xg)
+    assert len(calls) == 1 and calls[0] is not None, "the stack was supposed to take the fused kernels"
+    (got * wout.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert not fused.check_overflow()
+
+    def close(a, b, what, tol=2e-5):
+        a, b = a.detach().cpu().double(), b.detach()
+        assert a.shape == b.shape, what
+        err = float((a - b).abs().max())
+        assert err <= tol * max(1e-30, float(b.abs().max())), (what, err, float(b.abs().max()))
+
+    close(got, out_r, "output")
+    close(xg.grad, xr.grad, "d/d input")
+    for (name, pg), (_, pr) in zip(stack.named_parameters(), ref.named_parameters()):
+        close(pg.grad, pr.grad, "d/d " + name)
+    for (name, bg), (_, br) in zip(stack.named_buffers(), ref.named_buffers()):
+        if bg.dtype.is_floating_point:
+            close(bg, br, "buffer " + name)
+        else:
+            assert int(bg) == int(br), name
