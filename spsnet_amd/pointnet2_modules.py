@@ -128,6 +128,10 @@ FUSED_MLP_TRAINING = os.environ.get("SPS_FUSED_MLP_TRAINING", "1") != "0"
 # measured NOT to pay at the IA-SSD shapes -- these tensors are 2-8 MB, the stack is launch-bound either way, and the fused
 # form needs more launches than torch's (8.46 vs 8.31 ms per training step of SA layers 0-2).  Opt-in.
 FUSED_POINTWISE_TRAINING = os.environ.get("SPS_FUSED_POINTWISE_TRAINING", "0") != "0"
+# training: the scales of a layer on streams of their own (see _group_mlp_pool) -- measured SLOWER (8.72 vs 8.29 ms per step:
+# every fork / join is a cross-stream dependency that is actually waited for, ~12 us each, and the big kernels of both
+# chains are memory-bound and only share the bandwidth); kept as a switch, off
+SCALES_ON_STREAMS = os.environ.get("SPS_SCALES_ON_STREAMS", "0") != "0"
 
 
 class _GroupedMLPPoolTrain(torch.autograd.Function):
@@ -374,14 +378,49 @@ class _PointnetSAModuleBase(nn.Module):
                                       "gradients, max pooling, IA-SSD layer widths); cast to float32 for anything else")
         scales = []
         idxs = self._neighbour_indices(xyz, new_xyz)
-        for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
+
+        def one_scale(k, grouper, mlp):
             if idxs is not None:
                 grouped = pointnet2_utils.group_with_index(xyz, new_xyz, features, idxs[k], grouper.use_xyz)
             else:
                 grouped = grouper(xyz, new_xyz, features)      # (B, C, M, ns)
             pooled = _fused_mlp_pool_train(mlp, grouped, self.pool_method)
-            scales.append(pooled if pooled is not None else _pool_over_samples(_shared_mlp(mlp, grouped), self.pool_method))
+            return pooled if pooled is not None else _pool_over_samples(_shared_mlp(mlp, grouped), self.pool_method)
+
+        side = self._scale_streams(xyz) if (SCALES_ON_STREAMS and self.training and xyz.is_cuda and idxs is not None
+                                            and len(self.groupers) > 1 and torch.is_grad_enabled()) else None
+        if side is None:
+            for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
+                scales.append(one_scale(k, grouper, mlp))
+            return torch.cat(scales, dim=1)
+        # Training: a layer's scales are independent chains of ~12 launches forward and ~20 backward, many of them small
+        # (statistics finalizers, second-stage reductions): each chain on a stream of its own lets one scale's small
+        # launches and tails run beside the other's big ones.  autograd replays every backward node on the stream its
+        # forward ran on, so the backward splits the same way.
+        main = torch.cuda.current_stream(xyz.device)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
+            st = side[k % len(side)]
+            with torch.cuda.stream(st):
+                st.wait_event(fork)
+                scales.append(one_scale(k, grouper, mlp))
+                done = torch.cuda.Event()
+                done.record(st)
+            main.wait_event(done)
+            scales[-1].record_stream(main)
+            for t in (xyz, new_xyz, features) + tuple(idxs):
+                if t is not None:
+                    t.record_stream(st)
         return torch.cat(scales, dim=1)
+
+    _SCALE_STREAMS = {}
+
+    def _scale_streams(self, like):
+        key = (like.device.index, torch.cuda.current_stream(like.device).cuda_stream)
+        if key not in _PointnetSAModuleBase._SCALE_STREAMS:
+            _PointnetSAModuleBase._SCALE_STREAMS[key] = [torch.cuda.Stream(device=like.device) for _ in range(2)]
+        return _PointnetSAModuleBase._SCALE_STREAMS[key]
 
     def _neighbour_indices(self, xyz, new_xyz):
         """Ball-query rows of both scales of a two-radius layer on the op-by-op (training) path, or None: the rows

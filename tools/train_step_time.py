@@ -2,6 +2,7 @@
 op-by-op path (HIP sampling / query / group kernels + the train-mode conv / BatchNorm kernels).
 usage: python tools/train_step_time.py [B] [N] [reps] [ab]
   ab: alternate sa_stack.STREAM_TRAINING_QUERIES on / off inside one process (three rounds each) and print the medians
+  abs: the same for pointnet2_modules.SCALES_ON_STREAMS (a layer's scales on streams of their own)
   abf: the same for pointnet2_modules.FUSED_MLP_TRAINING (csrc/mlp_train.hip against the op-by-op kernels)"""
 import os, sys, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +12,7 @@ from spsnet_amd import pointnet2_modules as M, sa_stack, scenes
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-ab = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] in ("ab", "abf") else ""
+ab = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] in ("ab", "abf", "abs") else ""
 dev = torch.device("cuda:0")
 layers = sa_stack.build_sa_layers(M, sa_stack.IASSD_KITTI, seed=3).to(dev).train()
 xyz, feats = scenes.make_batch("kitti-lidar-v1", B, N, seed0=1)
@@ -44,12 +45,14 @@ if ab:
         for flag in (True, False):
             if ab == "ab":
                 sa_stack.STREAM_TRAINING_QUERIES = flag
+            elif ab == "abs":
+                M.SCALES_ON_STREAMS = flag
             else:
                 M.FUSED_MLP_TRAINING = flag
             step()
             res[flag].append(timed(reps))
     for flag in (True, False):
-        print(("STREAM_TRAINING_QUERIES" if ab == "ab" else "FUSED_MLP_TRAINING") + f"={flag}: " + " ".join(f"{v:.2f}" for v in res[flag]) +
+        print({"ab": "STREAM_TRAINING_QUERIES", "abs": "SCALES_ON_STREAMS", "abf": "FUSED_MLP_TRAINING"}[ab] + f"={flag}: " + " ".join(f"{v:.2f}" for v in res[flag]) +
               f"  median {statistics.median(res[flag]):.2f} ms", flush=True)
 else:
     ms = timed(reps)
