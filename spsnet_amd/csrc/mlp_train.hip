@@ -203,7 +203,42 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
     // workgroup at the widest shapes, longer than the workgroup's whole column range took); the transposed operand walks
     // the rows fastest so that consecutive lanes still read consecutive floats.
     const float sw = tpow2_scale(256.f, *a.wamax);
-    {
+    const bool quads = (reinterpret_cast<uintptr_t>(a.w) & 15) == 0 && ((a.trans ? a.co : a.ci) & 3) == 0;
+    if (quads) {
+        // 16-byte loads along the contiguous dimension of w (k for the plain operand, the output row for the transposed one)
+        constexpr int WQ = 8;
+        const int fast = a.trans ? rows_wg : cip;                  // extent of the contiguous dimension within this workgroup
+        const int nq = (rows_wg * cip) >> 2;
+        for (int base = 0; base < nq; base += 256 * WQ) {
+            f32x4 wq[WQ];
+#pragma unroll
+            for (int u = 0; u < WQ; ++u) {
+                const int idx = (base + u * 256 + (int)threadIdx.x) << 2;
+                const int slow = idx / fast, f0 = idx - slow * fast;
+                const int o = a.trans ? f0 : slow, k = a.trans ? slow : f0;
+                const int row = row0 + o;
+                wq[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (idx < 4 * nq && row < a.co && k < a.ci)
+                    wq[u] = *reinterpret_cast<const f32x4 *>(a.trans ? a.w + (size_t)k * a.co + row : a.w + (size_t)row * a.ci + k);
+            }
+#pragma unroll
+            for (int u = 0; u < WQ; ++u) {
+                const int idx = (base + u * 256 + (int)threadIdx.x) << 2;
+                if (idx >= 4 * nq) continue;
+                const int slow = idx / fast, f0 = idx - slow * fast;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int o = a.trans ? f0 + j : slow, k = a.trans ? slow : f0 + j;
+                    _Float16 hi, lo;
+                    tsplit(wq[u][j] * sw, hi, lo);
+                    const int t = o >> 4, i = o & 15, ss = k >> 5, qq = (k & 31) >> 3, e = k & 7;
+                    char *dst = wl + ((size_t)(t * S + ss) * 2) * 1024 + (qq * 16 + i) * 16 + e * 2;
+                    *reinterpret_cast<_Float16 *>(dst) = hi;
+                    *reinterpret_cast<_Float16 *>(dst + 1024) = lo;
+                }
+            }
+        }
+    } else {
         constexpr int WB = 16;
         const int nel = rows_wg * cip;
         for (int base = 0; base < nel; base += 256 * WB) {
