@@ -446,7 +446,7 @@ struct TWgradArgs {
 // tiles (t = wt, wt + 4, ..; u = wu, wu + 2, ..).  The next stage's global loads are in flight during the MFMAs.  NK widens
 // the stage for narrow layers (4 passes of 512 / (8 NK) rows cover 64 NK... rows): a stage then moves enough bytes to hide its
 // two barriers.
-template <int NK>
+template <int NK, bool DB>
 __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RS = 64 * NK + 16;            // LDS bytes per operand row
@@ -455,8 +455,12 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
     const int wt = wave >> 1, wu = wave & 1;
     const int T = (a.co + 15) >> 4, U = (a.ci + 15) >> 4;
     const int cop = 16 * T, cip = 16 * U;
-    char *ahi = smem, *alo = ahi + (size_t)cop * RS, *bhi = alo + (size_t)cop * RS, *blo = bhi + (size_t)cip * RS;
-    float *pd_l = reinterpret_cast<float *>(blo + (size_t)cip * RS);
+    // DB: two operand buffers, so that the waves that are done with a stage's products write the next stage while the others
+    // still multiply -- ONE barrier per stage instead of two (whoever writes buffer p again has passed the barrier of the stage
+    // in between, which everybody reaches only after its products on p)
+    const size_t opbytes = (size_t)(cop + cip) * 2 * RS;
+    char *ahi0 = smem, *alo0 = ahi0 + (size_t)cop * RS, *bhi0 = alo0 + (size_t)cop * RS, *blo0 = bhi0 + (size_t)cip * RS;
+    float *pd_l = reinterpret_cast<float *>(smem + (DB ? 2 : 1) * opbytes);
     float *px_l = pd_l + cop * TP;
     float *scratch = px_l + cip * TP;           // 8 floats + the poison flag
     float smax = 0.f;
@@ -519,6 +523,8 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
     };
     if (s0 < s1) prefetch(s0);
     for (long long st = s0; st < s1; ++st) {
+        const size_t boff = (DB && ((st - s0) & 1)) ? opbytes : 0;
+        char *ahi = ahi0 + boff, *alo = alo0 + boff, *bhi = bhi0 + boff, *blo = blo0 + boff;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int row = rr + RR * p;
@@ -565,7 +571,7 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
                     acc[i][j] = tmfma(fal, fbh, acc[i][j]);
                 }
             }
-        __syncthreads();
+        if (!DB) __syncthreads();
     }
     // an unrepresentable operand anywhere in this workgroup's columns: its whole partial is NaN
     float accbad = 0.f;     // a NaN operand went through the conversion and the matrix pipe: it shows on the accumulators
@@ -829,13 +835,19 @@ int tconv_launch_in(const TConvArgs &a, int in_mode, int epi, hipStream_t st) {
 }
 
 template <int NK>
-int twgrad_launch(const TWgradArgs &a, int parts, size_t lds, hipStream_t st) {
-    static LdsLimitOnce raised;
+int twgrad_launch(const TWgradArgs &a, int parts, hipStream_t st) {
+    const int cop = 16 * divup(a.co, 16), cip = 16 * divup(a.ci, 16);
+    const size_t op = (size_t)(cop + cip) * 2 * (64 * NK + 16), rest = (size_t)(cop + cip) * TP * 4 + 64;
+    const bool db = 2 * op + rest <= 150 * 1024;
+    const size_t lds = (db ? 2 : 1) * op + rest;
+    static LdsLimitOnce raised[2];
     if (lds > 64 * 1024) {
-        const int rc = raise_lds_limit((const void *)twgrad_kernel<NK>, 128 * 1024, raised, "twgrad");
+        const int rc = raise_lds_limit(db ? (const void *)twgrad_kernel<NK, true> : (const void *)twgrad_kernel<NK, false>, 150 * 1024,
+                                       raised[db ? 1 : 0], "twgrad");
         if (rc != SPS_OK) return rc;
     }
-    hipLaunchKernelGGL(twgrad_kernel<NK>, dim3(parts), dim3(512), lds, st, a);
+    if (db) hipLaunchKernelGGL((twgrad_kernel<NK, true>), dim3(parts), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((twgrad_kernel<NK, false>), dim3(parts), dim3(512), lds, st, a);
     return SPS_OK;
 }
 
@@ -984,6 +996,7 @@ extern "C" int sps_tbn_bwd_stats(int b, int c, long long l, const float *y, cons
 
 static int twgrad_nk(int co, int ci, long long l) {
     const int rows = 16 * divup(co > ci ? co : ci, 16);
+    if (rows <= 32 && l % 256 == 0) return 8;
     if (rows <= 64 && l % 128 == 0) return 4;
     if (rows <= 128 && l % 64 == 0) return 2;
     return 1;
@@ -1014,9 +1027,9 @@ extern "C" int sps_twgrad(int b, int co, int ci, long long l, int dmode, int xmo
     a.b = b; a.co = co; a.ci = ci; a.l = l; a.dmode = dmode; a.xmode = xmode; a.dA = dA; a.y = y; a.gout = gout; a.arg = arg;
     a.ns = nsample > 0 ? nsample : 4; a.m = m; a.pd = pd; a.x = x; a.px = px; a.partial = work; a.amax_in = amax_in; a.overflow = overflow;
     const int cop = 16 * divup(co, 16), cip = 16 * divup(ci, 16), nk = twgrad_nk(co, ci, l), parts = twgrad_parts(b, co, ci, l);
-    const size_t lds = (size_t)(cop + cip) * 2 * (64 * nk + 16) + (size_t)(cop + cip) * TP * 4 + 64;
     hipStream_t st = as_stream(stream);
-    const int rc = nk == 4 ? twgrad_launch<4>(a, parts, lds, st) : (nk == 2 ? twgrad_launch<2>(a, parts, lds, st) : twgrad_launch<1>(a, parts, lds, st));
+    const int rc = nk == 8 ? twgrad_launch<8>(a, parts, st)
+                           : (nk == 4 ? twgrad_launch<4>(a, parts, st) : (nk == 2 ? twgrad_launch<2>(a, parts, st) : twgrad_launch<1>(a, parts, st)));
     if (rc != SPS_OK) return rc;
     hipLaunchKernelGGL(twgrad_reduce_kernel, dim3(divup(co * ci, 256)), dim3(256), 0, st, co, ci, cip, cop, parts, work, dw);
     return check_launch("twgrad_kernel");
