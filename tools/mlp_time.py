@@ -1,6 +1,6 @@
 """Time ONE grouped-MLP launch (gather + 3 layers + max-pool) at a given shape, HIP events over 30 launches.
 Default: IA-SSD layer 5 (8 scenes, 512 points with 256 features -> 256 vote centres), both scales.
-usage: python tools/mlp_time.py [B N M c_feat]"""
+usage: python tools/mlp_time.py [B N M c_feat [l1]]     (l1: the widths / radii of IA-SSD layer 1, e.g. 8 4096 1024 64 l1)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,7 +14,10 @@ rng = np.random.default_rng(0)
 xyz = torch.from_numpy(rng.uniform(-20, 20, (B, N, 3)).astype(np.float32)).to(dev)
 feats = fused.attach_point_major_twin(torch.randn(B, c_feat, N, device=dev))
 new_xyz = xyz[:, :Mc].contiguous()
-for widths, ns, radius in (([256, 256, 512], 16, 4.8), ([256, 512, 1024], 32, 6.4)):
+SCALES = (([256, 256, 512], 16, 4.8), ([256, 512, 1024], 32, 6.4))
+if len(sys.argv) > 5 and sys.argv[5] == "l1":
+    SCALES = (([64, 64, 128], 16, 0.8), ([64, 96, 128], 32, 1.6))
+for widths, ns, radius in SCALES:
     mod = M.PointnetSAModuleMSG_WithSampling(
         npoint_list=[Mc], sample_range_list=[-1], sample_type_list=['D-FPS'], radii=[radius], nsamples=[ns],
         mlps=[[c_feat] + widths], use_xyz=True, dilated_group=False, aggregation_mlp=None, confidence_mlp=None,

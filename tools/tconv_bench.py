@@ -24,3 +24,16 @@ for ci, co in ((32, 64), (64, 64), (128, 128), (256, 256)):
         gb = (x.numel() + y.numel()) * 4 / 1e9
         print(f"ci={ci:3d} co={co:3d} B={B:3d} L={L:6d}: raw {gb / t_raw:6.0f} GB/s  bn+relu {gb / t_bn:6.0f} GB/s  "
               f"(torch copy {2 * x.numel() * 4 / 1e9 / t_copy:6.0f} GB/s)", flush=True)
+
+print("weight gradient (twgrad): dY from (dA, y), the other operand through BatchNorm + ReLU")
+for co, ci in ((32, 32), (64, 32), (128, 128), (256, 256)):
+    for B, L in ((8, 131072), (8, 16384)):
+        y = torch.randn(B, co, L, device=dev)
+        dA = torch.randn(B, co, L, device=dev) * 1e-4
+        x = torch.randn(B, ci, L, device=dev)
+        pd = torch.zeros(co, 8, device=dev); pd[:, 1] = 1.0; pd[:, 2] = 1.0
+        px = torch.zeros(ci, 8, device=dev); px[:, 2] = 1.0
+        am = torch.full((1,), 4e-4, device=dev)
+        t = timeit(lambda: ext.twgrad(y, pd, x, px, am, dA=dA))
+        gb = (y.numel() * 2 + x.numel()) * 4 / 1e9
+        print(f"co={co:3d} ci={ci:3d} B={B:3d} L={L:6d}: {gb / t:6.0f} GB/s  ({t * 1e6:6.1f} us)", flush=True)
