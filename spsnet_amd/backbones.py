@@ -160,7 +160,8 @@ class _PointBackbone(nn.Module):
             if res is not None:
                 return res
         if (i == 0 and layer.training and xyz_input.is_cuda and cls_pred is None and ctr_xyz is None
-                and self.layer_inputs[0] == 0 and sa_stack.STREAM_TRAINING_QUERIES):
+                and self.layer_inputs[0] == 0 and sa_stack.STREAM_TRAINING_QUERIES
+                and not sa_stack._prefetched_for(layer, xyz_input)):
             sa_stack._streamed_first_layer_queries(layer, xyz_input)   # training: the ball queries run beside the FPS
         if beside_fps is not None:
             beside_fps()   # no streamed layer 0: at least ahead of its kernels
@@ -174,7 +175,21 @@ class _PointBackbone(nn.Module):
             return layer(xyz_input, feature_input, cls_pred, ctr_xyz=ctr_xyz, **kw)
         finally:
             layer._on_new_xyz = None
-            layer._preball = None
+            if not (getattr(layer, "_presampled", None) is not None and len(layer._presampled) > 3):
+                layer._preball = None
+
+    def prefetch_sampling(self, batch_dict):
+        """For a training loop that already holds its NEXT batch: start layer 0's FPS and ball queries for it now, on a side
+        stream (sa_stack.prefetch_first_layer), e.g. right before `loss.backward()` of the current step; the forward over
+        the same `batch_dict['points']` tensor picks the results up.  Exact; returns False when layer 0 does not qualify."""
+        points = batch_dict['points']
+        if not (points.is_cuda and self.training and self.layer_inputs[0] == 0 and self.ctr_idx_list[0] == -1):
+            return False
+        xyz = points[:, 1:4].contiguous().view(batch_dict['batch_size'], -1, 3)
+        if not sa_stack.prefetch_first_layer(self.SA_modules[0], xyz):
+            return False
+        self._prefetched = (points, xyz)
+        return True
 
     def forward(self, batch_dict):
         """batch_dict: batch_size, points (B*N, 4 + C) [batch_idx, x, y, z, ...] (+ stds for PAGNet) -> batch_dict with
@@ -183,12 +198,16 @@ class _PointBackbone(nn.Module):
         batch_size = batch_dict['batch_size']
         points = batch_dict['points']
         batch_idx, xyz, features = self.break_up_pc(points)
+        pre, self._prefetched = getattr(self, "_prefetched", None), None
+        if pre is not None and pre[0] is points:
+            xyz = pre[1]          # prefetch_sampling already sampled / queried THIS tensor object for layer 0
         stds = batch_dict.get('stds', None) if self._surface else None
 
         # every scene must hold the same number of points (reference :109-113); on the GPU the verdict is read once the
         # whole forward is in the queue, on a stream of its own (equal_counts_check)
         counts_ok = equal_counts_check(batch_idx, batch_size)
-        xyz = xyz.view(batch_size, -1, 3)
+        if xyz.dim() != 3:        # (a prefetched tensor is (B, N, 3) already, and must stay the SAME object)
+            xyz = xyz.view(batch_size, -1, 3)
         features = (features.view(batch_size, -1, features.shape[-1]).permute(0, 2, 1).contiguous()
                     if features is not None else None)
 

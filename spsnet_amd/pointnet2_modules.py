@@ -428,6 +428,9 @@ class _PointnetSAModuleBase(nn.Module):
         both radii instead of one per scale (same rows: every row written, zeros for empty balls)."""
         pre, self._preball = getattr(self, "_preball", None), None
         if pre is not None and pre[0] is new_xyz:
+            cur = torch.cuda.current_stream(new_xyz.device)
+            for t in (new_xyz,) + tuple(pre[1]):      # (possibly produced on a prefetch stream: sa_stack.prefetch_first_layer)
+                t.record_stream(cur)
             return pre[1]
         if not (xyz.is_cuda and len(self.groupers) == 2 and xyz.dtype == torch.float32 and xyz.is_contiguous()
                 and all(type(g) is pointnet2_utils.QueryAndGroup for g in self.groupers)):

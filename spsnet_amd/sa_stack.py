@@ -421,6 +421,38 @@ def _streamed_first_layer_queries(layer, xyz):
     return True
 
 
+def prefetch_first_layer(layers_or_layer, xyz):
+    """For a TRAINING LOOP that already holds its next batch: start layer 0's sampling (D-FPS) and ball queries for `xyz` now,
+    on a side stream, so that they run beside whatever the caller enqueues next -- typically the previous step's backward.
+    FPS is a serial chain on one CU per scene (1.7 ms at 8 x 16384 -> 4096) that depends on nothing but the coordinates;
+    the next forward over the SAME tensor object (`run_sa_layers`, the backbones) picks the results up instead of sampling
+    again.  Exact: same kernels, same picks and rows.  Returns False (and does nothing) when layer 0 does not qualify.
+
+        for batch in loader:                       # reference loop: tools/train_utils/train_utils.py
+            out = model(batch); loss = criterion(out)
+            sa_stack.prefetch_first_layer(model.SA_modules, next_batch_xyz)    # <- one line
+            loss.backward(); optimizer.step()
+    """
+    layer = layers_or_layer[0] if isinstance(layers_or_layer, (list, tuple, torch.nn.ModuleList)) else layers_or_layer
+    if not (xyz.is_cuda and layer.training):
+        return False
+    dev = xyz.device
+    main = torch.cuda.current_stream(dev)
+    side = _helper_stream(dev, "prefetch")
+    ready = torch.cuda.Event()
+    ready.record(main)
+    xyz.record_stream(side)
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        ok = _streamed_first_layer_queries(layer, xyz)
+        if ok:
+            done = torch.cuda.Event()
+            done.record(side)
+            idx, _, src, new_xyz = layer._presampled
+            layer._presampled = (idx, done, src, new_xyz)
+    return bool(ok)
+
+
 _ZERO_POOL = {}
 
 
@@ -453,6 +485,12 @@ def _redo_layer(layer, plan, tail, xyz, new_xyz, features, idx_a, idx_b, out, ti
         tail.run(0, M, run_if=timed_out)
 
 
+def _prefetched_for(layer, xyz):
+    """True if prefetch_first_layer (or an earlier call) already sampled and queried `xyz` for this layer."""
+    pre, ball = getattr(layer, "_presampled", None), getattr(layer, "_preball", None)
+    return pre is not None and ball is not None and len(pre) > 3 and pre[2] is xyz and ball[0] is pre[3]
+
+
 def _is_plain_dfps(layer, n_in):
     """True if the layer's centroids are ONE D-FPS pick sequence over its whole input."""
     types = getattr(layer, "sample_type_list", None)
@@ -482,7 +520,7 @@ def run_sa_layers(layers, xyz, features, stds=None, overlap=True, stream_first_l
                 outs.append((xyz, features, cls_pred, idx))
                 continue
         if (k == 0 and stream_first_layer and prefetch and not use_overlap and cls_pred is None
-                and STREAM_TRAINING_QUERIES and layer.training):
+                and STREAM_TRAINING_QUERIES and layer.training and not _prefetched_for(layer, xyz)):
             _streamed_first_layer_queries(layer, xyz)
         if prefetch and nxt is not None and _can_prefetch(layer, nxt):
             ordered = _is_plain_dfps(layer, xyz.shape[1])
@@ -492,8 +530,9 @@ def run_sa_layers(layers, xyz, features, stds=None, overlap=True, stream_first_l
             xyz, features, cls_pred, idx, stds = layer(xyz, features, cls_pred, **kw)
         finally:
             layer._on_new_xyz = None
-            if k == 0:
-                layer._preball = None     # (consumed by the layer; dropped here if it declined or raised)
+            if k == 0 and not (getattr(layer, "_presampled", None) is not None and len(layer._presampled) > 3):
+                layer._preball = None     # (consumed by the layer; dropped here if it declined or raised -- a prefetch for a
+                                          #  FUTURE forward, made inside this one, carries its own `_presampled` and stays)
         outs.append((xyz, features, cls_pred, idx))
     return outs
 

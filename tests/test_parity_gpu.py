@@ -2391,3 +2391,53 @@ def test_fused_train_mode_pointwise_stack_matches_torch(dev, B, M, widths, tailc
             close(bg, br, "buffer " + name)
         else:
             assert int(bg) == int(br), name
+
+
+def test_training_prefetched_first_layer_equals_plain(G, dev):
+    """sa_stack.prefetch_first_layer: layer 0's FPS and ball queries of the NEXT batch started before the current step's
+    backward (on a side stream, beside it) -- every output and running statistic of the next forward bit-identical to a
+    forward that samples by itself, gradients within 1e-5; the prefetch is consumed exactly once and a forward over a
+    DIFFERENT tensor ignores it."""
+    import copy
+    from spsnet_amd import pointnet2_modules as M, sa_stack, scenes
+    base = sa_stack.build_sa_layers(M, sa_stack.scaled_config(npoints=[1024, 256, 128]), seed=11).to(dev).train()
+    xyz, feats = scenes.make_batch("kitti-lidar-v1", 2, 8192, seed0=5, dup_fraction=0.01)
+    x, f = G.t(xyz), G.t(feats)
+
+    def loss_of(outs):
+        return sum(o[1].square().mean() for o in outs) + sum(o[2].square().mean() for o in outs if o[2] is not None)
+
+    ref, got = copy.deepcopy(base), copy.deepcopy(base)
+    for _ in range(2):                                   # two plain steps
+        want = sa_stack.run_sa_layers(ref, x, f)
+        loss_of(want).backward()
+    outs = sa_stack.run_sa_layers(got, x, f)             # step 1, with the next batch (the same tensor) prefetched
+    loss = loss_of(outs)
+    assert sa_stack.prefetch_first_layer(got, x)
+    loss.backward()
+    calls = []
+    orig = sa_stack._streamed_first_layer_queries
+    sa_stack._streamed_first_layer_queries = lambda *a: calls.append(1) or orig(*a)
+    try:
+        outs = sa_stack.run_sa_layers(got, x, f)         # step 2 picks the prefetch up
+        assert calls == [], "the prefetched sampling was supposed to be used"
+        loss_of(outs).backward()
+        torch.cuda.synchronize()
+        for k, (la, lb) in enumerate(zip(outs, want)):
+            for ta, tb in zip(la, lb):
+                assert (ta is None and tb is None) or torch.equal(ta, tb), f"layer {k}"
+        for (name, pa), (_, pb) in zip(got.named_parameters(), ref.named_parameters()):
+            if pa.grad is not None:
+                err = float((pa.grad - pb.grad).abs().max())
+                assert err <= 1e-5 * max(1.0, float(pb.grad.abs().max())), (name, err)
+        for (name, ba), (_, bb) in zip(got.named_buffers(), ref.named_buffers()):
+            assert torch.equal(ba, bb), name
+        # a prefetch for one tensor, a forward over another: ignored (and the layer samples by itself)
+        assert sa_stack.prefetch_first_layer(got, x)
+        x2 = x.clone()
+        sa_stack.run_sa_layers(got, x2, f)
+        assert calls == [1, 1], "one call by the prefetch, one by the forward over the other tensor"
+        torch.cuda.synchronize()
+        assert not sa_stack.check_timeouts()
+    finally:
+        sa_stack._streamed_first_layer_queries = orig
