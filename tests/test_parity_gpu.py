@@ -2441,3 +2441,29 @@ def test_training_prefetched_first_layer_equals_plain(G, dev):
         assert not sa_stack.check_timeouts()
     finally:
         sa_stack._streamed_first_layer_queries = orig
+
+
+def test_backbone_prefetch_sampling_equals_plain(G, dev):
+    """IASSD_Backbone.prefetch_sampling(next batch) + forward over the same `points` tensor == a plain training forward
+    (the picked-up FPS / ball queries are the same kernels' results): every tensor of the output dict bit-identical."""
+    import copy
+    from spsnet_amd import backbones as BB, scenes
+    net = scenes.fill_parameters(BB.IASSD_Backbone(BB.scaled_cfg(BB.IASSD_KITTI_CFG, [1024, 256, 128, 64, -1, 64]), num_class=3,
+                                                   input_channels=4), 3).to(dev).train()
+    twin = copy.deepcopy(net)
+    xyz, feats = scenes.make_batch("kitti-lidar-v1", 2, 8192, seed0=9)
+    bidx = np.repeat(np.arange(2, dtype=np.float32), 8192)[:, None]
+    points = G.t(np.concatenate([bidx, xyz.reshape(-1, 3), feats.transpose(0, 2, 1).reshape(-1, 1)], 1).astype(np.float32))
+    want = twin(dict(batch_size=2, points=points))
+    assert net.prefetch_sampling(dict(batch_size=2, points=points))
+    got = net(dict(batch_size=2, points=points))
+    torch.cuda.synchronize()
+    assert net.SA_modules[0]._presampled is None, "the prefetch was supposed to be consumed"
+    for key, w in want.items():
+        g = got[key]
+        if isinstance(w, torch.Tensor):
+            assert torch.equal(g, w), key
+        elif isinstance(w, (list, tuple)):
+            for a, b in zip(g, w):
+                if isinstance(b, torch.Tensor):
+                    assert torch.equal(a, b), key

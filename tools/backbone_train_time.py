@@ -1,5 +1,6 @@
 """Time a training step (forward + backward) of IASSD_Backbone / PAGNet_Backbone at the KITTI configuration.
-usage: python tools/backbone_train_time.py [B] [N] [reps] [IASSD|PAGNet]"""
+usage: python tools/backbone_train_time.py [B] [N] [reps] [IASSD|PAGNet] [prefetch]
+  prefetch: net.prefetch_sampling(next batch) before every backward (the next batch's FPS + ball queries beside the backward)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,6 +11,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 only = sys.argv[4] if len(sys.argv) > 4 else ""
+PREFETCH = len(sys.argv) > 5 and sys.argv[5] == "prefetch"
 dev = torch.device("cuda:0")
 xyz, feats = scenes.make_batch("kitti-lidar-v1", B, N, seed0=1)
 bidx = np.repeat(np.arange(B, dtype=np.float32), N)[:, None]
@@ -32,6 +34,8 @@ for tag, cls, cfg in (("IASSD_Backbone", BB.IASSD_Backbone, BB.IASSD_KITTI_CFG),
             for t in out["sa_ins_preds"]:
                 if isinstance(t, torch.Tensor):
                     loss = loss + t[..., 1:].square().mean()
+            if PREFETCH:
+                net.prefetch_sampling(d)
             loss.backward()
         for _ in range(2):
             step()
@@ -49,5 +53,6 @@ for tag, cls, cfg in (("IASSD_Backbone", BB.IASSD_Backbone, BB.IASSD_KITTI_CFG),
             host += time.perf_counter() - t1
         torch.cuda.synchronize()
         note = "" if tag.startswith("IASSD") else (" (fused surface-feature training kernels)" if fused_fe else " (surface features op by op)")
-        print(f"{tag:16s} training step {B}x{N}: {ms:7.2f} ms, host enqueue {1e3 * host / reps:.2f} ms{note}", flush=True)
+        print(f"{tag:16s} training step {B}x{N}: {ms:7.2f} ms, host enqueue {1e3 * host / reps:.2f} ms{note}"
+              + (" [next batch's sampling prefetched]" if PREFETCH else ""), flush=True)
 SF.FUSED_TRAINING = True
