@@ -17,6 +17,8 @@ new_xyz = xyz[:, :Mc].contiguous()
 SCALES = (([256, 256, 512], 16, 4.8), ([256, 512, 1024], 32, 6.4))
 if len(sys.argv) > 5 and sys.argv[5] == "l1":
     SCALES = (([64, 64, 128], 16, 0.8), ([64, 96, 128], 32, 1.6))
+if len(sys.argv) > 5 and sys.argv[5] == "l2":       # e.g. 8 1024 512 128 l2
+    SCALES = (([128, 128, 256], 16, 1.6), ([128, 256, 256], 32, 4.8))
 for widths, ns, radius in SCALES:
     mod = M.PointnetSAModuleMSG_WithSampling(
         npoint_list=[Mc], sample_range_list=[-1], sample_type_list=['D-FPS'], radii=[radius], nsamples=[ns],
