@@ -2467,3 +2467,58 @@ def test_backbone_prefetch_sampling_equals_plain(G, dev):
             for a, b in zip(g, w):
                 if isinstance(b, torch.Tensor):
                     assert torch.equal(a, b), key
+
+
+@pytest.mark.parametrize("gscale", [1e-12, 1e-4, 1e4])
+def test_fused_train_mode_mlp_gradient_scale_invariance(dev, gscale, monkeypatch):
+    """The fp16 halves of the gradient operands carry an exact power-of-two scale (csrc/mlp_train.hip), so the accuracy of the
+    backward must not depend on the magnitude of the incoming gradient: 1e-12 .. 1e4 against float64 torch, every gradient
+    within 2e-5 of its own largest entry.  (Unscaled, gradients below ~1e-3 lose their low halves to fp16 denormals.)
+    Also: a frozen convolution weight gets no gradient, an input that does not require one neither, a zero BatchNorm weight
+    yields finite gradients."""
+    import copy
+    from spsnet_amd import fused, pointnet2_modules as PM
+    torch.manual_seed(3)
+    mlp = PM._conv_bn_relu_stack([19, 48, 64, 96], torch.nn.Conv2d, torch.nn.BatchNorm2d)
+    mlp[4].weight.data[5] = 0.0                          # a dead channel of the second BatchNorm
+    mlp[3].weight.requires_grad_(False)                  # a frozen convolution
+    ref = copy.deepcopy(mlp).double().train()
+    mlp = mlp.to(dev).train()
+    x0 = torch.randn(2, 19, 64, 16).abs() + 0.2
+    wout = torch.randn(2, 96, 64) * gscale
+    xr = x0.double().requires_grad_(True)
+    (ref(xr).max(dim=3)[0] * wout.double()).sum().backward()
+    monkeypatch.setattr(PM, "FUSED_MLP_TRAINING", True)
+    for needs_dx in (True, False):
+        for p in mlp.parameters():
+            p.grad = None
+        xg = x0.to(dev).requires_grad_(needs_dx)
+        out = PM._fused_mlp_pool_train(mlp, xg, 'max_pool')
+        assert out is not None
+        (out * wout.to(dev)).sum().backward()
+        torch.cuda.synchronize()
+        assert not fused.check_overflow()
+        assert mlp[3].weight.grad is None and (xg.grad is not None) == needs_dx
+        pairs = [(p.grad, q.grad, n) for (n, p), (_, q) in zip(mlp.named_parameters(), ref.named_parameters()) if q.grad is not None]
+        if needs_dx:
+            pairs.append((xg.grad, xr.grad, "input"))
+        for g, w, name in pairs:
+            assert torch.isfinite(g).all(), name
+            err = float((g.cpu().double() - w).abs().max())
+            assert err <= 2e-5 * float(w.abs().max()) + 1e-300, (name, err, float(w.abs().max()))
+
+
+def test_fused_train_mode_mlp_nan_input_propagates(dev, monkeypatch):
+    """A NaN in the grouped input reaches the pooled outputs that depend on it (as through torch's Conv / BatchNorm / ReLU /
+    max_pool2d, where it reaches all of them via the batch statistics) and raises the overflow flag; nothing is clamped."""
+    from spsnet_amd import fused, pointnet2_modules as PM
+    torch.manual_seed(0)
+    mlp = PM._conv_bn_relu_stack([4, 16, 32], torch.nn.Conv2d, torch.nn.BatchNorm2d).to(dev).train()
+    x = torch.randn(2, 4, 32, 16, device=dev)
+    x[0, 1, 7, 2] = float("nan")
+    monkeypatch.setattr(PM, "FUSED_MLP_TRAINING", True)
+    fused.check_overflow()
+    out = PM._fused_mlp_pool_train(mlp, x.requires_grad_(True), 'max_pool')
+    torch.cuda.synchronize()
+    assert out is not None and bool(torch.isnan(out).any())
+    assert fused.check_overflow()
