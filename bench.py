@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--cu-fence", action="store_true",
                     help="also in the sequential steps: layer-0 FPS on compute units of its own (CuFence)")
     ap.add_argument("--cpu-scenes", type=int, default=8, help="scenes in the bounded CPU-baseline sample")
+    ap.add_argument("--no-training-leg", action="store_true",
+                    help="skip the informational `training_step` object (forward + backward of the same SA layers in train() mode)")
     args = ap.parse_args()
     if args.config == 5:
         args.batch = 1 if args.batch is None else args.batch
@@ -241,6 +243,41 @@ def cpu_baseline(layers, args):
                                 "sample": f"{reps_one} pass(es) over 1 scene x {args.points} pts, 1 thread, {el_one:.1f} s"}
     O.set_threads(cores)
     return out
+
+
+def training_step_leg(modules_pkg, sa_stack, cfg, args, xyz, feats, dev, reps=10):
+    """Informational, never `value`: one TRAINING step (forward + backward, BatchNorm on batch statistics) of the same SA
+    layers on the same batch -- SURVEY 8 f-1.  Two timings: the step as a plain loop runs it, and with the next batch's
+    layer-0 sampling started beside the backward (sa_stack.prefetch_first_layer; here the next batch is the same tensor)."""
+    layers = sa_stack.build_sa_layers(modules_pkg, cfg, seed=0).to(dev).train()
+    f = feats.float()
+
+    def step(prefetch):
+        for p in layers.parameters():
+            p.grad = None
+        outs = sa_stack.run_sa_layers(layers, xyz, f)
+        loss = sum(o[1].square().mean() for o in outs) + sum(o[2].square().mean() for o in outs if o[2] is not None)
+        if prefetch:
+            sa_stack.prefetch_first_layer(layers, xyz)
+        loss.backward()
+
+    res = {}
+    for key, pre in (("ms", False), ("ms_next_batch_sampling_prefetched", True)):
+        layers[0]._presampled = layers[0]._preball = None
+        for _ in range(3):
+            step(pre)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step(pre)
+        torch.cuda.synchronize()
+        res[key] = 1e3 * (time.perf_counter() - t0) / reps
+    layers[0]._presampled = layers[0]._preball = None
+    res["points_per_s"] = xyz.shape[0] * xyz.shape[1] / (res["ms"] * 1e-3)
+    res["grouped_mlp"] = ("fused train-mode kernels (csrc/mlp_train.hip), split-fp16 MFMA with exact power-of-two operand scaling"
+                          if (modules_pkg.FUSED_MLP_TRAINING and args.mlp_precision != "fp32") else "op-by-op fp32 kernels")
+    res["note"] = "forward + backward of SA layers 0-2 in train() mode on the bench batch; informational, not the headline metric"
+    return res
 
 
 def same_outputs(got, want):
@@ -456,6 +493,11 @@ def main():
             line["roofline_mlp_fp32"] = mlp_roofline(fp32_leg[3], "fp32")
         if pipelined is not None:
             line["pipelined"] = pipelined
+        if world == 1 and not args.no_training_leg and args.config != 5 and args.mlp_precision != "fp16":
+            try:
+                line["training_step"] = training_step_leg(M, sa_stack, cfg, args, xyz, feats, dev)
+            except Exception as exc:   # informational only: never lose the headline line over it
+                line["training_step"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(layers, args)
         print(json.dumps(line), flush=True)
