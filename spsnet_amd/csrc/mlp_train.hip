@@ -20,9 +20,13 @@
 // Arithmetic: split-fp16 on v_mfma_f32_16x16x32_f16 (every fp32 operand as hi + lo halves, three products, fp32 accumulate:
 // ~22 significant bits, the same scheme as the inference kernels of sa_mlp_f16.hip) -- at 8 TB/s these GEMMs (64-256 channels
 // on either side) need ~500 TFLOP/s of issued matrix work to stay memory-bound, three times what the fp32 MFMA pipe has.
-// Operands beyond +-65504 or NaN / Inf are never clamped silently: the affected output columns (or the whole weight
-// gradient) are written as NaN and the overflow flag is raised.  Statistics are accumulated per lane in fp32 over a
-// workgroup's columns, then in fp64 in a fixed order (bit-reproducible from run to run).
+// Every operand tensor is first multiplied by an exact power of two that brings its largest magnitude near 2^10 (see
+// tpow2_scale: unscaled, the low half of a 1e-5 gradient is an fp16 denormal).  Operands beyond +-65504 after scaling, or
+// NaN / Inf, are never clamped silently: the outputs that depend on them (or the whole weight gradient) are written as NaN
+// and the overflow flag is raised.  Statistics are accumulated per lane in fp32 over a workgroup's columns, then in fp64
+// in a fixed order; weight-gradient partials are summed in launch order (bit-reproducible from run to run).
+// The kernels are HBM-streaming (3.5-4.6 TB/s at a million columns, tools/tconv_bench.py); DESIGN.md 4.5b2 has what
+// bounds them at the IA-SSD shapes and what was measured on the way.
 #include "sps_common.h"
 
 namespace sps {
@@ -30,7 +34,6 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 constexpr int TP = 8;   // floats per channel of a parameter block: mean, invstd, scale, shift, gamma, beta, c1, c2
 enum { TIN_RAW = 0, TIN_BNRELU = 1, TIN_BNBWD = 2, TIN_BNBWD_POOL = 3 };
@@ -38,10 +41,10 @@ enum { TEPI_NONE = 0, TEPI_STATS = 1, TEPI_BWD = 2 };
 
 __device__ __forceinline__ f32x4 tmfma(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
-// relu that keeps a NaN (torch's clamp_min does)
+// relu that keeps a NaN (torch's clamp_min does); the pool compares its results with `>`, hence the float form here
 __device__ __forceinline__ float trelu(float z) { return (z > 0.f || z != z) ? z : 0.f; }
 
-// hi / lo halves of a value clamped into the fp16 range (the caller tracks range violations separately)
+// hi / lo halves of a value clamped into the fp16 range (the weights: scaled to 2^8 before, so the clamp never acts)
 __device__ __forceinline__ void tsplit(float v, _Float16 &hi, _Float16 &lo) {
     const float c = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
     hi = (_Float16)c;
