@@ -37,8 +37,34 @@ def _need(t, numel, name):
         raise ValueError(f"{name} has {t.numel()} elements, the given sizes need {numel}")
 
 
+_SCOPE = None     # (device index, stream handle) while a launch_scope is open
+
+
 def _stream(t):
+    if _SCOPE is not None:
+        return _SCOPE[1]
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class launch_scope:
+    """A run of launches on ONE tensor's device and the current stream (the forward or the backward of a fused training
+    stack: ~10-20 launches): the stream handle is looked up once and the per-launch device guard is skipped -- these
+    lookups are a third of a wrapper call's host time, and the training step of the backbones is host-bound."""
+
+    def __init__(self, t):
+        self.t = t
+        self.guard = _on(t)
+
+    def __enter__(self):
+        global _SCOPE
+        self.prev = _SCOPE
+        self.guard.__enter__()
+        _SCOPE = (self.t.device.index, torch.cuda.current_stream(self.t.device).cuda_stream)
+
+    def __exit__(self, *exc):
+        global _SCOPE
+        _SCOPE = self.prev
+        self.guard.__exit__(*exc)
 
 
 class _on:
@@ -49,6 +75,8 @@ class _on:
         self.prev = None
 
     def __enter__(self):
+        if _SCOPE is not None and _SCOPE[0] == self.dev:
+            return                                   # inside a launch_scope on this device: already current
         cur = torch.cuda.current_device()
         if self.dev is not None and self.dev != cur:
             self.prev = cur
@@ -590,7 +618,10 @@ def _p(t):
 
 
 def tconv_parts(b, l, co):
-    return int(_L.sps_tconv_parts(b, l, co))
+    """= sps_tconv_parts (restated here to save the call; test_abi_cpu checks the two against each other)"""
+    if b <= 0 or l <= 0 or co <= 0:
+        return 0
+    return min((b * (l >> 6) + 3) // 4, 256 if co > 64 else 512)
 
 
 def tconv(w, wamax, in_mode, epi_mode, out, operand=None, y=None, gout=None, arg=None, nsample=0, pin=None, epi_y=None, pout=None,

@@ -145,6 +145,16 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, bns, pool, x, *wgb):
+        with _ext.launch_scope(x):
+            return _GroupedMLPPoolTrain._forward(ctx, bns, pool, x, *wgb)
+
+    @staticmethod
+    def backward(ctx, gout):
+        with _ext.launch_scope(gout):
+            return _GroupedMLPPoolTrain._backward(ctx, gout)
+
+    @staticmethod
+    def _forward(ctx, bns, pool, x, *wgb):
         n = len(bns)
         x = x.contiguous()
         B, tail = x.shape[0], tuple(x.shape[2:])
@@ -174,7 +184,7 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, gout):
+    def _backward(ctx, gout):
         n, ns, count, pool = ctx.n, ctx.ns, ctx.count, ctx.pool
         saved = ctx.saved_tensors
         x, arg, yarg = saved[0], saved[1], saved[2]

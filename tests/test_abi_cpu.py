@@ -141,3 +141,19 @@ def test_equal_counts_check_mirrors_the_reference_assert():
         equal_counts_check(torch.tensor([0., 0., 0., 1.]), 2)()
     with pytest.raises(AssertionError):
         equal_counts_check(torch.tensor([0., 0., 1., 1.]), 3)()                     # an empty scene
+
+
+def test_tconv_parts_restatement_matches_library():
+    """pointnet2_batch_cuda.tconv_parts restates sps_tconv_parts in Python (one ctypes call less per launch): same values."""
+    from spsnet_amd import _lib
+    import importlib
+    L = _lib.load()
+    # (the Python restatement lives in a module that needs no GPU to import its pure functions)
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spsnet_amd", "pointnet2_batch_cuda.py")).read()
+    ns = {}
+    start = src.index("def tconv_parts(b, l, co):")
+    exec(src[start:src.index("\n\n\n", start)], ns)
+    for b in (0, 1, 2, 8, 64):
+        for l in (0, 64, 192, 2048, 16384, 131072):
+            for co in (0, 3, 16, 64, 65, 128, 256):
+                assert ns["tconv_parts"](b, l, co) == L.sps_tconv_parts(b, l, co), (b, l, co)
