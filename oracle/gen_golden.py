@@ -311,12 +311,41 @@ def backbones():
         np.savez_compressed(os.path.join(OUT, f"backbone_{tag}.npz"), **d)
 
 
+POINTNET2MSG_NPOINTS = [1024, 256, 64, 16]
+POINTNET2MSG_SEED = 31
+
+
+def pointnet2msg():
+    """PointNet2MSG end to end (pcdet/models/backbones_3d/pointnet2_backbone.py:9-100, PointRCNN's backbone: four MSG SA
+    layers + four feature-propagation layers) at the shipped widths on 2 x 4096 points, centroid counts scaled down.
+    The reference file also imports the stacked-op package at module level, hence both harnesses."""
+    from oracle import ref_harness_stack
+    from spsnet_amd import backbones as B
+    ref_harness_stack.load_reference()
+    cfg = copy.deepcopy(B.POINTRCNN_KITTI_CFG)
+    cfg['SA_CONFIG']['NPOINTS'] = list(POINTNET2MSG_NPOINTS)
+    net = _load_backbone("pointnet2_backbone.py", "PointNet2MSG")(_attr(copy.deepcopy(cfg)), input_channels=4).eval()
+    scenes.fill_parameters(net, POINTNET2MSG_SEED)
+    xyz, feats = scenes.make_batch("kitti-lidar-v1", 2, 4096, seed0=900, dup_fraction=0.01)
+    bidx = np.repeat(np.arange(2, dtype=np.float32), 4096)[:, None]
+    points = np.concatenate([bidx, xyz.reshape(-1, 3), feats.transpose(0, 2, 1).reshape(-1, 1)], 1).astype(np.float32)
+    with torch.no_grad():
+        out = net(dict(batch_size=2, points=torch.from_numpy(points)))
+    np.savez_compressed(os.path.join(OUT, "backbone_pointnet2msg.npz"), points=points, npoints=np.asarray(POINTNET2MSG_NPOINTS),
+                        seed=np.asarray(POINTNET2MSG_SEED), point_features=_np(out["point_features"]),
+                        point_coords=_np(out["point_coords"]), num_point_features=np.asarray(net.num_point_features),
+                        n_state=np.asarray(len(net.state_dict())))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     U, M = ref_harness.load_reference()
     torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == "samplers_partitioned":   # (added later: regenerate only these)
         samplers_partitioned(M)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "pointnet2msg":
+        pointnet2msg()
         return
     ops_small(U)
     config1(M)
@@ -327,6 +356,7 @@ def main():
     fp_module(M)
     surface_features()
     backbones()
+    pointnet2msg()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

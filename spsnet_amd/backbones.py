@@ -351,6 +351,112 @@ SPSNET_KITTI_CFG['SA_CONFIG'].update(
 SPSNET_KITTI_CFG['SA_CONFIG']['MLPS'][1] = [[124, 64, 128], [124, 96, 128]]
 
 
+# tools/cfgs/kitti_models/pointrcnn.yaml: BACKBONE_3D of PointRCNN (the reference's other point-based detector)
+POINTRCNN_KITTI_CFG = dict(
+    NAME='PointNet2MSG',
+    SA_CONFIG=dict(
+        NPOINTS=[4096, 1024, 256, 64],
+        RADIUS=[[0.1, 0.5], [0.5, 1.0], [1.0, 2.0], [2.0, 4.0]],
+        NSAMPLE=[[16, 32], [16, 32], [16, 32], [16, 32]],
+        MLPS=[[[16, 16, 32], [32, 32, 64]], [[64, 64, 128], [64, 96, 128]], [[128, 196, 256], [128, 196, 256]],
+              [[256, 256, 512], [256, 384, 512]]]),
+    FP_MLPS=[[128, 128], [256, 256], [512, 512], [512, 512]])
+
+
+class PointNet2MSG(nn.Module):
+    """The encoder / decoder backbone of PointRCNN (pcdet/models/backbones_3d/pointnet2_backbone.py:9-100): a chain of
+    multi-scale-grouping SA layers with plain D-FPS, then feature-propagation layers that carry the coarse features back to
+    every input point (3-NN inverse-distance interpolation + a shared MLP over [interpolated | skip] channels).  Same
+    constructor arguments, `state_dict` keys (`SA_modules.k.*`, `FP_modules.k.mlp.*`), `num_point_features` and output
+    entries (`point_features` (B*N, C), `point_coords` (B*N, 4)) as the reference class; in inference every SA layer runs on
+    the fused kernels (one scan for both radii, gather + grouped MLP + max-pool on the matrix cores) and the next layer's
+    D-FPS -- a pick sequence over the previous layer's picks -- is the verified identity prefix, started the moment its
+    centroids exist."""
+
+    def __init__(self, model_cfg, input_channels, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        cfg = _Cfg(model_cfg)
+        sa = cfg.SA_CONFIG
+        use_xyz = sa.get('USE_XYZ', True)
+        self.SA_modules = nn.ModuleList()
+        width = input_channels - 3
+        skip_widths = [width]
+        for npoint, radii, nsamples, specs in zip(sa.NPOINTS, sa.RADIUS, sa.NSAMPLE, sa.MLPS):
+            mlps = [[width] + list(spec) for spec in specs]
+            self.SA_modules.append(pointnet2_modules.PointnetSAModuleMSG(
+                npoint=npoint, radii=list(radii), nsamples=list(nsamples), mlps=mlps, use_xyz=use_xyz))
+            width = sum(spec[-1] for spec in specs)
+            skip_widths.append(width)
+        fp = [list(m) for m in cfg.FP_MLPS]
+        self.FP_modules = nn.ModuleList()
+        for k, spec in enumerate(fp):
+            coarse = fp[k + 1][-1] if k + 1 < len(fp) else width     # what arrives from the coarser level
+            self.FP_modules.append(pointnet2_modules.PointnetFPModule(mlp=[coarse + skip_widths[k]] + spec))
+        self.num_point_features = fp[0][-1]
+
+    def _centroids(self, layer, cloud):
+        """The layer's D-FPS picks gathered from `cloud` (pointnet2_modules.py:59-63) -- from the early start on a side stream
+        when the previous layer's centroids were `cloud` (see forward), else sampled here."""
+        pre, layer._presampled = getattr(layer, "_presampled", None), None
+        idx = None
+        if pre is not None and pre[2] is cloud and pre[0].shape[1] == layer.npoint:
+            idx, done = pre[0], pre[1]
+            main = torch.cuda.current_stream(cloud.device)
+            main.wait_event(done)
+            idx.record_stream(main)
+        if idx is None:
+            idx = pointnet2_utils.farthest_point_sample(cloud, layer.npoint)
+        if cloud.is_cuda and not (torch.is_grad_enabled() and cloud.requires_grad):
+            return pointnet2_modules._ext.gather_xyz(cloud, idx)
+        return pointnet2_utils.gather_operation(cloud.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+
+    def forward(self, batch_dict):
+        batch_size = batch_dict['batch_size']
+        points = batch_dict['points']
+        batch_idx = points[:, 0]
+        counts_ok = equal_counts_check(batch_idx, batch_size)
+        xyz = points[:, 1:4].contiguous().view(batch_size, -1, 3)
+        feats = None
+        if points.size(-1) > 4:
+            feats = points[:, 4:].contiguous().view(batch_size, -1, points.size(-1) - 4).permute(0, 2, 1).contiguous()
+        level_xyz, level_feats = [xyz], [feats]
+        early = xyz.is_cuda          # sampling carries no gradient: the early start applies in training too
+        for k, layer in enumerate(self.SA_modules):
+            nxt = self.SA_modules[k + 1] if k + 1 < len(self.SA_modules) else None
+            new_xyz = self._centroids(layer, level_xyz[k]) if layer.npoint is not None else None
+            if (early and new_xyz is not None and nxt is not None and nxt.npoint is not None
+                    and nxt.npoint < new_xyz.shape[1] and level_xyz[k].shape[1] > layer.npoint):
+                # the next layer samples THESE centroids, a D-FPS pick sequence in pick order: its own D-FPS is the identity
+                # prefix up to exact distance ties (fps_verify.hip checks it in parallel), started now on a side stream
+                # beside this layer's ball queries and grouped MLPs
+                sa_stack._prefetch_dfps(_DfpsShim(nxt), new_xyz, fps_ordered=nxt.npoint <= pointnet2_modules._ext.ORDERED_PREFIX_MAX)
+            li_xyz, li_feats = layer(level_xyz[k], level_feats[k], new_xyz=new_xyz)
+            level_xyz.append(li_xyz)
+            level_feats.append(li_feats)
+        for k in range(len(self.FP_modules) - 1, -1, -1):
+            level_feats[k] = self.FP_modules[k](level_xyz[k], level_xyz[k + 1], level_feats[k], level_feats[k + 1])
+        point_features = level_feats[0].permute(0, 2, 1).contiguous()
+        batch_dict['point_features'] = point_features.view(-1, point_features.shape[-1])
+        batch_dict['point_coords'] = torch.cat((batch_idx[:, None].float(), xyz.view(-1, 3)), dim=1)
+        counts_ok()
+        return batch_dict
+
+
+class _DfpsShim:
+    """What sa_stack._prefetch_dfps needs of the layer it samples for: the pick count, and a place to leave the result."""
+
+    def __init__(self, layer):
+        self._layer = layer
+        self.npoint_list = [layer.npoint]
+
+    def __setattr__(self, key, value):
+        if key == "_presampled":
+            self._layer._presampled = value
+        else:
+            object.__setattr__(self, key, value)
+
+
 def scaled_cfg(base, npoints):
     """The same stack on a smaller cloud: NPOINT_LIST replaced (entries of -1 kept)."""
     cfg = copy.deepcopy(base)

@@ -113,6 +113,14 @@ def test_backbone_mirrors_have_reference_state_dict_keys():
         got = {k: tuple(v.shape) for k, v in mine.state_dict().items()}
         assert got == want
         assert mine.num_point_features == ref.num_point_features
+    # PointRCNN's backbone (pointnet2_backbone.py imports the stacked-op package at module level: both harnesses)
+    from oracle import ref_harness_stack
+    ref_harness_stack.load_reference()
+    cfg = BB.POINTRCNN_KITTI_CFG
+    ref = gen_golden._load_backbone("pointnet2_backbone.py", "PointNet2MSG")(gen_golden._attr(copy.deepcopy(cfg)), input_channels=4)
+    mine = BB.PointNet2MSG(copy.deepcopy(cfg), input_channels=4)
+    assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    assert mine.num_point_features == ref.num_point_features
 
 
 def test_fill_parameters_is_deterministic_and_name_keyed():

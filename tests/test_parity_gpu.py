@@ -2522,3 +2522,41 @@ def test_fused_train_mode_mlp_nan_input_propagates(dev, monkeypatch):
     torch.cuda.synchronize()
     assert out is not None and bool(torch.isnan(out).any())
     assert fused.check_overflow()
+
+
+@pytest.mark.parametrize("mode", ["inference", "gradients", "train"])
+def test_golden_pointnet2msg_backbone(G, dev, mode):
+    """PointNet2MSG (PointRCNN's backbone: four MSG SA layers + four feature-propagation layers,
+    pointnet2_backbone.py:9-100) on 2 x 4096 points at the shipped widths against the reference's own forward run over the
+    C oracle (oracle/gen_golden.py:pointnet2msg): per-point features to 1e-4, point coordinates exact.  `inference` = the
+    fused kernels with the next layer's D-FPS started early as a verified identity prefix, `gradients` = the reference's
+    op order with autograd (eval-mode BatchNorm); `train` only checks that a training step runs and yields finite
+    gradients (batch statistics: no golden)."""
+    import copy
+    from spsnet_amd import backbones as BB, scenes
+    g = np.load(os.path.join(GOLD, "backbone_pointnet2msg.npz"))
+    cfg = copy.deepcopy(BB.POINTRCNN_KITTI_CFG)
+    cfg['SA_CONFIG']['NPOINTS'] = [int(v) for v in g["npoints"]]
+    net = BB.PointNet2MSG(cfg, input_channels=4)
+    assert net.num_point_features == int(g["num_point_features"]) and len(net.state_dict()) == int(g["n_state"])
+    scenes.fill_parameters(net, int(g["seed"]))
+    net = net.to(dev)
+    batch = dict(batch_size=2, points=G.t(g["points"]))
+    if mode == "train":
+        out = net.train()(batch)
+        out["point_features"].square().mean().backward()
+        grads = [p.grad for p in net.parameters() if p.grad is not None]
+        assert len(grads) > 60 and all(torch.isfinite(x).all() for x in grads)
+        return
+    net.eval()
+    if mode == "inference":
+        with torch.no_grad():
+            out = net(batch)
+    else:
+        out = net(batch)
+        assert out["point_features"].requires_grad
+    want = g["point_features"]
+    got = G.n(out["point_features"])
+    assert got.shape == want.shape
+    assert float(np.abs(got - want).max()) <= 1e-4 * max(1.0, float(np.abs(want).max()))
+    np.testing.assert_array_equal(G.n(out["point_coords"]), g["point_coords"])

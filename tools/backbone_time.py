@@ -1,5 +1,5 @@
-"""Time IASSD_Backbone / PAGNet_Backbone.forward (spsnet_amd/backbones.py) at the KITTI configuration.
-usage: python tools/backbone_time.py [B] [N] [reps]"""
+"""Time IASSD_Backbone / PAGNet_Backbone / PointNet2MSG.forward (spsnet_amd/backbones.py) at the KITTI configuration.
+usage: python tools/backbone_time.py [B] [N] [reps] [name prefix]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,13 +9,18 @@ from spsnet_amd import backbones as BB, scenes
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+only = sys.argv[4] if len(sys.argv) > 4 else ""
 dev = torch.device("cuda:0")
 xyz, feats = scenes.make_batch("kitti-lidar-v1", B, N, seed0=1)
 bidx = np.repeat(np.arange(B, dtype=np.float32), N)[:, None]
 points = torch.from_numpy(np.concatenate([bidx, xyz.reshape(-1, 3), feats.transpose(0, 2, 1).reshape(-1, 1)], 1).astype(np.float32)).to(dev)
 stds = torch.from_numpy(np.random.default_rng(0).uniform(0, 40, (B, N)).astype(np.float32)).to(dev)
-for tag, cls, cfg in (("IASSD_Backbone", BB.IASSD_Backbone, BB.IASSD_KITTI_CFG), ("PAGNet_Backbone", BB.PAGNet_Backbone, BB.SPSNET_KITTI_CFG)):
-    net = scenes.fill_parameters(cls(cfg, num_class=3, input_channels=4), 5).to(dev).eval()
+for tag, cls, cfg in (("IASSD_Backbone", BB.IASSD_Backbone, BB.IASSD_KITTI_CFG), ("PAGNet_Backbone", BB.PAGNet_Backbone, BB.SPSNET_KITTI_CFG),
+                      ("PointNet2MSG", BB.PointNet2MSG, BB.POINTRCNN_KITTI_CFG)):
+    if only and not tag.startswith(only):
+        continue
+    kw = {} if tag == "PointNet2MSG" else {"num_class": 3}
+    net = scenes.fill_parameters(cls(cfg, input_channels=4, **kw), 5).to(dev).eval()
     def batch():
         d = dict(batch_size=B, points=points)
         if tag.startswith("PAG"):
