@@ -249,7 +249,7 @@ def test_group_gather_gradients(ext, G, oracle, dev):
 
 
 # ------------------------------------------------------------------ three_nn / interpolate
-@pytest.mark.parametrize("n,m", [(1, 1), (10, 2), (300, 3), (1000, 257), (4096, 1024)])
+@pytest.mark.parametrize("n,m", [(1, 1), (10, 2), (300, 3), (1000, 257), (4096, 1024), (700, 2048), (300, 2049), (5000, 4099)])
 def test_three_nn_and_interpolate(ext, G, oracle, dev, n, m):
     rng = np.random.default_rng(n + m)
     unknown = cloud(rng, 2, n, lattice=True)
