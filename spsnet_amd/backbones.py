@@ -351,6 +351,8 @@ SPSNET_KITTI_CFG['SA_CONFIG'].update(
 SPSNET_KITTI_CFG['SA_CONFIG']['MLPS'][1] = [[124, 64, 128], [124, 96, 128]]
 
 
+STREAM_FIRST_LAYER = True     # PointNet2MSG inference: layer 0 consumes its FPS picks while FPS runs (tests switch it off to compare)
+
 # tools/cfgs/kitti_models/pointrcnn.yaml: BACKBONE_3D of PointRCNN (the reference's other point-based detector)
 POINTRCNN_KITTI_CFG = dict(
     NAME='PointNet2MSG',
@@ -424,6 +426,16 @@ class PointNet2MSG(nn.Module):
         early = xyz.is_cuda          # sampling carries no gradient: the early start applies in training too
         for k, layer in enumerate(self.SA_modules):
             nxt = self.SA_modules[k + 1] if k + 1 < len(self.SA_modules) else None
+            if (k == 0 and early and STREAM_FIRST_LAYER and not torch.is_grad_enabled() and layer.npoint is not None
+                    and getattr(layer, "_presampled", None) is None):
+                # inference: the first layer's ball queries and grouped MLPs consume its FPS picks while FPS still samples,
+                # and the next layer's D-FPS is the verified identity prefix (sa_stack._streamed_first_layer; exact)
+                res = sa_stack._streamed_first_layer(_DfpsShim(layer), _DfpsShim(nxt) if nxt is not None and nxt.npoint else None,
+                                                     level_xyz[0], level_feats[0])
+                if res is not None:
+                    level_xyz.append(res[0])
+                    level_feats.append(res[1])
+                    continue
             new_xyz = self._centroids(layer, level_xyz[k]) if layer.npoint is not None else None
             if (early and new_xyz is not None and nxt is not None and nxt.npoint is not None
                     and nxt.npoint < new_xyz.shape[1] and level_xyz[k].shape[1] > layer.npoint):
@@ -444,17 +456,28 @@ class PointNet2MSG(nn.Module):
 
 
 class _DfpsShim:
-    """What sa_stack._prefetch_dfps needs of the layer it samples for: the pick count, and a place to leave the result."""
+    """A PointnetSAModuleMSG seen through the interface sa_stack's schedules are written against (the sampling SA module:
+    npoint_list / sample_type_list / sample_range_list, groupers, an optional aggregation tail): one plain D-FPS sampler over
+    the whole cloud, no tail.  `_presampled` (where the schedules leave an early-started sampling result) lands on the
+    wrapped module."""
+
+    aggregation_layer = None
+    confidence_layers = None
 
     def __init__(self, layer):
-        self._layer = layer
-        self.npoint_list = [layer.npoint]
+        object.__setattr__(self, "_layer", layer)
+        object.__setattr__(self, "npoint_list", [layer.npoint])
+        object.__setattr__(self, "sample_type_list", ['D-FPS'])
+        object.__setattr__(self, "sample_range_list", [-1])
+
+    def __getattr__(self, key):                     # groupers, mlps, training, _fused_plan, ...
+        return getattr(object.__getattribute__(self, "_layer"), key)
 
     def __setattr__(self, key, value):
-        if key == "_presampled":
-            self._layer._presampled = value
-        else:
-            object.__setattr__(self, key, value)
+        setattr(self._layer, key, value)
+
+    def _tail(self, pooled, half_out=False):
+        return pooled, None
 
 
 def scaled_cfg(base, npoints):

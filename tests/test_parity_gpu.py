@@ -2560,3 +2560,29 @@ def test_golden_pointnet2msg_backbone(G, dev, mode):
     assert got.shape == want.shape
     assert float(np.abs(got - want).max()) <= 1e-4 * max(1.0, float(np.abs(want).max()))
     np.testing.assert_array_equal(G.n(out["point_coords"]), g["point_coords"])
+
+
+def test_pointnet2msg_streamed_first_layer_equals_sequential(G, dev, monkeypatch):
+    """PointNet2MSG inference with layer 0 streamed against its own FPS (and layer 1's D-FPS taken from the verified identity
+    prefix) == the same forward layer by layer: per-point features bit-identical, no bounded wait gave up."""
+    import copy
+    from spsnet_amd import backbones as BB, sa_stack, scenes
+    cfg = copy.deepcopy(BB.POINTRCNN_KITTI_CFG)
+    cfg['SA_CONFIG']['NPOINTS'] = [1024, 256, 64, 16]
+    net = scenes.fill_parameters(BB.PointNet2MSG(cfg, input_channels=4), 4).to(dev).eval()
+    xyz, feats = scenes.make_batch("kitti-lidar-v1", 2, 8192, seed0=13, dup_fraction=0.01)
+    bidx = np.repeat(np.arange(2, dtype=np.float32), 8192)[:, None]
+    points = G.t(np.concatenate([bidx, xyz.reshape(-1, 3), feats.transpose(0, 2, 1).reshape(-1, 1)], 1).astype(np.float32))
+    calls = []
+    orig = sa_stack._streamed_first_layer
+    monkeypatch.setattr(sa_stack, "_streamed_first_layer", lambda *a, **k: calls.append(orig(*a, **k)) or calls[-1])
+    with torch.no_grad():
+        monkeypatch.setattr(BB, "STREAM_FIRST_LAYER", False)
+        want = net(dict(batch_size=2, points=points))["point_features"].clone()
+        assert calls == []
+        monkeypatch.setattr(BB, "STREAM_FIRST_LAYER", True)
+        got = net(dict(batch_size=2, points=points))["point_features"]
+    torch.cuda.synchronize()
+    assert len(calls) == 1 and calls[0] is not None, "layer 0 was supposed to be streamed"
+    assert not sa_stack.check_timeouts()
+    assert torch.equal(got, want)
