@@ -168,7 +168,114 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void pw_mlp_kernel(PwArgs a) {
     }   // tile loop
 }
 
+// ---- PointnetFPModule (pointnet2_modules.py:539-587) in inference, as ONE kernel -------------------------------------------
+//   three_interpolate(known_feats, idx, weight)  ->  cat([interpolated, unknow_feats], dim=1)  ->  [Conv2d 1x1 + BatchNorm2d +
+//   ReLU] x (1 | 2)
+// The reference runs an interpolation kernel, a concatenation copy and 3 launches per MLP layer over (B, C, n) tensors at the
+// resolution of the FINER level (PointRCNN's last feature-propagation layer: 8 x 16 384 points x 257 -> 128 -> 128).  Here a
+// workgroup owns 16 points: the [interpolated | skip] input columns are built straight in LDS (same contraction as
+// three_interpolate_kernel: w0 f0, then fma, fma -- the interpolated values are bit-identical to the unfused op), the layers
+// run as in pw_mlp_kernel (exact fp32 MFMA, BatchNorm folded), and only the last layer's output is written.
+struct FpArgs {
+    int n, m, c_known, c_skip, cin, c1, c2;      // cin = c_known + c_skip rounded up to 16; c2 = 0: a one-layer stack
+    const float *known_feats, *skip;             // (b, c_known, m), (b, c_skip, n) | NULL
+    const int *idx;                              // (b, n, 3)
+    const float *weight;                         // (b, n, 3)
+    const float *w1, *b1, *w2, *b2;
+    float *y;                                    // (b, c2 ? c2 : c1, n)
+};
+
+__global__ __launch_bounds__(64 * PW_MAX_WAVES) void fp_mlp_kernel(FpArgs a) {
+    extern __shared__ float pw_lds[];
+    const int r0 = (a.cin > a.c2 ? a.cin : a.c2) * PW_PAD;
+    float *xt = pw_lds, *act1 = pw_lds + r0;
+    __shared__ int s_idx[48];
+    __shared__ float s_w[48];
+    const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int scene = blockIdx.y;
+    const int m0 = blockIdx.x * 16;
+    if (threadIdx.x < 48) {
+        s_idx[threadIdx.x] = a.idx[((size_t)scene * a.n + m0) * 3 + threadIdx.x];
+        s_w[threadIdx.x] = a.weight[((size_t)scene * a.n + m0) * 3 + threadIdx.x];
+    }
+    __syncthreads();
+    // ---- the 16 input columns: interpolated channels, then the skip channels, then zero padding ----
+    const float *kf = a.known_feats + (size_t)scene * a.c_known * a.m;
+    for (int e = threadIdx.x; e < a.cin * 16; e += blockDim.x) {
+        const int ch = e >> 4, col = e & 15;
+        float v = 0.f;
+        if (ch < a.c_known) {
+            const float *f = kf + (size_t)ch * a.m;
+            float t = s_w[3 * col] * f[s_idx[3 * col]];
+            t = __builtin_fmaf(s_w[3 * col + 1], f[s_idx[3 * col + 1]], t);
+            v = __builtin_fmaf(s_w[3 * col + 2], f[s_idx[3 * col + 2]], t);
+        } else if (ch < a.c_known + a.c_skip) {
+            v = a.skip[((size_t)scene * a.c_skip + (ch - a.c_known)) * a.n + m0 + col];
+        }
+        xt[ch * PW_PAD + col] = v;
+    }
+    __syncthreads();
+    {
+        const int k16n = a.cin / 16;
+        for (int t = wv; t < a.c1 / 16; t += nw) {
+            f32x4 acc = *reinterpret_cast<const f32x4 *>(a.b1 + 16 * t + 4 * q);
+            acc = pw_tile(reinterpret_cast<const f32x4 *>(a.w1) + (size_t)t * k16n * 64 + lane, xt, k16n, q, c, acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * t + 4 * q + r;
+                const float v = pw_relu(acc[r]);
+                if (a.c2 == 0) a.y[((size_t)scene * a.c1 + row) * a.n + m0 + c] = v;
+                else act1[row * PW_PAD + c] = v;
+            }
+        }
+    }
+    if (a.c2 == 0) return;
+    __syncthreads();
+    {
+        const int k16n = a.c1 / 16;
+        for (int t = wv; t < a.c2 / 16; t += nw) {
+            f32x4 acc = *reinterpret_cast<const f32x4 *>(a.b2 + 16 * t + 4 * q);
+            acc = pw_tile(reinterpret_cast<const f32x4 *>(a.w2) + (size_t)t * k16n * 64 + lane, act1, k16n, q, c, acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.y[((size_t)scene * a.c2 + 16 * t + 4 * q + r) * a.n + m0 + c] = pw_relu(acc[r]);
+        }
+    }
+}
+
 }  // namespace sps
+
+// cin = c_known + c_skip rounded up to 16 (the packed w1 has cin columns, zero beyond the real ones); c1, c2 multiples of 16,
+// c2 = 0 (w2, b2 NULL) for a one-layer stack; n a multiple of 16; y (b, c2 ? c2 : c1, n).  Weights packed as for
+// sps_pointwise_mlp (BatchNorm folded, [tile][k16][lane][r]).
+extern "C" int sps_fp_module_mlp(int b, int n, int m, int c_known, int c_skip, int c1, int c2, const float *known_feats,
+                                 const float *skip, const int *idx, const float *weight, const float *w1, const float *b1,
+                                 const float *w2, const float *b2, float *y, sps_stream_t stream) {
+    using namespace sps;
+    if (b < 0 || n < 0 || m <= 0 || c_known <= 0 || c_skip < 0 || c1 <= 0 || c2 < 0)
+        return fail(SPS_ERR_INVALID, "fp_module_mlp: bad shape b=%d n=%d m=%d c_known=%d c_skip=%d c1=%d c2=%d", b, n, m, c_known, c_skip, c1, c2);
+    if (b == 0 || n == 0) return SPS_OK;
+    if (n % 16 || c1 % 16 || c2 % 16) return fail(SPS_ERR_INVALID, "fp_module_mlp: n, c1, c2 (%d, %d, %d) must be multiples of 16", n, c1, c2);
+    if (!known_feats || !idx || !weight || !w1 || !b1 || !y || (c_skip > 0 && !skip) || (c2 > 0 && (!w2 || !b2)))
+        return fail(SPS_ERR_INVALID, "fp_module_mlp: null pointer");
+    if (b > 65535) return fail(SPS_ERR_INVALID, "fp_module_mlp: batch %d exceeds the grid limit", b);
+    FpArgs a;
+    a.n = n; a.m = m; a.c_known = c_known; a.c_skip = c_skip; a.cin = 16 * divup(c_known + c_skip, 16); a.c1 = c1; a.c2 = c2;
+    a.known_feats = known_feats; a.skip = skip; a.idx = idx; a.weight = weight; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = y;
+    const int wide = c2 > a.cin ? c2 : a.cin;
+    const size_t lds = sizeof(float) * (size_t)PW_PAD * ((size_t)wide + (c2 ? c1 : 0));
+    if (lds > 148 * 1024) return fail(SPS_ERR_INVALID, "fp_module_mlp: widths (%d, %d, %d) need more LDS than a workgroup has", a.cin, c1, c2);
+    static LdsLimitOnce raised;
+    if (lds > 64 * 1024) {
+        const int rc = raise_lds_limit((const void *)fp_mlp_kernel, 148 * 1024, raised, "fp_module_mlp");
+        if (rc != SPS_OK) return rc;
+    }
+    int tiles = c1 / 16;
+    if (c2 / 16 > tiles) tiles = c2 / 16;
+    const int waves = tiles < 4 ? 4 : (tiles > PW_MAX_WAVES ? PW_MAX_WAVES : tiles);
+    hipLaunchKernelGGL(fp_mlp_kernel, dim3(n / 16, b), dim3(64 * waves), lds, as_stream(stream), a);
+    return check_launch("fp_mlp_kernel");
+}
 
 extern "C" int sps_pointwise_mlp_range(int b, int m, int j0, int jcount, int cin, int c1, int c2, int c3_real, const float *x,
                                        const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,

@@ -474,6 +474,62 @@ def pointwise_tail(agg, head, pooled, half_out=False, x_pm=False):
     return runner.result()
 
 
+class _PackedFp:
+    __slots__ = ("key", "c_in", "c1", "c2", "w1", "b1", "w2", "b2")
+
+
+def fp_module_mlp(mlp, known_feats, unknow_feats, idx, weight):
+    """PointnetFPModule.forward behind its three_nn (reference :571-587): interpolation of `known_feats` (B, C2, m) with
+    idx / weight (B, n, 3), concatenation with `unknow_feats` (B, C1, n) | None and the [Conv2d 1x1 + BatchNorm2d + ReLU]
+    stack (one or two layers), as ONE kernel (csrc/pw_mlp.hip fp_mlp_kernel, exact fp32, BatchNorm folded) -> (B, Cout, n),
+    or None when the fused path does not apply (training, gradients wanted, widths / n not multiples of 16, ...)."""
+    mods = list(mlp)
+    if len(mods) not in (3, 6) or mlp.training or not known_feats.is_cuda or known_feats.dtype != torch.float32:
+        return None
+    pairs = []
+    for conv, bn, act in zip(mods[0::3], mods[1::3], mods[2::3]):
+        if not (isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and isinstance(act, nn.ReLU)
+                and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and bn.track_running_stats):
+            return None
+        pairs.append((conv, bn))
+    tensors = [known_feats, weight] + ([unknow_feats] if unknow_feats is not None else [])
+    if torch.is_grad_enabled() and (any(t.requires_grad for t in tensors) or any(p.requires_grad for p in mlp.parameters())):
+        return None
+    B, c_known, m = known_feats.shape
+    n = idx.shape[1]
+    c_skip = unknow_feats.shape[1] if unknow_feats is not None else 0
+    c1 = pairs[0][0].out_channels
+    c2 = pairs[1][0].out_channels if len(pairs) > 1 else 0
+    cin_pad = _pad16(c_known + c_skip)
+    if (pairs[0][0].in_channels != c_known + c_skip or c1 % 16 or c2 % 16 or n % 16 or n == 0 or B > 65535
+            or (unknow_feats is not None and (unknow_feats.dtype != torch.float32 or unknow_feats.shape[2] != n))
+            or 17 * 4 * (max(cin_pad, c2) + (c1 if c2 else 0)) > 148 * 1024):
+        return None
+    key = _version_key(pairs, known_feats.device)
+    packed = getattr(mlp, "_sps_fp", None)
+    if packed is None or packed.key != key:
+        with torch.no_grad():
+            packed = _PackedFp()
+            packed.key, packed.c_in, packed.c1, packed.c2 = key, cin_pad, c1, c2
+            w, b = _fold(*pairs[0])
+            wp = w.new_zeros(c1, cin_pad)
+            wp[:, :c_known + c_skip] = w             # padded input channels read zeros and weigh nothing
+            packed.w1, packed.b1 = _pack_pw(wp, c1), b.contiguous()
+            packed.w2 = packed.b2 = None
+            if c2:
+                w2, b2 = _fold(*pairs[1])
+                packed.w2, packed.b2 = _pack_pw(w2, c2), b2.contiguous()
+        object.__setattr__(mlp, "_sps_fp", packed)
+    y = torch.empty((B, c2 if c2 else c1, n), dtype=torch.float32, device=known_feats.device)
+    kf, wt, ix = known_feats.contiguous(), weight.contiguous(), idx.contiguous()
+    sk = unknow_feats.contiguous() if unknow_feats is not None else None
+    _lib.check(_L.sps_fp_module_mlp(B, n, m, c_known, c_skip, c1, c2, kf.data_ptr(), sk.data_ptr() if sk is not None else 0,
+                                    ix.data_ptr(), wt.data_ptr(), packed.w1.data_ptr(), packed.b1.data_ptr(),
+                                    packed.w2.data_ptr() if c2 else 0, packed.b2.data_ptr() if c2 else 0, y.data_ptr(),
+                                    torch.cuda.current_stream(y.device).cuda_stream), "fp_module_mlp")
+    return y
+
+
 def vote_offsets(mlp, ctr_reg, parts):
     """Vote_layer's regression (pointnet2_modules.py:488-496: [Conv1d + BatchNorm1d + ReLU], Conv1d(C, 3, bias)) on the
     channel-wise concatenation of `parts` (each (B, Ci, M)) as ONE kernel -> offsets (B, M, 3), or None when the fused

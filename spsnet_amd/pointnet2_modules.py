@@ -885,6 +885,9 @@ class PointnetFPModule(nn.Module):
             dist, idx = pointnet2_utils.three_nn(unknown, known)
             inv = 1.0 / (dist + 1e-8)
             weight = inv / torch.sum(inv, dim=2, keepdim=True)
+            fused = _fused.fp_module_mlp(self.mlp, known_feats, unknow_feats, idx, weight)   # inference: one kernel
+            if fused is not None:
+                return fused
             spread = pointnet2_utils.three_interpolate(known_feats, idx, weight)
         else:
             spread = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))

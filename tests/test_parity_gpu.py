@@ -2586,3 +2586,32 @@ def test_pointnet2msg_streamed_first_layer_equals_sequential(G, dev, monkeypatch
     assert len(calls) == 1 and calls[0] is not None, "layer 0 was supposed to be streamed"
     assert not sa_stack.check_timeouts()
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("n,m,c_known,c_skip,widths", [(64, 16, 32, 16, [48, 32]), (256, 77, 20, 0, [64]), (1024, 256, 256, 1, [128, 128]),
+                                                       (48, 9, 100, 37, [16, 512]), (32, 5, 512, 512, [256, 256])])
+def test_fp_module_fused_kernel_matches_op_sequence(dev, n, m, c_known, c_skip, widths):
+    """PointnetFPModule in inference: the one-kernel form (three_interpolate + cat + [Conv2d + BatchNorm2d + ReLU] x (1 | 2),
+    csrc/pw_mlp.hip fp_mlp_kernel) against the module's own op sequence with gradients enabled (the unfused kernels, pinned
+    by the reference-generated fp_module golden): 1e-4.  No skip features, one layer, channel counts that are not multiples
+    of 16 and 1024 input channels included."""
+    from spsnet_amd import fused, pointnet2_modules as M, scenes
+    torch.manual_seed(n + c_known)
+    fp = scenes.fill_parameters(M.PointnetFPModule(mlp=[c_known + c_skip] + widths), 3).to(dev).eval()
+    unknown = torch.rand(2, n, 3, device=dev) * 4
+    known = torch.rand(2, m, 3, device=dev) * 4
+    kf = torch.randn(2, c_known, m, device=dev)
+    uf = torch.randn(2, c_skip, n, device=dev) if c_skip else None
+    calls = []
+    orig = fused.fp_module_mlp
+    fused.fp_module_mlp = lambda *a: calls.append(orig(*a)) or calls[-1]
+    try:
+        with torch.no_grad():
+            got = fp(unknown, known, uf, kf)
+        assert len(calls) == 1 and calls[0] is not None, "the fused kernel was supposed to serve this shape"
+        want = fp(unknown, known, uf, kf.clone().requires_grad_(True))      # gradients wanted: the op sequence
+        assert len(calls) == 2 and calls[1] is None
+    finally:
+        fused.fp_module_mlp = orig
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
