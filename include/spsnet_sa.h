@@ -481,7 +481,7 @@ int sps_conv1x1_wgrad(int b, int ci, int co, long long l, const float *x, const 
 
 /* PointnetFPModule.forward (pointnet2_modules.py:539-587) in inference as one kernel: three_interpolate of known_feats
  * (b, c_known, m) with idx / weight (b, n, 3), concatenation with the skip features (b, c_skip, n) (NULL when c_skip = 0),
- * then [Conv2d 1x1 + BatchNorm2d + ReLU] x (1 | 2) with BatchNorm folded; exact fp32.  y (b, c2 ? c2 : c1, n); n, c1, c2
+ * then [Conv2d 1x1 + BatchNorm2d + ReLU] x (1 | 2) with BatchNorm folded; exact fp32.  y (b, c2 ? c2 : c1, n); c1, c2
  * multiples of 16, c2 = 0 and w2 = b2 = NULL for a one-layer stack; w1 has 16 ceil((c_known + c_skip) / 16) input columns
  * (zero beyond the real ones); weights packed as for sps_pointwise_mlp. */
 int sps_fp_module_mlp(int b, int n, int m, int c_known, int c_skip, int c1, int c2, const float *known_feats, const float *skip,

@@ -185,49 +185,99 @@ struct FpArgs {
     float *y;                                    // (b, c2 ? c2 : c1, n)
 };
 
+// one 16-row output tile against NT column tiles of an LDS image [k][16 NT + 1]: the weight fragments of a 16-channel step
+// feed NT times four MFMAs (at the finest level a layer has 131 072 points: per-16-point weight streams would be 1.6 GB)
+template <int NT>
+__device__ __forceinline__ void fp_tile(const f32x4 *__restrict__ wp, const float *__restrict__ act, int k16n, int q, int c,
+                                        f32x4 (&acc)[NT]) {
+    constexpr int PITCH = 16 * NT + 1;
+    constexpr int G = 4;
+    const float *ap = act + q * PITCH + c;
+    f32x4 cur[G], nxt[G];
+    int k = 0;
+    if (k16n >= G) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) cur[u] = wp[(size_t)u * 64];
+        for (; k + G <= k16n; k += G) {
+            const bool more = k + 2 * G <= k16n;
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) nxt[u] = wp[(size_t)(k + G + u) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt] = pw_mfma(cur[u][r], ap[(16 * (k + u) + 4 * r) * PITCH + 16 * nt], acc[nt]);
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) cur[u] = nxt[u];
+            }
+        }
+    }
+    for (; k < k16n; ++k) {
+        const f32x4 w = wp[(size_t)k * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = pw_mfma(w[r], ap[(16 * k + 4 * r) * PITCH + 16 * nt], acc[nt]);
+    }
+}
+
+template <int NT>
 __global__ __launch_bounds__(64 * PW_MAX_WAVES) void fp_mlp_kernel(FpArgs a) {
     extern __shared__ float pw_lds[];
-    const int r0 = (a.cin > a.c2 ? a.cin : a.c2) * PW_PAD;
+    constexpr int PITCH = 16 * NT + 1, COLS = 16 * NT;
+    const int r0 = (a.cin > a.c2 ? a.cin : a.c2) * PITCH;
     float *xt = pw_lds, *act1 = pw_lds + r0;
-    __shared__ int s_idx[48];
-    __shared__ float s_w[48];
+    __shared__ int s_idx[3 * COLS];
+    __shared__ float s_w[3 * COLS];
     const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     const int scene = blockIdx.y;
-    const int m0 = blockIdx.x * 16;
-    if (threadIdx.x < 48) {
-        s_idx[threadIdx.x] = a.idx[((size_t)scene * a.n + m0) * 3 + threadIdx.x];
-        s_w[threadIdx.x] = a.weight[((size_t)scene * a.n + m0) * 3 + threadIdx.x];
+    const int m0 = blockIdx.x * COLS;
+    for (int e = threadIdx.x; e < 3 * COLS; e += blockDim.x) {
+        const bool in = m0 + e / 3 < a.n;
+        s_idx[e] = in ? a.idx[((size_t)scene * a.n + m0) * 3 + e] : 0;
+        s_w[e] = in ? a.weight[((size_t)scene * a.n + m0) * 3 + e] : 0.f;
     }
     __syncthreads();
-    // ---- the 16 input columns: interpolated channels, then the skip channels, then zero padding ----
+    // ---- the input columns: interpolated channels, then the skip channels, then zero padding ----
     const float *kf = a.known_feats + (size_t)scene * a.c_known * a.m;
-    for (int e = threadIdx.x; e < a.cin * 16; e += blockDim.x) {
-        const int ch = e >> 4, col = e & 15;
+    for (int e = threadIdx.x; e < a.cin * COLS; e += blockDim.x) {
+        const int ch = e / COLS, col = e - ch * COLS;
         float v = 0.f;
-        if (ch < a.c_known) {
-            const float *f = kf + (size_t)ch * a.m;
-            float t = s_w[3 * col] * f[s_idx[3 * col]];
-            t = __builtin_fmaf(s_w[3 * col + 1], f[s_idx[3 * col + 1]], t);
-            v = __builtin_fmaf(s_w[3 * col + 2], f[s_idx[3 * col + 2]], t);
-        } else if (ch < a.c_known + a.c_skip) {
-            v = a.skip[((size_t)scene * a.c_skip + (ch - a.c_known)) * a.n + m0 + col];
+        if (m0 + col < a.n) {
+            if (ch < a.c_known) {
+                const float *f = kf + (size_t)ch * a.m;
+                float t = s_w[3 * col] * f[s_idx[3 * col]];
+                t = __builtin_fmaf(s_w[3 * col + 1], f[s_idx[3 * col + 1]], t);
+                v = __builtin_fmaf(s_w[3 * col + 2], f[s_idx[3 * col + 2]], t);
+            } else if (ch < a.c_known + a.c_skip) {
+                v = a.skip[((size_t)scene * a.c_skip + (ch - a.c_known)) * a.n + m0 + col];
+            }
         }
-        xt[ch * PW_PAD + col] = v;
+        xt[ch * PITCH + col] = v;
     }
     __syncthreads();
     {
         const int k16n = a.cin / 16;
         for (int t = wv; t < a.c1 / 16; t += nw) {
-            f32x4 acc = *reinterpret_cast<const f32x4 *>(a.b1 + 16 * t + 4 * q);
-            acc = pw_tile(reinterpret_cast<const f32x4 *>(a.w1) + (size_t)t * k16n * 64 + lane, xt, k16n, q, c, acc);
+            const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.b1 + 16 * t + 4 * q);
+            f32x4 acc[NT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * t + 4 * q + r;
-                const float v = pw_relu(acc[r]);
-                if (a.c2 == 0) a.y[((size_t)scene * a.c1 + row) * a.n + m0 + c] = v;
-                else act1[row * PW_PAD + c] = v;
-            }
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = bias;
+            fp_tile<NT>(reinterpret_cast<const f32x4 *>(a.w1) + (size_t)t * k16n * 64 + lane, xt, k16n, q, c, acc);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * t + 4 * q + r, col = 16 * nt + c;
+                    const float v = pw_relu(acc[nt][r]);
+                    if (a.c2 != 0) act1[row * PITCH + col] = v;
+                    else if (m0 + col < a.n) a.y[((size_t)scene * a.c1 + row) * a.n + m0 + col] = v;
+                }
         }
     }
     if (a.c2 == 0) return;
@@ -235,18 +285,37 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void fp_mlp_kernel(FpArgs a) {
     {
         const int k16n = a.c1 / 16;
         for (int t = wv; t < a.c2 / 16; t += nw) {
-            f32x4 acc = *reinterpret_cast<const f32x4 *>(a.b2 + 16 * t + 4 * q);
-            acc = pw_tile(reinterpret_cast<const f32x4 *>(a.w2) + (size_t)t * k16n * 64 + lane, act1, k16n, q, c, acc);
+            const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.b2 + 16 * t + 4 * q);
+            f32x4 acc[NT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a.y[((size_t)scene * a.c2 + 16 * t + 4 * q + r) * a.n + m0 + c] = pw_relu(acc[r]);
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = bias;
+            fp_tile<NT>(reinterpret_cast<const f32x4 *>(a.w2) + (size_t)t * k16n * 64 + lane, act1, k16n, q, c, acc);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = 16 * nt + c;
+                    if (m0 + col < a.n) a.y[((size_t)scene * a.c2 + 16 * t + 4 * q + r) * a.n + m0 + col] = pw_relu(acc[nt][r]);
+                }
         }
     }
+}
+
+template <int NT>
+static int fp_launch(const FpArgs &a, int b, size_t lds, int waves, hipStream_t st) {
+    static LdsLimitOnce raised;
+    if (lds > 64 * 1024) {
+        const int rc = raise_lds_limit((const void *)fp_mlp_kernel<NT>, 148 * 1024, raised, "fp_module_mlp");
+        if (rc != SPS_OK) return rc;
+    }
+    hipLaunchKernelGGL(fp_mlp_kernel<NT>, dim3(divup(a.n, 16 * NT), b), dim3(64 * waves), lds, st, a);
+    return check_launch("fp_mlp_kernel");
 }
 
 }  // namespace sps
 
 // cin = c_known + c_skip rounded up to 16 (the packed w1 has cin columns, zero beyond the real ones); c1, c2 multiples of 16,
-// c2 = 0 (w2, b2 NULL) for a one-layer stack; n a multiple of 16; y (b, c2 ? c2 : c1, n).  Weights packed as for
+// c2 = 0 (w2, b2 NULL) for a one-layer stack; y (b, c2 ? c2 : c1, n).  Weights packed as for
 // sps_pointwise_mlp (BatchNorm folded, [tile][k16][lane][r]).
 extern "C" int sps_fp_module_mlp(int b, int n, int m, int c_known, int c_skip, int c1, int c2, const float *known_feats,
                                  const float *skip, const int *idx, const float *weight, const float *w1, const float *b1,
@@ -255,7 +324,7 @@ extern "C" int sps_fp_module_mlp(int b, int n, int m, int c_known, int c_skip, i
     if (b < 0 || n < 0 || m <= 0 || c_known <= 0 || c_skip < 0 || c1 <= 0 || c2 < 0)
         return fail(SPS_ERR_INVALID, "fp_module_mlp: bad shape b=%d n=%d m=%d c_known=%d c_skip=%d c1=%d c2=%d", b, n, m, c_known, c_skip, c1, c2);
     if (b == 0 || n == 0) return SPS_OK;
-    if (n % 16 || c1 % 16 || c2 % 16) return fail(SPS_ERR_INVALID, "fp_module_mlp: n, c1, c2 (%d, %d, %d) must be multiples of 16", n, c1, c2);
+    if (c1 % 16 || c2 % 16) return fail(SPS_ERR_INVALID, "fp_module_mlp: c1, c2 (%d, %d) must be multiples of 16", c1, c2);
     if (!known_feats || !idx || !weight || !w1 || !b1 || !y || (c_skip > 0 && !skip) || (c2 > 0 && (!w2 || !b2)))
         return fail(SPS_ERR_INVALID, "fp_module_mlp: null pointer");
     if (b > 65535) return fail(SPS_ERR_INVALID, "fp_module_mlp: batch %d exceeds the grid limit", b);
@@ -263,18 +332,19 @@ extern "C" int sps_fp_module_mlp(int b, int n, int m, int c_known, int c_skip, i
     a.n = n; a.m = m; a.c_known = c_known; a.c_skip = c_skip; a.cin = 16 * divup(c_known + c_skip, 16); a.c1 = c1; a.c2 = c2;
     a.known_feats = known_feats; a.skip = skip; a.idx = idx; a.weight = weight; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = y;
     const int wide = c2 > a.cin ? c2 : a.cin;
-    const size_t lds = sizeof(float) * (size_t)PW_PAD * ((size_t)wide + (c2 ? c1 : 0));
+    const size_t rows = (size_t)wide + (c2 ? c1 : 0);
+    // as many 16-point column tiles per workgroup as the LDS images allow (the weights stream once per workgroup)
+    int nt = 4;
+    while (nt > 1 && (sizeof(float) * (16 * nt + 1) * rows > 140 * 1024 || 16 * (nt / 2) >= n)) nt >>= 1;
+    const size_t lds = sizeof(float) * (size_t)(16 * nt + 1) * rows;
     if (lds > 148 * 1024) return fail(SPS_ERR_INVALID, "fp_module_mlp: widths (%d, %d, %d) need more LDS than a workgroup has", a.cin, c1, c2);
-    static LdsLimitOnce raised;
-    if (lds > 64 * 1024) {
-        const int rc = raise_lds_limit((const void *)fp_mlp_kernel, 148 * 1024, raised, "fp_module_mlp");
-        if (rc != SPS_OK) return rc;
-    }
     int tiles = c1 / 16;
     if (c2 / 16 > tiles) tiles = c2 / 16;
     const int waves = tiles < 4 ? 4 : (tiles > PW_MAX_WAVES ? PW_MAX_WAVES : tiles);
-    hipLaunchKernelGGL(fp_mlp_kernel, dim3(n / 16, b), dim3(64 * waves), lds, as_stream(stream), a);
-    return check_launch("fp_mlp_kernel");
+    hipStream_t st = as_stream(stream);
+    if (nt == 4) return fp_launch<4>(a, b, lds, waves, st);
+    if (nt == 2) return fp_launch<2>(a, b, lds, waves, st);
+    return fp_launch<1>(a, b, lds, waves, st);
 }
 
 extern "C" int sps_pointwise_mlp_range(int b, int m, int j0, int jcount, int cin, int c1, int c2, int c3_real, const float *x,

@@ -482,7 +482,7 @@ def fp_module_mlp(mlp, known_feats, unknow_feats, idx, weight):
     """PointnetFPModule.forward behind its three_nn (reference :571-587): interpolation of `known_feats` (B, C2, m) with
     idx / weight (B, n, 3), concatenation with `unknow_feats` (B, C1, n) | None and the [Conv2d 1x1 + BatchNorm2d + ReLU]
     stack (one or two layers), as ONE kernel (csrc/pw_mlp.hip fp_mlp_kernel, exact fp32, BatchNorm folded) -> (B, Cout, n),
-    or None when the fused path does not apply (training, gradients wanted, widths / n not multiples of 16, ...)."""
+    or None when the fused path does not apply (training, gradients wanted, widths not multiples of 16, ...)."""
     mods = list(mlp)
     if len(mods) not in (3, 6) or mlp.training or not known_feats.is_cuda or known_feats.dtype != torch.float32:
         return None
@@ -501,7 +501,7 @@ def fp_module_mlp(mlp, known_feats, unknow_feats, idx, weight):
     c1 = pairs[0][0].out_channels
     c2 = pairs[1][0].out_channels if len(pairs) > 1 else 0
     cin_pad = _pad16(c_known + c_skip)
-    if (pairs[0][0].in_channels != c_known + c_skip or c1 % 16 or c2 % 16 or n % 16 or n == 0 or B > 65535
+    if (pairs[0][0].in_channels != c_known + c_skip or c1 % 16 or c2 % 16 or n == 0 or B > 65535
             or (unknow_feats is not None and (unknow_feats.dtype != torch.float32 or unknow_feats.shape[2] != n))
             or 17 * 4 * (max(cin_pad, c2) + (c1 if c2 else 0)) > 148 * 1024):
         return None

@@ -2589,7 +2589,8 @@ def test_pointnet2msg_streamed_first_layer_equals_sequential(G, dev, monkeypatch
 
 
 @pytest.mark.parametrize("n,m,c_known,c_skip,widths", [(64, 16, 32, 16, [48, 32]), (256, 77, 20, 0, [64]), (1024, 256, 256, 1, [128, 128]),
-                                                       (48, 9, 100, 37, [16, 512]), (32, 5, 512, 512, [256, 256])])
+                                                       (48, 9, 100, 37, [16, 512]), (32, 5, 512, 512, [256, 256]), (1000, 300, 64, 3, [32, 32]),
+                                                       (7, 4, 16, 0, [16])])
 def test_fp_module_fused_kernel_matches_op_sequence(dev, n, m, c_known, c_skip, widths):
     """PointnetFPModule in inference: the one-kernel form (three_interpolate + cat + [Conv2d + BatchNorm2d + ReLU] x (1 | 2),
     csrc/pw_mlp.hip fp_mlp_kernel) against the module's own op sequence with gradients enabled (the unfused kernels, pinned
