@@ -128,6 +128,9 @@ FUSED_MLP_TRAINING = os.environ.get("SPS_FUSED_MLP_TRAINING", "1") != "0"
 # measured NOT to pay at the IA-SSD shapes -- these tensors are 2-8 MB, the stack is launch-bound either way, and the fused
 # form needs more launches than torch's (8.46 vs 8.31 ms per training step of SA layers 0-2).  Opt-in.
 FUSED_POINTWISE_TRAINING = os.environ.get("SPS_FUSED_POINTWISE_TRAINING", "0") != "0"
+# PointnetFPModule in training: its stack runs on the fused train-mode kernels from this many input elements on (below, the
+# stack is launch-bound either way, as the aggregation stacks are)
+FUSED_FP_TRAINING_MIN = int(os.environ.get("SPS_FUSED_FP_TRAINING_MIN", str(1 << 21)))
 # training: the scales of a layer on streams of their own (see _group_mlp_pool) -- measured SLOWER (8.72 vs 8.29 ms per step:
 # every fork / join is a cross-stream dependency that is actually waited for, ~12 us each, and the big kernels of both
 # chains are memory-bound and only share the bandwidth); kept as a switch, off
@@ -180,6 +183,7 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
             out = _ext.tbn_apply_relu(ys[-1], ps[-1])
             arg = yarg = out.new_empty((0,))
         ctx.n, ctx.ns, ctx.count, ctx.pool = n, ns, count, pool
+        ctx.wshapes = [tuple(wgb[3 * k].shape) for k in range(n)]
         ctx.save_for_backward(x, arg, yarg, *ys, *ps, *ws, *was)
         return out
 
@@ -206,7 +210,7 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
             if ctx.needs_input_grad[3 + 3 * k]:
                 src = dict(gout=gout, arg=arg, nsample=ns) if routed else dict(dA=dA)
                 dw = _ext.twgrad(ys[k], ps[k], ys[k - 1] if k else x, ps[k - 1] if k else None, amax[k:], overflow=flag, **src)
-                grads[3 * k] = dw.view(wgb_shape(ctx, k, dw))
+                grads[3 * k] = dw.view(ctx.wshapes[k])
             din = dict(gout=gout, arg=arg, nsample=ns) if routed else dict(operand=dA)
             mode = _ext.TIN_BNBWD_POOL if routed else _ext.TIN_BNBWD
             if k > 0:
@@ -222,15 +226,12 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
         return (None, None, dx) + tuple(grads)
 
 
-def wgb_shape(ctx, k, dw):
-    """(co, ci) -> the convolution weight's own shape: (co, ci, 1, 1) for Conv2d, (co, ci, 1) for Conv1d"""
-    return (dw.shape[0], dw.shape[1], 1, 1) if ctx.pool else (dw.shape[0], dw.shape[1], 1)
-
-
 def _fused_stack_train(mods, x, pool: bool):
     """[conv 1x1 (no bias), BatchNorm on batch statistics, ReLU] x n (+ max over the last axis when pool) through
     _GroupedMLPPoolTrain, or None when the modules / shapes do not qualify.  mods: the flat module list."""
-    conv_t, bn_t = (nn.Conv2d, nn.BatchNorm2d) if pool else (nn.Conv1d, nn.BatchNorm1d)
+    # pool: Conv2d / BatchNorm2d on (B, C, M, ns); without: Conv1d / BatchNorm1d, or Conv2d 1x1 / BatchNorm2d (the
+    # feature-propagation stacks, which the reference applies to (B, C, N, 1)), on a (B, C, L) tensor
+    conv_t, bn_t = (nn.Conv2d, nn.BatchNorm2d) if pool else ((nn.Conv1d, nn.Conv2d), (nn.BatchNorm1d, nn.BatchNorm2d))
     if not (FUSED_MLP_TRAINING and _fused.PRECISION != "fp32" and x.is_cuda and x.dtype == torch.float32
             and x.dim() == (4 if pool else 3) and torch.is_grad_enabled()):
         return None
@@ -892,6 +893,11 @@ class PointnetFPModule(nn.Module):
         else:
             spread = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         stacked = torch.cat([spread, unknow_feats], dim=1) if unknow_feats is not None else spread
+        if self.mlp.training and stacked.numel() >= FUSED_FP_TRAINING_MIN:
+            # training at the resolution of a fine level: the stack on the fused train-mode kernels (no pool behind it)
+            out = _fused_stack_train(list(self.mlp), stacked.contiguous(), False)
+            if out is not None:
+                return out
         return self.mlp(stacked.unsqueeze(-1)).squeeze(-1)
 
 

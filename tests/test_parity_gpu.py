@@ -2616,3 +2616,35 @@ def test_fp_module_fused_kernel_matches_op_sequence(dev, n, m, c_known, c_skip, 
         fused.fp_module_mlp = orig
     assert got.shape == want.shape
     assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+
+
+def test_fp_module_training_on_fused_kernels_matches_torch(dev, monkeypatch):
+    """PointnetFPModule in train() mode with its [Conv2d 1x1, BatchNorm2d, ReLU] stack on the fused train-mode kernels
+    (no pool) against the module's plain torch op sequence: output, running statistics and every gradient (incl. the
+    gradient that flows back through the interpolation into the coarse features)."""
+    import copy
+    from spsnet_amd import pointnet2_modules as M, scenes
+    torch.manual_seed(5)
+    fp = scenes.fill_parameters(M.PointnetFPModule(mlp=[40 + 9, 64, 32]), 2).to(dev).train()
+    ref = copy.deepcopy(fp)
+    unknown = torch.rand(2, 2048, 3, device=dev) * 4
+    known = torch.rand(2, 256, 3, device=dev) * 4
+    kf0 = torch.randn(2, 40, 256, device=dev)
+    uf0 = torch.randn(2, 9, 2048, device=dev)
+    wout = torch.randn(2, 32, 2048, device=dev) * 1e-3
+    res = []
+    for mod, fused_on in ((fp, True), (ref, False)):
+        monkeypatch.setattr(M, "FUSED_FP_TRAINING_MIN", 0 if fused_on else 1 << 62)
+        calls = []
+        orig = M._fused_stack_train
+        monkeypatch.setattr(M, "_fused_stack_train", lambda *a: calls.append(orig(*a)) or calls[-1])
+        kf, uf = kf0.clone().requires_grad_(True), uf0.clone().requires_grad_(True)
+        out = mod(unknown, known, uf, kf)
+        (out * wout).sum().backward()
+        monkeypatch.setattr(M, "_fused_stack_train", orig)
+        assert (len(calls) == 1 and calls[0] is not None) == fused_on
+        res.append([out.detach(), kf.grad, uf.grad] + [p.grad for p in mod.parameters()] + [b.detach().float() for b in mod.buffers()])
+    torch.cuda.synchronize()
+    for a, b in zip(*res):
+        err = float((a - b).abs().max())
+        assert err <= 2e-5 * max(1e-30, float(b.abs().max())) + 1e-12, (err, float(b.abs().max()))

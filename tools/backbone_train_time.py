@@ -17,8 +17,24 @@ xyz, feats = scenes.make_batch("kitti-lidar-v1", B, N, seed0=1)
 bidx = np.repeat(np.arange(B, dtype=np.float32), N)[:, None]
 points = torch.from_numpy(np.concatenate([bidx, xyz.reshape(-1, 3), feats.transpose(0, 2, 1).reshape(-1, 1)], 1).astype(np.float32)).to(dev)
 stds = torch.from_numpy(np.random.default_rng(0).uniform(0, 40, (B, N)).astype(np.float32)).to(dev)
-for tag, cls, cfg in (("IASSD_Backbone", BB.IASSD_Backbone, BB.IASSD_KITTI_CFG), ("PAGNet_Backbone", BB.PAGNet_Backbone, BB.SPSNET_KITTI_CFG)):
+for tag, cls, cfg in (("IASSD_Backbone", BB.IASSD_Backbone, BB.IASSD_KITTI_CFG), ("PAGNet_Backbone", BB.PAGNet_Backbone, BB.SPSNET_KITTI_CFG),
+                      ("PointNet2MSG", BB.PointNet2MSG, BB.POINTRCNN_KITTI_CFG)):
     if only and not tag.startswith(only):
+        continue
+    if tag == "PointNet2MSG":       # (PointRCNN's backbone: per-point features out, no votes / class scores)
+        net = scenes.fill_parameters(cls(cfg, input_channels=4), 5).to(dev).train()
+        def step():
+            for p in net.parameters():
+                p.grad = None
+            net(dict(batch_size=B, points=points))["point_features"].square().mean().backward()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        print(f"{tag:16s} training step {B}x{N}: {1e3 * (time.perf_counter() - t0) / reps:7.2f} ms", flush=True)
         continue
     for fused_fe in ((True, False) if tag.startswith("PAG") and not only else (True,)):
         SF.FUSED_TRAINING = fused_fe
