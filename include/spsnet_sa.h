@@ -499,7 +499,7 @@ int sps_fp_module_mlp(int b, int n, int m, int c_known, int c_skip, int c1, int 
  * c1 = mean(dZ), c2 = mean(dZ xhat)}; sps_tbn_finalize writes the first six from the statistics, sps_tbn_bwd_finalize the last
  * two (plus d gamma, d beta).
  *
- * sps_tconv: out (b, co, l) = A . T(in), A[o][i] = trans ? w[i co + o] : w[o ci + i], ci <= 256.
+ * sps_tconv: out (b, co, l) = A . T(in), A[o][i] = trans ? w[i co + o] : w[o ci + i], ci <= 288.
  *   in_mode 0: T = identity                     1: T = relu(fma(in, scale, shift))   (pin = params of the input rows)
  *           2: T = scale (dZ - c1 - xhat c2), dZ = in [fma(in2, scale, shift) > 0], xhat = (in2 - mean) invstd
  *           3: as 2 with `in` = the pooled gradient gout (b, ci, m) routed by arg (b, ci, m) u8 (nsample % 4 == 0)

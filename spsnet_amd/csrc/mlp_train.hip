@@ -869,7 +869,7 @@ extern "C" int sps_tconv(int b, int ci, int co, long long l, int in_mode, int ep
                          const float *in2, const float *gout, const unsigned char *arg, int nsample, int m, const float *pin,
                          float *out, const float *epi_y, const float *pout, double *partial, const float *amax_in,
                          float *amax_out, const float *wamax, int *overflow, sps_stream_t stream) {
-    if (b < 0 || ci <= 0 || co <= 0 || l < 0 || ci > 256) return fail(SPS_ERR_INVALID, "tconv: bad shape b=%d ci=%d co=%d l=%lld", b, ci, co, l);
+    if (b < 0 || ci <= 0 || co <= 0 || l < 0 || ci > 288) return fail(SPS_ERR_INVALID, "tconv: bad shape b=%d ci=%d co=%d l=%lld", b, ci, co, l);
     if (b == 0 || l == 0) return SPS_OK;
     if (l % 64) return fail(SPS_ERR_INVALID, "tconv: l = %lld must be a multiple of 64", l);
     if (in_mode < TIN_RAW || in_mode > TIN_BNBWD_POOL || epi_mode < TEPI_NONE || epi_mode > TEPI_BWD)
@@ -887,7 +887,7 @@ extern "C" int sps_tconv(int b, int ci, int co, long long l, int in_mode, int ep
     hipStream_t st = as_stream(stream);
     if (co <= 16) return tconv_launch_in<1>(a, in_mode, epi_mode, st);
     if (co <= 32) return tconv_launch_in<2>(a, in_mode, epi_mode, st);
-    if (co <= 64) return tconv_launch_in<4>(a, in_mode, epi_mode, st);
+    if (co <= 64 || a.S > 8) return tconv_launch_in<4>(a, in_mode, epi_mode, st);   // (nine k-steps: 128 rows of weights would not fit the LDS)
     return tconv_launch_in<8>(a, in_mode, epi_mode, st);        // 128 rows per workgroup (blockIdx.z walks the rest)
 }
 

@@ -474,6 +474,63 @@ def pointwise_tail(agg, head, pooled, half_out=False, x_pm=False):
     return runner.result()
 
 
+class _PackedGeneric:
+    __slots__ = ("key", "ws", "wamax", "params")
+
+
+def generic_mlp_pool(mlp, grouped):
+    """max over the samples of [Conv2d 1x1 + BatchNorm2d(eval) + ReLU] x n on a grouped tensor (B, C0, M, ns) for stacks NO
+    specialised kernel serves (widths outside the IA-SSD / SPSNet table, any depth): the streaming convolution kernels of
+    csrc/mlp_train.hip with the BatchNorm of the running statistics applied in the next layer's operand load and in the
+    pool (split-fp16 MFMA, <= 2e-5 relative) -- n + 1 launches and two HBM crossings per activation instead of torch's
+    3 n + 1 launches and five.  -> (B, Cn, M), or None when it does not apply (training, gradients wanted, fp32 mode, more
+    than 288 input channels of a layer, nsample outside {4, 8, 16, 32, 64}, M * ns not a multiple of 64)."""
+    from . import pointnet2_batch_cuda as _ext
+    mods = list(mlp)
+    if (PRECISION == "fp32" or len(mods) % 3 or not mods or mlp.training or not grouped.is_cuda or grouped.dtype != torch.float32
+            or grouped.dim() != 4):
+        return None
+    B, c0, M, ns = grouped.shape
+    if ns not in (4, 8, 16, 32, 64) or (M * ns) % 64 or c0 > 288 or grouped.numel() == 0:
+        return None
+    pairs = []
+    for conv, bn, act in zip(mods[0::3], mods[1::3], mods[2::3]):
+        if not (isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and isinstance(act, nn.ReLU)
+                and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and conv.bias is None
+                and bn.track_running_stats and bn.affine and conv.in_channels <= 288 and conv.out_channels <= 1024
+                and conv.weight.dtype == torch.float32):
+            return None
+        pairs.append((conv, bn))
+    if torch.is_grad_enabled() and (grouped.requires_grad or any(p.requires_grad for p in mlp.parameters())):
+        return None
+    key = _version_key(pairs, grouped.device)
+    packed = getattr(mlp, "_sps_generic", None)
+    if packed is None or packed.key != key:
+        with torch.no_grad():
+            packed = _PackedGeneric()
+            packed.key = key
+            packed.ws = [c.weight.detach().reshape(c.out_channels, c.in_channels).contiguous() for c, _ in pairs]
+            packed.wamax = _ext.weights_amax(packed.ws)
+            packed.params = []
+            for _, bn in pairs:
+                invstd = 1.0 / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+                scale = bn.weight.detach().float() * invstd
+                shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+                zero = torch.zeros_like(scale)
+                packed.params.append(torch.stack([bn.running_mean.detach().float(), invstd, scale, shift, bn.weight.detach().float(),
+                                                  bn.bias.detach().float(), zero, zero], dim=1).contiguous())
+        object.__setattr__(mlp, "_sps_generic", packed)
+    flag = _overflow_flag(grouped.device)
+    operand, pin, mode = grouped.contiguous(), None, _ext.TIN_RAW
+    with _ext.launch_scope(operand):
+        for k, w in enumerate(packed.ws):
+            y = torch.empty((B, w.shape[0], M, ns), dtype=torch.float32, device=grouped.device)
+            _ext.tconv(w, packed.wamax[k:k + 1], mode, _ext.TEPI_NONE, y, operand=operand, pin=pin, overflow=flag)
+            operand, pin, mode = y, packed.params[k], _ext.TIN_BNRELU
+        out, _, _ = _ext.tpool_fwd(operand, pin)
+    return out
+
+
 class _PackedFp:
     __slots__ = ("key", "c_in", "c1", "c2", "w1", "b1", "w2", "b2")
 

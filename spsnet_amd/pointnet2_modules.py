@@ -396,6 +396,8 @@ class _PointnetSAModuleBase(nn.Module):
             else:
                 grouped = grouper(xyz, new_xyz, features)      # (B, C, M, ns)
             pooled = _fused_mlp_pool_train(mlp, grouped, self.pool_method)
+            if pooled is None and self.pool_method == 'max_pool' and not mlp.training:
+                pooled = _fused.generic_mlp_pool(mlp, grouped)     # inference at widths no specialised kernel serves
             return pooled if pooled is not None else _pool_over_samples(_shared_mlp(mlp, grouped), self.pool_method)
 
         side = self._scale_streams(xyz) if (SCALES_ON_STREAMS and self.training and xyz.is_cuda and idxs is not None

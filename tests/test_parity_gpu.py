@@ -2648,3 +2648,22 @@ def test_fp_module_training_on_fused_kernels_matches_torch(dev, monkeypatch):
     for a, b in zip(*res):
         err = float((a - b).abs().max())
         assert err <= 2e-5 * max(1e-30, float(b.abs().max())) + 1e-12, (err, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("B,M,ns,widths", [(2, 64, 16, [259, 128, 196, 256]), (2, 128, 32, [20, 40, 24]), (1, 32, 8, [7, 100]),
+                                           (2, 32, 32, [288, 272, 384])])
+def test_generic_eval_mlp_pool_matches_torch(dev, B, M, ns, widths):
+    """fused.generic_mlp_pool (inference at widths outside the specialised kernels' table: the streaming convolution kernels
+    with the running-statistics BatchNorm applied in the operand loads and the pool) against torch's eval-mode op sequence:
+    1e-4 (the arithmetic is split-fp16, <= 2e-5)."""
+    from spsnet_amd import fused, pointnet2_modules as PM, scenes
+    torch.manual_seed(M + ns)
+    mlp = scenes.fill_parameters(PM._conv_bn_relu_stack(list(widths), torch.nn.Conv2d, torch.nn.BatchNorm2d), 6).to(dev).eval()
+    x = torch.randn(B, widths[0], M, ns, device=dev)
+    with torch.no_grad():
+        got = fused.generic_mlp_pool(mlp, x)
+        want = mlp(x).max(dim=3)[0]
+    assert got is not None and got.shape == want.shape
+    assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+    assert not fused.check_overflow()
+    assert fused.generic_mlp_pool(mlp, x.clone().requires_grad_(True)) is None      # gradients wanted: declined
