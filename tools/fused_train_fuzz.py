@@ -31,12 +31,18 @@ for case in range(cases):
     x0 = torch.randn(B, widths[0], M, ns) * float(rng.uniform(0.1, 5)) + float(rng.uniform(-1, 1))
     wout = torch.randn(B, widths[-1], M) * gscale
     xr = x0.double().requires_grad_(True)
-    yr = ref(xr)
+    yr, cond = xr, 0.0
+    for mod in ref:      # conditioning of the BatchNorms: |mean| / std of the pre-activation (the kernels' error is relative to |y|)
+        yr = mod(yr)
+        if isinstance(mod, torch.nn.Conv2d):
+            yd = yr.detach()
+            cond = max(cond, float((yd.mean(dim=(0, 2, 3)).abs() / yd.std(dim=(0, 2, 3)).clamp_min(1e-12)).max()))
     out_r = yr.max(dim=3)[0]
     (out_r * wout.double()).sum().backward()
     # near-ties of the arg-max (top two within 1e-5 relative) make the gradient routing ill-defined: skip such cases
     top2 = yr.detach().topk(2, dim=3)[0] if ns > 1 else None
-    tie = bool(((top2[..., 0] - top2[..., 1]).abs() <= 1e-5 * top2[..., 0].abs().clamp_min(1e-3)).any() & (top2[..., 0] > 0).any())
+    # (the kernels' 22-bit arithmetic is accurate relative to the LARGEST activation, so the gap is measured against that)
+    tie = bool((((top2[..., 0] - top2[..., 1]) <= 2e-5 * (1.0 + cond) * float(yr.detach().abs().max())) & (top2[..., 0] > 0)).any())
     xg = x0.to(dev).requires_grad_(True)
     got = PM._fused_mlp_pool_train(mlp, xg, 'max_pool')
     assert got is not None, (B, M, ns, widths)
@@ -50,6 +56,6 @@ for case in range(cases):
         worst[name] = max(worst.get(name, 0.0), err)
         if err > 5e-5:
             bad += 1
-            print("MISS", name, f"{err:.2e}", dict(B=B, M=M, ns=ns, widths=widths, gscale=gscale, tie=tie), flush=True)
+            print("MISS", name, f"{err:.2e}", dict(B=B, M=M, ns=ns, widths=widths, gscale=gscale, tie=tie, cond=round(cond, 1)), flush=True)
 print("cases", cases, "worst relative errors:", {k: f"{v:.1e}" for k, v in worst.items()}, "misses", bad, flush=True)
 sys.exit(1 if bad else 0)
