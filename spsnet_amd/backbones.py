@@ -351,6 +351,7 @@ SPSNET_KITTI_CFG['SA_CONFIG'].update(
 SPSNET_KITTI_CFG['SA_CONFIG']['MLPS'][1] = [[124, 64, 128], [124, 96, 128]]
 
 
+SEARCH_BESIDE_ENCODER = True  # PointNet2MSG inference: the decoder's 3-NN searches run beside the encoder
 STREAM_FIRST_LAYER = True     # PointNet2MSG inference: layer 0 consumes its FPS picks while FPS runs (tests switch it off to compare)
 
 # tools/cfgs/kitti_models/pointrcnn.yaml: BACKBONE_3D of PointRCNN (the reference's other point-based detector)
@@ -413,6 +414,22 @@ class PointNet2MSG(nn.Module):
             return pointnet2_modules._ext.gather_xyz(cloud, idx)
         return pointnet2_utils.gather_operation(cloud.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
 
+    def _search_beside(self, unknown, known):
+        """three_nn(unknown, known) on a side stream -> (dist, idx, event)"""
+        dev = unknown.device
+        main = torch.cuda.current_stream(dev)
+        side = sa_stack._helper_stream(dev, "search")
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for t in (unknown, known):
+            t.record_stream(side)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            done = torch.cuda.Event()
+            done.record(side)
+        return dist, idx, done
+
     def forward(self, batch_dict):
         batch_size = batch_dict['batch_size']
         points = batch_dict['points']
@@ -424,6 +441,10 @@ class PointNet2MSG(nn.Module):
             feats = points[:, 4:].contiguous().view(batch_size, -1, points.size(-1) - 4).permute(0, 2, 1).contiguous()
         level_xyz, level_feats = [xyz], [feats]
         early = xyz.is_cuda          # sampling carries no gradient: the early start applies in training too
+        # the decoder's 3-NN searches need coordinates only: each starts on a side stream the moment its two levels exist and
+        # runs beside the encoder (inference; 0.33 ms of the forward at 8 x 16 384)
+        beside = xyz.is_cuda and not torch.is_grad_enabled() and SEARCH_BESIDE_ENCODER
+        searches = []
         for k, layer in enumerate(self.SA_modules):
             nxt = self.SA_modules[k + 1] if k + 1 < len(self.SA_modules) else None
             if (k == 0 and early and STREAM_FIRST_LAYER and not torch.is_grad_enabled() and layer.npoint is not None
@@ -435,6 +456,7 @@ class PointNet2MSG(nn.Module):
                 if res is not None:
                     level_xyz.append(res[0])
                     level_feats.append(res[1])
+                    searches.append(self._search_beside(level_xyz[k], level_xyz[k + 1]) if beside else None)
                     continue
             new_xyz = self._centroids(layer, level_xyz[k]) if layer.npoint is not None else None
             if (early and new_xyz is not None and nxt is not None and nxt.npoint is not None
@@ -443,11 +465,23 @@ class PointNet2MSG(nn.Module):
                 # prefix up to exact distance ties (fps_verify.hip checks it in parallel), started now on a side stream
                 # beside this layer's ball queries and grouped MLPs
                 sa_stack._prefetch_dfps(_DfpsShim(nxt), new_xyz, fps_ordered=nxt.npoint <= pointnet2_modules._ext.ORDERED_PREFIX_MAX)
+            if beside and new_xyz is not None and k < len(self.FP_modules):
+                searches.append(self._search_beside(level_xyz[k], new_xyz))    # before the layer's own kernels are enqueued
+            else:
+                searches.append(None)
             li_xyz, li_feats = layer(level_xyz[k], level_feats[k], new_xyz=new_xyz)
             level_xyz.append(li_xyz)
             level_feats.append(li_feats)
         for k in range(len(self.FP_modules) - 1, -1, -1):
-            level_feats[k] = self.FP_modules[k](level_xyz[k], level_xyz[k + 1], level_feats[k], level_feats[k + 1])
+            nn_k = None
+            if k < len(searches) and searches[k] is not None:
+                dist, idx, done = searches[k]
+                main = torch.cuda.current_stream(xyz.device)
+                main.wait_event(done)
+                dist.record_stream(main)
+                idx.record_stream(main)
+                nn_k = (dist, idx)
+            level_feats[k] = self.FP_modules[k](level_xyz[k], level_xyz[k + 1], level_feats[k], level_feats[k + 1], neighbours=nn_k)
         point_features = level_feats[0].permute(0, 2, 1).contiguous()
         batch_dict['point_features'] = point_features.view(-1, point_features.shape[-1])
         batch_dict['point_coords'] = torch.cat((batch_idx[:, None].float(), xyz.view(-1, 3)), dim=1)

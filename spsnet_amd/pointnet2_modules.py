@@ -882,10 +882,12 @@ class PointnetFPModule(nn.Module):
         self.mlp = _conv_bn_relu_stack(list(mlp), nn.Conv2d, nn.BatchNorm2d)
 
     def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
-                known_feats: torch.Tensor) -> torch.Tensor:
-        """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n), known_feats (B,C2,m) -> (B,mlp[-1],n)."""
+                known_feats: torch.Tensor, neighbours=None) -> torch.Tensor:
+        """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n), known_feats (B,C2,m) -> (B,mlp[-1],n).
+        neighbours: (dist, idx) of three_nn(unknown, known) when the caller already has them (the search needs coordinates
+        only, so a backbone can run it beside the encoder: backbones.PointNet2MSG)."""
         if known is not None:
-            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            dist, idx = neighbours if neighbours is not None else pointnet2_utils.three_nn(unknown, known)
             inv = 1.0 / (dist + 1e-8)
             weight = inv / torch.sum(inv, dim=2, keepdim=True)
             fused = _fused.fp_module_mlp(self.mlp, known_feats, unknow_feats, idx, weight)   # inference: one kernel
