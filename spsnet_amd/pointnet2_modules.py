@@ -137,6 +137,30 @@ FUSED_FP_TRAINING_MIN = int(os.environ.get("SPS_FUSED_FP_TRAINING_MIN", str(1 <<
 SCALES_ON_STREAMS = os.environ.get("SPS_SCALES_ON_STREAMS", "0") != "0"
 
 
+def _sync_group(bn):
+    """(process group, world size) when `bn` is a SyncBatchNorm that really synchronises in this process, else (None, 1)"""
+    if not isinstance(bn, nn.SyncBatchNorm):
+        return None, 1
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None, 1
+    group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    world = dist.get_world_size(group)
+    return (group, world) if world > 1 or _SYNC_ALWAYS else (None, 1)
+
+
+_SYNC_ALWAYS = False      # tests: take the synchronised code path in a one-process group too
+
+
+def _all_reduce_sums(partial, group):
+    """(parts, C, 2) local partial sums -> ((1, C, 2) sums over ALL ranks of `group`, (C, 2) local sums)"""
+    import torch.distributed as dist
+    local = partial.sum(dim=0)
+    total = local.clone()
+    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    return total.unsqueeze(0).contiguous(), local
+
+
 class _GroupedMLPPoolTrain(torch.autograd.Function):
     """pool=True: max_s relu(bn_n(conv_n(... relu(bn_1(conv_1(x)))))) for a (B, C0, M, ns) grouped tensor in train() mode ->
     (B, Cn, M); pool=False: the same stack without the pool on a (B, C0, L) tensor -> (B, Cn, L) (the aggregation /
@@ -164,7 +188,7 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
         ns = tail[1] if pool else 1
         count = x.numel() // x.shape[1]
         flag = _fused._overflow_flag(x.device)
-        ys, ps = [], []
+        ys, ps, syncs = [], [], []
         ws = [wgb[3 * k].detach().reshape(wgb[3 * k].shape[0], wgb[3 * k].shape[1]).contiguous() for k in range(n)]
         wamax = _ext.weights_amax(ws)          # (the kernels scale the weights by a power of two derived from it)
         was = [wamax[k:k + 1] for k in range(n)]
@@ -174,7 +198,11 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
             y = torch.empty((B, w.shape[0]) + tail, dtype=torch.float32, device=x.device)
             partial = _ext.tconv(w, was[k], mode, _ext.TEPI_STATS, y, operand=operand, pin=pin, overflow=flag)
             params = torch.empty((w.shape[0], _ext.TRAIN_PARAMS), dtype=torch.float32, device=x.device)
-            _ext.tbn_finalize(partial, count, bn, params)      # (also counts the batch: num_batches_tracked += 1)
+            group, world = _sync_group(bn)
+            if group is not None:        # SyncBatchNorm: the statistics of the whole (equally sharded) global batch
+                partial, _ = _all_reduce_sums(partial, group)
+            _ext.tbn_finalize(partial, count * world, bn, params)      # (also counts the batch: num_batches_tracked += 1)
+            syncs.append((group, world))
             ys.append(y); ps.append(params)
             operand, pin, mode = y, params, _ext.TIN_BNRELU
         if pool:
@@ -184,6 +212,7 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
             arg = yarg = out.new_empty((0,))
         ctx.n, ctx.ns, ctx.count, ctx.pool = n, ns, count, pool
         ctx.wshapes = [tuple(wgb[3 * k].shape) for k in range(n)]
+        ctx.syncs = syncs
         ctx.save_for_backward(x, arg, yarg, *ys, *ps, *ws, *was)
         return out
 
@@ -203,7 +232,17 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
         # the dense incoming gradient of a stack without a pool
         last = (_ext.tpool_bwd_stats(yarg, gout, ps[-1], amax_out=amax[n - 1:]) if pool
                 else _ext.tbn_bwd_stats(ys[-1], gout, ps[-1], amax_out=amax[n - 1:]))
-        grads[3 * n - 2], grads[3 * n - 1] = _ext.tbn_bwd_finalize(last, count, ps[-1])
+        def finalize_bwd(partial, k):
+            """BatchNorm-backward sums of layer k -> ps[k][:, 6:8] (means over the GLOBAL batch under SyncBatchNorm) and the
+            (local) gradients of its weight and bias, as torch's SyncBatchNorm returns them"""
+            group, world = ctx.syncs[k]
+            if group is None:
+                return _ext.tbn_bwd_finalize(partial, count, ps[k])
+            total, local = _all_reduce_sums(partial, group)
+            _ext.tbn_bwd_finalize(total, count * world, ps[k])
+            return local[:, 1].float(), local[:, 0].float()
+
+        grads[3 * n - 2], grads[3 * n - 1] = finalize_bwd(last, n - 1)
         dA, dx = (None if pool else gout), None
         for k in range(n - 1, -1, -1):
             routed = pool and k == n - 1            # the incoming gradient is the pooled one, routed by the arg-max in the load
@@ -217,7 +256,7 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
                 prev = torch.empty_like(ys[k - 1])
                 partial = _ext.tconv(ws[k], was[k], mode, _ext.TEPI_BWD, prev, y=ys[k], pin=ps[k], epi_y=ys[k - 1], pout=ps[k - 1],
                                      transposed=True, overflow=flag, amax_in=amax[k:], amax_out=amax[k - 1:], **din)
-                grads[3 * k - 2], grads[3 * k - 1] = _ext.tbn_bwd_finalize(partial, count, ps[k - 1])
+                grads[3 * k - 2], grads[3 * k - 1] = finalize_bwd(partial, k - 1)
                 dA = prev
             elif ctx.needs_input_grad[2]:
                 dx = torch.empty_like(x)
@@ -231,7 +270,9 @@ def _fused_stack_train(mods, x, pool: bool):
     _GroupedMLPPoolTrain, or None when the modules / shapes do not qualify.  mods: the flat module list."""
     # pool: Conv2d / BatchNorm2d on (B, C, M, ns); without: Conv1d / BatchNorm1d, or Conv2d 1x1 / BatchNorm2d (the
     # feature-propagation stacks, which the reference applies to (B, C, N, 1)), on a (B, C, L) tensor
-    conv_t, bn_t = (nn.Conv2d, nn.BatchNorm2d) if pool else ((nn.Conv1d, nn.Conv2d), (nn.BatchNorm1d, nn.BatchNorm2d))
+    # (nn.SyncBatchNorm -- tools/train.py --sync_bn converts every BatchNorm -- takes the same kernels with its sums all-reduced)
+    conv_t = nn.Conv2d if pool else (nn.Conv1d, nn.Conv2d)
+    bn_t = (nn.BatchNorm2d, nn.SyncBatchNorm) if pool else (nn.BatchNorm1d, nn.BatchNorm2d, nn.SyncBatchNorm)
     if not (FUSED_MLP_TRAINING and _fused.PRECISION != "fp32" and x.is_cuda and x.dtype == torch.float32
             and x.dim() == (4 if pool else 3) and torch.is_grad_enabled()):
         return None

@@ -2667,3 +2667,43 @@ def test_generic_eval_mlp_pool_matches_torch(dev, B, M, ns, widths):
     assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
     assert not fused.check_overflow()
     assert fused.generic_mlp_pool(mlp, x.clone().requires_grad_(True)) is None      # gradients wanted: declined
+
+
+def test_fused_train_mode_mlp_under_sync_batchnorm(dev, monkeypatch):
+    """tools/train.py --sync_bn converts every BatchNorm to nn.SyncBatchNorm: the fused train-mode stack then all-reduces its
+    statistics (forward) and its BatchNorm-backward sums, and returns LOCAL weight / bias gradients, as torch's SyncBatchNorm
+    does.  In a one-process group the synchronised path must reproduce the plain one (output, running statistics,
+    gradients), and both must agree with torch's own SyncBatchNorm op sequence."""
+    import copy
+    import torch.distributed as dist
+    from spsnet_amd import pointnet2_modules as PM
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29713")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        torch.manual_seed(8)
+        plain = PM._conv_bn_relu_stack([12, 32, 48], torch.nn.Conv2d, torch.nn.BatchNorm2d).to(dev).train()
+        synced = torch.nn.SyncBatchNorm.convert_sync_batchnorm(copy.deepcopy(plain)).to(dev).train()
+        torch_ref = copy.deepcopy(synced)
+        x0 = torch.randn(2, 12, 64, 16, device=dev)
+        wout = torch.randn(2, 48, 64, device=dev) * 1e-3
+        monkeypatch.setattr(PM, "FUSED_MLP_TRAINING", True)
+        monkeypatch.setattr(PM, "_SYNC_ALWAYS", True)
+        res = []
+        for mlp, fused_on in ((plain, True), (synced, True), (torch_ref, False)):
+            x = x0.clone().requires_grad_(True)
+            out = PM._fused_mlp_pool_train(mlp, x, 'max_pool') if fused_on else mlp(x).max(dim=3)[0]
+            assert out is not None
+            (out * wout).sum().backward()
+            res.append([out.detach(), x.grad] + [p.grad for p in mlp.parameters()] + [b.detach().float() for b in mlp.buffers()])
+        torch.cuda.synchronize()
+        for other, tol in ((res[1], 1e-6), (res[2], 2e-5)):
+            for a, b in zip(res[0], other):
+                err = float((a - b).abs().max())
+                assert err <= tol * max(1e-30, float(b.abs().max())) + 1e-12, (err, float(b.abs().max()))
+    finally:
+        if created:
+            dist.destroy_process_group()
