@@ -2679,9 +2679,11 @@ def test_fused_train_mode_mlp_under_sync_batchnorm(dev, monkeypatch):
     from spsnet_amd import pointnet2_modules as PM
     created = False
     if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29713")
-        dist.init_process_group("nccl", rank=0, world_size=1)
+        import socket
+        with socket.socket() as sock:            # a free port of this host
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
         created = True
     try:
         torch.manual_seed(8)
