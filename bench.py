@@ -296,7 +296,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # Rehearsal of the N > 1 launch on a one-GPU box (SPS_BENCH_REHEARSAL=one-gpu): every rank on cuda:0, gloo collectives
+    # (RCCL refuses two ranks on one device).  Same code path otherwise; the line it prints says so and is no measurement.
+    rehearsal = world > 1 and os.environ.get("SPS_BENCH_REHEARSAL", "") == "one-gpu"
+    if rehearsal:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local = 0
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -445,6 +452,8 @@ def main():
                        "global_batch": world * args.batch, "points_per_scene": args.points,
                        "parallelism": f"scene-sharded x{world}, no data-path collective"},
         }
+        if rehearsal:
+            line["data"] = "synthetic; REHEARSAL: all ranks share one GPU over gloo -- not a measurement"
         if checked is not None:
             line["validated"] = checked
         if fp32_leg is not None:
