@@ -37,6 +37,7 @@ struct PcShared {
     PcSortShared sort;
     __attribute__((aligned(16))) int soa[2][6][2 * PF_WAVES];  // the workgroup's own 16 records: round parity x field x record
     __attribute__((aligned(16))) int xr[6][PC_MAXR];           // the round's published records of all K workgroups
+    int part[PF_WAVES][64];                                    // acceptance: per-wave partial counts of a lane's pairs
 };
 
 template <int R, int ROWS, class F>
@@ -378,17 +379,25 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
             nbef += before ? 1 : 0;
             nbad += (before & (lowered | hidden)) ? 1 : 0;
         };
-#pragma unroll
-        for (int q4 = 0; q4 < PC_MAXR / 8; ++q4) {
-            const int i0 = h * (PC_MAXR / 2) + q4 * 4;
+        {
+            // the 16 i-records of a lane's half are dealt over the eight waves, two each (every wave evaluating all of them
+            // was 3.0 k cycles of a 14.9 k round: two waves per SIMD issuing the same ~400 VALU instructions); the partial
+            // counts meet in LDS behind one more barrier, which aligned waves cross in a few hundred cycles
+            static_assert(PC_MAXR == 4 * PF_WAVES, "two i-records per wave and half");
+            const int i0 = h * (PC_MAXR / 2) + wave * 2;
             // (slots beyond R hold records that are never "before" anything)
-            const int4 id = *(const int4 *)&sh.xr[0][i0], ik = *(const int4 *)&sh.xr[1][i0];
-            const int4 ixv = *(const int4 *)&sh.xr[2][i0], iyv = *(const int4 *)&sh.xr[3][i0];
-            const int4 izv = *(const int4 *)&sh.xr[4][i0], ibv = *(const int4 *)&sh.xr[5][i0];
+            const int2 id = *(const int2 *)&sh.xr[0][i0], ik = *(const int2 *)&sh.xr[1][i0];
+            const int2 ixv = *(const int2 *)&sh.xr[2][i0], iyv = *(const int2 *)&sh.xr[3][i0];
+            const int2 izv = *(const int2 *)&sh.xr[4][i0], ibv = *(const int2 *)&sh.xr[5][i0];
             pair(id.x, ik.x, ixv.x, iyv.x, izv.x, ibv.x);
             pair(id.y, ik.y, ixv.y, iyv.y, izv.y, ibv.y);
-            pair(id.z, ik.z, ixv.z, iyv.z, izv.z, ibv.z);
-            pair(id.w, ik.w, ixv.w, iyv.w, izv.w, ibv.w);
+            sh.part[wave][lane] = nbef | (nbad << 8);
+            __syncthreads();
+            int sum = 0;
+#pragma unroll
+            for (int w = 0; w < PF_WAVES; ++w) sum += sh.part[w][lane];
+            nbef = sum & 0xFF;
+            nbad = sum >> 8;
         }
         int cnt = nbef | (nbad << 8);
         cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]: the other half
