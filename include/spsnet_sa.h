@@ -164,6 +164,13 @@ int sps_query_and_group(int b, int n, int m, int c, float radius, int nsample, i
 int sps_group_concat(int b, int n, int m, int c, int nsample, int use_xyz, const float *xyz, const float *new_xyz,
                      const float *features, const int *idx, float *out, sps_stream_t stream);
 
+/* sps_group_points_grad_kernel_launcher_fast for a grad_out that is a channel slice of a wider tensor (the feature rows of
+ * the (B, 3+C, M, nsample) gradient sps_group_concat's output receives: group_points_gpu.cu:53-71 behind the slice that
+ * torch.cat's backward makes in pointnet2_utils.py:316-320): scene s's c rows start at grad_out + s * grad_batch_stride
+ * floats (>= c * npoints * nsample).  grad_points (b, c, n) is accumulated into (zero it first), summation order unspecified. */
+int sps_group_points_grad_strided(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                                  long long grad_batch_stride, const int *idx, float *grad_points, sps_stream_t stream);
+
 /* new_xyz (B,M,3) = rows idx (B,M) of xyz (B,N,3): the transpose + gather_points + transpose of
  * pointnet2_modules.py:261,423-424 without the two layout copies (same values, it is a pure copy). */
 int sps_gather_xyz(int b, int n, int m, const float *xyz, const int *idx, float *out, sps_stream_t stream);

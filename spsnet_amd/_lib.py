@@ -43,6 +43,7 @@ _PROTOS = {
     "sps_score_topk_gather": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_query_and_group": [_i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_group_concat": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_group_points_grad_strided": [_i, _i, _i, _i, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp],
     "sps_gather_xyz": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "sps_ball_query_full": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
     "sps_ball_query_full2": [_i, _i, _i, _f, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp],

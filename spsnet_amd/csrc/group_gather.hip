@@ -30,8 +30,9 @@ __global__ __launch_bounds__(GG_THREADS) void group_kernel(
     for (int ch = c0; ch < c1; ++ch, p += n, o += cols) *o = *p;
 }
 
+// (gstride: floats between two scenes of grad_out -- c * cols, or more when grad_out is a channel slice of a wider tensor)
 __global__ __launch_bounds__(GG_THREADS) void group_grad_kernel(
-    int c, int n, int cols, const float *__restrict__ grad_out, const int *__restrict__ idx,
+    int c, int n, int cols, size_t gstride, const float *__restrict__ grad_out, const int *__restrict__ idx,
     float *__restrict__ grad_points) {
     const int scene = blockIdx.y;
     const int e = blockIdx.x * GG_THREADS + threadIdx.x;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(GG_THREADS) void group_grad_kernel(
     const int dst = idx[(size_t)scene * cols + e];
     const int c0 = blockIdx.z * GG_CCHUNK;
     const int c1 = (c0 + GG_CCHUNK < c) ? c0 + GG_CCHUNK : c;
-    const float *g = grad_out + ((size_t)scene * c + c0) * cols + e;
+    const float *g = grad_out + (size_t)scene * gstride + (size_t)c0 * cols + e;
     float *p = grad_points + ((size_t)scene * c + c0) * n + dst;
     for (int ch = c0; ch < c1; ++ch, g += cols, p += n) atomicAdd(p, *g);
 }
@@ -52,13 +53,14 @@ __global__ __launch_bounds__(GG_THREADS) void group_grad_kernel(
 // all give 340 us for B=8, C=24, 16 384 x 16 columns), i.e. ~200 G adds/s chip-wide -- 10x the global rate, 3x below the
 // coalesced read of grad_out.  Summation order is unspecified, as with the reference's atomicAdd.
 constexpr int GGL_THREADS = 512;
-__global__ __launch_bounds__(GGL_THREADS) void group_grad_lds_kernel(int c, int n, int cols, const float *__restrict__ grad_out,
+__global__ __launch_bounds__(GGL_THREADS) void group_grad_lds_kernel(int c, int n, int cols, size_t gstride,
+                                                                     const float *__restrict__ grad_out,
                                                                      const int *__restrict__ idx, float *__restrict__ grad_points) {
     extern __shared__ float gg_acc[];
     const int scene = blockIdx.y, ch = blockIdx.x;
     for (int k = threadIdx.x; k < n; k += GGL_THREADS) gg_acc[k] = 0.f;
     __syncthreads();
-    const float *g = grad_out + ((size_t)scene * c + ch) * cols;
+    const float *g = grad_out + (size_t)scene * gstride + (size_t)ch * cols;
     const int *ix = idx + (size_t)scene * cols;
     const bool vec = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(ix)) & 15) == 0;
     const int cols4 = vec ? (cols & ~3) : 0;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(GG_THREADS) void gather_xyz_kernel(int n, int m, in
 }
 
 static int launch_group(bool grad, const char *what, int b, int c, int n, int npoints, int nsample,
-                        const float *src, const int *idx, float *dst, hipStream_t st) {
+                        const float *src, const int *idx, float *dst, hipStream_t st, long long grad_batch_stride = -1) {
     if (b < 0 || c < 0 || n < 0 || npoints < 0 || nsample < 0)
         return fail(SPS_ERR_INVALID, "%s: bad shape b=%d c=%d n=%d npoints=%d nsample=%d", what, b, c, n, npoints, nsample);
     const long long cols_ll = (long long)npoints * nsample;
@@ -109,6 +111,9 @@ static int launch_group(bool grad, const char *what, int b, int c, int n, int np
     if (n == 0) return fail(SPS_ERR_INVALID, "%s: n == 0 with a non-empty index", what);
     if (!src || !idx || !dst) return fail(SPS_ERR_INVALID, "%s: null pointer", what);
     if (b > 65535 || divup(c, GG_CCHUNK) > 65535) return fail(SPS_ERR_INVALID, "%s: grid too large", what);
+    if (grad_batch_stride >= 0 && grad_batch_stride < (long long)c * cols)
+        return fail(SPS_ERR_INVALID, "%s: batch stride %lld below c * npoints * nsample", what, grad_batch_stride);
+    const size_t gstride = grad_batch_stride >= 0 ? (size_t)grad_batch_stride : (size_t)c * cols;
     if (grad && cols >= 1024 && (size_t)n * 4 <= 150 * 1024 && c <= 65535 && (long long)b * c >= 64) {
         const size_t lds = (size_t)n * 4;
         static LdsLimitOnce raised;
@@ -116,11 +121,11 @@ static int launch_group(bool grad, const char *what, int b, int c, int n, int np
             const int rc = raise_lds_limit((const void *)group_grad_lds_kernel, 150 * 1024, raised, what);
             if (rc != SPS_OK) return rc;
         }
-        hipLaunchKernelGGL(group_grad_lds_kernel, dim3(c, b), dim3(GGL_THREADS), lds, st, c, n, cols, src, idx, dst);
+        hipLaunchKernelGGL(group_grad_lds_kernel, dim3(c, b), dim3(GGL_THREADS), lds, st, c, n, cols, gstride, src, idx, dst);
         return check_launch(what);
     }
     dim3 grid(divup(cols, GG_THREADS), b, divup(c, GG_CCHUNK)), block(GG_THREADS);
-    if (grad) hipLaunchKernelGGL(group_grad_kernel, grid, block, 0, st, c, n, cols, src, idx, dst);
+    if (grad) hipLaunchKernelGGL(group_grad_kernel, grid, block, 0, st, c, n, cols, gstride, src, idx, dst);
     else hipLaunchKernelGGL(group_kernel, grid, block, 0, st, c, n, cols, src, idx, dst);
     return check_launch(what);
 }
@@ -169,6 +174,14 @@ extern "C" int sps_group_points_grad_kernel_launcher_fast(int b, int c, int n, i
                                                           float *grad_points, sps_stream_t stream) {
     return sps::launch_group(true, "group_points_grad", b, c, n, npoints, nsample, grad_out, idx, grad_points,
                              sps::as_stream(stream));
+}
+
+extern "C" int sps_group_points_grad_strided(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                                             long long grad_batch_stride, const int *idx, float *grad_points,
+                                             sps_stream_t stream) {
+    if (grad_batch_stride < 0) return sps::fail(SPS_ERR_INVALID, "group_points_grad_strided: negative batch stride");
+    return sps::launch_group(true, "group_points_grad_strided", b, c, n, npoints, nsample, grad_out, idx, grad_points,
+                             sps::as_stream(stream), grad_batch_stride);
 }
 
 // ---- deterministic gradients ---------------------------------------------------------------------------------

@@ -606,6 +606,22 @@ def group_concat(xyz, new_xyz, features, idx, use_xyz=True):
     return out
 
 
+def group_concat_grad_features(grad_out, idx, n, channel_offset):
+    """The feature rows [channel_offset:] of the gradient group_concat's output receives, (B, C_all, M, nsample) contiguous,
+    scattered back to the points -> (B, C_all - channel_offset, n): group_points_grad read in place from the wider tensor
+    (the reference slices it first: torch.cat's backward, pointnet2_utils.py:316-320)."""
+    B, call, M, nsample = grad_out.shape
+    C = call - channel_offset
+    _need(idx, B * M * nsample, "idx")
+    out = torch.zeros((B, C, n), dtype=F32, device=grad_out.device)
+    if C > 0 and B > 0:
+        cols = M * nsample
+        with _on(grad_out):
+            _lib.check(_L.sps_group_points_grad_strided(B, C, n, M, nsample, _ptr(grad_out, F32, "grad_out") + 4 * channel_offset * cols,
+                                                        call * cols, _ptr(idx, I32, "idx"), out.data_ptr(), _stream(grad_out)),
+                       "group_points_grad_strided")
+    return out
+
 
 # ---- the fused train-mode grouped MLP (csrc/mlp_train.hip) ----------------------------------------------------------------
 TIN_RAW, TIN_BNRELU, TIN_BNBWD, TIN_BNBWD_POOL = 0, 1, 2, 3

@@ -8,6 +8,7 @@ through one helper, outputs are allocated on the input's device with torch.empty
 index ops are marked non-differentiable, and QueryAndGroup uses the fused
 `sps_query_and_group` kernel whenever no gradient is required.
 """
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -32,6 +33,9 @@ _FPS_TEMP_INIT = 1e10  # reference pointnet2_utils.py:26
 # run to run).  True, or torch.use_deterministic_algorithms(True), selects the fixed-order kernels instead
 # (csrc/group_gather.hip: sps_index_add_deterministic; bit-identical to a sequential CPU loop).
 DETERMINISTIC_BACKWARD = False
+# group_with_index when gradients are wanted: one launch each way (_GroupConcat) instead of grouping_operation x 2, subtract,
+# cat and their backward nodes (A/B switch for tools/train_step_time.py; same values, gradients within summation order)
+GROUP_CONCAT_TRAINING = os.environ.get("SPS_GROUP_CONCAT_TRAINING", "1") != "0"
 
 
 def _deterministic():
@@ -261,6 +265,31 @@ def _group_with_index(xyz, new_xyz, features, idx, use_xyz):
     return torch.cat([rel, grouped], dim=1) if use_xyz else grouped
 
 
+class _GroupConcat(Function):
+    """_group_with_index as ONE launch forward (sps_group_concat) and one backward: the gradient's feature rows are scattered
+    back to the points straight from the (B, 3+C, M, ns) tensor (no slice copy), new_xyz receives minus the sum of a
+    centroid's relative-xyz rows.  xyz gets no gradient here (group_with_index keeps the op sequence when it wants one)."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, features, idx, use_xyz):
+        out = _ext.group_concat(xyz.contiguous(), new_xyz.contiguous(), features.contiguous(), idx, use_xyz)
+        ctx.save_for_backward(idx)
+        ctx.n, ctx.use_xyz = xyz.shape[1], bool(use_xyz)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        off = 3 if ctx.use_xyz else 0
+        d_new = d_feat = None
+        if ctx.needs_input_grad[2]:
+            d_feat = _ext.group_concat_grad_features(grad_out, idx, ctx.n, off)
+        if ctx.needs_input_grad[1] and ctx.use_xyz:
+            d_new = -grad_out[:, :3].sum(dim=3).transpose(1, 2)
+        return None, d_new, d_feat, None, None
+
+
 def group_with_index(xyz, new_xyz, features, idx, use_xyz=True):
     """QueryAndGroup.forward behind its ball query (reference :312-320) for neighbour indices that exist already -- both
     radii of a layer from one scan, or queries that ran while the layer's FPS was still sampling: one launch when no
@@ -270,6 +299,9 @@ def group_with_index(xyz, new_xyz, features, idx, use_xyz=True):
     if xyz.is_cuda and not _needs_grad(xyz, new_xyz, features):
         feats = features.contiguous() if features is not None else None
         return _ext.group_concat(xyz.contiguous(), new_xyz.contiguous(), feats, idx, use_xyz)
+    if (GROUP_CONCAT_TRAINING and xyz.is_cuda and features is not None and features.dtype == torch.float32
+            and not xyz.requires_grad and not _deterministic()):
+        return _GroupConcat.apply(xyz, new_xyz, features, idx, use_xyz)
     return _group_with_index(xyz, new_xyz, features, idx, use_xyz)
 
 

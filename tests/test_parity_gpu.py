@@ -2393,6 +2393,48 @@ def test_fused_train_mode_pointwise_stack_matches_torch(dev, B, M, widths, tailc
             assert int(bg) == int(br), name
 
 
+@pytest.mark.parametrize("B,N,M,ns,C,use_xyz,new_grad", [(2, 3000, 256, 16, 24, True, False), (3, 1024, 100, 32, 7, True, True),
+                                                         (1, 20000, 64, 8, 40, False, False), (2, 500, 33, 5, 3, True, True)])
+def test_group_concat_with_gradients_matches_op_sequence(G, dev, B, N, M, ns, C, use_xyz, new_grad, monkeypatch):
+    """group_with_index when gradients are wanted (_GroupConcat: one launch forward, the feature gradient scattered straight
+    from the wide gradient tensor by sps_group_points_grad_strided) against the differentiable op sequence it replaces
+    (grouping_operation x 2, subtract, cat: pointnet2_utils.py:312-320 of the reference): values bit-identical, gradients
+    of the features and of new_xyz within fp32 summation order; covers the LDS and the global-atomic scatter kernels."""
+    from spsnet_amd import pointnet2_utils as U
+    gen = torch.Generator().manual_seed(N + M)
+    xyz = (torch.rand(B, N, 3, generator=gen) * 10).to(dev)
+    idx = torch.randint(0, N, (B, M, ns), generator=gen, dtype=torch.int32)
+    idx[:, :, ns // 2:] = idx[:, :, :1]                      # padded balls repeat their first hit
+    idx = idx.to(dev)
+    feats0 = torch.randn(B, C, N, generator=gen)
+    new0 = torch.rand(B, M, 3, generator=gen) * 10
+    wout = torch.randn(B, C + (3 if use_xyz else 0), M, ns, generator=gen).to(dev)
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(U, "GROUP_CONCAT_TRAINING", flag)
+        f = feats0.to(dev).requires_grad_(True)
+        q = new0.to(dev).requires_grad_(new_grad)
+        out = U.group_with_index(xyz, q, f, idx, use_xyz)
+        assert (type(out.grad_fn).__name__ == "_GroupConcatBackward") == flag
+        (out * wout).sum().backward()
+        res[flag] = (out.detach(), f.grad, q.grad)
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b, what in ((res[True][1], res[False][1], "features"), (res[True][2], res[False][2], "new_xyz")):
+        if b is None:
+            assert a is None, what
+            continue
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max())), what
+    # deterministic mode and a cloud that wants gradients itself keep the op sequence
+    monkeypatch.setattr(U, "GROUP_CONCAT_TRAINING", True)
+    monkeypatch.setattr(U, "DETERMINISTIC_BACKWARD", True)
+    out = U.group_with_index(xyz, new0.to(dev), feats0.to(dev).requires_grad_(True), idx, use_xyz)
+    assert type(out.grad_fn).__name__ != "_GroupConcatBackward"
+    monkeypatch.setattr(U, "DETERMINISTIC_BACKWARD", False)
+    out = U.group_with_index(xyz.clone().requires_grad_(True), new0.to(dev), feats0.to(dev), idx, use_xyz)
+    assert type(out.grad_fn).__name__ != "_GroupConcatBackward"
+
+
 def test_training_prefetched_first_layer_equals_plain(G, dev):
     """sa_stack.prefetch_first_layer: layer 0's FPS and ball queries of the NEXT batch started before the current step's
     backward (on a side stream, beside it) -- every output and running statistic of the next forward bit-identical to a

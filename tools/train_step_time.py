@@ -4,7 +4,8 @@ usage: python tools/train_step_time.py [B] [N] [reps] [ab]
   ab: alternate sa_stack.STREAM_TRAINING_QUERIES on / off inside one process (three rounds each) and print the medians
   abs: the same for pointnet2_modules.SCALES_ON_STREAMS (a layer's scales on streams of their own)
   abp: the same with sa_stack.prefetch_first_layer for the next batch issued before every backward
-  abf: the same for pointnet2_modules.FUSED_MLP_TRAINING (csrc/mlp_train.hip against the op-by-op kernels)"""
+  abf: the same for pointnet2_modules.FUSED_MLP_TRAINING (csrc/mlp_train.hip against the op-by-op kernels)
+  abc: the same for pointnet2_utils.GROUP_CONCAT_TRAINING (grouping with gradients as one launch each way)"""
 import os, sys, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,7 +14,7 @@ from spsnet_amd import pointnet2_modules as M, sa_stack, scenes
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-ab = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] in ("ab", "abf", "abs", "abp") else ""
+ab = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] in ("ab", "abf", "abs", "abp", "abc") else ""
 PREFETCH = False
 dev = torch.device("cuda:0")
 layers = sa_stack.build_sa_layers(M, sa_stack.IASSD_KITTI, seed=3).to(dev).train()
@@ -51,6 +52,9 @@ if ab:
                 sa_stack.STREAM_TRAINING_QUERIES = flag
             elif ab == "abs":
                 M.SCALES_ON_STREAMS = flag
+            elif ab == "abc":
+                from spsnet_amd import pointnet2_utils as _U
+                _U.GROUP_CONCAT_TRAINING = flag
             elif ab == "abp":
                 PREFETCH = flag
                 layers[0]._presampled = layers[0]._preball = None
@@ -59,7 +63,7 @@ if ab:
             step()
             res[flag].append(timed(reps))
     for flag in (True, False):
-        print({"ab": "STREAM_TRAINING_QUERIES", "abs": "SCALES_ON_STREAMS", "abf": "FUSED_MLP_TRAINING", "abp": "prefetch_first_layer"}[ab] + f"={flag}: " + " ".join(f"{v:.2f}" for v in res[flag]) +
+        print({"ab": "STREAM_TRAINING_QUERIES", "abs": "SCALES_ON_STREAMS", "abf": "FUSED_MLP_TRAINING", "abp": "prefetch_first_layer", "abc": "GROUP_CONCAT_TRAINING"}[ab] + f"={flag}: " + " ".join(f"{v:.2f}" for v in res[flag]) +
               f"  median {statistics.median(res[flag]):.2f} ms", flush=True)
 else:
     ms = timed(reps)
