@@ -134,6 +134,15 @@ int sps_fps_ordered_prefix_begin(int b, int n, int m, const float *xyz, const fl
                                  sps_stream_t stream);
 int sps_fps_ordered_prefix_finish(int b, int n, int m, const float *xyz, float *temp, int *idxs, const float *work_T,
                                   float *work_temp, int *flags, const int *force_redo, sps_stream_t stream);
+/* Pass 2 in pieces, for a caller that receives the cloud piecewise (sa_stack's streamed first layer): its points are
+ * independent, so _check_range covers the points [k0, k0 + kcount) of every scene (k0 a multiple of 64) as soon as THEY exist
+ * (and the first m: pass 1 must have run), and _finish_from checks what is left, [k_from, n) (k_from a multiple of 64 below
+ * n), reads force_redo and resolves -- sps_fps_ordered_prefix_finish is _finish_from with k_from = 0. */
+int sps_fps_ordered_prefix_check_range(int b, int n, int m, int k0, int kcount, const float *xyz, const float *temp, int *idxs,
+                                       const float *work_T, float *work_temp, int *flags, sps_stream_t stream);
+int sps_fps_ordered_prefix_finish_from(int b, int n, int m, int k_from, const float *xyz, float *temp, int *idxs,
+                                       const float *work_T, float *work_temp, int *flags, const int *force_redo,
+                                       sps_stream_t stream);
 
 /* ---- fused entry points for the SA module layer (pointnet2_modules.py) ----------------- */
 

@@ -27,6 +27,8 @@ _PROTOS = {
     "sps_fps_ordered_prefix": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_fps_ordered_prefix_begin": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_fps_ordered_prefix_finish": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_fps_ordered_prefix_check_range": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_fps_ordered_prefix_finish_from": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_debug_fps_profile": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_farthest_point_sampling_kernel_launcher": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "sps_furthest_point_sampling_with_dist_kernel_launcher": [_i, _i, _i, _vp, _vp, _vp, _vp],

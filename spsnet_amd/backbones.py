@@ -405,9 +405,10 @@ class PointNet2MSG(nn.Module):
         idx = None
         if pre is not None and pre[2] is cloud and pre[0].shape[1] == layer.npoint:
             idx, done = pre[0], pre[1]
-            main = torch.cuda.current_stream(cloud.device)
-            main.wait_event(done)
-            idx.record_stream(main)
+            if done is not None:            # (None: produced in line on this stream already)
+                main = torch.cuda.current_stream(cloud.device)
+                main.wait_event(done)
+                idx.record_stream(main)
         if idx is None:
             idx = pointnet2_utils.farthest_point_sample(cloud, layer.npoint)
         if cloud.is_cuda and not (torch.is_grad_enabled() and cloud.requires_grad):

@@ -73,14 +73,14 @@ __global__ __launch_bounds__(FV_THREADS) void fps_prefix_dist_kernel(int n, int 
 __global__ __launch_bounds__(FV_THREADS) void fps_prefix_check_kernel(
     int n, int m, int bs, int l2, int rb, const float *__restrict__ xyz, const float *__restrict__ temp,
     const float *__restrict__ T, float *__restrict__ temp_done, int *__restrict__ idx, int *__restrict__ bad,
-    const int *__restrict__ force_bad) {
+    const int *__restrict__ force_bad, int kblock0) {
     extern __shared__ __attribute__((aligned(16))) char fv_smem[];
     float4 *step = reinterpret_cast<float4 *>(fv_smem);                                   // step j (1 <= j < m): {centre j-1, T[j]} at step[j-1]
     unsigned *srank = reinterpret_cast<unsigned *>(fv_smem + (size_t)m * 16);            // tie-break rank of point j, at srank[j-1]
     float (*segmin)[64] = reinterpret_cast<float (*)[64]>(fv_smem + (size_t)m * 20);     // [FV_SEG][64]
     const int scene = blockIdx.y;
     const int lane = threadIdx.x & 63, seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int k = blockIdx.x * 64 + lane;
+    const int k = (kblock0 + blockIdx.x) * 64 + lane;   // (points are independent: a launch may cover any range of blocks)
     xyz += (size_t)scene * n * 3;
     T += (size_t)scene * m;
     const int steps = m - 1;
@@ -157,14 +157,13 @@ extern "C" int sps_fps_ordered_prefix_begin(int b, int n, int m, const float *xy
     return check_launch("fps_prefix_dist_kernel");
 }
 
-extern "C" int sps_fps_ordered_prefix_finish(int b, int n, int m, const float *xyz, float *temp, int *idxs,
-                                             const float *work_T, float *work_temp, int *flags, const int *force_redo,
-                                             sps_stream_t stream) {
+// pass 2 over the points [k0, k0 + kcount) of every scene (k0 a multiple of 64; the range is clipped to the cloud)
+static int fv_launch_check(int b, int n, int m, int k0, int kcount, const float *xyz, const float *temp, int *idxs,
+                           const float *work_T, float *work_temp, int *flags, const int *force_redo, hipStream_t st) {
     using namespace sps;
-    int rc = fv_check_args("fps_ordered_prefix_finish", b, n, m, xyz, temp, work_T, flags);
-    if (rc != SPS_OK || b == 0 || m == 0) return rc;
-    if (!idxs || !work_temp) return fail(SPS_ERR_INVALID, "fps_ordered_prefix_finish: null pointer");
-    hipStream_t st = as_stream(stream);
+    if (k0 < 0 || kcount < 0 || (k0 & 63)) return fail(SPS_ERR_INVALID, "fps_ordered_prefix: bad point range [%d,+%d)", k0, kcount);
+    const int kend = (long long)k0 + kcount < n ? k0 + kcount : n;
+    if (kend <= k0) return SPS_OK;
     const int bs = sps_opt_n_threads(n);
     int l2 = 0;
     while ((1 << (l2 + 1)) <= bs) ++l2;
@@ -173,15 +172,44 @@ extern "C" int sps_fps_ordered_prefix_finish(int b, int n, int m, const float *x
     const size_t lds = (size_t)m * 20 + sizeof(float) * FV_SEG * 64;
     static LdsLimitOnce raised;
     if (lds > 64 * 1024) {
-        rc = raise_lds_limit((const void *)fps_prefix_check_kernel, 160 * 1024, raised, "fps_prefix_check_kernel");
+        const int rc = raise_lds_limit((const void *)fps_prefix_check_kernel, 160 * 1024, raised, "fps_prefix_check_kernel");
         if (rc != SPS_OK) return rc;
     }
-    hipLaunchKernelGGL(fps_prefix_check_kernel, dim3(divup(n, 64), b), dim3(FV_THREADS), lds, st, n, m, bs, l2, rb, xyz,
-                       temp, work_T, work_temp, idxs, flags, force_redo);
-    rc = check_launch("fps_prefix_check_kernel");
+    hipLaunchKernelGGL(fps_prefix_check_kernel, dim3(divup(kend - k0, 64), b), dim3(FV_THREADS), lds, st, n, m, bs, l2, rb, xyz,
+                       temp, work_T, work_temp, idxs, flags, force_redo, k0 / 64);
+    return check_launch("fps_prefix_check_kernel");
+}
+
+extern "C" int sps_fps_ordered_prefix_check_range(int b, int n, int m, int k0, int kcount, const float *xyz, const float *temp,
+                                                  int *idxs, const float *work_T, float *work_temp, int *flags,
+                                                  sps_stream_t stream) {
+    using namespace sps;
+    int rc = fv_check_args("fps_ordered_prefix_check_range", b, n, m, xyz, temp, work_T, flags);
+    if (rc != SPS_OK || b == 0 || m == 0) return rc;
+    if (!idxs || !work_temp) return fail(SPS_ERR_INVALID, "fps_ordered_prefix_check_range: null pointer");
+    return fv_launch_check(b, n, m, k0, kcount, xyz, temp, idxs, work_T, work_temp, flags, nullptr, as_stream(stream));
+}
+
+extern "C" int sps_fps_ordered_prefix_finish_from(int b, int n, int m, int k_from, const float *xyz, float *temp, int *idxs,
+                                                  const float *work_T, float *work_temp, int *flags, const int *force_redo,
+                                                  sps_stream_t stream) {
+    using namespace sps;
+    int rc = fv_check_args("fps_ordered_prefix_finish", b, n, m, xyz, temp, work_T, flags);
+    if (rc != SPS_OK || b == 0 || m == 0) return rc;
+    if (!idxs || !work_temp) return fail(SPS_ERR_INVALID, "fps_ordered_prefix_finish: null pointer");
+    if (k_from < 0 || k_from >= n || (k_from & 63))   // (at least one block is left: it is the one that reads force_redo)
+        return fail(SPS_ERR_INVALID, "fps_ordered_prefix_finish: k_from=%d must be a multiple of 64 below n=%d", k_from, n);
+    hipStream_t st = as_stream(stream);
+    rc = fv_launch_check(b, n, m, k_from, n - k_from, xyz, temp, idxs, work_T, work_temp, flags, force_redo, st);
     if (rc != SPS_OK) return rc;
     // confirmed scenes: copy work_temp -> temp and stop; flagged scenes: the ordinary FPS kernel recomputes them
     return launch_fps_resolve(b, n, m, xyz, temp, idxs, flags, work_temp, st);
+}
+
+extern "C" int sps_fps_ordered_prefix_finish(int b, int n, int m, const float *xyz, float *temp, int *idxs,
+                                             const float *work_T, float *work_temp, int *flags, const int *force_redo,
+                                             sps_stream_t stream) {
+    return sps_fps_ordered_prefix_finish_from(b, n, m, 0, xyz, temp, idxs, work_T, work_temp, flags, force_redo, stream);
 }
 
 extern "C" int sps_fps_ordered_prefix(int b, int n, int m, const float *xyz, float *temp, int *idxs, float *work_T,

@@ -419,16 +419,34 @@ class OrderedPrefix:
             _lib.check(_L.sps_fps_ordered_prefix_begin(B, N, self.npoint, _ptr(self.xyz, F32, "xyz"), self.temp.data_ptr(),
                                                         self.work_t.data_ptr(), self.flags.data_ptr(), _stream(self.xyz)),
                        "fps_ordered_prefix_begin")
+        self.begun, self.checked = True, 0
+
+    begun, checked = False, 0
+
+    def check_upto(self, k1):
+        """The second pass for the points [checked, k1) of every scene -- they exist already, the rest does not yet (k1 a
+        multiple of 64; after begin(), stream-ordered behind it): finish() then has only the remaining points to check."""
+        B, N, _ = self.xyz.shape
+        k1 = min(int(k1), N) & ~63
+        if not self.begun or k1 <= self.checked or k1 >= N:
+            return
+        with _on(self.xyz):
+            _lib.check(_L.sps_fps_ordered_prefix_check_range(B, N, self.npoint, self.checked, k1 - self.checked,
+                                                              _ptr(self.xyz, F32, "xyz"), self.temp.data_ptr(), self.idx.data_ptr(),
+                                                              self.work_t.data_ptr(), self.work_temp.data_ptr(),
+                                                              self.flags.data_ptr(), _stream(self.xyz)),
+                       "fps_ordered_prefix_check_range")
+        self.checked = k1
 
     def finish(self, force_redo=None):
         """force_redo: device int32; non-zero = the inputs of begin() were not ready, recompute every scene."""
         B, N, _ = self.xyz.shape
         with _on(self.xyz):
-            _lib.check(_L.sps_fps_ordered_prefix_finish(B, N, self.npoint, _ptr(self.xyz, F32, "xyz"), self.temp.data_ptr(),
-                                                         self.idx.data_ptr(), self.work_t.data_ptr(),
-                                                         self.work_temp.data_ptr(), self.flags.data_ptr(),
-                                                         0 if force_redo is None else _ptr(force_redo, I32, "force_redo"),
-                                                         _stream(self.xyz)), "fps_ordered_prefix_finish")
+            _lib.check(_L.sps_fps_ordered_prefix_finish_from(B, N, self.npoint, self.checked, _ptr(self.xyz, F32, "xyz"),
+                                                              self.temp.data_ptr(), self.idx.data_ptr(), self.work_t.data_ptr(),
+                                                              self.work_temp.data_ptr(), self.flags.data_ptr(),
+                                                              0 if force_redo is None else _ptr(force_redo, I32, "force_redo"),
+                                                              _stream(self.xyz)), "fps_ordered_prefix_finish")
         return self.idx
 
 

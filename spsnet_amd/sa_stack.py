@@ -7,9 +7,8 @@ IASSD_backbone.py:128-134: layer k consumes layer k-1's (xyz, features, cls pred
 Only the SA layers are built -- heads, losses and the voting branch stay out of scope.
 """
 import copy
-from typing import List, Optional
-
 import os
+from typing import List, Optional
 
 import torch
 import torch.nn as nn
@@ -195,6 +194,8 @@ def _can_prefetch(layer, nxt):
 # long way to go, small ones at the end (what is left to do after the last pick is the last chunk's work; a chunk
 # costs ~70 us however small it is -- one wave scans the whole cloud per centroid -- so finer tails only add launches)
 _CHUNK_ENDS_16 = (4, 8, 12, 14, 15, 16)
+# the second pass of the next layer's identity-prefix check chunk by chunk beside the producer instead of whole behind it
+EARLY_PREFIX_CHECK = os.environ.get("SPS_EARLY_PREFIX_CHECK", "1") != "0"
 _TIMEOUT_FLAGS = []   # device flags of recent streamed passes (diagnostics only: see check_timeouts)
 
 
@@ -301,7 +302,7 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
 
     def consume(j0, j1, wait):
         """gather -> ball query -> grouped MLPs -> aggregation for the centroids [j0, j1) of every scene, on the current stream"""
-        nonlocal xyz_ready
+        nonlocal xyz_ready, verify, verified_inline
         chunk = j1 - j0
         if wait:
             _ext.wait_progress(progress, j1, timed_out, patient=(j1 == M))
@@ -325,16 +326,27 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
         if verify is not None and j0 < verify.npoint <= j1:
             verify.begin()
         if j1 == M:
-            xyz_ready = torch.cuda.Event()
-            xyz_ready.record(torch.cuda.current_stream(dev))
+            if verify is not None and verify.checked > 0:
+                # the centroids of the earlier chunks went through the second pass as they arrived (below): what is left is
+                # this chunk's share, ~5 us -- in line, so that the next layer's sampling costs no stream hop at all
+                nxt._presampled = (verify.finish(force_redo=timed_out), None, new_xyz)
+                verify, verified_inline = None, True
+            else:
+                xyz_ready = torch.cuda.Event()
+                xyz_ready.record(torch.cuda.current_stream(dev))
         off = 0
         for ix, packed in zip((idx_a, idx_b), plan):
             _fused.group_mlp_pool(xyz, new_xyz, features, ix, packed, out, off, j0, chunk, full_range_if=repair)
             off += packed.c3_real
         if tail is not None:
             tail.run(j0, chunk, full_range_if=repair)
+        if verify is not None and j1 < M and EARLY_PREFIX_CHECK:
+            # second pass of the next layer's identity-prefix check for the centroids that exist by now: the stream would
+            # otherwise idle in the next chunk's wait (a chunk whose wait gave up checks garbage -- finish() is then told to
+            # recompute every scene: force_redo)
+            verify.check_upto(j1)
 
-    xyz_ready = None
+    xyz_ready, verified_inline = None, False
     # units of one centroid meet through an atomic max when a ball has more than 32 samples: a repair then needs `out`
     # zeroed again, which takes the separate predicated launches of _redo_layer
     self_repair = max(ga.nsample, gb.nsample) <= 32
@@ -363,7 +375,7 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
         for t in verify.tensors() + (new_xyz,):
             t.record_stream(third)
         nxt._presampled = (nidx, vdone, new_xyz)   # (derived from the repaired centroids; flagged scenes are recomputed)
-    elif nxt is not None and _can_prefetch(layer, nxt):
+    elif nxt is not None and _can_prefetch(layer, nxt) and not verified_inline:
         _prefetch_dfps(nxt, new_xyz, True)
     new_features, cls = tail.result() if tail is not None else layer._tail(out, half)
     if stds is not None:  # the layer's sampler thins the stability scores with its picks (reference :307-310)

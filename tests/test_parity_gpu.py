@@ -804,6 +804,44 @@ def test_fps_ordered_prefix_with_ties(ext, G, oracle, N, m):
     np.testing.assert_array_equal(G.n(temp), want_t)
 
 
+@pytest.mark.parametrize("kind,N,m,cuts", [("lidar", 4096, 1024, (1024, 2048, 3584, 3840)), ("lidar", 2048, 512, (1000, 1990)),
+                                           ("lattice", 4096, 1024, (2048, 3840)), ("lidar", 4096, 1024, ())])
+def test_fps_ordered_prefix_second_pass_in_pieces(ext, G, oracle, kind, N, m, cuts):
+    """OrderedPrefix as the streamed first layer drives it: begin(), then the second pass for the points that exist so far
+    (check_upto after every chunk, cut points rounded down to 64), then finish() for the rest -- the same indices, final
+    running distances and flags as the one-call form and the oracle; a destroyed scene and a lattice cloud (exact ties)
+    are recomputed; force_redo recomputes everything."""
+    from spsnet_amd import scenes
+    if kind == "lattice":
+        base = cloud(np.random.default_rng(N), 3, 4 * N, lattice=True)
+    else:
+        base, _ = scenes.make_batch("kitti-lidar-v1", 3, 4 * N, seed0=N + m)
+    x1 = gather_xyz(base, oracle.fps(base, N))
+    x1[2] = x1[2][np.random.default_rng(0).permutation(N)]
+    want, want_t = oracle.fps(x1, m, return_temp=True)
+    ref_idx, ref_flags, ref_temp = ext.fps_ordered_prefix(G.t(x1), m, return_flags=True)
+    np.testing.assert_array_equal(G.n(ref_idx), want)
+    for force in (None, 0, 1):
+        op = ext.OrderedPrefix(G.t(x1), m)
+        op.check_upto(cuts[0] if cuts else 64)          # before begin(): ignored
+        assert op.checked == 0
+        op.begin()
+        for c in cuts:
+            op.check_upto(c)
+            assert op.checked == (min(c, N) & ~63)
+        flag = None if force is None else torch.full((1,), force, dtype=torch.int32, device=op.flags.device)
+        idx = op.finish(force_redo=flag)
+        np.testing.assert_array_equal(G.n(idx), want)
+        np.testing.assert_array_equal(G.n(op.temp), want_t)
+        if force == 1:
+            assert G.n(op.flags).tolist() == [1, 1, 1]
+        else:
+            np.testing.assert_array_equal(G.n(op.flags), G.n(ref_flags))
+            assert G.n(op.flags)[2] == 1
+            if kind == "lidar":
+                assert G.n(op.flags)[:2].tolist() == [0, 0]
+
+
 @pytest.mark.parametrize("N,M,ra,nsa,rb,nsb", [(16384, 4096, 0.2, 16, 0.8, 32), (4096, 1000, 0.8, 16, 1.6, 32),
                                                 (1024, 512, 1.6, 16, 4.8, 32), (333, 70, 0.5, 4, 0.3, 64)])
 def test_ball_query_dual_radius(ext, G, oracle, N, M, ra, nsa, rb, nsb):
