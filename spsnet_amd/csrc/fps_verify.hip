@@ -20,6 +20,7 @@ namespace sps {
 
 constexpr int FV_SEG = 8;                    // waves per workgroup = segments of the centre range
 constexpr int FV_THREADS = 64 * FV_SEG;
+constexpr int FV_FINE_MAX_POINTS = 1 << 16;  // launches of at most this many points (all scenes) take the 16-point check kernel
 constexpr int FV_MAX_M = 7168;               // centres staged in LDS: 20 B each (+ 2 KiB) of the 160 KiB, dynamic
 
 __device__ __forceinline__ unsigned fv_rank(unsigned k, int bs, int l2, int rb) {
@@ -69,18 +70,26 @@ __global__ __launch_bounds__(FV_THREADS) void fps_prefix_dist_kernel(int n, int 
     }
 }
 
-// pass 2: point k replays its running distance and checks every step of the guess
+// pass 2: point k replays its running distance and checks every step of the guess.
+// PTS points per workgroup (64 or 16): with 16, a wave holds four segments of the centre range side by side (lane = 16 sub +
+// point), 32 segments in all -- a quarter of the serial chain per lane.  The chain (two passes over a segment's centres, ~14 us
+// of a 21 us launch at 1024 centres whatever the number of workgroups) is all a small launch costs, and the streamed layer's
+// last piece -- 256 centroids per scene, on the critical path behind the producer's last pick -- is such a launch.
+template <int PTS>
 __global__ __launch_bounds__(FV_THREADS) void fps_prefix_check_kernel(
     int n, int m, int bs, int l2, int rb, const float *__restrict__ xyz, const float *__restrict__ temp,
     const float *__restrict__ T, float *__restrict__ temp_done, int *__restrict__ idx, int *__restrict__ bad,
-    const int *__restrict__ force_bad, int kblock0) {
+    const int *__restrict__ force_bad, int k0) {
+    constexpr int SUB = 64 / PTS;            // segments side by side in a wave
+    constexpr int NSEG = FV_SEG * SUB;
     extern __shared__ __attribute__((aligned(16))) char fv_smem[];
     float4 *step = reinterpret_cast<float4 *>(fv_smem);                                   // step j (1 <= j < m): {centre j-1, T[j]} at step[j-1]
     unsigned *srank = reinterpret_cast<unsigned *>(fv_smem + (size_t)m * 16);            // tie-break rank of point j, at srank[j-1]
-    float (*segmin)[64] = reinterpret_cast<float (*)[64]>(fv_smem + (size_t)m * 20);     // [FV_SEG][64]
+    float (*segmin)[PTS] = reinterpret_cast<float (*)[PTS]>(fv_smem + (size_t)m * 20);   // [NSEG][PTS]
     const int scene = blockIdx.y;
-    const int lane = threadIdx.x & 63, seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int k = (kblock0 + blockIdx.x) * 64 + lane;   // (points are independent: a launch may cover any range of blocks)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & (PTS - 1), seg = wave * SUB + lane / PTS;
+    const int k = k0 + blockIdx.x * PTS + pt;   // (points are independent: a launch may cover any range of them)
     xyz += (size_t)scene * n * 3;
     T += (size_t)scene * m;
     const int steps = m - 1;
@@ -92,17 +101,17 @@ __global__ __launch_bounds__(FV_THREADS) void fps_prefix_check_kernel(
     const bool live = k < n;
     const int kk = live ? k : 0;
     const float px = xyz[kk * 3], py = xyz[kk * 3 + 1], pz = xyz[kk * 3 + 2];
-    const int len = (steps + FV_SEG - 1) / FV_SEG;
-    const int ibeg = seg * len, iend = (ibeg + len < steps) ? ibeg + len : steps;
+    const int len = (steps + NSEG - 1) / NSEG;
+    const int ibeg = seg * len < steps ? seg * len : steps, iend = (ibeg + len < steps) ? ibeg + len : steps;
     float local = INFINITY;
     for (int i = ibeg; i < iend; ++i) {
         const float4 c = step[i];
         local = fminf(sqdist(px, py, pz, c.x, c.y, c.z), local);
     }
-    segmin[seg][lane] = local;
+    segmin[seg][pt] = local;
     __syncthreads();
     float t = temp[(size_t)scene * n + kk];
-    for (int s = 0; s < seg; ++s) t = fminf(segmin[s][lane], t);
+    for (int s = 0; s < seg; ++s) t = fminf(segmin[s][pt], t);
     const unsigned myrank = fv_rank((unsigned)kk, bs, l2, rb);
     bool violated = false;
     for (int i = ibeg; i < iend; ++i) {  // step j = i + 1: centre i has been applied, the guess says point j is picked now
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(FV_THREADS) void fps_prefix_check_kernel(
         violated |= (k != i + 1) & ((t > c.w) | ((t == c.w) & (myrank < srank[i])));
     }
     if (live) {
-        if (seg == FV_SEG - 1) {
+        if (seg == NSEG - 1) {
             float r = fminf(local, t);  // == t when the last segment is not empty
             temp_done[(size_t)scene * n + k] = r;  // the reference's final `temp` if the guess holds
             if (k < m) idx[(size_t)scene * m + k] = k;
@@ -159,7 +168,8 @@ extern "C" int sps_fps_ordered_prefix_begin(int b, int n, int m, const float *xy
 
 // pass 2 over the points [k0, k0 + kcount) of every scene (k0 a multiple of 64; the range is clipped to the cloud)
 static int fv_launch_check(int b, int n, int m, int k0, int kcount, const float *xyz, const float *temp, int *idxs,
-                           const float *work_T, float *work_temp, int *flags, const int *force_redo, hipStream_t st) {
+                           const float *work_T, float *work_temp, int *flags, const int *force_redo, hipStream_t st,
+                           bool may_be_fine) {
     using namespace sps;
     if (k0 < 0 || kcount < 0 || (k0 & 63)) return fail(SPS_ERR_INVALID, "fps_ordered_prefix: bad point range [%d,+%d)", k0, kcount);
     const int kend = (long long)k0 + kcount < n ? k0 + kcount : n;
@@ -169,14 +179,24 @@ static int fv_launch_check(int b, int n, int m, int k0, int kcount, const float 
     while ((1 << (l2 + 1)) <= bs) ++l2;
     int rb = 0;
     while ((1 << rb) < divup(n, bs)) ++rb;
-    const size_t lds = (size_t)m * 20 + sizeof(float) * FV_SEG * 64;
-    static LdsLimitOnce raised;
+    const size_t lds = (size_t)m * 20 + sizeof(float) * FV_SEG * 64;   // (segmin: NSEG * PTS = 512 floats either way)
+    // the launch somebody waits for (the streamed layer's last piece, a whole cloud of moderate size): the 16-point form --
+    // more, shorter workgroups.  The early pieces run BESIDE the producer and nobody waits for them: four times the
+    // workgroups (each staging all m centres) only take cycles from its compute units (config 5: the clustered FPS
+    // 7.88 -> 8.36 ms with 16-point pieces beside it), so they keep the 64-point form.
+    const bool fine = may_be_fine && (long long)b * (kend - k0) <= FV_FINE_MAX_POINTS;
+    const void *fn = fine ? (const void *)fps_prefix_check_kernel<16> : (const void *)fps_prefix_check_kernel<64>;
+    static LdsLimitOnce raised64, raised16;
     if (lds > 64 * 1024) {
-        const int rc = raise_lds_limit((const void *)fps_prefix_check_kernel, 160 * 1024, raised, "fps_prefix_check_kernel");
+        const int rc = raise_lds_limit(fn, 160 * 1024, fine ? raised16 : raised64, "fps_prefix_check_kernel");
         if (rc != SPS_OK) return rc;
     }
-    hipLaunchKernelGGL(fps_prefix_check_kernel, dim3(divup(kend - k0, 64), b), dim3(FV_THREADS), lds, st, n, m, bs, l2, rb, xyz,
-                       temp, work_T, work_temp, idxs, flags, force_redo, k0 / 64);
+    if (fine)
+        hipLaunchKernelGGL(fps_prefix_check_kernel<16>, dim3(divup(kend - k0, 16), b), dim3(FV_THREADS), lds, st, n, m, bs, l2, rb,
+                           xyz, temp, work_T, work_temp, idxs, flags, force_redo, k0);
+    else
+        hipLaunchKernelGGL(fps_prefix_check_kernel<64>, dim3(divup(kend - k0, 64), b), dim3(FV_THREADS), lds, st, n, m, bs, l2, rb,
+                           xyz, temp, work_T, work_temp, idxs, flags, force_redo, k0);
     return check_launch("fps_prefix_check_kernel");
 }
 
@@ -187,7 +207,7 @@ extern "C" int sps_fps_ordered_prefix_check_range(int b, int n, int m, int k0, i
     int rc = fv_check_args("fps_ordered_prefix_check_range", b, n, m, xyz, temp, work_T, flags);
     if (rc != SPS_OK || b == 0 || m == 0) return rc;
     if (!idxs || !work_temp) return fail(SPS_ERR_INVALID, "fps_ordered_prefix_check_range: null pointer");
-    return fv_launch_check(b, n, m, k0, kcount, xyz, temp, idxs, work_T, work_temp, flags, nullptr, as_stream(stream));
+    return fv_launch_check(b, n, m, k0, kcount, xyz, temp, idxs, work_T, work_temp, flags, nullptr, as_stream(stream), false);
 }
 
 extern "C" int sps_fps_ordered_prefix_finish_from(int b, int n, int m, int k_from, const float *xyz, float *temp, int *idxs,
@@ -200,7 +220,7 @@ extern "C" int sps_fps_ordered_prefix_finish_from(int b, int n, int m, int k_fro
     if (k_from < 0 || k_from >= n || (k_from & 63))   // (at least one block is left: it is the one that reads force_redo)
         return fail(SPS_ERR_INVALID, "fps_ordered_prefix_finish: k_from=%d must be a multiple of 64 below n=%d", k_from, n);
     hipStream_t st = as_stream(stream);
-    rc = fv_launch_check(b, n, m, k_from, n - k_from, xyz, temp, idxs, work_T, work_temp, flags, force_redo, st);
+    rc = fv_launch_check(b, n, m, k_from, n - k_from, xyz, temp, idxs, work_T, work_temp, flags, force_redo, st, true);
     if (rc != SPS_OK) return rc;
     // confirmed scenes: copy work_temp -> temp and stop; flagged scenes: the ordinary FPS kernel recomputes them
     return launch_fps_resolve(b, n, m, xyz, temp, idxs, flags, work_temp, st);
