@@ -409,6 +409,7 @@ class OrderedPrefix:
         self.work_t = torch.empty((B, max(npoint, 1)), dtype=F32, device=dev)
         self.work_temp = torch.empty((B, N), dtype=F32, device=dev)
         self.flags = torch.empty((B,), dtype=I32, device=dev)
+        self.begun, self.checked = False, 0      # checked: points [0, checked) went through the second pass already
 
     def tensors(self):
         return (self.temp, self.idx, self.work_t, self.work_temp, self.flags)
@@ -420,8 +421,6 @@ class OrderedPrefix:
                                                         self.work_t.data_ptr(), self.flags.data_ptr(), _stream(self.xyz)),
                        "fps_ordered_prefix_begin")
         self.begun, self.checked = True, 0
-
-    begun, checked = False, 0
 
     def check_upto(self, k1):
         """The second pass for the points [checked, k1) of every scene -- they exist already, the rest does not yet (k1 a
