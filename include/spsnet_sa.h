@@ -503,6 +503,13 @@ int sps_conv1x1_wgrad(int b, int ci, int co, long long l, const float *x, const 
 int sps_fp_module_mlp(int b, int n, int m, int c_known, int c_skip, int c1, int c2, const float *known_feats, const float *skip,
                       const int *idx, const float *weight, const float *w1, const float *b1, const float *w2, const float *b2,
                       float *y, sps_stream_t stream);
+/* ... with the interpolation weights formed in the kernel from three_nn's distances (weights_from_dist != 0: `weight` holds
+ * dist (b, n, 3); 1 / (dist + 1e-8) normalised over the three neighbours, pointnet2_modules.py:572-574) and / or the output
+ * written point-major, y (b, n, c2 ? c2 : c1) (y_point_major != 0: the per-point rows a backbone hands out,
+ * pcdet/models/backbones_3d/pointnet2_backbone.py:91). */
+int sps_fp_module_mlp_ex(int b, int n, int m, int c_known, int c_skip, int c1, int c2, const float *known_feats, const float *skip,
+                         const int *idx, const float *weight, int weights_from_dist, const float *w1, const float *b1,
+                         const float *w2, const float *b2, float *y, int y_point_major, sps_stream_t stream);
 
 /* The grouped MLP of an SA layer in TRAINING mode ([Conv2d 1x1, BatchNorm2d on batch statistics, ReLU] x n + max-pool,
  * pointnet2_modules.py:203-211, 432-444), fused along its memory passes (csrc/mlp_train.hip): only the pre-BatchNorm

@@ -71,6 +71,7 @@ _PROTOS = {
     "sps_three_interpolate_kernel_launcher_stack": [_i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_three_interpolate_grad_kernel_launcher_stack": [_i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_fp_module_mlp": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sps_fp_module_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "sps_tconv_parts": [_i, ctypes.c_longlong, _i],
     "sps_tconv": [_i, _i, _i, ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                   _vp, _vp],

@@ -482,8 +482,13 @@ class PointNet2MSG(nn.Module):
                 dist.record_stream(main)
                 idx.record_stream(main)
                 nn_k = (dist, idx)
-            level_feats[k] = self.FP_modules[k](level_xyz[k], level_xyz[k + 1], level_feats[k], level_feats[k + 1], neighbours=nn_k)
-        point_features = level_feats[0].permute(0, 2, 1).contiguous()
+            # (the last module's output leaves as per-point rows: in inference its kernel writes them that way)
+            level_feats[k] = self.FP_modules[k](level_xyz[k], level_xyz[k + 1], level_feats[k], level_feats[k + 1], neighbours=nn_k,
+                                                point_major_ok=(k == 0))
+        if getattr(level_feats[0], "_sps_point_major", False):
+            point_features = level_feats[0]
+        else:
+            point_features = level_feats[0].permute(0, 2, 1).contiguous()
         batch_dict['point_features'] = point_features.view(-1, point_features.shape[-1])
         batch_dict['point_coords'] = torch.cat((batch_idx[:, None].float(), xyz.view(-1, 3)), dim=1)
         counts_ok()

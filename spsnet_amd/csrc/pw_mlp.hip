@@ -182,7 +182,9 @@ struct FpArgs {
     const int *idx;                              // (b, n, 3)
     const float *weight;                         // (b, n, 3)
     const float *w1, *b1, *w2, *b2;
-    float *y;                                    // (b, c2 ? c2 : c1, n)
+    float *y;                                    // (b, c2 ? c2 : c1, n), or point-major (b, n, c2 ? c2 : c1) with y_pm
+    int from_dist;                               // `weight` holds three_nn's distances: the weights are formed here
+    int y_pm;
 };
 
 // one 16-row output tile against NT column tiles of an LDS image [k][16 NT + 1]: the weight fragments of a 16-channel step
@@ -243,6 +245,15 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void fp_mlp_kernel(FpArgs a) {
         s_w[e] = in ? a.weight[((size_t)scene * a.n + m0) * 3 + e] : 0.f;
     }
     __syncthreads();
+    if (a.from_dist) {
+        // the module's own arithmetic (pointnet2_modules.py:572-574): 1 / (dist + 1e-8), normalised by the sum of the three
+        for (int p = threadIdx.x; p < COLS; p += blockDim.x) {
+            const float i0 = 1.0f / (s_w[3 * p] + 1e-8f), i1 = 1.0f / (s_w[3 * p + 1] + 1e-8f), i2 = 1.0f / (s_w[3 * p + 2] + 1e-8f);
+            const float sum = (i0 + i1) + i2;
+            s_w[3 * p] = i0 / sum; s_w[3 * p + 1] = i1 / sum; s_w[3 * p + 2] = i2 / sum;
+        }
+        __syncthreads();
+    }
     // ---- the input columns: interpolated channels, then the skip channels, then zero padding ----
     const float *kf = a.known_feats + (size_t)scene * a.c_known * a.m;
     for (int e = threadIdx.x; e < a.cin * COLS; e += blockDim.x) {
@@ -276,8 +287,18 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void fp_mlp_kernel(FpArgs a) {
                     const int row = 16 * t + 4 * q + r, col = 16 * nt + c;
                     const float v = pw_relu(acc[nt][r]);
                     if (a.c2 != 0) act1[row * PITCH + col] = v;
-                    else if (m0 + col < a.n) a.y[((size_t)scene * a.c1 + row) * a.n + m0 + col] = v;
+                    else if (m0 + col < a.n && !a.y_pm) a.y[((size_t)scene * a.c1 + row) * a.n + m0 + col] = v;
                 }
+            if (a.c2 == 0 && a.y_pm) {   // point-major: a lane's four rows are one 16-byte store, a point's 16 channels 64 bytes
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = 16 * nt + c;
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = pw_relu(acc[nt][r]);
+                    if (m0 + col < a.n) *reinterpret_cast<f32x4 *>(a.y + ((size_t)scene * a.n + m0 + col) * a.c1 + 16 * t + 4 * q) = v;
+                }
+            }
         }
     }
     if (a.c2 == 0) return;
@@ -295,8 +316,18 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void fp_mlp_kernel(FpArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int col = 16 * nt + c;
-                    if (m0 + col < a.n) a.y[((size_t)scene * a.c2 + 16 * t + 4 * q + r) * a.n + m0 + col] = pw_relu(acc[nt][r]);
+                    if (m0 + col < a.n && !a.y_pm) a.y[((size_t)scene * a.c2 + 16 * t + 4 * q + r) * a.n + m0 + col] = pw_relu(acc[nt][r]);
                 }
+            if (a.y_pm) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = 16 * nt + c;
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = pw_relu(acc[nt][r]);
+                    if (m0 + col < a.n) *reinterpret_cast<f32x4 *>(a.y + ((size_t)scene * a.n + m0 + col) * a.c2 + 16 * t + 4 * q) = v;
+                }
+            }
         }
     }
 }
@@ -320,6 +351,16 @@ static int fp_launch(const FpArgs &a, int b, size_t lds, int waves, hipStream_t 
 extern "C" int sps_fp_module_mlp(int b, int n, int m, int c_known, int c_skip, int c1, int c2, const float *known_feats,
                                  const float *skip, const int *idx, const float *weight, const float *w1, const float *b1,
                                  const float *w2, const float *b2, float *y, sps_stream_t stream) {
+    return sps_fp_module_mlp_ex(b, n, m, c_known, c_skip, c1, c2, known_feats, skip, idx, weight, 0, w1, b1, w2, b2, y, 0, stream);
+}
+
+// weights_from_dist: `weight` holds three_nn's distances (b, n, 3) and the interpolation weights are formed in the kernel
+// (pointnet2_modules.py:572-574); y_point_major: y is (b, n, c2 ? c2 : c1) -- what a backbone that hands out per-point rows
+// (pcdet/models/backbones_3d/pointnet2_backbone.py:91) wants from its last module.
+extern "C" int sps_fp_module_mlp_ex(int b, int n, int m, int c_known, int c_skip, int c1, int c2, const float *known_feats,
+                                    const float *skip, const int *idx, const float *weight, int weights_from_dist,
+                                    const float *w1, const float *b1, const float *w2, const float *b2, float *y,
+                                    int y_point_major, sps_stream_t stream) {
     using namespace sps;
     if (b < 0 || n < 0 || m <= 0 || c_known <= 0 || c_skip < 0 || c1 <= 0 || c2 < 0)
         return fail(SPS_ERR_INVALID, "fp_module_mlp: bad shape b=%d n=%d m=%d c_known=%d c_skip=%d c1=%d c2=%d", b, n, m, c_known, c_skip, c1, c2);
@@ -331,6 +372,7 @@ extern "C" int sps_fp_module_mlp(int b, int n, int m, int c_known, int c_skip, i
     FpArgs a;
     a.n = n; a.m = m; a.c_known = c_known; a.c_skip = c_skip; a.cin = 16 * divup(c_known + c_skip, 16); a.c1 = c1; a.c2 = c2;
     a.known_feats = known_feats; a.skip = skip; a.idx = idx; a.weight = weight; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = y;
+    a.from_dist = weights_from_dist != 0; a.y_pm = y_point_major != 0;
     const int wide = c2 > a.cin ? c2 : a.cin;
     const size_t rows = (size_t)wide + (c2 ? c1 : 0);
     // as many 16-point column tiles per workgroup as the LDS images allow (the weights stream once per workgroup)

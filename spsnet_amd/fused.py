@@ -535,14 +535,22 @@ class _PackedFp:
     __slots__ = ("key", "c_in", "c1", "c2", "w1", "b1", "w2", "b2")
 
 
-def fp_module_mlp(mlp, known_feats, unknow_feats, idx, weight):
+def fp_module_mlp(mlp, known_feats, unknow_feats, idx, weight, dist=None, point_major=False):
     """PointnetFPModule.forward behind its three_nn (reference :571-587): interpolation of `known_feats` (B, C2, m) with
     idx / weight (B, n, 3), concatenation with `unknow_feats` (B, C1, n) | None and the [Conv2d 1x1 + BatchNorm2d + ReLU]
     stack (one or two layers), as ONE kernel (csrc/pw_mlp.hip fp_mlp_kernel, exact fp32, BatchNorm folded) -> (B, Cout, n),
-    or None when the fused path does not apply (training, gradients wanted, widths not multiples of 16, ...)."""
+    or None when the fused path does not apply (training, gradients wanted, widths not multiples of 16, ...).
+    dist (with weight None): three_nn's distances -- the weights are formed inside the kernel (the module's own three small
+    torch ops otherwise); point_major: the output as per-point rows (B, n, Cout), tagged `_sps_point_major`."""
     mods = list(mlp)
     if len(mods) not in (3, 6) or mlp.training or not known_feats.is_cuda or known_feats.dtype != torch.float32:
         return None
+    if weight is None:
+        if dist is None or dist.dtype != torch.float32:
+            return None
+        weight, from_dist = dist, 1
+    else:
+        from_dist = 0
     pairs = []
     for conv, bn, act in zip(mods[0::3], mods[1::3], mods[2::3]):
         if not (isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and isinstance(act, nn.ReLU)
@@ -577,13 +585,16 @@ def fp_module_mlp(mlp, known_feats, unknow_feats, idx, weight):
                 w2, b2 = _fold(*pairs[1])
                 packed.w2, packed.b2 = _pack_pw(w2, c2), b2.contiguous()
         object.__setattr__(mlp, "_sps_fp", packed)
-    y = torch.empty((B, c2 if c2 else c1, n), dtype=torch.float32, device=known_feats.device)
+    cout = c2 if c2 else c1
+    y = torch.empty((B, n, cout) if point_major else (B, cout, n), dtype=torch.float32, device=known_feats.device)
     kf, wt, ix = known_feats.contiguous(), weight.contiguous(), idx.contiguous()
     sk = unknow_feats.contiguous() if unknow_feats is not None else None
-    _lib.check(_L.sps_fp_module_mlp(B, n, m, c_known, c_skip, c1, c2, kf.data_ptr(), sk.data_ptr() if sk is not None else 0,
-                                    ix.data_ptr(), wt.data_ptr(), packed.w1.data_ptr(), packed.b1.data_ptr(),
-                                    packed.w2.data_ptr() if c2 else 0, packed.b2.data_ptr() if c2 else 0, y.data_ptr(),
-                                    torch.cuda.current_stream(y.device).cuda_stream), "fp_module_mlp")
+    _lib.check(_L.sps_fp_module_mlp_ex(B, n, m, c_known, c_skip, c1, c2, kf.data_ptr(), sk.data_ptr() if sk is not None else 0,
+                                       ix.data_ptr(), wt.data_ptr(), from_dist, packed.w1.data_ptr(), packed.b1.data_ptr(),
+                                       packed.w2.data_ptr() if c2 else 0, packed.b2.data_ptr() if c2 else 0, y.data_ptr(),
+                                       1 if point_major else 0, torch.cuda.current_stream(y.device).cuda_stream), "fp_module_mlp")
+    if point_major:
+        y._sps_point_major = True
     return y
 
 

@@ -923,17 +923,20 @@ class PointnetFPModule(nn.Module):
         self.mlp = _conv_bn_relu_stack(list(mlp), nn.Conv2d, nn.BatchNorm2d)
 
     def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
-                known_feats: torch.Tensor, neighbours=None) -> torch.Tensor:
+                known_feats: torch.Tensor, neighbours=None, point_major_ok=False) -> torch.Tensor:
         """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n), known_feats (B,C2,m) -> (B,mlp[-1],n).
         neighbours: (dist, idx) of three_nn(unknown, known) when the caller already has them (the search needs coordinates
-        only, so a backbone can run it beside the encoder: backbones.PointNet2MSG)."""
+        only, so a backbone can run it beside the encoder: backbones.PointNet2MSG).
+        point_major_ok: the caller wants per-point rows and takes (B,n,mlp[-1]) tagged `_sps_point_major` when the fused
+        inference kernel serves the module (it then writes them directly; anything else returns the usual layout)."""
         if known is not None:
             dist, idx = neighbours if neighbours is not None else pointnet2_utils.three_nn(unknown, known)
-            inv = 1.0 / (dist + 1e-8)
-            weight = inv / torch.sum(inv, dim=2, keepdim=True)
-            fused = _fused.fp_module_mlp(self.mlp, known_feats, unknow_feats, idx, weight)   # inference: one kernel
+            # inference: one kernel, the weights (reference :572-574) formed inside it
+            fused = _fused.fp_module_mlp(self.mlp, known_feats, unknow_feats, idx, None, dist=dist, point_major=point_major_ok)
             if fused is not None:
                 return fused
+            inv = 1.0 / (dist + 1e-8)
+            weight = inv / torch.sum(inv, dim=2, keepdim=True)
             spread = pointnet2_utils.three_interpolate(known_feats, idx, weight)
         else:
             spread = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))

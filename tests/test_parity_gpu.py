@@ -2685,17 +2685,29 @@ def test_fp_module_fused_kernel_matches_op_sequence(dev, n, m, c_known, c_skip, 
     uf = torch.randn(2, c_skip, n, device=dev) if c_skip else None
     calls = []
     orig = fused.fp_module_mlp
-    fused.fp_module_mlp = lambda *a: calls.append(orig(*a)) or calls[-1]
+    fused.fp_module_mlp = lambda *a, **k: calls.append(orig(*a, **k)) or calls[-1]
     try:
         with torch.no_grad():
             got = fp(unknown, known, uf, kf)
-        assert len(calls) == 1 and calls[0] is not None, "the fused kernel was supposed to serve this shape"
-        want = fp(unknown, known, uf, kf.clone().requires_grad_(True))      # gradients wanted: the op sequence
-        assert len(calls) == 2 and calls[1] is None
+            rows = fp(unknown, known, uf, kf, point_major_ok=True)
+        assert len(calls) == 2 and calls[0] is not None and calls[1] is not None, "the fused kernel was supposed to serve this shape"
+        want = fp(unknown, known, uf, kf.clone().requires_grad_(True), point_major_ok=True)      # gradients wanted: the op sequence
+        assert len(calls) == 3 and calls[2] is None and not getattr(want, "_sps_point_major", False)
     finally:
         fused.fp_module_mlp = orig
     assert got.shape == want.shape
     assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+    # per-point rows straight from the kernel: the same numbers, transposed
+    assert getattr(rows, "_sps_point_major", False) and rows.shape == (2, n, widths[-1]) and rows.is_contiguous()
+    assert torch.equal(rows.transpose(1, 2), got)
+    # the weights formed inside the kernel from three_nn's distances against the module's three torch ops
+    from spsnet_amd import pointnet2_utils as U
+    with torch.no_grad():
+        dist, idx = U.three_nn(unknown, known)
+        inv = 1.0 / (dist + 1e-8)
+        weight = inv / torch.sum(inv, dim=2, keepdim=True)
+        given = fused.fp_module_mlp(fp.mlp, kf, uf, idx, weight)
+    assert float((given - got).abs().max()) <= 2e-6 * max(1.0, float(got.abs().max()))
 
 
 def test_fp_module_training_on_fused_kernels_matches_torch(dev, monkeypatch):
