@@ -478,29 +478,35 @@ class _PackedGeneric:
     __slots__ = ("key", "ws", "wamax", "params")
 
 
+_GENERIC_MAX_CIN = 288      # input channels of a layer that sps_tconv serves (weights resident in LDS as split halves)
+
+
 def generic_mlp_pool(mlp, grouped):
     """max over the samples of [Conv2d 1x1 + BatchNorm2d(eval) + ReLU] x n on a grouped tensor (B, C0, M, ns) for stacks NO
     specialised kernel serves (widths outside the IA-SSD / SPSNet table, any depth): the streaming convolution kernels of
     csrc/mlp_train.hip with the BatchNorm of the running statistics applied in the next layer's operand load and in the
     pool (split-fp16 MFMA, <= 2e-5 relative) -- n + 1 launches and two HBM crossings per activation instead of torch's
-    3 n + 1 launches and five.  -> (B, Cn, M), or None when it does not apply (training, gradients wanted, fp32 mode, more
-    than 288 input channels of a layer, nsample outside {4, 8, 16, 32, 64}, M * ns not a multiple of 64)."""
+    3 n + 1 launches and five; a layer with more than 288 input channels runs as a library GEMM on the materialised
+    activation.  -> (B, Cn, M), or None when it does not apply (training, gradients wanted, fp32 mode, nsample outside
+    {4, 8, 16, 32, 64}, M * ns not a multiple of 64)."""
     from . import pointnet2_batch_cuda as _ext
     mods = list(mlp)
     if (PRECISION == "fp32" or len(mods) % 3 or not mods or mlp.training or not grouped.is_cuda or grouped.dtype != torch.float32
             or grouped.dim() != 4):
         return None
     B, c0, M, ns = grouped.shape
-    if ns not in (4, 8, 16, 32, 64) or (M * ns) % 64 or c0 > 288 or grouped.numel() == 0:
+    if ns not in (4, 8, 16, 32, 64) or (M * ns) % 64 or grouped.numel() == 0:
         return None
     pairs = []
     for conv, bn, act in zip(mods[0::3], mods[1::3], mods[2::3]):
         if not (isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and isinstance(act, nn.ReLU)
                 and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and conv.bias is None
-                and bn.track_running_stats and bn.affine and conv.in_channels <= 288 and conv.out_channels <= 1024
+                and bn.track_running_stats and bn.affine and conv.out_channels <= 1024
                 and conv.weight.dtype == torch.float32):
             return None
         pairs.append((conv, bn))
+    if pairs[0][0].in_channels != c0:
+        return None
     if torch.is_grad_enabled() and (grouped.requires_grad or any(p.requires_grad for p in mlp.parameters())):
         return None
     key = _version_key(pairs, grouped.device)
@@ -524,8 +530,14 @@ def generic_mlp_pool(mlp, grouped):
     operand, pin, mode = grouped.contiguous(), None, _ext.TIN_RAW
     with _ext.launch_scope(operand):
         for k, w in enumerate(packed.ws):
-            y = torch.empty((B, w.shape[0], M, ns), dtype=torch.float32, device=grouped.device)
-            _ext.tconv(w, packed.wamax[k:k + 1], mode, _ext.TEPI_NONE, y, operand=operand, pin=pin, overflow=flag)
+            if w.shape[1] > _GENERIC_MAX_CIN:
+                # more input channels than the streaming kernel keeps weights for in LDS (PointRCNN's coarsest level: 515 and
+                # 384): a library GEMM (exact fp32) on the materialised activation -- still one or two launches for the layer
+                a = operand if pin is None else _ext.tbn_apply_relu(operand, pin)
+                y = torch.matmul(w, a.view(B, w.shape[1], M * ns)).view(B, w.shape[0], M, ns)
+            else:
+                y = torch.empty((B, w.shape[0], M, ns), dtype=torch.float32, device=grouped.device)
+                _ext.tconv(w, packed.wamax[k:k + 1], mode, _ext.TEPI_NONE, y, operand=operand, pin=pin, overflow=flag)
             operand, pin, mode = y, packed.params[k], _ext.TIN_BNRELU
         out, _, _ = _ext.tpool_fwd(operand, pin)
     return out

@@ -2743,7 +2743,7 @@ def test_fp_module_training_on_fused_kernels_matches_torch(dev, monkeypatch):
 
 
 @pytest.mark.parametrize("B,M,ns,widths", [(2, 64, 16, [259, 128, 196, 256]), (2, 128, 32, [20, 40, 24]), (1, 32, 8, [7, 100]),
-                                           (2, 32, 32, [288, 272, 384])])
+                                           (2, 32, 32, [288, 272, 384]), (2, 64, 16, [515, 256, 256, 512]), (2, 64, 32, [515, 256, 384, 512])])
 def test_generic_eval_mlp_pool_matches_torch(dev, B, M, ns, widths):
     """fused.generic_mlp_pool (inference at widths outside the specialised kernels' table: the streaming convolution kernels
     with the running-statistics BatchNorm applied in the operand loads and the pool) against torch's eval-mode op sequence:
