@@ -332,6 +332,15 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void fp_mlp_kernel(FpArgs a) {
     }
 }
 
+// LDS a workgroup may take for its images, KiB: half a CU's, so that two workgroups share one and the input stage of one
+// (scattered reads of the coarse level) overlaps the matrix stage of the other -- PointNet2MSG forward 3.96 ms at 140, 3.90 at
+// 74, 3.99 at 48 (fewer points per weight stream).  SPS_FP_LDS_KB overrides (read per launch: experiments).
+static int fp_lds_budget() {
+    const char *e = getenv("SPS_FP_LDS_KB");
+    const int v = e ? atoi(e) : 0;
+    return v >= 16 && v <= 140 ? v : 74;
+}
+
 template <int NT>
 static int fp_launch(const FpArgs &a, int b, size_t lds, int waves, hipStream_t st) {
     static LdsLimitOnce raised;
@@ -377,7 +386,7 @@ extern "C" int sps_fp_module_mlp_ex(int b, int n, int m, int c_known, int c_skip
     const size_t rows = (size_t)wide + (c2 ? c1 : 0);
     // as many 16-point column tiles per workgroup as the LDS images allow (the weights stream once per workgroup)
     int nt = 4;
-    while (nt > 1 && (sizeof(float) * (16 * nt + 1) * rows > 140 * 1024 || 16 * (nt / 2) >= n)) nt >>= 1;
+    while (nt > 1 && (sizeof(float) * (16 * nt + 1) * rows > (size_t)fp_lds_budget() * 1024 || 16 * (nt / 2) >= n)) nt >>= 1;
     const size_t lds = sizeof(float) * (size_t)(16 * nt + 1) * rows;
     if (lds > 148 * 1024) return fail(SPS_ERR_INVALID, "fp_module_mlp: widths (%d, %d, %d) need more LDS than a workgroup has", a.cin, c1, c2);
     int tiles = c1 / 16;
