@@ -3,7 +3,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pn2prof
 rm -rf $O; mkdir -p $O
 cd $R
-rocprofv3 --output-format csv --kernel-trace --stats -d $O/kt -o kt -- python3 tools/backbone_time.py 8 16384 10 PointNet2 > $O/log.txt 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $O/kt -o kt -- python3 tools/backbone_time.py 8 16384 10 ${1:-PointNet2} > $O/log.txt 2>&1
 python3 - <<'PY'
 import csv, glob, os
 O = os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/pn2prof"
