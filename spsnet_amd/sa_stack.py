@@ -340,10 +340,12 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
             off += packed.c3_real
         if tail is not None:
             tail.run(j0, chunk, full_range_if=repair)
-        if verify is not None and j1 < M and EARLY_PREFIX_CHECK:
+        if verify is not None and j1 < M and EARLY_PREFIX_CHECK and N <= 16384:
             # second pass of the next layer's identity-prefix check for the centroids that exist by now: the stream would
             # otherwise idle in the next chunk's wait (a chunk whose wait gave up checks garbage -- finish() is then told to
-            # recompute every scene: force_redo)
+            # recompute every scene: force_redo).  Not beside the clustered large-scene producer: its workgroups wait on each
+            # other every round, and pieces that stage 4 096 centres per workgroup on their compute units cost it 0.5 ms of
+            # 7.8 (config 5, measured) -- there the whole pass runs behind the last pick on a third stream, as before.
             verify.check_upto(j1)
 
     xyz_ready, verified_inline = None, False
