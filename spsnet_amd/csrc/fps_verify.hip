@@ -20,7 +20,7 @@ namespace sps {
 
 constexpr int FV_SEG = 8;                    // waves per workgroup = segments of the centre range
 constexpr int FV_THREADS = 64 * FV_SEG;
-constexpr int FV_FINE_MAX_POINTS = 1 << 16;  // launches of at most this many points (all scenes) take the 16-point check kernel
+constexpr int FV_FINE_MAX_POINTS = 4096;     // launches of at most this many points (all scenes) take the 16-point check kernel
 constexpr int FV_MAX_M = 7168;               // centres staged in LDS: 20 B each (+ 2 KiB) of the 160 KiB, dynamic
 
 __device__ __forceinline__ unsigned fv_rank(unsigned k, int bs, int l2, int rb) {
@@ -180,8 +180,9 @@ static int fv_launch_check(int b, int n, int m, int k0, int kcount, const float 
     int rb = 0;
     while ((1 << rb) < divup(n, bs)) ++rb;
     const size_t lds = (size_t)m * 20 + sizeof(float) * FV_SEG * 64;   // (segmin: NSEG * PTS = 512 floats either way)
-    // the launch somebody waits for (the streamed layer's last piece, a whole cloud of moderate size): the 16-point form --
-    // more, shorter workgroups.  The early pieces run BESIDE the producer and nobody waits for them: four times the
+    // the SMALL launch somebody waits for (the streamed layer's last piece): the 16-point form -- more, shorter workgroups; a
+    // whole cloud is throughput, not latency, and the 16-point form's extra staging makes it 5-8 % slower there (measured:
+    // 8 x 4096 -> 1024 50.5 vs 53.4 us per call, 1 x 16 384 -> 4096 129 vs 137 us).  The early pieces run BESIDE the producer and nobody waits for them: four times the
     // workgroups (each staging all m centres) only take cycles from its compute units (config 5: the clustered FPS
     // 7.88 -> 8.36 ms with 16-point pieces beside it), so they keep the 64-point form.
     const bool fine = may_be_fine && (long long)b * (kend - k0) <= FV_FINE_MAX_POINTS;
