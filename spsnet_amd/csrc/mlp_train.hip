@@ -601,25 +601,39 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
     }
 }
 
-// dw[o][i] = sum over the workgroup partials, in launch order (eight loads in flight per thread)
+// dw[o][i] = sum over the workgroup partials in a FIXED order: a workgroup owns 32 elements, its eight 32-thread groups
+// take the partials k = g, g + 8, ... (eight loads in flight each), the eight group sums meet in LDS and are added in group
+// order.  (One thread per element walking all partials was 32 dependent round trips: ~12 us per launch whatever the size,
+// eighteen launches per training step.)
 __global__ __launch_bounds__(256) void twgrad_reduce_kernel(int co, int ci, int cip, int cop, int nparts, const float *__restrict__ partial,
                                                             float *__restrict__ dw) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= co * ci) return;
-    const int o = e / ci, i = e - o * ci;
-    const float *p = partial + (size_t)o * cip + i;
-    const size_t stride = (size_t)cop * cip;
+    __shared__ float part[8][32];
+    const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
+    const bool live = e < co * ci;
     float s = 0.f;
-    int k = 0;
-    for (; k + 8 <= nparts; k += 8) {
-        float v[8];
+    if (live) {
+        const int o = e / ci, i = e - o * ci;
+        const float *p = partial + (size_t)o * cip + i;
+        const size_t stride = (size_t)cop * cip;
+        int k = g;
+        for (; k + 56 < nparts; k += 64) {
+            float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * stride];
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + 8 * u) * stride];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < nparts; k += 8) s += p[(size_t)k * stride];
     }
-    for (; k < nparts; ++k) s += p[(size_t)k * stride];
-    dw[e] = s;
+    part[g][el] = s;
+    __syncthreads();
+    if (g == 0 && live) {
+        float t = part[0][el];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) t += part[u][el];
+        dw[e] = t;
+    }
 }
 
 // ---- statistics -> parameter blocks -----------------------------------------------------------------------------------------
@@ -1034,6 +1048,6 @@ extern "C" int sps_twgrad(int b, int co, int ci, long long l, int dmode, int xmo
     const int rc = nk == 8 ? twgrad_launch<8>(a, parts, st)
                            : (nk == 4 ? twgrad_launch<4>(a, parts, st) : (nk == 2 ? twgrad_launch<2>(a, parts, st) : twgrad_launch<1>(a, parts, st)));
     if (rc != SPS_OK) return rc;
-    hipLaunchKernelGGL(twgrad_reduce_kernel, dim3(divup(co * ci, 256)), dim3(256), 0, st, co, ci, cip, cop, parts, work, dw);
+    hipLaunchKernelGGL(twgrad_reduce_kernel, dim3(divup(co * ci, 32)), dim3(256), 0, st, co, ci, cip, cop, parts, work, dw);
     return check_launch("twgrad_kernel");
 }
