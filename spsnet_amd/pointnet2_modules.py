@@ -876,8 +876,9 @@ class Vote_layer(nn.Module):
 
     def _limit_on(self, device):
         cached = getattr(self, '_limit_cache', None)
-        if cached is None or cached.device != device:
-            cached = self.max_offset_limit.to(device).view(1, 1, 3)
+        if cached is None or cached[0].device != device:
+            limit = self.max_offset_limit.to(device).view(1, 1, 3)
+            cached = (limit, -limit)         # (both bounds once: no negation launch per forward)
             object.__setattr__(self, '_limit_cache', cached)
         return cached
 
@@ -898,9 +899,9 @@ class Vote_layer(nn.Module):
         new_features = offsets[..., 3:]                      # empty: ctr_reg has exactly 3 outputs
         ctr_offsets = offsets[..., :3]
         if self.max_offset_limit is not None:
-            limit = self._limit_on(xyz.device)
+            limit, lower = self._limit_on(xyz.device)
             # where(o > l, l, o) then where(. < -l, -l, .) of the reference (:505-507) in one op; NaN stays NaN either way
-            vote_xyz = xyz + torch.clamp(ctr_offsets, min=-limit, max=limit)
+            vote_xyz = xyz + torch.clamp(ctr_offsets, min=lower, max=limit)
         else:
             vote_xyz = xyz + ctr_offsets
         return vote_xyz, new_features, xyz, ctr_offsets
