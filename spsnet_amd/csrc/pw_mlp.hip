@@ -262,8 +262,9 @@ __global__ __launch_bounds__(64 * PW_MAX_WAVES) void fp_mlp_kernel(FpArgs a) {
         if (m0 + col < a.n) {
             if (ch < a.c_known) {
                 const float *f = kf + (size_t)ch * a.m;
-                float t = s_w[3 * col] * f[s_idx[3 * col]];
-                t = __builtin_fmaf(s_w[3 * col + 1], f[s_idx[3 * col + 1]], t);
+                // same three-term order as three_interpolate_kernel (interpolate.hip): w1*f1 first
+                float t = s_w[3 * col + 1] * f[s_idx[3 * col + 1]];
+                t = __builtin_fmaf(s_w[3 * col], f[s_idx[3 * col]], t);
                 v = __builtin_fmaf(s_w[3 * col + 2], f[s_idx[3 * col + 2]], t);
             } else if (ch < a.c_known + a.c_skip) {
                 v = a.skip[((size_t)scene * a.c_skip + (ch - a.c_known)) * a.n + m0 + col];
