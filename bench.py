@@ -8,9 +8,14 @@ One "step" = one full pass of the IA-SSD set-abstraction stack L0-L2 (D-FPS 16 3
 D-FPS ->1 024, ctr-aware top-k ->512; per layer two ball-query radii, grouping, grouped MLP,
 max-pool, aggregation and confidence heads; tools/cfgs/kitti_models/IA-SSD.yaml:35-55) over one
 batch of 8 synthetic KITTI-shaped scenes per GPU (BASELINE.json configs[1]).  Inputs are resident
-in HBM before the timed region.  Scenes shard over ranks with no data-path collective (weak
-scaling, DESIGN.md "multi-GPU"); each rank all-gathers its sampled indices once after the timed
-region only to prove the exchange path works.
+in HBM before the timed region.  Scenes shard over ranks (weak scaling, DESIGN.md "multi-GPU").
+At N > 1 the step is BASELINE configs[2]: it ends with the path's one exchange, the packed RCCL
+all-gather of every layer's sampled indices (int32 (8, 4096 + 1024 + 512) per rank),
+INSIDE the timed region; `ms_per_step_no_exchange` is the same K steps without it.
+
+The headline `value` is the reference's arithmetic: every grouped MLP in strict fp32 (fp32 MFMA).  The
+split-fp16 form of the wide scales (hi + lo halves, ~22-bit products, <= 2e-5 relative) is timed the
+same way and reported beside it as `value_fp16x2`.
 
 `--config 4` selects BASELINE configs[3] (stability top-k at layer 2), `--config 5` the per-GPU share of
 configs[4] (1 scene x 180 000 points -> 16 384 / 4 096 / 1 024, nsample 64, fp16 features on MFMA).
@@ -18,12 +23,17 @@ configs[4] (1 scene x 180 000 points -> 16 384 / 4 096 / 1 024, nsample 64, fp16
 Prints ONE JSON line (rank 0) with value = total points/s over all ranks, plus
   validated    -- what was checked about the timed work after the timed region (no progress-wait timeout, no
                   split-fp16 overflow, last step's outputs bit-identical to one plain sequential pass);
-  value_fp32   -- the same K steps with the grouped MLP in strict fp32 (`--mlp-precision fp32`), timed the same way;
+  value_fp16x2 -- the same K steps with the wide grouped-MLP scales as split-fp16 pairs, timed the same way;
   ms_per_step_median -- median of the K per-step HIP-event times (ms_per_step is elapsed / K);
   roofline     -- the dominant kernel (layer-0 FPS) on ALGORITHMIC touched bytes (SURVEY.md 8d:
                   20*N*(m-1) B per scene) over its HIP-event time measured inside the timed region;
   roofline_mlp -- the largest grouped-MLP launch: algorithmic FLOP over its HIP-event time (measured after the timed
                   region on the launch's own arguments) and the MFMA-busy fraction from the committed PMC pass;
+  roofline_ball_query -- layer 0's two-radius ball query (whole layer, one scan): pair tests / s and algorithmic bytes
+                  12 (N + M) + 4 M (ns_a + ns_b) per scene over its HIP-event time, plus the chunked launches of the
+                  streamed pass as the step runs them;
+  roofline_gather -- the gather / group side of the fused grouped-MLP launches: bytes gathered + written per launch
+                  over its HIP-event time, per scale;
   cpu_baseline -- the CPU oracle port of the same stack on the host cores, all cores and one thread (rank 0, N=1 only).
 """
 import argparse
@@ -44,7 +54,7 @@ import torch.distributed as dist  # noqa: E402
 METRIC = "points/sec through SA stack (FPS+ball-query+grouped-MLP), KITTI 16k→512"
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TF = {"fp32": 157.3, "fp16x2": 2500.0, "fp16": 2500.0}  # dense peaks: fp32 MFMA, fp16 MFMA (no sparsity)
-PROFILE_DIRS = ("round2", "round1")
+PROFILE_DIRS = ("round3", "round2", "round1")
 
 
 def parse():
@@ -66,7 +76,11 @@ def parse():
     ap.add_argument("--no-stream-first-layer", dest="stream_first_layer", action="store_false",
                     help="do not let layer 0's ball query / MLP consume the D-FPS picks while FPS is still running")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the strict-fp32 repetition (value_fp32)")
+    ap.add_argument("--no-fp16x2-leg", "--no-fp32-leg", dest="no_second_leg", action="store_true",
+                    help="skip the repetition in the other grouped-MLP arithmetic (value_fp16x2; value_fp32 when "
+                         "--mlp-precision fp16x2 is the headline)")
+    ap.add_argument("--no-exchange", action="store_true",
+                    help="N > 1: leave the all-gather of the sampled indices out of the step (config 2 x N instead of configs[2])")
     ap.add_argument("--no-validate", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pipelined", action="store_true",
                     help="also time the same passes with two batches in flight (informational object)")
@@ -85,7 +99,7 @@ def parse():
         args.mlp_precision = args.mlp_precision or "fp16"
     args.batch = 8 if args.batch is None else args.batch
     args.points = 16384 if args.points is None else args.points
-    args.mlp_precision = args.mlp_precision or "fp16x2"
+    args.mlp_precision = args.mlp_precision or "fp32"     # the reference's arithmetic is the headline
     if args.sampler is None:
         args.sampler = "sss_aware" if args.config == 4 else "ctr_aware"
     return args
@@ -173,6 +187,133 @@ class MlpProbe:
                 "packed_columns": kw.get("columns") is not None,
                 "nsample": int(idx.shape[2]), "columns": int(flop / (2.0 * (packed.cin * packed.c1 + packed.c1 * packed.c2
                                                                            + packed.c2 * packed.c3_real)))}
+
+
+def _event_times(fn, reps, warm=3):
+    """Median / mean HIP-event time (ms) of fn() on the stream it launches on (torch's current stream)."""
+    for _ in range(warm):
+        fn()
+    pairs = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        pairs.append((s, e))
+    torch.cuda.synchronize()
+    ms = [s.elapsed_time(e) for s, e in pairs]
+    return float(np.median(ms)), float(np.mean(ms))
+
+
+class ChunkProbe:
+    """HIP events around every chunked two-radius ball-query launch of the streamed first layer (the consumer stream, behind
+    the chunk's progress wait) -- switched on for a few probe steps AFTER the timed region, never inside it."""
+
+    def __init__(self, ext):
+        self.ext, self.orig, self.on, self.pairs = ext, ext.ball_query_full2_range, False, []
+        ext.ball_query_full2_range = self
+
+    def __call__(self, ra, rb, xyz, new_xyz, idx_a, idx_b, j0, jcount, **kw):
+        if not self.on:
+            return self.orig(ra, rb, xyz, new_xyz, idx_a, idx_b, j0, jcount, **kw)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = self.orig(ra, rb, xyz, new_xyz, idx_a, idx_b, j0, jcount, **kw)
+        e.record()
+        self.pairs.append((s, e, xyz.shape[0] * jcount * xyz.shape[1]))
+        return r
+
+    def summary(self, steps):
+        if not self.pairs or steps <= 0:
+            return None
+        ms = sum(s.elapsed_time(e) for s, e, _ in self.pairs) / steps
+        tests = sum(t for _, _, t in self.pairs) / steps
+        n = len(self.pairs) // steps
+        self.pairs = []
+        return {"launches_per_step": n, "ms_per_step": ms, "pair_tests_per_step": tests, "pair_tests_per_s": tests / (ms * 1e-3)}
+
+
+def ball_query_roofline(ext, layers, xyz, outs, chunk_stats):
+    """Layer 0's two-radius ball query (`12 (N + M) + 4 M ns` compulsory bytes per scene and radius -- one scan
+    serves both radii here, so the coordinates are counted once; `M N` pair tests per scene)."""
+    ga, gb = layers[0].groupers
+    new_xyz = outs[0][0]
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    keep = ext.BQ_GRID_MIN
+    try:
+        ext.BQ_GRID_MIN = None                     # the lane-per-centroid SCAN kernel: every one of the M N pairs is tested
+        scan_ms, _ = _event_times(lambda: ext.ball_query_full2(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz, new_xyz), 20)
+        ext.BQ_GRID_MIN = (0, 0)                   # the cell-grid kernel chain: same rows from far fewer tests
+        grid_ms, _ = _event_times(lambda: ext.ball_query_full2(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz, new_xyz), 20)
+    finally:
+        ext.BQ_GRID_MIN = keep
+    algo = float(B) * (12.0 * (N + M) + 4.0 * M * (ga.nsample + gb.nsample))
+    tests = float(B) * M * N
+    ach = algo / (scan_ms * 1e-3) / 1e9
+    traffic = None
+    data, where = _profile_json("pmc_traffic.json")
+    rec = (data or {}).get("ball_query_dual_kernel")
+    if rec and (rec["batch"], rec["n"], rec["m"]) == (B, N, M):
+        traffic = (rec["fetch_kb"] + rec["write_kb"]) * 1024.0
+    out = {"bound": "hbm", "kernel": f"ball_query_dual_kernel (layer 0, both radii in one scan: {M} centroids x {N} points, "
+                                     f"r {ga.radius}/{gb.radius}, nsample {ga.nsample}/{gb.nsample})",
+           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+           "launch_ms": scan_ms, "algorithmic_bytes": algo, "pair_tests": tests, "pair_tests_per_s": tests / (scan_ms * 1e-3),
+           "grid_variant_ms": grid_ms,
+           "note": "algorithmic bytes = the compulsory 12 (N + M) + 4 M (ns_a + ns_b) per scene; the kernel is VALU-bound on "
+                   "its M N pair tests (3 sub, 1 mul, 2 fma, 2 compares each), not on HBM: the cloud is re-read from the "
+                   "scalar cache / L2, so `frac` is small by construction and pair_tests_per_s is the figure of merit; "
+                   "grid_variant_ms = the same rows through the cell-grid kernels (ball_query_grid.hip)"}
+    if chunk_stats is not None:
+        out["streamed_chunks"] = dict(chunk_stats, kernel="ball_query_wave_multi_kernel / ball_query_wave_seg_kernel "
+                                      "(the step's chunked launches, each gathering its own centroids)")
+    return out
+
+
+def gather_roofline(fused, layers, xyz, feats, outs):
+    """The gather / group side of the fused grouped-MLP launches (group_points + cat + centring in the reference,
+    group_points_gpu.cu:14-50): per scale, bytes a launch gathers (4 (3 + C) per grouped column + its 4-byte index) and
+    writes (4 C_out per centroid), over the HIP-event time of the whole-layer launch on the pass's own tensors."""
+    from spsnet_amd import pointnet2_batch_cuda as ext
+    rows = []
+    src_xyz, src_f = xyz, feats
+    for k, layer in enumerate(layers):
+        new_xyz, new_f = outs[k][0], outs[k][1]
+        plan = layer._fused_plan(src_xyz, new_xyz, src_f)
+        if not plan or len(layer.groupers) != 2:
+            src_xyz, src_f = new_xyz, new_f
+            continue
+        ga, gb = layer.groupers
+        ia, ib = ext.ball_query_full2(ga.radius, ga.nsample, gb.radius, gb.nsample, src_xyz, new_xyz)
+        B, M = new_xyz.shape[0], new_xyz.shape[1]
+        out = torch.zeros((B, sum(p.c3_real for p in plan), M), dtype=torch.float32, device=xyz.device)
+        off = 0
+        for ix, packed in zip((ia, ib), plan):
+            ms, _ = _event_times(lambda ix=ix, packed=packed, off=off:
+                                 fused.group_mlp_pool(src_xyz, new_xyz, src_f, ix, packed, out, off), 10)
+            cols = float(ix.numel())
+            cin = 3 + (0 if src_f is None else src_f.shape[1])
+            esz = 2.0 if (src_f is not None and src_f.dtype == torch.float16) else 4.0
+            gathered = cols * (12.0 + esz * (cin - 3) + 4.0)
+            written = 4.0 * B * M * packed.c3_real
+            rows.append({"layer": k, "widths": [packed.cin, packed.c1, packed.c2, packed.c3_real], "nsample": int(ix.shape[2]),
+                         "columns": int(cols), "gathered_bytes": gathered, "written_bytes": written, "launch_ms": ms,
+                         "GB_per_s": (gathered + written) / (ms * 1e-3) / 1e9})
+            off += packed.c3_real
+        src_xyz, src_f = new_xyz, new_f
+    if not rows:
+        return None
+    top = max(rows, key=lambda r: r["gathered_bytes"] + r["written_bytes"])
+    ach = top["GB_per_s"]
+    return {"bound": "hbm", "kernel": f"gather inside the fused grouped MLP, layer {top['layer']} scale "
+                                      f"{'->'.join(str(w) for w in top['widths'])}, nsample {top['nsample']}",
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "launch_ms": top["launch_ms"], "per_scale": rows,
+            "note": "bytes = what the reference's group_points + cat would move for the same columns (gathered inputs + "
+                    "pooled output; its (B, C, M, ns) intermediates never exist here); the launch time is the WHOLE fused "
+                    "kernel (gather + three layers on MFMA + pool), so this is a lower bound on the gather's own rate -- "
+                    "wide scales are MFMA-bound, layer 0's are gather/VALU-bound"}
 
 
 def _profile_json(name):
@@ -348,10 +489,18 @@ def main():
         sa_stack.enable_cu_fence(dev, scenes=args.batch)
     probe = FpsProbe(ext, args.points)
     mlp_probe = MlpProbe(fused)
+    chunk_probe = ChunkProbe(ext)
+    # BASELINE configs[2]: at N > 1 every step ends with the ONE exchange the sharded path has -- the global-batch view of each
+    # layer's sampled indices, all three layers packed into one all-gather (RCCL over xGMI; latency-bound: 22 KiB per rank)
+    exchange = world > 1 and not args.no_exchange
+    state = {"exchange": exchange, "gathered": None}
 
     def step(**kw):
         with torch.no_grad():
-            return sa_stack.run_sa_layers(layers, xyz, feats, stds, stream_first_layer=args.stream_first_layer, **kw)
+            outs = sa_stack.run_sa_layers(layers, xyz, feats, stds, stream_first_layer=args.stream_first_layer, **kw)
+            if state["exchange"]:
+                state["gathered"] = all_gather_sampled_idx([o[3] for o in outs])
+            return outs
 
     def timed(steps, warmup):
         """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks.
@@ -403,22 +552,44 @@ def main():
     elapsed, per_step, outs = timed(args.steps, args.warmup)
     fps = probe.summary()
     checked = validate(outs)
-    if world > 1:
-        # the one exchange the sharded path has: global view of every layer's sampled indices
-        gathered = all_gather_sampled_idx([o[3] for o in outs])
-        assert gathered[0].shape[0] == world * args.batch
-    mlp = mlp_probe.measure() if world == 1 or rank == 0 else None
-
-    # the same K steps in strict fp32 (every grouped-MLP scale on the exact fp32 MFMA kernel), timed the same way
-    fp32_leg = None
-    if not args.no_fp32_leg and args.mlp_precision != "fp32" and args.config != 5:
-        fused.set_precision("fp32")
-        mlp_probe.best = None            # (the costliest launch of THIS leg: same shape, weights packed for the fp32 kernel)
-        el32, per32, outs32 = timed(args.steps, max(args.warmup, 2))
+    no_exchange = None
+    if exchange:
+        g = state["gathered"]
+        mine = [o[3] for o in outs]
+        assert all(t.shape[0] == world * args.batch for t in g)
+        assert all(torch.equal(t[rank * args.batch:(rank + 1) * args.batch], m.to(torch.int32)) for t, m in zip(g, mine)), \
+            "the gathered sampled indices do not hold this rank's rows at its offset"
+        state["exchange"] = False        # the same K steps without the exchange: what the all-gather costs a step
+        el_ne, per_ne, _ = timed(args.steps, max(2, args.warmup // 2))
         probe.summary()
-        chk32 = validate(outs32)
-        mlp32 = mlp_probe.measure() if world == 1 or rank == 0 else None   # the same launch on the exact fp32 MFMA kernel
-        fp32_leg = (el32, per32, chk32, mlp32)
+        no_exchange = (el_ne, per_ne)
+        state["exchange"] = True
+    mlp = mlp_probe.measure() if world == 1 or rank == 0 else None
+    bq_line = gather_line = None
+    if rank == 0 and args.config != 5:
+        # per-kernel lines for the gather side (after the timed region; the chunked ball queries over a few probed steps)
+        chunk_probe.on, keep_x = True, state["exchange"]
+        state["exchange"] = False
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        chunk_probe.on, state["exchange"] = False, keep_x
+        with torch.no_grad():
+            bq_line = ball_query_roofline(ext, layers, xyz, outs, chunk_probe.summary(5))
+            gather_line = gather_roofline(fused, layers, xyz, feats, outs)
+
+    # the same K steps in the OTHER grouped-MLP arithmetic, timed the same way: split-fp16 pairs for the wide scales when the
+    # headline is strict fp32 (the default), strict fp32 when --mlp-precision fp16x2 made the split form the headline
+    other = {"fp32": "fp16x2", "fp16x2": "fp32"}.get(args.mlp_precision)
+    second_leg = None
+    if not args.no_second_leg and other is not None and args.config != 5:
+        fused.set_precision(other)
+        mlp_probe.best = None            # (the costliest launch of THIS leg: same shape, weights packed for its kernel)
+        el2, per2, outs2 = timed(args.steps, max(args.warmup, 2))
+        probe.summary()
+        chk2 = validate(outs2)
+        mlp2 = mlp_probe.measure() if world == 1 or rank == 0 else None
+        second_leg = (el2, per2, chk2, mlp2)
         fused.set_precision(args.mlp_precision)
 
     # Extra, reported separately (never `value`): the same K complete passes with TWO batches in flight on two
@@ -446,24 +617,37 @@ def main():
             "ms_per_step_median": float(statistics.median(per_step)),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_txt,
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{args.config - 1}]: batch={args.batch}/GPU x {args.points} pts "
-                                   f"({args.dataset}), IA-SSD SA L0-L2 ({shape_txt}, layer-2 sampler {args.sampler}), "
-                                   f"grouped MLP {args.mlp_precision}",
+            "config": {"workload": (f"BASELINE configs[2]: batch={world * args.batch} sharded {world}-way ({args.batch}/GPU) x "
+                                    f"{args.points} pts" if exchange else
+                                    f"BASELINE configs[{args.config - 1}]: batch={args.batch}/GPU x {args.points} pts") +
+                                   f" ({args.dataset}), IA-SSD SA L0-L2 ({shape_txt}, layer-2 sampler {args.sampler}), "
+                                   f"grouped MLP {args.mlp_precision}" +
+                                   (", one packed RCCL all-gather of the sampled indices per step" if exchange else ""),
                        "global_batch": world * args.batch, "points_per_scene": args.points,
-                       "parallelism": f"scene-sharded x{world}, no data-path collective"},
+                       "parallelism": (f"scene-sharded x{world}; per step one all-gather of the layers' sampled indices "
+                                       f"(int32 ({args.batch}, sum M) per rank) inside the timed region" if exchange else
+                                       f"scene-sharded x{world}, no data-path collective")},
         }
+        if no_exchange is not None:
+            line["ms_per_step_no_exchange"] = 1e3 * no_exchange[0] / args.steps
+            line["ms_per_step_no_exchange_median"] = float(statistics.median(no_exchange[1]))
+            line["exchange"] = {"collective": "all_gather_into_tensor (RCCL)", "per_step": 1,
+                                "bytes_per_rank": int(4 * args.batch * sum(o[3].shape[1] for o in outs)),
+                                "checked": "every rank's rows found at its offset of the gathered tensors"}
         if rehearsal:
             line["data"] = "synthetic; REHEARSAL: all ranks share one GPU over gloo -- not a measurement"
         if checked is not None:
             line["validated"] = checked
-        if fp32_leg is not None:
-            el32, per32, chk32, mlp32 = fp32_leg
-            line["value_fp32"] = total_points / el32
-            line["ms_per_step_fp32"] = 1e3 * el32 / args.steps
-            line["ms_per_step_fp32_median"] = float(statistics.median(per32))
-            if chk32 is not None:
-                line["validated_fp32"] = chk32
-        elif args.mlp_precision == "fp32":
+        if second_leg is not None:
+            el2, per2, chk2, mlp2 = second_leg
+            line[f"value_{other}"] = total_points / el2
+            line[f"ms_per_step_{other}"] = 1e3 * el2 / args.steps
+            line[f"ms_per_step_{other}_median"] = float(statistics.median(per2))
+            line[f"dtype_{other}"] = {"fp32": "f32", "fp16x2": "f32 results from split-fp16 operands (hi + lo halves, 3 MFMAs per "
+                                      "product block, fp32 accumulate; <= 2e-5 relative to fp32) on the wide grouped-MLP scales"}[other]
+            if chk2 is not None:
+                line[f"validated_{other}"] = chk2
+        if args.mlp_precision == "fp32":
             line["value_fp32"] = line["value"]
         if fps is not None:
             mean_ms, min_ms, b, n, m = fps
@@ -498,8 +682,12 @@ def main():
                         "SQ_VALU_MFMA_BUSY_CYCLES / (kernel duration x 1024 SIMDs x 2.4 GHz) from the committed PMC pass"}
         if mlp is not None:
             line["roofline_mlp"] = mlp_roofline(mlp, args.mlp_precision)
-        if fp32_leg is not None and fp32_leg[3] is not None:   # the strict-fp32 leg's dominant launch (fp32 MFMA pipe, 157 TF)
-            line["roofline_mlp_fp32"] = mlp_roofline(fp32_leg[3], "fp32")
+        if second_leg is not None and second_leg[3] is not None:   # the other leg's dominant launch on its own pipe
+            line[f"roofline_mlp_{other}"] = mlp_roofline(second_leg[3], other)
+        if bq_line is not None:
+            line["roofline_ball_query"] = bq_line
+        if gather_line is not None:
+            line["roofline_gather"] = gather_line
         if pipelined is not None:
             line["pipelined"] = pipelined
         if world == 1 and not args.no_training_leg and args.config != 5 and args.mlp_precision != "fp16":

@@ -217,6 +217,9 @@ int sps_sa_group_mlp_supported(int c1, int c2, int nsample);
 /* 1 if only the shared-stream split-fp16 kernel (sps_sa_group_mlp_ex mode 2) serves these padded widths
  * (IA-SSD layer 5: 256-256-512 / 256-512-1024). */
 int sps_sa_group_mlp_supported_stream(int c1, int c2, int c3, int nsample);
+/* 1 if the exact-fp32 kernel for point-major features (sps_sa_group_mlp_ex mode 4) serves c_feat channels and these
+ * padded widths. */
+int sps_sa_group_mlp_pm_supported(int c_feat, int c1, int c2, int c3, int nsample);
 /* Arithmetic of sps_sa_group_mlp: 0 = exact fp32 MFMA (default), 1 = split-fp16: every operand as hi+lo halves,
  * three v_mfma_f32_16x16x16_f16 per product block, fp32 accumulate (~1e-6 relative, csrc/sa_mlp_f16.hip).  The
  * weight buffers passed afterwards must be packed for the selected mode (spsnet_amd/fused.py).  Returns the old mode. */
@@ -236,8 +239,14 @@ int sps_set_mlp_precision(int mode);
  * chunk of a streamed layer -- whose wait is patient, so its inputs are final -- passes full_range_if = timed_out: it
  * redoes every chunk when a wait did give up and costs nothing otherwise (one predicated centroid gather is the only extra
  * launch).  force_redo = timed_out goes to sps_fps_ordered_prefix_finish, which then recomputes every scene.
- * sps_debug_set_wait_spins: DIAGNOSTIC, the spin bound of sps_wait_progress (tests force the redo path with it). */
+ * sps_debug_set_wait_spins: DIAGNOSTIC, the spin bound of sps_wait_progress (tests force the redo path with it;
+ * 0xFFFFFFFF: every wait gives up without looking at the counter; 0 restores the default).
+ * sps_debug_set_exchange_spins: DIAGNOSTIC, the spin bound of the cross-workgroup polls inside the FPS kernels (the K-way
+ * sort of the pre-pass / clustered kernel and the clustered kernel's record exchange).  A poll that runs out never traps:
+ * it raises the scene's give-up word, the scene's workgroups leave, and the launcher's follow-up launch (always enqueued,
+ * normally empty) samples the scene with the one-workgroup kernel.  Same encoding as above. */
 unsigned sps_debug_set_wait_spins(unsigned spins);
+unsigned sps_debug_set_exchange_spins(unsigned spins);
 /* sps_wait_progress sets timed_out[0 .. b) (one flag per scene, all of them) when it gives up.
  * sps_fps_redo_where: the ordinary FPS for the scenes with redo[scene] != 0 only (temp must be pre-filled with 1e10 for
  * them); the other scenes keep idxs / temp untouched. */
@@ -278,8 +287,10 @@ int sps_sa_group_mlp_range(int b, int n, int m, int j0, int jcount, int c_feat, 
  * (fp16 features in HBM, BASELINE configs[4]), weights are fp16 fragments of 1 KiB, one MFMA per product block, fp32
  * accumulate, hidden widths multiples of 32; weights packed accordingly by the caller; + 4:
  * `features` is point-major (b, n, c_feat), c_feat % 4 == 0, and layer 1's input channels are ordered
- * [features, xyz] instead of [xyz, features] -- a neighbour's channels are then contiguous 16-byte loads) and,
- * for the split-fp16 kernel, a device flag that is set to 1 if an operand left the exactly splittable range
+ * [features, xyz] instead of [xyz, features] -- a neighbour's channels are then contiguous 16-byte loads; with
+ * arithmetic 0 (value 4: exact fp32 on point-major features, csrc/sa_mlp_pm.hip) c_feat % 16 == 0, w1 holds the
+ * coordinate fragments [c1/16][64] followed by layer 1 over the features packed like w2 / w3, and the widths must be
+ * listed by sps_sa_group_mlp_pm_supported) and, for the split-fp16 kernel, a device flag that is set to 1 if an operand left the exactly splittable range
  * (|x| > 65 504: the value was clamped).  overflow_flag may be NULL. */
 int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,
                         const float *new_xyz, const float *features, const int *idx, int c1, int c2, int c3,
@@ -545,6 +556,13 @@ int sps_tconv(int b, int ci, int co, long long l, int in_mode, int epi_mode, int
 int sps_tbn_finalize(int c, int nparts, double count, const double *partial, const float *gamma, const float *beta, float eps,
                      float momentum, float *running_mean, float *running_var, float *params, long long *num_batches_tracked,
                      sps_stream_t stream);   /* num_batches_tracked (int64 device scalar, may be NULL) += 1 */
+/* the same with the element count on the device (count_dev, may be NULL = use `count`): nn.SyncBatchNorm's GLOBAL count,
+ * all-reduced beside the sums so that ranks with different local batch sizes agree (torch gathers per-rank counts too) */
+int sps_tbn_finalize_dc(int c, int nparts, double count, const double *count_dev, const double *partial, const float *gamma,
+                        const float *beta, float eps, float momentum, float *running_mean, float *running_var, float *params,
+                        long long *num_batches_tracked, sps_stream_t stream);
+int sps_tbn_bwd_finalize_dc(int c, int nparts, double count, const double *count_dev, const double *partial, float *params,
+                            float *dgamma, float *dbeta, sps_stream_t stream);
 /* out[k] = max |p_k[0 .. n_k)| for `count` <= 4 arrays in one launch (the `wamax` scalars of a grouped MLP's layers) */
 int sps_tamax4(int count, const float *p0, long long n0, const float *p1, long long n1, const float *p2, long long n2,
                const float *p3, long long n3, float *out, sps_stream_t stream);

@@ -162,6 +162,9 @@ def samplers_partitioned(M):
              ss_nsamples=[8], **small), fwd_kw=dict(stds=stds), seed=12)
     _sa_case(M, "sampler_dsfps", xyz, feats, dict(npoint_list=[256], sample_type_list=['ds-FPS'], **small), seed=13)
     _sa_case(M, "sampler_ryfps", xyz, feats, dict(npoint_list=[256], sample_type_list=['ry-FPS'], **small), seed=14)
+    # Rand (pointnet2_modules.py:370-371): one torch.randperm prefix shared by the batch.  The fixture pins what happens WITH the
+    # permutation (prefix, int32, repeated per scene, then gather / group / MLP); the test feeds the same permutation back in.
+    _sa_case(M, "sampler_rand", xyz, feats, dict(npoint_list=[256], sample_type_list=['Rand'], **small), seed=16)
     # 4096 of 8192 picks with a tight stability ball: scene 0 keeps >= 3500 distinct picks -> the stable picks are used
     xyz_l, _ = scenes.make_batch("kitti-lidar-v1", 2, 8192, seed0=401)
     feats_l = rng.normal(size=(2, 2, 8192)).astype(np.float32)

@@ -56,6 +56,7 @@ _PROTOS = {
     "sps_set_mlp_precision": [_i],
     "sps_index_add_deterministic": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_sa_group_mlp_supported_stream": [_i, _i, _i, _i],
+    "sps_sa_group_mlp_pm_supported": [_i, _i, _i, _i, _i],
     "sps_fps_with_workspace": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_pointwise_mlp_range": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_pointwise_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
@@ -78,6 +79,8 @@ _PROTOS = {
     "sps_tbn_finalize": [_i, _i, ctypes.c_double, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "sps_tamax4": [_i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp],
     "sps_tbn_bwd_finalize": [_i, _i, ctypes.c_double, _vp, _vp, _vp, _vp, _vp],
+    "sps_tbn_finalize_dc": [_i, _i, ctypes.c_double, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "sps_tbn_bwd_finalize_dc": [_i, _i, ctypes.c_double, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_tbn_apply_relu": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp],
     "sps_tbn_bwd_stats": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_tpool_fwd": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -117,7 +120,8 @@ _PROTOS = {
 }
 EXPORTS = ["sps_abi_version", "sps_last_error", "sps_opt_n_threads", "sps_fps_workspace_floats",
            "sps_index_add_workspace_ints", "sps_ball_query_grid_workspace_ints", "sps_bn_train_workspace_doubles", "sps_conv1x1_wgrad_workspace_floats",
-           "sps_pack_columns_capacity", "sps_debug_set_wait_spins", "sps_twgrad_workspace_floats"] + list(_PROTOS)
+           "sps_pack_columns_capacity", "sps_debug_set_wait_spins", "sps_debug_set_exchange_spins",
+           "sps_twgrad_workspace_floats"] + list(_PROTOS)
 
 _lib = None
 
@@ -154,6 +158,8 @@ def load():
     lib.sps_index_add_workspace_ints.argtypes = [_i, _i, _i]
     lib.sps_debug_set_wait_spins.argtypes = [ctypes.c_uint]
     lib.sps_debug_set_wait_spins.restype = ctypes.c_uint
+    lib.sps_debug_set_exchange_spins.argtypes = [ctypes.c_uint]
+    lib.sps_debug_set_exchange_spins.restype = ctypes.c_uint
     lib.sps_twgrad_workspace_floats.argtypes = [_i, _i, _i, ctypes.c_longlong]
     lib.sps_twgrad_workspace_floats.restype = ctypes.c_longlong
     lib.sps_pack_columns_capacity.argtypes = [_i, _i, _i]

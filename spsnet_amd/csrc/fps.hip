@@ -269,7 +269,9 @@ extern "C" int sps_debug_fps_profile(int b, int n, int m, const float *dataset, 
 static unsigned g_wait_spins = 1u << 22;   // seconds: the producer is gone
 
 // DIAGNOSTIC: the spin bound of sps_wait_progress (0 restores the default).  A tiny bound makes every wait give up at once,
-// which is how the tests drive sa_stack's redo path.  Returns the previous bound.
+// which is how the tests drive sa_stack's redo path; 0xFFFFFFFF makes every wait give up WITHOUT looking at the counter (a
+// producer that is already done would otherwise let a one-spin wait through, and a test that asserts on the flag would
+// depend on the host's pace).  Returns the previous bound.
 extern "C" unsigned sps_debug_set_wait_spins(unsigned spins) {
     const unsigned old = g_wait_spins;
     g_wait_spins = spins ? spins : (1u << 22);
@@ -278,6 +280,10 @@ extern "C" unsigned sps_debug_set_wait_spins(unsigned spins) {
 
 __global__ __launch_bounds__(64) void wait_progress_kernel(const int *progress, int b, int need, int *timed_out, unsigned bound) {
     const int lane = threadIdx.x;
+    if (bound == 0xFFFFFFFFu) {   // forced by sps_debug_set_wait_spins
+        for (int s2 = lane; s2 < b; s2 += 64) timed_out[s2] = 1;
+        return;
+    }
     for (int base = 0; base < b; base += 64) {
         const int sc = base + lane;
         bool done = sc >= b;

@@ -17,7 +17,8 @@ namespace sps {
 __global__ __launch_bounds__(PF_THREADS) void fps_presort_kernel(int b, int K, int n, int bs, int l2, int rb, int npad,
                                                                  long long stride, const float *__restrict__ dataset,
                                                                  const float *__restrict__ temp, float *__restrict__ work,
-                                                                 int spread, unsigned long long *flags, unsigned epoch) {
+                                                                 int spread, unsigned long long *flags, unsigned epoch,
+                                                                 unsigned spin_limit) {
     __shared__ PcSortShared sh;
     // blocks s, s + 8, s + 16, ... share an XCD (observed dispatch order): a scene's K workgroups sit on one L2
     // (spread: DIAGNOSTIC mapping that puts a scene's workgroups on consecutive blocks = different XCDs; tests run the
@@ -30,9 +31,17 @@ __global__ __launch_bounds__(PF_THREADS) void fps_presort_kernel(int b, int K, i
     float *sx = work + (size_t)scene * stride, *sy = sx + npad, *sz = sy + npad, *st = sz + npad;
     int *srk = reinterpret_cast<int *>(st + npad);
     unsigned long long *xg = reinterpret_cast<unsigned long long *>(work + (size_t)scene * stride + (size_t)5 * npad);
-    // (the launch's end hands the sorted scene over; the flags of the histogram exchange: this launch's slot of the pool)
-    pc_sort_split(sh, cu, K, n, npad, bs, l2, rb, xyz, temp, xg, sx, sy, sz, st, srk, false, flags + (size_t)scene * 2 * PC_MAXK, epoch);
+    // (the launch's end hands the sorted scene over; the flags of the histogram exchange: this launch's slot of the pool.
+    //  The second round of flags is not used by the pre-pass: its first granule is the scene's give-up word -- a poll that gave
+    //  up leaves it tagged with this launch's epoch, the FPS kernel behind skips the scene and the launcher's predicated
+    //  follow-up launch samples it with the in-kernel sort, see presort_gate)
+    unsigned long long *fl = flags + (size_t)scene * 2 * PC_MAXK;
+    const PcGiveUp gu{fl + PC_MAXK, epoch, spin_limit};
+    (void)pc_sort_split(sh, cu, K, n, npad, bs, l2, rb, xyz, temp, xg, sx, sy, sz, st, srk, false, gu, fl, epoch);
 }
+
+static std::atomic<unsigned> g_spin_limit{PC_SPIN_LIMIT};
+unsigned pc_spin_limit() { return g_spin_limit.load(std::memory_order_relaxed); }
 
 size_t fps_cluster_exchange_floats();   // fps_pruned_cluster.hip
 int fps_cluster_spread();
@@ -51,14 +60,19 @@ static unsigned long long *presort_flag_pool(int dev) {
         const size_t bytes = (size_t)PS_SLOTS * PS_SCENES * 2 * PC_MAXK * sizeof(unsigned long long);
         void *p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-        if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        // (null-stream memset, then a device-wide wait: the first pre-pass is launched on a non-blocking stream and must not
+        //  overtake the zeroes -- once per device and process)
+        if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
         pool[dev] = static_cast<unsigned long long *>(p);
     }
     return pool[dev];
 }
 
-// sorted scenes -> work (b * stride floats); temp may be NULL (all running distances 1e10)
-int launch_fps_presort(int b, int n, const float *dataset, const float *temp, float *work, long long stride, hipStream_t st) {
+// sorted scenes -> work (b * stride floats); temp may be NULL (all running distances 1e10).  *gate: where the FPS kernels
+// behind this launch find out which scenes the pre-pass gave up on (scene s: gate.word + s * gate.stride, raised = its tag
+// equals gate.tag).
+int launch_fps_presort(int b, int n, const float *dataset, const float *temp, float *work, long long stride, hipStream_t st,
+                       PresortGate *gate) {
     int K = PC_MAXK;
     while (K > 1 && b * K > 64) K >>= 1;   // the K workgroups of a scene spin on each other: all of them resident
     if (b * K > 128 || b > PS_SCENES) return -1;
@@ -77,8 +91,19 @@ int launch_fps_presort(int b, int n, const float *dataset, const float *temp, fl
     if ((ticket << 1) == 0u) ticket = counter.fetch_add(1, std::memory_order_relaxed) + 1u;   // tag 0 = the zeroed pool
     unsigned long long *flags = pool + (size_t)(ticket % PS_SLOTS) * PS_SCENES * 2 * PC_MAXK;
     hipLaunchKernelGGL(fps_presort_kernel, dim3(8 * K * divup(b, 8)), dim3(PF_THREADS), 0, st, b, K, n, bs, l2, rb, npad, stride,
-                       dataset, temp, work, fps_cluster_spread(), flags, ticket << 1);
+                       dataset, temp, work, fps_cluster_spread(), flags, ticket << 1, pc_spin_limit());
+    // (SPS_FPS_PRESORT_GATE=0, DIAGNOSTIC / A-B timing only: no gate, no follow-up launch -- a pre-pass that gave up would then
+    //  leave its scenes unsampled)
+    static const bool gate_on = [] { const char *e = getenv("SPS_FPS_PRESORT_GATE"); return !(e && *e == '0'); }();
+    if (gate) *gate = gate_on ? PresortGate{flags + PC_MAXK, 2 * PC_MAXK, ticket << 1} : PresortGate{nullptr, 0, 0u};
     return check_launch("fps_presort_kernel");
 }
 
 }  // namespace sps
+
+// DIAGNOSTIC: the spin bound of every cross-workgroup poll of the FPS kernels (the split sort of fps_presort.hip /
+// fps_pruned_cluster.hip and the clustered kernel's record exchange); 0 restores the default, 0xFFFFFFFF makes every poll
+// give up without looking -- how the tests drive the give-up -> redo path.  Returns the previous bound.
+extern "C" unsigned sps_debug_set_exchange_spins(unsigned spins) {
+    return sps::g_spin_limit.exchange(spins ? spins : sps::PC_SPIN_LIMIT, std::memory_order_relaxed);
+}

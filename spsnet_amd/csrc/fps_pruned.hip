@@ -24,6 +24,7 @@
 // The arithmetic on every point that IS evaluated is exactly the reference's, and skipped points are
 // provably unchanged, so indices and the final `temp` array are bit-identical to the brute-force sweep.
 #include "fps_pruned_util.h"
+#include "fps_sort_split.h"
 
 #include <math.h>
 
@@ -56,12 +57,21 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_kernel(
     int n, int m, int bs, int l2, int rb, const float *__restrict__ dataset, float *__restrict__ temp,
     int *__restrict__ idxs, unsigned long long *__restrict__ dbg = nullptr, const int *__restrict__ redo = nullptr,
     const float *__restrict__ temp_done = nullptr, int *__restrict__ progress = nullptr,
-    const float *__restrict__ presorted = nullptr, long long pstride = 0) {
+    const float *__restrict__ presorted = nullptr, long long pstride = 0,
+    const unsigned long long *__restrict__ gate = nullptr, int gate_stride = 0, unsigned gate_tag = 0) {
     if (m <= 0) return;
     __shared__ PfShared sh;
     __shared__ unsigned short sorted[PRESORT ? 64 : P * PF_THREADS];
 
     const int scene = blockIdx.x;
+    // gate = the sorting pre-pass's per-scene give-up words (fps_presort.hip): the PRESORT launch skips a scene whose
+    // pre-pass gave up (its workspace is incomplete), the launcher's follow-up launch of the self-sorting kernel takes
+    // exactly those scenes -- normally none, a launch that ends here
+    if (gate) {
+        const bool raised = (unsigned)(__hip_atomic_load(gate + (size_t)scene * gate_stride, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT) >> 32) == gate_tag;
+        if (raised == PRESORT) return;
+    }
     if constexpr (RESOLVE) {
         if (fps_already_done(redo, temp_done, temp, scene, n)) return;
     }
@@ -513,7 +523,8 @@ int launch_fps_pruned_profile(int b, int n, int m, const float *dataset, float *
 }
 
 // publishing variant for chunked consumers; -1 if the pruned kernel does not apply to this size
-int launch_fps_presort(int b, int n, const float *dataset, const float *temp, float *work, long long stride, hipStream_t st);
+int launch_fps_presort(int b, int n, const float *dataset, const float *temp, float *work, long long stride, hipStream_t st,
+                       PresortGate *gate);
 
 int launch_fps_pruned_publish(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress,
                               hipStream_t st, float *work, long long stride) {
@@ -525,12 +536,19 @@ int launch_fps_pruned_publish(int b, int n, int m, const float *dataset, float *
     while ((1 << rb) < divup(n, bs)) ++rb;
     const int P = divup(n, PF_THREADS);
     dim3 grid(b), block(PF_THREADS);
-    if (work && launch_fps_presort(b, n, dataset, temp, work, stride, st) == SPS_OK) {   // sorted by a pre-pass of K workgroups per scene
+    PresortGate gate{};
+    if (work && launch_fps_presort(b, n, dataset, temp, work, stride, st, &gate) == SPS_OK) {   // sorted by a pre-pass of K workgroups per scene
+        // (behind it: the scenes the pre-pass gave up on -- a bounded poll that ran out, normally none -- through the kernel
+        //  that sorts for itself; it publishes the same way)
 #define SPS_PFS_CASE(PP)                                                                                         \
         if (P <= PP) {                                                                                           \
             hipLaunchKernelGGL((fps_pruned_kernel<PP, false, false, true, true>), grid, block, 0, st, n, m, bs, l2, rb, dataset, \
                                temp, idxs, (unsigned long long *)nullptr, (const int *)nullptr, (const float *)nullptr, \
-                               progress, (const float *)work, stride);                                           \
+                               progress, (const float *)work, stride, gate.word, gate.stride, gate.tag);         \
+            if (gate.word)                                                                                       \
+            hipLaunchKernelGGL((fps_pruned_kernel<PP, false, false, true>), grid, block, 0, st, n, m, bs, l2, rb, dataset, \
+                               temp, idxs, (unsigned long long *)nullptr, (const int *)nullptr, (const float *)nullptr, \
+                               progress, (const float *)nullptr, 0ll, gate.word, gate.stride, gate.tag);         \
             return check_launch("fps_pruned_kernel<publish, presorted>");                                       \
         }
         SPS_PFS_CASE(16)
@@ -563,12 +581,17 @@ int launch_fps_pruned(int b, int n, int m, const float *dataset, float *temp, in
     while ((1 << rb) < divup(n, bs)) ++rb;
     const int P = divup(n, PF_THREADS);
     dim3 grid(b), block(PF_THREADS);
-    if (work && !redo && P > 8 && launch_fps_presort(b, n, dataset, temp, work, stride, st) == SPS_OK) {
+    PresortGate gate{};
+    if (work && !redo && P > 8 && launch_fps_presort(b, n, dataset, temp, work, stride, st, &gate) == SPS_OK) {
 #define SPS_PFS_CASE(PP)                                                                                       \
         if (P <= PP) {                                                                                         \
             hipLaunchKernelGGL((fps_pruned_kernel<PP, false, false, false, true>), grid, block, 0, st, n, m, bs, l2, rb, dataset, \
                                temp, idxs, (unsigned long long *)nullptr, (const int *)nullptr, (const float *)nullptr, \
-                               (int *)nullptr, (const float *)work, stride);                                   \
+                               (int *)nullptr, (const float *)work, stride, gate.word, gate.stride, gate.tag); \
+            if (gate.word)                                                                                     \
+            hipLaunchKernelGGL((fps_pruned_kernel<PP, false, false>), grid, block, 0, st, n, m, bs, l2, rb, dataset,  \
+                               temp, idxs, (unsigned long long *)nullptr, (const int *)nullptr, (const float *)nullptr, \
+                               (int *)nullptr, (const float *)nullptr, 0ll, gate.word, gate.stride, gate.tag); \
             return check_launch("fps_pruned_kernel<presorted>");                                              \
         }
         SPS_PFS_CASE(16)

@@ -52,12 +52,21 @@ template <int ROWS>
 __global__ __launch_bounds__(PF_THREADS) void fps_pruned_big_kernel(int n, int m, int bs, int l2, int rb, int npad,
                                                                     long long stride, const float *__restrict__ dataset,
                                                                     float *__restrict__ temp, int *__restrict__ idxs,
-                                                                    float *__restrict__ work) {
+                                                                    float *__restrict__ work, int only_given_up = 0,
+                                                                    int *__restrict__ progress = nullptr) {
+    // only_given_up: the follow-up launch of the clustered kernel (fps_pruned_cluster.hip) -- it takes the scenes whose
+    // give-up word (granule 0 of the exchange area behind the scene's 5 npad workspace floats) was raised by a bounded poll
+    // that ran out; temp may then be NULL (all running distances start at 1e10, nothing handed back) and progress[scene],
+    // when given, is set to m once every pick is visible: the consumers of a publishing launch wait for exactly that.
     if (m <= 0) return;
     __shared__ PbShared sh;
     const int scene = blockIdx.x;
+    if (only_given_up) {
+        const unsigned long long *xg = reinterpret_cast<const unsigned long long *>(work + (size_t)scene * stride + (size_t)5 * npad);
+        if (__hip_atomic_load(xg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) return;
+    }
     const float *xyz = dataset + (size_t)scene * n * 3;
-    temp += (size_t)scene * n;
+    if (temp) temp += (size_t)scene * n;
     idxs += (size_t)scene * m;
     float *sx = work + (size_t)scene * stride, *sy = sx + npad, *sz = sy + npad, *st = sz + npad;
     int *srk = reinterpret_cast<int *>(st + npad);
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_big_kernel(int n, int m
             const int kk = k < n ? k : k0;
 #pragma unroll
             for (int a = 0; a < 3; ++a) v[u][a] = xyz[(size_t)kk * 3 + a];
-            tv[u] = temp[kk];
+            tv[u] = temp ? temp[kk] : 1e10f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -379,10 +388,13 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_big_kernel(int n, int m
     // the reference leaves the final running min-distances in `temp` (original order)
     __threadfence();
     __syncthreads();
-    for (int p = tid; p < n; p += PF_THREADS) {
-        const float tv = __hip_atomic_load(st + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        temp[pf_unrank((unsigned)srk[p], l2, rb)] = tv;
-    }
+    if (temp)
+        for (int p = tid; p < n; p += PF_THREADS) {
+            const float tv = __hip_atomic_load(st + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            temp[pf_unrank((unsigned)srk[p], l2, rb)] = tv;
+        }
+    if (progress && tid == 0)   // (behind the fence + barrier above: every pick of this workgroup is visible device-wide)
+        __hip_atomic_store(progress + scene, m, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 size_t fps_cluster_exchange_floats();
@@ -446,6 +458,32 @@ int launch_fps_pruned_big(int b, int n, int m, const float *dataset, float *temp
     SPS_PB_CASE(8)
 #undef SPS_PB_CASE
     return -1;
+}
+
+// Behind a clustered launch: the one-workgroup kernel for the scenes whose give-up word is up (a bounded cross-workgroup poll
+// ran out -- e.g. the K workgroups were not resident together); the other scenes' workgroups leave at once.
+int launch_fps_big_redo_given_up(int b, int n, int m, const float *dataset, float *temp, int *idxs, float *work, int *progress,
+                                 hipStream_t st) {
+    const int bs = sps_opt_n_threads(n);
+    int l2 = 0;
+    while ((1 << (l2 + 1)) <= bs) ++l2;
+    int rb = 0;
+    while ((1 << rb) < divup(n, bs)) ++rb;
+    const int npad = divup(n, 64) * 64;
+    const long long stride = (long long)fps_big_workspace_elems(n);
+    const int rows = divup(npad / 64, 64 * PF_WAVES);
+    dim3 grid(b), block(PF_THREADS);
+#define SPS_PB_CASE(R)                                                                                               \
+    if (rows <= R) {                                                                                                 \
+        hipLaunchKernelGGL((fps_pruned_big_kernel<R>), grid, block, 0, st, n, m, bs, l2, rb, npad, stride, dataset, temp, idxs, work, \
+                           1, progress);                                                                             \
+        return check_launch("fps_pruned_big_kernel<given up>");                                                     \
+    }
+    SPS_PB_CASE(2)
+    SPS_PB_CASE(4)
+    SPS_PB_CASE(8)
+#undef SPS_PB_CASE
+    return fail(SPS_ERR_INVALID, "fps(cluster): no one-workgroup kernel for n=%d", n);
 }
 
 // publishing variant for chunked consumers (large scenes: the clustered kernel only); -1 if it does not apply

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
                                                                         const float *__restrict__ dataset,
                                                                         float *__restrict__ temp, int *__restrict__ idxs,
                                                                         float *__restrict__ work, int *__restrict__ progress,
-                                                                        int spread) {
+                                                                        int spread, unsigned spin_limit) {
     // progress != NULL: consumers on other CUs read idxs while this kernel runs (sa_stack's streamed first layer) -- picks
     // are stored write-through and progress[scene] counts the published ones (every 64 picks; fps_pruned.hip's protocol).
     // temp may then be NULL: all running distances start at 1e10 and are not handed back.
@@ -82,7 +82,11 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
     const int R = K * T;       // records per round
 
     // ------------------------------------------------------------------ spatial sort (once), split over the K workgroups
-    pc_sort_split(sh.sort, cu, K, n, npad, bs, l2, rb, xyz, temp, xg, sx, sy, sz, st, srk, true);
+    // Every cross-workgroup poll is bounded; one that gives up raises the scene's give-up word (granule 0 of the zeroed
+    // exchange area), all K workgroups leave, and the launcher's follow-up launch samples the scene with the one-workgroup
+    // kernel (fps_pruned_big.hip) -- nothing written so far is used (temp is only written at the very end).
+    const PcGiveUp gu{xg, 1u, spin_limit};
+    if (!pc_sort_split(sh.sort, cu, K, n, npad, bs, l2, rb, xyz, temp, xg, sx, sy, sz, st, srk, true, gu)) return;
 
     // ------------------------------------------------------------------ bucket metadata
     // bucket g = v * nwaves + gwave is slot v of this wave: row v / 64, lane v % 64
@@ -352,17 +356,16 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
         {
             const int ng = R * 6;
             if (tid < ng) {
-                unsigned spins = 0;
-                unsigned long long g = granule_load(xround + tid);
-                while ((unsigned)(g >> 32) != tag) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > PC_SPIN_LIMIT) __builtin_trap();
-                    g = granule_load(xround + tid);
+                unsigned long long g = 0;
+                if (!pc_bounded_poll(gu, 1, [&] { g = granule_load(xround + tid); return (unsigned)(g >> 32) == tag; })) {
+                    sh.sort.giveup = 1;
+                    gu.raise();
                 }
                 sh.xr[tid % 6][tid / 6] = (int)(unsigned)g;
             }
         }
         __syncthreads();
+        if (sh.sort.giveup) return;
         PC_STAMP(p5);
         // ---- acceptance over the R records: lane (rj, h) evaluates record rj against the i-records of half h
         const int rj = lane >> 1, h = lane & 1;
@@ -459,6 +462,9 @@ int fps_cluster_spread() {
 }
 
 // K workgroups per scene publishing T records each; -1: shape not served
+int launch_fps_big_redo_given_up(int b, int n, int m, const float *dataset, float *temp, int *idxs, float *work, int *progress,
+                                 hipStream_t st);   // fps_pruned_big.hip
+
 int launch_fps_pruned_cluster(int b, int K, int T, int n, int m, const float *dataset, float *temp, int *idxs, float *work,
                               long long stride, int *progress, hipStream_t st) {
     if (K < 2 || K > PC_MAXK || T < 1 || T > PC_MAXT || K * T > PC_MAXR || b * K > 64 || !work) return -1;
@@ -478,8 +484,10 @@ int launch_fps_pruned_cluster(int b, int K, int T, int n, int m, const float *da
 #define SPS_PC_CASE(RW)                                                                                                \
     if (rows <= RW) {                                                                                                  \
         hipLaunchKernelGGL((fps_pruned_cluster_kernel<RW>), grid, block, 0, st, b, K, T, n, m, bs, l2, rb, npad, stride, \
-                           dataset, temp, idxs, work, progress, fps_cluster_spread());                                 \
-        return check_launch("fps_pruned_cluster_kernel");                                                             \
+                           dataset, temp, idxs, work, progress, fps_cluster_spread(), pc_spin_limit());                \
+        if (check_launch("fps_pruned_cluster_kernel") != SPS_OK) return SPS_ERR_LAUNCH;                               \
+        /* the scenes a bounded poll gave up on (normally none: a launch whose workgroups leave at once) */           \
+        return launch_fps_big_redo_given_up(b, n, m, dataset, temp, idxs, work, progress, st);                        \
     }
     SPS_PC_CASE(1)
     SPS_PC_CASE(2)

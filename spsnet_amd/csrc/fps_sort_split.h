@@ -8,7 +8,10 @@
 // (C) it scatters its points {x, y, z, running distance, rank} with LDS atomics on those slots; optionally release + flag
 // again so that every workgroup may read the whole sorted scene.  The order inside a cell is as arbitrary as with one
 // workgroup's atomics and as irrelevant (ties are decided by rank).  The granules must be zeroed before the launch;
-// all K workgroups of a scene must be resident at once (they spin on each other, bounded: a stuck exchange traps).
+// all K workgroups of a scene should be resident at once (they spin on each other).  The spins are BOUNDED and a poll that
+// gives up never traps: it raises the scene's give-up word, every workgroup of the scene leaves (pc_sort_split returns
+// false to all its threads), and the launcher's predicated follow-up launch redoes the scene with the one-workgroup
+// kernel -- correct or redo, the pattern of sa_stack's bounded progress waits.
 #pragma once
 #include "fps_pruned_util.h"
 
@@ -21,7 +24,16 @@ constexpr int PC_MAXR = 32;       // records per round (K T) at most: two lanes 
 // [2][K]; behind the granules the K cell histograms of the sort (ints).  The launchers zero the granules per launch.
 constexpr int PC_FLAG_AT = 8 + 2 * PC_MAXR * 6;
 constexpr int PC_GRANULES = PC_FLAG_AT + 2 * PC_MAXK + 8;
-constexpr unsigned PC_SPIN_LIMIT = 1u << 24;          // polls before a stuck exchange traps (~ seconds)
+constexpr unsigned PC_SPIN_LIMIT = 1u << 24;          // polls before a stuck exchange gives up (~ seconds)
+constexpr unsigned PC_SPIN_FORCED = 0xFFFFFFFFu;      // diagnostic bound: every poll gives up without looking (tests)
+// the bound in force (fps_presort.hip; sps_debug_set_exchange_spins)
+unsigned pc_spin_limit();
+// where a launch behind the sorting pre-pass reads the pre-pass's per-scene give-up words (fps_presort.hip)
+struct PresortGate {
+    const unsigned long long *word;   // scene 0's word (NULL: no gate)
+    int stride;                       // granules between the words of consecutive scenes
+    unsigned tag;                     // a word is raised when its tag half equals this
+};
 
 __device__ __forceinline__ void granule_store(unsigned long long *p, int value, unsigned tag) {
     __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -35,16 +47,45 @@ struct PcSortShared {
     int hist[PF_BINS];
     float red[6][PF_WAVES];
     int wsum[PF_WAVES];
+    int giveup;          // a bounded poll of this workgroup gave up (or saw the scene's give-up word): everybody leaves
 };
 
+// A scene's give-up word: an 8-byte granule whose tag says "this launch"; raised by the first poll that gives up, read by
+// the siblings' polls (they leave early instead of running into their own bounds) and by the launcher's follow-up launch.
+struct PcGiveUp {
+    unsigned long long *word;
+    unsigned tag;
+    unsigned limit;      // spin bound of every poll (PC_SPIN_FORCED: give up at once)
+    __device__ __forceinline__ bool raised() const { return (unsigned)(granule_load(word) >> 32) == tag; }
+    __device__ __forceinline__ void raise() const { granule_store(word, 1, tag); }
+};
+// spin until `ready()`; false when the bound was hit or the scene has been given up by a sibling
+template <class Ready>
+__device__ __forceinline__ bool pc_bounded_poll(const PcGiveUp &gu, int sleep, Ready ready) {
+    if (gu.limit == PC_SPIN_FORCED) return false;
+    unsigned spins = 0;
+    while (!ready()) {
+        if (sleep == 1) __builtin_amdgcn_s_sleep(1);
+        else if (sleep == 2) __builtin_amdgcn_s_sleep(2);
+        else __builtin_amdgcn_s_sleep(4);
+        if (++spins > gu.limit) return false;
+        if ((spins & 1023u) == 0u && gu.raised()) return false;
+    }
+    return true;
+}
+
 // xg: the scene's exchange area (the cell histograms live behind its granules); sx .. srk: the scene's sorted arrays (npad entries each); hand_over: every workgroup
-// waits until ALL of them have scattered (needed when they go on to read each other's points in the same launch)
-__device__ __forceinline__ void pc_sort_split(PcSortShared &sh, int cu, int K, int n, int npad, int bs, int l2, int rb,
+// waits until ALL of them have scattered (needed when they go on to read each other's points in the same launch).
+// -> false (to every thread of the workgroup alike) when a poll gave up: the scene's give-up word is raised, nothing this
+// workgroup wrote may be used, the caller returns.
+__device__ __forceinline__ bool pc_sort_split(PcSortShared &sh, int cu, int K, int n, int npad, int bs, int l2, int rb,
                                               const float *__restrict__ xyz, const float *__restrict__ temp,
                                               unsigned long long *xg, float *sx, float *sy, float *sz, float *st, int *srk,
-                                              bool hand_over, unsigned long long *xflag = nullptr, unsigned tag0 = 2u) {
+                                              bool hand_over, const PcGiveUp &gu, unsigned long long *xflag = nullptr,
+                                              unsigned tag0 = 2u) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) sh.giveup = 0;      // (several barriers lie between this store and the first poll)
     {
         // the two rounds of flags [2][PC_MAXK]: in the (zeroed) exchange area with tags 2 / 3, or wherever the caller keeps
         // them with a tag of its own (fps_presort.hip: a library-owned pool and a launch epoch -- nothing to zero per launch)
@@ -60,13 +101,10 @@ __device__ __forceinline__ void pc_sort_split(PcSortShared &sh, int cu, int K, i
                 granule_store(xflag + slot * PC_MAXK + cu, 1, tg);
             }
             if (wave == 0) {
-                if (lane < K) {
-                    unsigned spins = 0;
-                    while ((unsigned)(granule_load(xflag + slot * PC_MAXK + lane) >> 32) != tg) {
-                        __builtin_amdgcn_s_sleep(4);
-                        if (++spins > PC_SPIN_LIMIT) __builtin_trap();
-                    }
-                }
+                bool ok = true;
+                if (lane < K)
+                    ok = pc_bounded_poll(gu, 4, [&] { return (unsigned)(granule_load(xflag + slot * PC_MAXK + lane) >> 32) == tg; });
+                if (__ballot(!ok) != 0ull && lane == 0) { sh.giveup = 1; gu.raise(); }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -140,14 +178,13 @@ __device__ __forceinline__ void pc_sort_split(PcSortShared &sh, int cu, int K, i
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) granule_store(xflag + cu, 1, tag0);
-        if (wave == 0 && lane < K) {
-            unsigned spins = 0;
-            while ((unsigned)(granule_load(xflag + lane) >> 32) != tag0) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > PC_SPIN_LIMIT) __builtin_trap();
-            }
+        if (wave == 0) {
+            bool ok = true;
+            if (lane < K) ok = pc_bounded_poll(gu, 2, [&] { return (unsigned)(granule_load(xflag + lane) >> 32) == tag0; });
+            if (__ballot(!ok) != 0ull && lane == 0) { sh.giveup = 1; gu.raise(); }
         }
         __syncthreads();
+        if (sh.giveup) return false;   // (the histograms of a sibling that never arrived would be garbage offsets)
         {   // exclusive prefix sum over the cells of the summed histograms, plus what the workgroups before me put in each cell
             int loc[PER], before[PER], sum = 0;
             unsigned long long h64[PC_MAXK][PER / 2];
@@ -209,8 +246,12 @@ __device__ __forceinline__ void pc_sort_split(PcSortShared &sh, int cu, int K, i
             for (int p = n + tid; p < npad; p += PF_THREADS) {  // padding: never inside a box, distance stays -1, worst rank
                 sx[p] = NAN; sy[p] = NAN; sz[p] = NAN; st[p] = -1.f; srk[p] = 0x0FFFFFFF;
             }
-        if (hand_over) flag_and_wait(1, tag0 + 1u);
+        if (hand_over) {
+            flag_and_wait(1, tag0 + 1u);
+            if (sh.giveup) return false;
+        }
     }
+    return true;
 }
 
 }  // namespace sps

@@ -649,13 +649,17 @@ __device__ __forceinline__ void tsum_parts(const double *partial, int c, int ch,
     s1 = d1; s2 = d2;
 }
 
+// count_dev != NULL: the element count lives on the device (SyncBatchNorm: the all-reduced sum of the ranks' counts, which
+// may differ from rank to rank -- torch's SyncBatchNorm gathers them too)
 __global__ __launch_bounds__(256) void tbn_finalize_kernel(int c, int nparts, double count, const double *__restrict__ partial,
                                                            const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                            float momentum, float *__restrict__ running_mean,
                                                            float *__restrict__ running_var, float *__restrict__ P,
-                                                           long long *__restrict__ num_batches_tracked) {
+                                                           long long *__restrict__ num_batches_tracked,
+                                                           const double *__restrict__ count_dev) {
     const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ch >= c) return;
+    if (count_dev) count = *count_dev;
     if (ch == 0 && (threadIdx.x & 63) == 0 && num_batches_tracked) *num_batches_tracked += 1;   // nn.BatchNorm2d.forward's counter
     double s1, s2;
     tsum_parts(partial, c, ch, nparts, s1, s2);
@@ -676,9 +680,11 @@ __global__ __launch_bounds__(256) void tbn_finalize_kernel(int c, int nparts, do
 }
 
 __global__ __launch_bounds__(256) void tbn_bwd_finalize_kernel(int c, int nparts, double inv_count, const double *__restrict__ partial,
-                                                               float *__restrict__ P, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+                                                               float *__restrict__ P, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                               const double *__restrict__ count_dev) {
     const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ch >= c) return;
+    if (count_dev) inv_count = 1.0 / *count_dev;
     double s1, s2;
     tsum_parts(partial, c, ch, nparts, s1, s2);
     if ((threadIdx.x & 63) != 0) return;
@@ -949,17 +955,35 @@ extern "C" int sps_tamax4(int count, const float *p0, long long n0, const float 
 extern "C" int sps_tbn_finalize(int c, int nparts, double count, const double *partial, const float *gamma, const float *beta,
                                 float eps, float momentum, float *running_mean, float *running_var, float *params,
                                 long long *num_batches_tracked, sps_stream_t stream) {
-    if (c <= 0 || nparts <= 0 || count <= 0.0 || !partial || !params) return fail(SPS_ERR_INVALID, "tbn_finalize: bad arguments");
+    if (count <= 0.0) return fail(SPS_ERR_INVALID, "tbn_finalize: bad arguments");
+    return sps_tbn_finalize_dc(c, nparts, count, nullptr, partial, gamma, beta, eps, momentum, running_mean, running_var, params,
+                               num_batches_tracked, stream);
+}
+
+// count_dev (device double, may be NULL): when given it replaces `count` -- the element count of a SyncBatchNorm's GLOBAL
+// batch, all-reduced together with the sums, so that ranks with different local batch sizes normalise alike
+extern "C" int sps_tbn_finalize_dc(int c, int nparts, double count, const double *count_dev, const double *partial,
+                                   const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
+                                   float *running_var, float *params, long long *num_batches_tracked, sps_stream_t stream) {
+    if (c <= 0 || nparts <= 0 || (!count_dev && count <= 0.0) || !partial || !params)
+        return fail(SPS_ERR_INVALID, "tbn_finalize: bad arguments");
     hipLaunchKernelGGL(tbn_finalize_kernel, dim3(divup(c, 4)), dim3(256), 0, as_stream(stream), c, nparts, count, partial, gamma, beta,
-                       eps, momentum, running_mean, running_var, params, num_batches_tracked);
+                       eps, momentum, running_mean, running_var, params, num_batches_tracked, count_dev);
     return check_launch("tbn_finalize_kernel");
 }
 
 extern "C" int sps_tbn_bwd_finalize(int c, int nparts, double count, const double *partial, float *params, float *dgamma,
                                     float *dbeta, sps_stream_t stream) {
-    if (c <= 0 || nparts <= 0 || count <= 0.0 || !partial || !params) return fail(SPS_ERR_INVALID, "tbn_bwd_finalize: bad arguments");
-    hipLaunchKernelGGL(tbn_bwd_finalize_kernel, dim3(divup(c, 4)), dim3(256), 0, as_stream(stream), c, nparts, 1.0 / count, partial,
-                       params, dgamma, dbeta);
+    if (count <= 0.0) return fail(SPS_ERR_INVALID, "tbn_bwd_finalize: bad arguments");
+    return sps_tbn_bwd_finalize_dc(c, nparts, count, nullptr, partial, params, dgamma, dbeta, stream);
+}
+
+extern "C" int sps_tbn_bwd_finalize_dc(int c, int nparts, double count, const double *count_dev, const double *partial,
+                                       float *params, float *dgamma, float *dbeta, sps_stream_t stream) {
+    if (c <= 0 || nparts <= 0 || (!count_dev && count <= 0.0) || !partial || !params)
+        return fail(SPS_ERR_INVALID, "tbn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(tbn_bwd_finalize_kernel, dim3(divup(c, 4)), dim3(256), 0, as_stream(stream), c, nparts,
+                       count_dev ? 0.0 : 1.0 / count, partial, params, dgamma, dbeta, count_dev);
     return check_launch("tbn_bwd_finalize_kernel");
 }
 

@@ -31,6 +31,7 @@
 namespace sps {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int SPS_MLP_MAX_C3 = 256;   // widest last layer of the per-wave kernels (its biases are staged in LDS)
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -60,6 +61,17 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
     constexpr int CPP = COLS >= NS ? COLS / NS : 1;  // whole centroids per unit (1 or 2) ...
     constexpr bool PART = COLS < NS;                  // ... or a unit is a slice of one centroid's samples (nsample 64)
     static_assert((COLS % NS == 0 || NS % COLS == 0) && (NS % 16) == 0, "units and centroids must nest");
+
+    // The biases live in LDS for the whole launch.  Loaded from global memory where an output tile begins, each drew an
+    // `s_waitcnt vmcnt(0)` -- which also waits for the weight chunk requested just before it: one full memory round trip per
+    // output tile (40 per unit at the widest scale) with nothing else to hide it at one or two waves per SIMD.  An LDS read
+    // counts on lgkmcnt and leaves the weight stream's counted vmcnt waits alone.
+    __shared__ __attribute__((aligned(16))) float sbias[C1 + C2 + SPS_MLP_MAX_C3];
+    for (int i = threadIdx.x; i < C1; i += blockDim.x) sbias[i] = a.b1[i];
+    for (int i = threadIdx.x; i < C2; i += blockDim.x) sbias[C1 + i] = a.b2[i];
+    for (int i = threadIdx.x; i < a.c3; i += blockDim.x) sbias[C1 + C2 + i] = a.b3[i];
+    __syncthreads();
+    const float *b1l = sbias, *b2l = sbias + C1, *b3l = sbias + C1 + C2;
 
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, c = lane & 15;
@@ -95,7 +107,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
             f32x4 h1[T1][NT];
 #pragma unroll
             for (int t = 0; t < T1; ++t) {
-                const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.b1 + 16 * t + 4 * q);
+                const f32x4 bias = *reinterpret_cast<const f32x4 *>(b1l + 16 * t + 4 * q);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) h1[t][nt] = bias;
             }
@@ -159,7 +171,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (ch == 0) {
-                        const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.b2 + 16 * mt + 4 * q);
+                        const f32x4 bias = *reinterpret_cast<const f32x4 *>(b2l + 16 * mt + 4 * q);
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) acc[nt] = bias;
                     }
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
 #pragma unroll
             for (int u = 0; u < Q4; ++u) wfirst[u] = wload4(rs, lane * 16, u * 1024);
             for (int mt = 0; mt < MT3; ++mt) {
-                const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.b3 + 16 * mt + 4 * q);
+                const f32x4 bias = *reinterpret_cast<const f32x4 *>(b3l + 16 * mt + 4 * q);
                 const int tile_off = mt * (KS / 4) * 1024;                                  // bytes, wave-uniform
                 const int next_off = ((mt + 1 < MT3) ? mt + 1 : mt) * (KS / 4) * 1024;
                 f32x4 w[2][Q4];
@@ -354,13 +366,15 @@ extern "C" int sps_sa_group_mlp_packed(int b, int n, int m, int j0, int jcount, 
         out_c_off < 0 || out_c_off + c3_real > out_c_total || j0 < 0 || jcount < 0 || j0 + jcount > m)
         return fail(SPS_ERR_INVALID, "sa_group_mlp: bad shape");
     if (b == 0 || (jcount == 0 && !cols)) return SPS_OK;
+    if ((split_fp16 & 3) != 2 && c3 > 256) return fail(SPS_ERR_INVALID, "sa_group_mlp: last layer wider than 256 (%d)", c3);
     if (!xyz || !new_xyz || (!idx && !cols) || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !out || (c_feat > 0 && !features))
         return fail(SPS_ERR_INVALID, "sa_group_mlp: null pointer");
     if (cols && (!meta || !ntiles || tile_cap <= 0 || tile_cap > 0x7FFFFFF || (tile_cap & 3) || m >= (1 << 20) || b > 256))
         return fail(SPS_ERR_INVALID, "sa_group_mlp: packed columns need meta, ntiles, a tile capacity that is a multiple of 4, "
                                      "m < 2^20 and b <= 256");
-    if ((split_fp16 & 8) && !cols && (split_fp16 & 3) != 2)
-        return fail(SPS_ERR_INVALID, "sa_group_mlp: a point-major `out` is served by the packed-column and shared-stream kernels");
+    if ((split_fp16 & 8) && !cols && (split_fp16 & 3) != 2 && (split_fp16 & 7) != 4)
+        return fail(SPS_ERR_INVALID, "sa_group_mlp: a point-major `out` is served by the packed-column, shared-stream and "
+                                     "point-major fp32 kernels");
     if (cols && (split_fp16 & 3) == 2)
         return fail(SPS_ERR_INVALID, "sa_group_mlp: the shared-stream kernel (mode 2) does not take packed columns");
     const long long cols_total = (long long)b * m * nsample;
@@ -382,9 +396,13 @@ extern "C" int sps_sa_group_mlp_packed(int b, int n, int m, int j0, int jcount, 
     a.overflow = overflow_flag;
     const int arith = split_fp16 & 3;
     a.feat_pm = (split_fp16 & 4) ? 1 : 0;
-    if (a.feat_pm && (arith == 0 || c_feat < 4 || (c_feat % 4)))
-        return fail(SPS_ERR_INVALID, "sa_group_mlp: point-major features need a split-fp16 mode and c_feat %% 4 == 0 (got %d)", c_feat);
+    if (a.feat_pm && (c_feat < 4 || (c_feat % 4)))
+        return fail(SPS_ERR_INVALID, "sa_group_mlp: point-major features need c_feat %% 4 == 0 (got %d)", c_feat);
+    if (a.feat_pm && arith == 0 && (cols || !sps_sa_group_mlp_pm_supported(c_feat, c1, c2, c3, nsample)))
+        return fail(SPS_ERR_INVALID, "sa_group_mlp: no exact-fp32 kernel for point-major features with %d channels, widths "
+                                     "(%d, %d, %d), nsample %d", c_feat, c1, c2, c3, nsample);
     hipStream_t st = as_stream(stream);
+    if (a.feat_pm && arith == 0) return launch_sa_mlp_pm(a, c1, c2, nsample, st);   // sa_mlp_pm.hip
     if (arith == 2) return launch_sa_mlp_f16_lds(a, c1, c2, nsample, st);
     if (arith) return launch_sa_mlp_f16(a, c1, c2, nsample, st, arith == 3);   // 3: `features` holds halves (fp16 in HBM)
 #define SPS_MLP_CASE(C1, C2, NT, NS) \

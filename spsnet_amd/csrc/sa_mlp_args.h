@@ -207,5 +207,7 @@ extern int g_mlp_f16;
 int launch_sa_mlp_f16(const SaMlpArgs &a, int c1, int c2, int nsample, hipStream_t st, bool pure = false);
 // sa_mlp_f16_lds.hip: the same arithmetic with the weight stream shared through LDS (a.w1 = concatenated stream)
 int launch_sa_mlp_f16_lds(const SaMlpArgs &a, int c1, int c2, int nsample, hipStream_t st);
+// exact fp32 with point-major features (sa_mlp_pm.hip)
+int launch_sa_mlp_pm(const SaMlpArgs &a, int c1, int c2, int nsample, hipStream_t st);
 
 }  // namespace sps

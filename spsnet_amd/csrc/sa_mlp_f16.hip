@@ -135,6 +135,14 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
             ws3.rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.w3, 0, n3, 0x00020000);
         }
     }
+    // biases in LDS for the whole launch (see sa_mlp.hip: a global load where a tile begins draws a vmcnt(0) wait -- with
+    // the weights in LDS that is the bias's own round trip, exposed once per output tile)
+    __shared__ __attribute__((aligned(16))) float sbias[C1 + C2 + 256];
+    for (int i = threadIdx.x; i < C1; i += blockDim.x) sbias[i] = a.b1[i];
+    for (int i = threadIdx.x; i < C2; i += blockDim.x) sbias[C1 + i] = a.b2[i];
+    for (int i = threadIdx.x; i < a.c3; i += blockDim.x) sbias[C1 + C2 + i] = a.b3[i];
+    __syncthreads();
+    const float *b1l = sbias, *b2l = sbias + C1, *b3l = sbias + C1 + C2;
     bool any_bad = false;   // some unit of this wave met an operand beyond the representable range (or NaN / Inf)
     constexpr bool packed = PACKED;   // a separate instantiation: the padded form keeps its register budget
     const MlpRange rg = mlp_range(a);
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
             f32x4 acc1[T1][NT];
 #pragma unroll
             for (int t = 0; t < T1; ++t) {
-                const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.b1 + 16 * t + 4 * q);
+                const f32x4 bias = *reinterpret_cast<const f32x4 *>(b1l + 16 * t + 4 * q);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc1[t][nt] = bias;
             }
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (ch == 0) {
-                        const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.b2 + 16 * mt + 4 * q);
+                        const f32x4 bias = *reinterpret_cast<const f32x4 *>(b2l + 16 * mt + 4 * q);
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) acc[nt] = bias;
                     }
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
 #pragma unroll
             for (int u = 0; u < KCH; ++u) wfirst[u] = ws3.load(lane * 16, u * FRAG);
             for (int mt = 0; mt < MT3; ++mt) {
-                const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.b3 + 16 * mt + 4 * q);
+                const f32x4 bias = *reinterpret_cast<const f32x4 *>(b3l + 16 * mt + 4 * q);
                 const int tile_off = mt * S2 * FRAG;
                 const int next_off = ((mt + 1 < MT3) ? mt + 1 : mt) * S2 * FRAG;
                 WFrag w[2][KCH];

@@ -48,6 +48,17 @@ def _pack_next(w, cout_pad, cin_pad):
     return wp.view(cout_pad // 16, 16, cin_pad // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous().view(-1)
 
 
+def _pack_first_pm(w, cout_pad, c_feat):
+    """Layer 1 of the exact-fp32 kernel for point-major features (csrc/sa_mlp_pm.hip): w (cout, 3 + c_feat) in the reference's
+    channel order [x, y, z, features] -> [coordinate fragments [tile][lane = 16 q + i]: slot q < 3 = axis q, slot 3 = 0]
+    followed by the feature part packed like a chained layer (k-step (t, r) <-> feature channel 16 t + 4 q + r)."""
+    cout = w.shape[0]
+    wx = w.new_zeros(cout_pad, 4)
+    wx[:cout, :3] = w[:, :3]
+    coord = wx.view(cout_pad // 16, 16, 4).permute(0, 2, 1).contiguous().view(-1)
+    return torch.cat([coord, _pack_next(w[:, 3:], cout_pad, c_feat)])
+
+
 def _split_halves(frag_f32, lanes_inner=4):
     """fp32 fragment tensor [..., lane, 4] -> int16-bit tensor [..., lane, hi x4 | lo x4] (the split-fp16 kernel's
     16-byte-per-lane weight fragment)."""
@@ -136,10 +147,17 @@ def _stack_layers(mlp):
 
 
 def _version_key(pairs, device):
+    """What a folded / packed inference cache of these (conv, bn) pairs depends on.  The running statistics' own versions are
+    NOT enough: torch's native batch_norm updates running_mean / running_var inside the kernel without touching their version
+    counters (and so did this library's train-mode kernels, which bump them now), so an eval() forward after train-mode
+    forwards with frozen weights (BatchNorm recalibration, swa_utils.update_bn, lr = 0) would reuse stale folds.  Every
+    train-mode forward of a BatchNorm module does move `num_batches_tracked` (nn.BatchNorm.forward: add_(1)); it is part of
+    the key."""
     vs = [device]
     for conv, bn in pairs:
-        for t in (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var):
-            vs.append((t.data_ptr(), t._version))
+        for t in (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, getattr(bn, "num_batches_tracked", None)):
+            if t is not None:
+                vs.append((t.data_ptr(), t._version))
     return tuple(vs)
 
 
@@ -150,6 +168,9 @@ def _version_key(pairs, device):
 PRECISION = "fp16x2"
 # wide split-fp16 scales: the four waves of a workgroup share one weight stream through LDS (csrc/sa_mlp_f16_lds.hip)
 SHARE_WEIGHTS = True
+# exact-fp32 scales whose input features carry a point-major twin run on csrc/sa_mlp_pm.hip (one 16-byte load per four
+# channels, a unit's inputs requested one unit ahead) instead of the channel-major gathers of csrc/sa_mlp.hip
+PM_FP32 = __import__("os").environ.get("SPS_PM_FP32", "1") != "0"
 _OVERFLOW = {}
 
 
@@ -198,15 +219,17 @@ def pack_scale(mlp, nsample, point_major=False, half=False):
         return None
     device = c1m.weight.device
     c_feat = c1m.in_channels - 3
-    point_major = bool(point_major and (half or PRECISION == "fp16x2") and c1 >= 32 and c_feat >= 4 and c_feat % 4 == 0)
-    key = _version_key(pairs, device) + (PRECISION, SHARE_WEIGHTS, point_major, half)
+    pm32 = bool(point_major and not half and PM_FP32 and PRECISION == "fp32" and c_feat % 16 == 0
+                and _L.sps_sa_group_mlp_pm_supported(c_feat, c1, c2, c3, nsample))   # exact fp32 on the twin (sa_mlp_pm.hip)
+    point_major = pm32 or bool(point_major and (half or PRECISION == "fp16x2") and c1 >= 32 and c_feat >= 4 and c_feat % 4 == 0)
+    key = _version_key(pairs, device) + (PRECISION, SHARE_WEIGHTS, point_major, half, pm32)
     slot = ("_sps_packed_pm" if point_major else "_sps_packed") + ("_h" if half else "")
     cached = getattr(mlp, slot, None)
     if cached is not None and cached.key == key:
         return cached
     with torch.no_grad():
         (w1, b1), (w2, b2), (w3, b3) = (_fold(c, b) for c, b in pairs)
-        if point_major:
+        if point_major and not pm32:
             w1 = torch.cat([w1[:, 3:], w1[:, :3]], dim=1)  # grouped channels as [features, xyz]
         p = PackedScale()
         p.point_major, p.half = point_major, bool(half)
@@ -224,6 +247,8 @@ def pack_scale(mlp, nsample, point_major=False, half=False):
             p.w2 = p.w3 = p.w1
         elif p.split:
             p.w1, p.w2, p.w3 = _pack_f16(w1, c1, cin_pad), _pack_f16(w2, c2, c1), _pack_f16(w3, c3, c2)
+        elif pm32:
+            p.w1, p.w2, p.w3 = _pack_first_pm(w1, c1, c_feat), _pack_next(w2, c2, c1), _pack_next(w3, c3, c2)
         else:
             p.w1, p.w2, p.w3 = _pack_first(w1, c1), _pack_next(w2, c2, c1), _pack_next(w3, c3, c2)
         p.b1, p.b2, p.b3 = _pad_bias(b1, c1), _pad_bias(b2, c2), _pad_bias(b3, c3)
@@ -295,6 +320,8 @@ def want_packed(idx_shape, packed):
     B, M, ns = idx_shape
     cols = B * M * ns
     if not PACK_COLUMNS or packed.split == 2 or ns > 64 or B > 256 or M >= (1 << 20) or cols < PACK_MIN_COLUMNS:
+        return False
+    if packed.split == 0 and packed.point_major:     # the exact-fp32 kernel on point-major features takes idx rows only
         return False
     if PACK_COLUMNS == "always":
         return True

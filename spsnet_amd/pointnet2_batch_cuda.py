@@ -12,6 +12,7 @@ Differences from the reference, both deliberate:
   * kernels run on torch's *current* stream rather than the legacy default stream.
 """
 import os
+import threading
 
 import torch
 
@@ -37,13 +38,29 @@ def _need(t, numel, name):
         raise ValueError(f"{name} has {t.numel()} elements, the given sizes need {numel}")
 
 
-_SCOPE = None     # (device index, stream handle) while a launch_scope is open
+class _ScopeState(threading.local):
+    """(device index, stream handle) while a launch_scope is open -- per THREAD: autograd's per-device backward threads and
+    nn.DataParallel replicas run beside the thread that opened a scope and must not inherit its stream or device."""
+    scope = None
+
+
+_TLS = _ScopeState()
 
 
 def _stream(t):
-    if _SCOPE is not None:
-        return _SCOPE[1]
+    sc = _TLS.scope
+    if sc is not None and sc[0] == t.device.index:     # a tensor of another device never takes the scoped stream
+        return sc[1]
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _bump_versions(*tensors):
+    """Tell torch that a kernel wrote these tensors through their raw pointers.  fused._version_key keys every folded /
+    packed inference cache on (data_ptr, _version) of the BatchNorm running statistics: without the bump an eval() forward
+    after train-mode forwards with frozen weights (BN recalibration, swa_utils.update_bn, lr = 0) reuses stale folds."""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
 
 
 class launch_scope:
@@ -56,14 +73,12 @@ class launch_scope:
         self.guard = _on(t)
 
     def __enter__(self):
-        global _SCOPE
-        self.prev = _SCOPE
+        self.prev = _TLS.scope
         self.guard.__enter__()
-        _SCOPE = (self.t.device.index, torch.cuda.current_stream(self.t.device).cuda_stream)
+        _TLS.scope = (self.t.device.index, torch.cuda.current_stream(self.t.device).cuda_stream)
 
     def __exit__(self, *exc):
-        global _SCOPE
-        _SCOPE = self.prev
+        _TLS.scope = self.prev
         self.guard.__exit__(*exc)
 
 
@@ -75,8 +90,9 @@ class _on:
         self.prev = None
 
     def __enter__(self):
-        if _SCOPE is not None and _SCOPE[0] == self.dev:
-            return                                   # inside a launch_scope on this device: already current
+        sc = _TLS.scope
+        if sc is not None and sc[0] == self.dev:
+            return                                   # inside this thread's launch_scope on this device: already current
         cur = torch.cuda.current_device()
         if self.dev is not None and self.dev != cur:
             self.prev = cur
@@ -229,6 +245,7 @@ def bn_relu_train_fwd(x, weight, bias, eps, momentum, running_mean, running_var)
         _lib.check(_L.sps_bn_relu_train_fwd(B, C, L, _ptr(x, F32, "x"), opt(weight), opt(bias), float(eps), float(momentum),
                                             opt(running_mean), opt(running_var), mean.data_ptr(), invstd.data_ptr(),
                                             y.data_ptr(), work.data_ptr(), _stream(x)), "bn_relu_train_fwd")
+    _bump_versions(running_mean, running_var)
     return y, mean, invstd
 
 
@@ -692,23 +709,27 @@ def weights_amax(ws):
     return out
 
 
-def tbn_finalize(partial, count, bn, params):
-    """statistics -> params[:, 0:6] (+ the module's running statistics and batch counter, torch semantics)"""
+def tbn_finalize(partial, count, bn, params, count_dev=None):
+    """statistics -> params[:, 0:6] (+ the module's running statistics and batch counter, torch semantics).
+    count_dev (device float64 scalar): the GLOBAL element count under SyncBatchNorm, used instead of `count`."""
     parts, c = partial.shape[0], partial.shape[1]
     with _on(params):
-        _lib.check(_L.sps_tbn_finalize(c, parts, float(count), partial.data_ptr(), _p(bn.weight), _p(bn.bias), float(bn.eps),
-                                       float(bn.momentum), _p(bn.running_mean), _p(bn.running_var), params.data_ptr(),
-                                       _p(bn.num_batches_tracked), _stream(params)), "tbn_finalize")
+        _lib.check(_L.sps_tbn_finalize_dc(c, parts, float(count), 0 if count_dev is None else _ptr(count_dev, torch.float64, "count"),
+                                          partial.data_ptr(), _p(bn.weight), _p(bn.bias), float(bn.eps),
+                                          float(bn.momentum), _p(bn.running_mean), _p(bn.running_var), params.data_ptr(),
+                                          _p(bn.num_batches_tracked), _stream(params)), "tbn_finalize")
+    _bump_versions(bn.running_mean, bn.running_var, bn.num_batches_tracked)
 
 
-def tbn_bwd_finalize(partial, count, params):
+def tbn_bwd_finalize(partial, count, params, count_dev=None):
     """BatchNorm-backward sums -> params[:, 6:8]; returns (d gamma, d beta)"""
     parts, c = partial.shape[0], partial.shape[1]
     dg = torch.empty((c,), dtype=F32, device=params.device)
     db = torch.empty((c,), dtype=F32, device=params.device)
     with _on(params):
-        _lib.check(_L.sps_tbn_bwd_finalize(c, parts, float(count), partial.data_ptr(), params.data_ptr(), dg.data_ptr(),
-                                           db.data_ptr(), _stream(params)), "tbn_bwd_finalize")
+        _lib.check(_L.sps_tbn_bwd_finalize_dc(c, parts, float(count), 0 if count_dev is None else _ptr(count_dev, torch.float64, "count"),
+                                              partial.data_ptr(), params.data_ptr(), dg.data_ptr(),
+                                              db.data_ptr(), _stream(params)), "tbn_bwd_finalize")
     return dg, db
 
 

@@ -152,13 +152,19 @@ def _sync_group(bn):
 _SYNC_ALWAYS = False      # tests: take the synchronised code path in a one-process group too
 
 
-def _all_reduce_sums(partial, group):
-    """(parts, C, 2) local partial sums -> ((1, C, 2) sums over ALL ranks of `group`, (C, 2) local sums)"""
+def _all_reduce_sums(partial, group, count=None):
+    """(parts, C, 2) local partial sums -> ((1, C, 2) sums over ALL ranks of `group`, (C, 2) local sums[, global count]).
+    count: this rank's element count; it rides in the same all-reduce (one more float64) and comes back as the GLOBAL count,
+    a device scalar -- ranks may hold different numbers of elements (torch's SyncBatchNorm gathers per-rank counts too)."""
     import torch.distributed as dist
     local = partial.sum(dim=0)
-    total = local.clone()
-    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
-    return total.unsqueeze(0).contiguous(), local
+    if count is None:
+        total = local.clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+        return total.unsqueeze(0).contiguous(), local
+    buf = torch.cat([local.reshape(-1), local.new_full((1,), float(count))])
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf[:-1].view(1, *local.shape), local, buf[-1:]
 
 
 class _GroupedMLPPoolTrain(torch.autograd.Function):
@@ -199,10 +205,11 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
             partial = _ext.tconv(w, was[k], mode, _ext.TEPI_STATS, y, operand=operand, pin=pin, overflow=flag)
             params = torch.empty((w.shape[0], _ext.TRAIN_PARAMS), dtype=torch.float32, device=x.device)
             group, world = _sync_group(bn)
-            if group is not None:        # SyncBatchNorm: the statistics of the whole (equally sharded) global batch
-                partial, _ = _all_reduce_sums(partial, group)
-            _ext.tbn_finalize(partial, count * world, bn, params)      # (also counts the batch: num_batches_tracked += 1)
-            syncs.append((group, world))
+            gcount = None
+            if group is not None:        # SyncBatchNorm: the statistics AND the element count of the whole global batch
+                partial, _, gcount = _all_reduce_sums(partial, group, count)
+            _ext.tbn_finalize(partial, count, bn, params, count_dev=gcount)   # (also counts the batch: num_batches_tracked += 1)
+            syncs.append((group, gcount))
             ys.append(y); ps.append(params)
             operand, pin, mode = y, params, _ext.TIN_BNRELU
         if pool:
@@ -235,11 +242,11 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
         def finalize_bwd(partial, k):
             """BatchNorm-backward sums of layer k -> ps[k][:, 6:8] (means over the GLOBAL batch under SyncBatchNorm) and the
             (local) gradients of its weight and bias, as torch's SyncBatchNorm returns them"""
-            group, world = ctx.syncs[k]
+            group, gcount = ctx.syncs[k]
             if group is None:
                 return _ext.tbn_bwd_finalize(partial, count, ps[k])
             total, local = _all_reduce_sums(partial, group)
-            _ext.tbn_bwd_finalize(total, count * world, ps[k])
+            _ext.tbn_bwd_finalize(total, count, ps[k], count_dev=gcount)     # (the forward's all-reduced global count)
             return local[:, 1].float(), local[:, 0].float()
 
         grads[3 * n - 2], grads[3 * n - 1] = finalize_bwd(last, n - 1)

@@ -31,6 +31,12 @@ def test_two_rank_launch_prints_one_valid_line():
     assert line["validated"] == {"progress_wait_timeouts": False, "split_fp16_overflow": False,
                                  "last_step_bit_identical_to_sequential_pass": True}
     assert "REHEARSAL" in line["data"]
+    # BASELINE configs[2]: the one packed all-gather of the sampled indices is INSIDE the timed step, and the same steps
+    # were timed without it as well
+    assert line["config"]["workload"].startswith("BASELINE configs[2]") and "all-gather" in line["config"]["parallelism"]
+    assert line["exchange"]["per_step"] == 1 and line["exchange"]["bytes_per_rank"] == 4 * 8 * (4096 + 1024 + 512)
+    assert line["ms_per_step_no_exchange"] > 0
+    assert line["dtype"] == "f32" and "value_fp16x2" in line
     # whole-job aggregate: both ranks' points over the slowest rank's time
     assert abs(line["value"] - 2 * 8 * 16384 * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-6 * line["value"]
     assert "cpu_baseline" not in line and "training_step" not in line    # N = 1 only

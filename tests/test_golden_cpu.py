@@ -157,3 +157,13 @@ def test_stack3_indices(oracle):
     ref_scores = 1.0 / (1.0 + np.exp(-g["l1_cls"].max(-1).astype(np.float64)))
     topk_equivalent(oracle.topk_desc(s, 64), g["l2_idx"], ref_scores, 1e-6)
     np.testing.assert_array_equal(gather_xyz(x2, g["l2_idx"]), g["l2_new_xyz"])
+
+
+def test_rand_sampler_fixture_is_one_shared_permutation_prefix():
+    """pointnet2_modules.py:370-371: `randperm(N)[None, :npoint].int().repeat(B, 1)` -- the reference's rows are one prefix of
+    one permutation (distinct, in range, identical for every scene) and its centroids are exactly those points."""
+    g = load("sampler_rand")
+    idx, xyz = g["idx"], g["xyz"]
+    assert idx.dtype == np.int32 and idx.shape == (xyz.shape[0], 256)
+    assert (idx == idx[:1]).all() and np.unique(idx[0]).size == 256 and idx.min() >= 0 and idx.max() < xyz.shape[1]
+    np.testing.assert_array_equal(g["new_xyz"], np.take_along_axis(xyz, idx[..., None].astype(np.int64), 1))

@@ -410,14 +410,25 @@ SA_CASES = {
                           mlps=[[2, 8, 8]], aggregation_mlp=None, confidence_mlp=None),
     "sampler_ryfps": dict(npoint_list=[256], sample_range_list=[-1], sample_type_list=['ry-FPS'], radii=[1.6], nsamples=[8],
                           mlps=[[2, 8, 8]], aggregation_mlp=None, confidence_mlp=None),
+    "sampler_rand": dict(npoint_list=[256], sample_range_list=[-1], sample_type_list=['Rand'], radii=[1.6], nsamples=[8],
+                         mlps=[[2, 8, 8]], aggregation_mlp=None, confidence_mlp=None),
 }
 
 
 @pytest.mark.parametrize("name", sorted(SA_CASES))
-def test_golden_sa_module(ext, G, dev, name):
+def test_golden_sa_module(ext, G, dev, name, monkeypatch):
     """PointnetSAModuleMSG_WithSampling against the reference module's outputs on the same weights."""
     from spsnet_amd import pointnet2_modules as M
     g = np.load(os.path.join(GOLD, name + ".npz"))
+    if name == "sampler_rand":
+        # the reference drew its permutation from torch's CPU generator; hand the same one to the module (its prefix is the
+        # fixture's index row) -- what is pinned is everything the branch does with it (pointnet2_modules.py:370-371)
+        n = g["xyz"].shape[1]
+        head = g["idx"][0].astype(np.int64)
+        assert (g["idx"] == g["idx"][:1]).all()
+        rest = np.setdiff1d(np.arange(n), head)
+        perm = torch.from_numpy(np.concatenate([head, rest]))
+        monkeypatch.setattr(torch, "randperm", lambda count, device=None, **kw: perm.to(device) if count == n else None)
     kw = dict(use_xyz=True, dilated_group=False, num_class=3)
     kw.update(SA_CASES[name])
     mod = _load_sd(M.PointnetSAModuleMSG_WithSampling(**kw), g).to(dev).eval()
@@ -1231,6 +1242,63 @@ def test_fps_presorted_register_kernel(ext, G, oracle, N, m, B):
     np.testing.assert_array_equal(G.n(temp), want_t)
 
 
+@pytest.mark.parametrize("N,m,B", [(16384, 1024, 3), (8192, 700, 2), (40000, 2048, 2), (70000, 1500, 1)])
+def test_fps_exchange_give_up_is_redone(ext, G, oracle, N, m, B, monkeypatch):
+    """Every cross-workgroup poll of the FPS kernels is FORCED to give up (sps_debug_set_exchange_spins(0xFFFFFFFF)): the
+    K-way sorting pre-pass of the register kernel (<= 16 384 points) and the clustered large-scene kernel then raise their
+    scenes' give-up words and leave -- no trap -- and the launcher's follow-up launch (self-sorting register kernel /
+    one-workgroup large-scene kernel) samples those scenes: indices and final running distances bit-exact with the oracle.
+    Then once more with the default bound (the follow-up launch is empty) for the same result."""
+    from spsnet_amd import _lib
+    L = _lib.load()
+    monkeypatch.delenv("SPS_FPS_CLUSTER", raising=False)
+    rng = np.random.default_rng(N + m)
+    xyz = cloud(rng, B, N, dup=0.05)
+    x = G.t(xyz)
+    wf = int(L.sps_fps_workspace_floats(N))
+    assert wf > 0
+    want, want_t = oracle.fps(xyz, m, return_temp=True)
+    for bound in (0xFFFFFFFF, 0):
+        old = L.sps_debug_set_exchange_spins(bound)
+        try:
+            temp = torch.full((B, N), 1e10, dtype=torch.float32, device=x.device)
+            idx = torch.full((B, m), -7, dtype=torch.int32, device=x.device)
+            work = torch.empty((B * wf,), dtype=torch.float32, device=x.device)
+            _lib.check(L.sps_fps_with_workspace(B, N, m, x.data_ptr(), temp.data_ptr(), idx.data_ptr(), work.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream), "fps")
+            torch.cuda.synchronize()
+        finally:
+            L.sps_debug_set_exchange_spins(old)
+        np.testing.assert_array_equal(G.n(idx), want)
+        np.testing.assert_array_equal(G.n(temp), want_t)
+
+
+@pytest.mark.parametrize("B,N,npts", [(2, 16384, None), (1, 40000, [4096, 1024, 256])])
+def test_streamed_first_layer_survives_exchange_give_up(G, dev, B, N, npts):
+    """The PUBLISHING producers behind a forced give-up of every cross-workgroup poll: the streamed first layer's consumers
+    wait on the progress counter that the follow-up launch publishes (register kernel: as it samples; one-workgroup
+    large-scene kernel: once at its end) -- every output of every layer bit-identical to the sequential pass."""
+    from spsnet_amd import _lib, pointnet2_modules as M, sa_stack, scenes
+    L = _lib.load()
+    layers = sa_stack.build_sa_layers(M, sa_stack.scaled_config(npoints=npts), seed=12).to(dev)
+    xyz, feats = scenes.make_batch("kitti-lidar-v1", B, N, seed0=63, dup_fraction=0.01)
+    x, f = G.t(xyz), G.t(feats)
+    with torch.no_grad():
+        want = sa_stack.run_sa_layers(layers, x, f, overlap=False, stream_first_layer=False)
+        torch.cuda.synchronize()
+        sa_stack.check_timeouts()
+        old = L.sps_debug_set_exchange_spins(0xFFFFFFFF)
+        try:
+            got = sa_stack.run_sa_layers(layers, x, f)
+            torch.cuda.synchronize()
+        finally:
+            L.sps_debug_set_exchange_spins(old)
+        sa_stack.check_timeouts()     # (a consumer's bounded wait may or may not have run out behind the slower producer)
+        for k, (la, lb) in enumerate(zip(got, want)):
+            for ta, tb in zip(la, lb):
+                assert (ta is None and tb is None) or torch.equal(ta, tb), f"layer {k}"
+
+
 def test_fps_presorted_degenerate_clouds(ext, G, oracle):
     """All-equal, collinear and NaN / Inf clouds through the sorting pre-pass (its box comes from a strided sample)."""
     from spsnet_amd import _lib
@@ -1451,6 +1519,57 @@ def test_training_mode_matches_torch_reference(ext, G, dev, oracle):
     for (name, bg), (_, br) in zip(mod.named_buffers(), ref.named_buffers()):
         if bg.dtype.is_floating_point:
             close(bg, br, "buffer " + name)
+
+
+@pytest.mark.parametrize("input_grad", [False, True])
+@pytest.mark.parametrize("fused_train", [True, False])
+def test_eval_after_frozen_weight_training_forwards_sees_new_running_stats(dev, fused_train, input_grad, monkeypatch):
+    """eval -> train-mode forwards with FROZEN weights (BatchNorm recalibration, swa_utils.update_bn, lr = 0) -> eval: the
+    kernels write running_mean / running_var through raw pointers, and the folded inference caches are keyed on those
+    tensors' versions -- the second eval must use the NEW statistics.  Checked against a twin module run through torch's own
+    Conv / BatchNorm on the same inputs (grouping replayed from this module's indices is not needed: the layer is run on
+    identical data by both, and only the statistics differ between the two eval passes).  input_grad: the train-mode forwards
+    run with autograd on and an input that wants gradients, i.e. through this library's own train-mode kernels
+    (mlp_train.hip / bn_relu_train.hip, which write the statistics through raw pointers); without it they run under
+    no_grad through torch's batch_norm -- which does not move the statistics' version counters either."""
+    import copy
+    from spsnet_amd import pointnet2_modules as M, scenes
+    monkeypatch.setattr(M, "FUSED_MLP_TRAINING", fused_train)
+    torch.manual_seed(3)
+    mod = M.PointnetSAModuleMSG_WithSampling(
+        npoint_list=[256], sample_range_list=[-1], sample_type_list=['D-FPS'], radii=[0.6, 1.2], nsamples=[16, 32],
+        mlps=[[4, 16, 16, 32], [4, 32, 32, 64]], use_xyz=True, dilated_group=False, aggregation_mlp=[64], confidence_mlp=[32],
+        num_class=3)
+    scenes.fill_parameters(mod, 5)
+    mod = mod.to(dev)
+    for p in mod.parameters():
+        p.requires_grad_(False)
+    rng = np.random.default_rng(8)
+    xyz = torch.from_numpy(rng.uniform(-3, 3, (2, 2048, 3)).astype(np.float32)).to(dev)
+    feats = torch.from_numpy((3.0 * rng.normal(size=(2, 4, 2048)) + 1.5).astype(np.float32)).to(dev)
+    with torch.no_grad():
+        mod.eval()
+        first = mod(xyz, feats)[1].clone()
+        before = {k: v.clone() for k, v in mod.named_buffers() if v.dtype.is_floating_point}
+        mod.train()
+        for _ in range(3):
+            if input_grad:
+                with torch.enable_grad():
+                    mod(xyz, feats.clone().requires_grad_(True))
+            else:
+                mod(xyz, feats)
+        mod.eval()
+        second = mod(xyz, feats)[1].clone()
+        moved = max(float((v - before[k]).abs().max()) for k, v in mod.named_buffers() if v.dtype.is_floating_point)
+        assert moved > 1e-3, "the train-mode forwards were supposed to move the running statistics"
+        # a twin built from the CURRENT state (fresh caches by construction) is the expected result of the second eval
+        twin = copy.deepcopy(mod).eval()
+        for m_ in twin.modules():
+            for attr in [a for a in vars(m_) if a.startswith("_sps")]:
+                delattr(m_, attr)
+        want = twin(xyz, feats)[1]
+    assert float((second - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    assert float((second - first).abs().max()) > 1e-4, "the second eval pass still uses the statistics of the first"
 
 
 # ------------------------------------------------------------------ pointnet2_stack: ragged batches (parity unpinned by the reference)
@@ -2219,7 +2338,7 @@ def test_streamed_first_layer_repairs_timed_out_waits(G, dev, npts, ns, half):
         want = sa_stack.run_sa_layers(layers, x, f, overlap=False, stream_first_layer=False)
         torch.cuda.synchronize()
         sa_stack.check_timeouts()
-        old = L.sps_debug_set_wait_spins(1)
+        old = L.sps_debug_set_wait_spins(0xFFFFFFFF)   # give up without looking: independent of the host's pace
         try:
             for rep in range(2):
                 junk = torch.full((16 << 20,), 5 + rep, dtype=torch.int32, device=dev)   # stale memory = wrong but in-range values
@@ -2265,7 +2384,7 @@ def test_training_streamed_queries_equal_unstreamed(G, dev, force_timeouts, monk
     ref_layers, got_layers = copy.deepcopy(base), copy.deepcopy(base)
     want = run(ref_layers, False)
     sa_stack.check_timeouts()
-    old = L.sps_debug_set_wait_spins(1) if force_timeouts else None
+    old = L.sps_debug_set_wait_spins(0xFFFFFFFF) if force_timeouts else None
     try:
         calls = []
         orig = sa_stack._streamed_first_layer_queries

@@ -19,7 +19,7 @@ def _make(seed=21):
     return mlp, x, wout
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, bounds):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -28,12 +28,12 @@ def _worker(rank, world, port, q):
         dev = torch.device("cuda:0")
         mlp, x, wout = _make()
         mlp = torch.nn.SyncBatchNorm.convert_sync_batchnorm(mlp).to(dev).train()
-        per = x.shape[0] // world
-        xs = x[rank * per:(rank + 1) * per].to(dev).requires_grad_(True)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        xs = x[lo:hi].to(dev).requires_grad_(True)
         PM.FUSED_MLP_TRAINING = True
         out = PM._fused_mlp_pool_train(mlp, xs, 'max_pool')
         assert out is not None
-        (out * wout[rank * per:(rank + 1) * per].to(dev)).sum().backward()
+        (out * wout[lo:hi].to(dev)).sum().backward()
         torch.cuda.synchronize()
         grads = [p.grad.detach().cpu().double() for p in mlp.parameters()]
         for g in grads:                                   # what DDP does with parameter gradients (sum here, not mean)
@@ -46,7 +46,10 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.gpu
-def test_two_ranks_sync_batchnorm_equal_one_process_plain_batchnorm():
+@pytest.mark.parametrize("bounds", [(0, 2, 4), (0, 3, 4)], ids=["equal-shards", "unequal-shards"])
+def test_two_ranks_sync_batchnorm_equal_one_process_plain_batchnorm(bounds):
+    """bounds = the scenes each rank holds: (0, 3, 4) gives the ranks DIFFERENT element counts -- the global count rides in
+    the statistics' all-reduce (torch's SyncBatchNorm gathers per-rank counts the same way)."""
     from spsnet_amd import pointnet2_modules as PM
     dev = torch.device("cuda:0")
     mlp, x, wout = _make()
@@ -65,7 +68,7 @@ def test_two_ranks_sync_batchnorm_equal_one_process_plain_batchnorm():
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, bounds)) for r in range(2)]
     for p in procs:
         p.start()
     results = {}
@@ -80,13 +83,13 @@ def test_two_ranks_sync_batchnorm_equal_one_process_plain_batchnorm():
         err = float((a.double() - b.double()).abs().max())
         assert err <= tol * max(1e-30, float(b.abs().max())), (what, err, float(b.abs().max()))
 
-    per = x.shape[0] // 2
     for r in range(2):
+        lo, hi = bounds[r], bounds[r + 1]
         out, dx, grads, bufs = results[r]
         out, dx = torch.from_numpy(out), torch.from_numpy(dx)
         grads, bufs = [torch.from_numpy(g) for g in grads], [torch.from_numpy(b) for b in bufs]
-        close(out, want[r * per:(r + 1) * per].detach().cpu(), f"rank {r} output")
-        close(dx, xg.grad[r * per:(r + 1) * per].cpu(), f"rank {r} input gradient")
+        close(out, want[lo:hi].detach().cpu(), f"rank {r} output")
+        close(dx, xg.grad[lo:hi].cpu(), f"rank {r} input gradient")
         for (name, p), g in zip(mlp.named_parameters(), grads):
             close(g, p.grad.cpu(), f"rank {r} summed gradient of {name}")
         for (name, b), bb in zip(mlp.named_buffers(), bufs):

@@ -1,6 +1,7 @@
 """Time ONE grouped-MLP launch (gather + 3 layers + max-pool) at a given shape, HIP events over 30 launches.
 Default: IA-SSD layer 5 (8 scenes, 512 points with 256 features -> 256 vote centres), both scales.
-usage: python tools/mlp_time.py [B N M c_feat [l1]]     (l1: the widths / radii of IA-SSD layer 1, e.g. 8 4096 1024 64 l1)"""
+usage: python tools/mlp_time.py [B N M c_feat [l1|l2|l5 [fp32|fp16x2]]]   (l1: the widths / radii of IA-SSD layer 1, e.g. 8 4096 1024 64 l1;
+SPS_PM_FP32=0 selects the channel-major fp32 kernel for an A/B)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,6 +9,8 @@ import torch
 from spsnet_amd import fused, pointnet2_modules as M, pointnet2_utils as U
 
 B, N, Mc, c_feat = (int(a) for a in sys.argv[1:5]) if len(sys.argv) >= 5 else (8, 512, 256, 256)
+if len(sys.argv) > 6:
+    fused.set_precision(sys.argv[6])
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 rng = np.random.default_rng(0)
@@ -40,5 +43,6 @@ for widths, ns, radius in SCALES:
         torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 30 * 1e3
     flop = 2.0 * B * Mc * ns * ((c_feat + 3) * widths[0] + widths[0] * widths[1] + widths[1] * widths[2])
-    print(f"{c_feat + 3}->{widths} ns {ns}: {us:8.1f} us  {flop / us / 1e6:7.1f} TFLOP/s algorithmic "
+    print(f"[{fused.PRECISION} split={plan[0].split} pm={plan[0].point_major}] "
+          f"{c_feat + 3}->{widths} ns {ns}: {us:8.1f} us  {flop / us / 1e6:7.1f} TFLOP/s algorithmic "
           f"(split-fp16: x3 issued = {3 * flop / us / 1e6 / 2500 * 100:.1f} % of the 2.5 PF peak)", flush=True)
