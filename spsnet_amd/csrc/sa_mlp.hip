@@ -398,7 +398,7 @@ extern "C" int sps_sa_group_mlp_packed(int b, int n, int m, int j0, int jcount, 
     a.feat_pm = (split_fp16 & 4) ? 1 : 0;
     if (a.feat_pm && (c_feat < 4 || (c_feat % 4)))
         return fail(SPS_ERR_INVALID, "sa_group_mlp: point-major features need c_feat %% 4 == 0 (got %d)", c_feat);
-    if (a.feat_pm && arith == 0 && (cols || !sps_sa_group_mlp_pm_supported(c_feat, c1, c2, c3, nsample)))
+    if (a.feat_pm && arith == 0 && !sps_sa_group_mlp_pm_supported(c_feat, c1, c2, c3, nsample))
         return fail(SPS_ERR_INVALID, "sa_group_mlp: no exact-fp32 kernel for point-major features with %d channels, widths "
                                      "(%d, %d, %d), nsample %d", c_feat, c1, c2, c3, nsample);
     hipStream_t st = as_stream(stream);

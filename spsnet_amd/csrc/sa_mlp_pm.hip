@@ -160,7 +160,9 @@ __device__ __forceinline__ void chain_layer_rt(const float *w, const float *bias
 // CF: feature channels of the point-major twin (a multiple of 16); C1, C2, C3: padded widths; NT: 16-column tiles per unit.
 // Weights: a.w1 = [C1/16 tiles][lane] coordinate fragments (k-slot q < 3 = centred x, y, z; slot 3 = zero), then layer 1 over
 // the features as [tile][CF/16][lane][4]; a.w2, a.w3 as in sa_mlp.hip (fused._pack_next).
-template <int CF, int C1, int C2, int C3, int NT, int NS>
+// PACKED: the columns come from sps_pack_columns (only the distinct neighbours of every ball, in power-of-two slots): a unit is
+// COLS consecutive entries of a.cols / a.meta, the pool is segmented per slot (pool_write_packed) -- same pooled values bit for bit.
+template <int CF, int C1, int C2, int C3, int NT, int NS, bool PACKED>
 __global__ __launch_bounds__(256) void sa_group_mlp_pm_kernel(SaMlpArgs a) {
     if (a.run_if && *a.run_if == 0) return;
     constexpr int T0 = CF / 16, T1 = C1 / 16, T2 = C2 / 16, MT3 = C3 / 16;
@@ -186,46 +188,66 @@ __global__ __launch_bounds__(256) void sa_group_mlp_pm_kernel(SaMlpArgs a) {
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
     const MlpRange rg = mlp_range(a);
+    const int nunits = PACKED ? (*a.ntiles) / NT : rg.units;   // packed: as many units as pack_columns produced tiles for
     const float *w1f = a.w1 + (size_t)T1 * 64;   // layer 1 over the features, behind the coordinate fragments
 
     // a unit's inputs: requested one unit ahead
     f32x4 xin[T0][NT];
     float xq[NT];
     int src[NT];
+    PackedUnit<NT> pun, pu;      // meta words of the unit being requested / being computed (PACKED)
     auto col0_of = [&](int unit, int &ub) -> long long {
         ub = unit / rg.ups;
         return ((long long)ub * a.m + rg.j0) * NS + (long long)(unit - ub * rg.ups) * COLS;
     };
     auto load_idx = [&](int unit) {
-        int ub;
-        const long long col0 = col0_of(unit, ub);
+        if constexpr (PACKED) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) src[nt] = a.idx[col0 + nt * 16 + c];
+            for (int nt = 0; nt < NT; ++nt) {
+                const size_t e = (size_t)unit * COLS + nt * 16 + c;
+                src[nt] = a.cols[e];
+                pun.w[nt] = a.meta[e];
+            }
+        } else {
+            int ub;
+            const long long col0 = col0_of(unit, ub);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) src[nt] = a.idx[col0 + nt * 16 + c];
+        }
     };
-    auto load_inputs = [&](int unit) {   // (uses src[] of the same unit)
-        int ub;
-        const long long col0 = col0_of(unit, ub);
+    auto load_inputs = [&](int unit) {   // (uses src[] / pun of the same unit)
+        int ub = 0;
+        long long col0 = 0;
+        if constexpr (!PACKED) col0 = col0_of(unit, ub);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
+            long long bj;
+            if constexpr (PACKED) {   // a tile never straddles scenes: the scene stays wave-uniform (scalar address arithmetic)
+                ub = __builtin_amdgcn_readfirstlane((int)((pun.w[nt] >> 20) & 0xFFu));
+                bj = (long long)ub * a.m + (int)(pun.w[nt] & 0xFFFFFu);
+            } else {
+                bj = (col0 + nt * 16 + c) / NS;
+            }
             const size_t pt = (size_t)ub * a.n + src[nt];
             const float *row = a.feat + pt * CF + 4 * q;
 #pragma unroll
             for (int t = 0; t < T0; ++t) xin[t][nt] = *reinterpret_cast<const f32x4 *>(row + 16 * t);
-            const long long bj = (col0 + nt * 16 + c) / NS;
             const int ax = q < 3 ? q : 0;
             const float d = a.xyz[pt * 3 + ax] - a.new_xyz[(size_t)bj * 3 + ax];
             xq[nt] = q < 3 ? d : 0.f;
         }
     };
-    if (wave < rg.units) {
+    if (wave < nunits) {
         load_idx(wave);
         load_inputs(wave);
     }
-    for (int unit = wave; unit < rg.units; unit += nwaves) {
-        int ub;
-        const long long col0 = col0_of(unit, ub);
+    for (int unit = wave; unit < nunits; unit += nwaves) {
+        int ub = 0;
+        long long col0 = 0;
+        if constexpr (!PACKED) col0 = col0_of(unit, ub);
+        if constexpr (PACKED) pu = pun;
         const int nxt = unit + nwaves;
-        const bool more = nxt < rg.units;
+        const bool more = nxt < nunits;
         // ---------------- layer 1: the coordinate k-step, then the chain over the twin's channels ----------------
         f32x4 h1[T1][NT];
         {
@@ -263,6 +285,10 @@ __global__ __launch_bounds__(256) void sa_group_mlp_pm_kernel(SaMlpArgs a) {
         const long long bj0 = col0 / NS;
         chain_layer_rt<C2, MT3, NT>(a.w3, sbias + C1 + C2, lane, q, h2,
             [&](int mt, f32x4 (&acc)[NT]) {
+                if constexpr (PACKED) {
+                    pool_write_packed<NT>(a, acc, pu, mt, q, c);
+                    return;
+                }
                 f32x4 best[CPP];
 #pragma unroll
                 for (int cc = 0; cc < CPP; ++cc) best[cc] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -298,23 +324,28 @@ template <int CF, int C1, int C2, int C3, int NT, int NS>
 static int launch_pm_variant(const SaMlpArgs &a, hipStream_t st) {
     constexpr int UNIT = 16 * NT;
     SaMlpArgs k = a;
-    const long long cols_scene = (long long)a.ups * NS;   // caller passes centroids per scene in `ups`, scenes in `units`
-    if (cols_scene % UNIT != 0)
-        return fail(SPS_ERR_INVALID, "sa_group_mlp(pm): centroids*nsample per scene (%lld) not a multiple of %d", cols_scene, UNIT);
-    k.ups = (int)(cols_scene / UNIT);
-    k.units = a.units * k.ups;
-    k.alt_j0 = 0;
-    k.alt_ups = (int)((long long)a.m * NS / UNIT);
-    k.alt_units = a.units * k.alt_ups;
-    if (a.alt && ((long long)a.m * NS) % UNIT != 0)
-        return fail(SPS_ERR_INVALID, "sa_group_mlp(pm): centroids*nsample per scene not a multiple of %d", UNIT);
+    if (a.cols) {                      // packed columns: `units` = tile capacity on entry; the kernel reads the real count
+        k.ups = 1;
+        k.units = a.units / NT;
+    } else {
+        const long long cols_scene = (long long)a.ups * NS;   // caller passes centroids per scene in `ups`, scenes in `units`
+        if (cols_scene % UNIT != 0)
+            return fail(SPS_ERR_INVALID, "sa_group_mlp(pm): centroids*nsample per scene (%lld) not a multiple of %d", cols_scene, UNIT);
+        k.ups = (int)(cols_scene / UNIT);
+        k.units = a.units * k.ups;
+        k.alt_j0 = 0;
+        k.alt_ups = (int)((long long)a.m * NS / UNIT);
+        k.alt_units = a.units * k.alt_ups;
+        if (a.alt && ((long long)a.m * NS) % UNIT != 0)
+            return fail(SPS_ERR_INVALID, "sa_group_mlp(pm): centroids*nsample per scene not a multiple of %d", UNIT);
+    }
     const int waves_per_block = 4;
     // as many workgroups as the chip holds at this kernel's occupancy, dealt evenly: every wave walks the same number of
     // units (+-1), each of which prefetches the next one's inputs
     static int occ = 0;     // (per instantiation; the same on every device of the node)
     if (occ == 0) {
         int o = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, sa_group_mlp_pm_kernel<CF, C1, C2, C3, NT, NS>, 64 * waves_per_block, 0)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, sa_group_mlp_pm_kernel<CF, C1, C2, C3, NT, NS, false>, 64 * waves_per_block, 0)
                 != hipSuccess || o < 1)
             o = 1;
         occ = o > 4 ? 4 : o;
@@ -326,7 +357,10 @@ static int launch_pm_variant(const SaMlpArgs &a, hipStream_t st) {
         if (v > 0) max_blocks = v;
     }
     if (blocks > max_blocks) blocks = max_blocks;
-    hipLaunchKernelGGL((sa_group_mlp_pm_kernel<CF, C1, C2, C3, NT, NS>), dim3(blocks), dim3(64 * waves_per_block), 0, st, k);
+    if (a.cols)
+        hipLaunchKernelGGL((sa_group_mlp_pm_kernel<CF, C1, C2, C3, NT, NS, true>), dim3(blocks), dim3(64 * waves_per_block), 0, st, k);
+    else
+        hipLaunchKernelGGL((sa_group_mlp_pm_kernel<CF, C1, C2, C3, NT, NS, false>), dim3(blocks), dim3(64 * waves_per_block), 0, st, k);
     return check_launch("sa_group_mlp_pm_kernel");
 }
 

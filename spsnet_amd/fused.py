@@ -280,6 +280,8 @@ def point_major_twin(features):
 # generator's M = N layer (many rounds, but VALU-bound narrow widths) lost 0.87 -> 0.91 ms to the packed kernels' larger
 # register footprint.  Kept as a tested option (bit-identical results) for shapes with many rounds of wide units.
 PACK_COLUMNS = {"1": True, "2": "always"}.get(__import__("os").environ.get("SPS_PACK_COLUMNS", "0"), False)
+PACK_PM32 = __import__("os").environ.get("SPS_PACK_PM32", "1") != "0"
+PACK_PM32_MIN_COLUMNS = 1 << 16
 PACK_MIN_COLUMNS = 1 << 15
 PACK_BIG_COLUMNS = 1 << 20
 _COUNTERS = {}
@@ -319,9 +321,13 @@ def want_packed(idx_shape, packed):
     the padded columns was measured to pay for the extra launch (see PACK_COLUMNS)."""
     B, M, ns = idx_shape
     cols = B * M * ns
-    if not PACK_COLUMNS or packed.split == 2 or ns > 64 or B > 256 or M >= (1 << 20) or cols < PACK_MIN_COLUMNS:
+    if packed.split == 2 or ns > 64 or B > 256 or M >= (1 << 20):
         return False
-    if packed.split == 0 and packed.point_major:     # the exact-fp32 kernel on point-major features takes idx rows only
+    if packed.split == 0 and packed.point_major and PACK_PM32 and PACK_COLUMNS != "always":
+        # the exact-fp32 kernel on point-major features (sa_mlp_pm.hip) runs at ~75 % of the matrix pipe whatever the launch
+        # size, so its time follows the column count: pack wherever a launch is long enough to pay for the pack launch
+        return cols >= PACK_PM32_MIN_COLUMNS
+    if not PACK_COLUMNS or cols < PACK_MIN_COLUMNS:
         return False
     if PACK_COLUMNS == "always":
         return True
