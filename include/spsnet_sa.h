@@ -307,6 +307,10 @@ int sps_sa_group_mlp_ex(int b, int n, int m, int j0, int jcount, int c_feat, int
 long long sps_pack_columns_capacity(int b, int jcount, int nsample);
 int sps_pack_columns(int b, int m, int j0, int jcount, int nsample, const int *idx, int *cols, unsigned *meta, int *ntiles,
                      long long tile_cap, sps_stream_t stream);
+/* both grouping scales of a layer (same b, m, range) in one launch */
+int sps_pack_columns2(int b, int m, int j0, int jcount, int nsample_a, const int *idx_a, int *cols_a, unsigned *meta_a,
+                      int *ntiles_a, long long tile_cap_a, int nsample_b, const int *idx_b, int *cols_b, unsigned *meta_b,
+                      int *ntiles_b, long long tile_cap_b, sps_stream_t stream);
 /* sps_sa_group_mlp_ex over either idx + range or (cols != NULL) a packed column stream; split_fp16 + 8: `out` is
  * point-major (b, m, out_c_total).  With packed columns and nsample 64 `out` must be zero-filled as before. */
 int sps_sa_group_mlp_packed(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,

@@ -106,6 +106,7 @@ _PROTOS = {
     "sps_sa_group_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                             _vp, _vp, _i, _i, _i, _vp, _vp],
     "sps_pack_columns": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _vp],
+    "sps_pack_columns2": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _vp],
     "sps_sa_group_mlp_packed": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _i,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sps_fps_redo_where": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],

@@ -23,10 +23,16 @@ namespace sps {
 
 constexpr int PACK_WINDOW = 64;
 
+// (the second argument set: a layer's other grouping scale, packed by the blocks with blockIdx.y == 1 of the same launch --
+//  sps_pack_columns2; a launch costs ~6-9 us on the critical path behind the ball query, whatever it packs)
 __global__ __launch_bounds__(256) void pack_columns_kernel(int m, int ns, int j0, int jcount, const int *__restrict__ idx,
                                                            int *__restrict__ cols, unsigned *__restrict__ meta,
-                                                           int *__restrict__ ntiles, int tile_cap) {
+                                                           int *__restrict__ ntiles, int tile_cap, int ns2 = 0,
+                                                           const int *__restrict__ idx2 = nullptr, int *__restrict__ cols2 = nullptr,
+                                                           unsigned *__restrict__ meta2 = nullptr, int *__restrict__ ntiles2 = nullptr,
+                                                           int tile_cap2 = 0) {
     extern __shared__ int s_idx[];   // [PACK_WINDOW][ns]
+    if (blockIdx.y == 1) { ns = ns2; idx = idx2; cols = cols2; meta = meta2; ntiles = ntiles2; tile_cap = tile_cap2; }
     __shared__ int s_cnt[PACK_WINDOW], s_lg[PACK_WINDOW], s_pos[PACK_WINDOW];
     __shared__ int s_total, s_base;
     const int windows = (jcount + PACK_WINDOW - 1) / PACK_WINDOW;
@@ -116,4 +122,27 @@ extern "C" int sps_pack_columns(int b, int m, int j0, int jcount, int nsample, c
     hipLaunchKernelGGL(pack_columns_kernel, dim3(b * windows), dim3(256), (size_t)PACK_WINDOW * nsample * sizeof(int),
                        as_stream(stream), m, nsample, j0, jcount, idx, cols, meta, ntiles, (int)tile_cap);
     return check_launch("pack_columns_kernel");
+}
+
+// Both grouping scales of a layer in ONE launch (same b, m and centroid range; each with its own nsample, rows and outputs).
+extern "C" int sps_pack_columns2(int b, int m, int j0, int jcount, int nsample_a, const int *idx_a, int *cols_a, unsigned *meta_a,
+                                 int *ntiles_a, long long tile_cap_a, int nsample_b, const int *idx_b, int *cols_b,
+                                 unsigned *meta_b, int *ntiles_b, long long tile_cap_b, sps_stream_t stream) {
+    using namespace sps;
+    if (b < 0 || m <= 0 || j0 < 0 || jcount < 0 || j0 + jcount > m || nsample_a <= 0 || nsample_a > 64 || nsample_b <= 0 ||
+        nsample_b > 64 || m >= (1 << 20) || b > 256)
+        return fail(SPS_ERR_INVALID, "pack_columns2: bad shape (b=%d m=%d range [%d, +%d) nsample=%d/%d)", b, m, j0, jcount,
+                    nsample_a, nsample_b);
+    if (b == 0 || jcount == 0) return SPS_OK;
+    if (!idx_a || !cols_a || !meta_a || !ntiles_a || !idx_b || !cols_b || !meta_b || !ntiles_b)
+        return fail(SPS_ERR_INVALID, "pack_columns2: null pointer");
+    if (tile_cap_a < sps_pack_columns_capacity(b, jcount, nsample_a) || tile_cap_a > 0x7FFFFFF ||
+        tile_cap_b < sps_pack_columns_capacity(b, jcount, nsample_b) || tile_cap_b > 0x7FFFFFF)
+        return fail(SPS_ERR_INVALID, "pack_columns2: tile capacity too small");
+    const int windows = (jcount + PACK_WINDOW - 1) / PACK_WINDOW;
+    const int nsmax = nsample_a > nsample_b ? nsample_a : nsample_b;
+    hipLaunchKernelGGL(pack_columns_kernel, dim3(b * windows, 2), dim3(256), (size_t)PACK_WINDOW * nsmax * sizeof(int),
+                       as_stream(stream), m, nsample_a, j0, jcount, idx_a, cols_a, meta_a, ntiles_a, (int)tile_cap_a, nsample_b, idx_b,
+                       cols_b, meta_b, ntiles_b, (int)tile_cap_b);
+    return check_launch("pack_columns_kernel<2>");
 }

@@ -316,6 +316,26 @@ def pack_columns(idx, j0=0, jcount=None):
     return p
 
 
+def pack_columns2(idx_a, idx_b):
+    """pack_columns for both grouping scales of a layer in ONE launch -> (PackedColumns, PackedColumns)."""
+    B, M, _ = idx_a.shape
+    assert idx_b.shape[:2] == (B, M)
+    out = []
+    for idx in (idx_a, idx_b):
+        p = PackedColumns()
+        p.cap = int(_L.sps_pack_columns_capacity(B, M, idx.shape[2]))
+        p.cols = torch.empty((p.cap * 16,), dtype=torch.int32, device=idx.device)
+        p.meta = torch.empty((p.cap * 16,), dtype=torch.int32, device=idx.device)
+        p.ntiles = _zero_counter(idx.device)
+        out.append(p)
+    a, b = out
+    _lib.check(_L.sps_pack_columns2(B, M, 0, M, idx_a.shape[2], idx_a.data_ptr(), a.cols.data_ptr(), a.meta.data_ptr(),
+                                    a.ntiles.data_ptr(), a.cap, idx_b.shape[2], idx_b.data_ptr(), b.cols.data_ptr(),
+                                    b.meta.data_ptr(), b.ntiles.data_ptr(), b.cap,
+                                    torch.cuda.current_stream(idx_a.device).cuda_stream), "pack_columns2")
+    return a, b
+
+
 def want_packed(idx_shape, packed):
     """Pack a launch over idx of this (B, M, nsample) shape?  Whole-layer launches of the per-wave kernels where dropping
     the padded columns was measured to pay for the extra launch (see PACK_COLUMNS)."""

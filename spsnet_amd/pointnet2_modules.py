@@ -135,6 +135,8 @@ FUSED_FP_TRAINING_MIN = int(os.environ.get("SPS_FUSED_FP_TRAINING_MIN", str(1 <<
 # every fork / join is a cross-stream dependency that is actually waited for, ~12 us each, and the big kernels of both
 # chains are memory-bound and only share the bandwidth); kept as a switch, off
 SCALES_ON_STREAMS = os.environ.get("SPS_SCALES_ON_STREAMS", "0") != "0"
+# inference, exact fp32: the smaller grouping scale of a layer on a second stream behind the larger one (see _group_mlp_pool)
+FILL_WITH_SMALL_SCALE = os.environ.get("SPS_FILL_WITH_SMALL_SCALE", "1") != "0"
 
 
 def _sync_group(bn):
@@ -425,10 +427,36 @@ class _PointnetSAModuleBase(nn.Module):
                 idxs = _ext.ball_query_full2(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz_c, new_c)
             else:
                 idxs = [_ext.ball_query_full(g.radius, g.nsample, xyz_c, new_c) for g in self.groupers]
-            for idx, packed, pk in zip(idxs, plan, pack):
-                columns = _fused.pack_columns(idx) if pk else None
-                _fused.group_mlp_pool(xyz_c, new_c, feats_c, idx, packed, out, offset, columns=columns, out_point_major=pm)
-                offset += packed.c3_real
+            both = _fused.pack_columns2(idxs[0], idxs[1]) if (len(plan) == 2 and all(pack)) else None   # one launch for both scales
+            cols = [both[k] if both is not None else (_fused.pack_columns(idx) if pk else None)
+                    for k, (idx, pk) in enumerate(zip(idxs, pack))]
+            offsets = [sum(p.c3_real for p in plan[:k]) for k in range(len(plan))]
+            if both is not None and FILL_WITH_SMALL_SCALE and all(p.split == 0 and p.point_major for p in plan):
+                # The exact-fp32 kernels run one wave per SIMD, each wave walking its units: a launch ends when the waves with
+                # one unit more than the others do, and for that last round half the chip idles (3640 units on 1024 waves = 4
+                # rounds for 568 of them).  The launch with fewer columns goes to a second stream BEHIND the big one: its
+                # workgroups land on the compute units the big launch's short workgroups free first.
+                order = sorted(range(2), key=lambda k: -(idxs[k].shape[2] * plan[k].c3))
+                main = torch.cuda.current_stream(xyz_c.device)
+                side = self._scale_streams(xyz_c)[0]
+                k0, k1 = order
+                ready = torch.cuda.Event()
+                ready.record(main)
+                _fused.group_mlp_pool(xyz_c, new_c, feats_c, idxs[k0], plan[k0], out, offsets[k0], columns=cols[k0], out_point_major=pm)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    _fused.group_mlp_pool(xyz_c, new_c, feats_c, idxs[k1], plan[k1], out, offsets[k1], columns=cols[k1],
+                                          out_point_major=pm)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                main.wait_event(done)
+                for t in (xyz_c, new_c, feats_c, idxs[k1], out, cols[k1].cols, cols[k1].meta, cols[k1].ntiles) + \
+                        ((_fused.point_major_twin(feats_c),) if plan[k1].point_major else ()):
+                    if t is not None:
+                        t.record_stream(side)
+            else:
+                for k, (idx, packed) in enumerate(zip(idxs, plan)):
+                    _fused.group_mlp_pool(xyz_c, new_c, feats_c, idx, packed, out, offsets[k], columns=cols[k], out_point_major=pm)
             if pm:
                 out._sps_point_major = True
             return out

@@ -12,6 +12,7 @@ import sys
 
 SIMDS, CLOCK_HZ, XCDS = 1024, 2.4e9, 8
 PATTERNS = [  # kernel-name regex -> (c1, c2, nsample) groups; trailing template arguments (flags) are free
+    (re.compile(r"sa_group_mlp_pm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)[^>]*>"), lambda m: (m[2], m[3], m[6])),
     (re.compile(r"sa_group_mlp_f16_lds_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)[^>]*>"), lambda m: (m[1], m[2], m[5])),
     (re.compile(r"sa_group_mlp_f16_kernel<(\d+), (\d+), (\d+), (\d+)[^>]*>"), lambda m: (m[1], m[2], m[4])),
     (re.compile(r"sa_group_mlp_kernel<(\d+), (\d+), (\d+), (\d+)[^>]*>"), lambda m: (m[1], m[2], m[4])),

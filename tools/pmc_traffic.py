@@ -11,6 +11,9 @@ import sys
 
 KERNELS = [  # key in the json, kernel-name regex, (batch, n, m) of the bench launch
     ("fps_pruned_kernel<32>", re.compile(r"fps_pruned_kernel<32, false, false, true"), (8, 16384, 4096)),
+    ("sa_group_mlp_pm_kernel<128,128,256,256,2,32>", re.compile(r"sa_group_mlp_pm_kernel<128, 128, 256, 256, 2, 32"), (8, 1024, 512)),
+    ("sa_group_mlp_pm_kernel<64,64,96,128,2,32>", re.compile(r"sa_group_mlp_pm_kernel<64, 64, 96, 128, 2, 32"), (8, 4096, 1024)),
+    ("ball_query_dual_kernel", re.compile(r"ball_query_dual_kernel"), (8, 16384, 4096)),
     ("sa_group_mlp_f16_lds_kernel<128,256,256,1,32,4>", re.compile(r"sa_group_mlp_f16_lds_kernel<128, 256, 256, 1, 32, 4"), (8, 1024, 512)),
     ("sa_group_mlp_f16_kernel<64,96,2,32,lds-weights>", re.compile(r"sa_group_mlp_f16_kernel<64, 96, 2, 32, true"), (8, 4096, 1024)),
     ("ball_query_wave_multi_kernel<4,8,8>", re.compile(r"ball_query_wave_multi_kernel<4, 8, 8>"), (8, 16384, 4096)),
