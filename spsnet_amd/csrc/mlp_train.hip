@@ -25,7 +25,7 @@
 // NaN / Inf, are never clamped silently: the outputs that depend on them (or the whole weight gradient) are written as NaN
 // and the overflow flag is raised.  Statistics are accumulated per lane in fp32 over a workgroup's columns, then in fp64
 // in a fixed order; weight-gradient partials are summed in launch order (bit-reproducible from run to run).
-// The kernels are HBM-streaming (3.5-4.6 TB/s at a million columns, tools/tconv_bench.py); DESIGN.md 4.5b2 has what
+// The kernels are HBM-streaming (3.5-4.6 TB/s at a million columns, tools/tconv_bench.py); DESIGN.md 4.6 / profiles/README.md have what
 // bounds them at the IA-SSD shapes and what was measured on the way.
 #include "sps_common.h"
 

@@ -43,7 +43,7 @@ __device__ __forceinline__ f32x4 pw_mfma(float a, float b, f32x4 c) { return __b
 // one 16-row output tile: acc += W[tile] * act (act = LDS image [k][17]).  A tile is a serial chain of MFMAs fed by weight
 // fragments streamed from L2 (~1-2 us per round trip under load): the fragments of the NEXT eight 16-channel steps are
 // requested before the current eight are multiplied, so that only the first round trip of a tile is exposed (four steps
-// per trip and no overlap cost 8 + 4 + 4 exposed round trips per workgroup at IA-SSD layer 2: 26 us -> see DESIGN.md 4.5).
+// per trip and no overlap cost 8 + 4 + 4 exposed round trips per workgroup at IA-SSD layer 2: 26 us -> see DESIGN.md 4.4).
 __device__ __forceinline__ f32x4 pw_tile(const f32x4 *__restrict__ wp, const float *__restrict__ act, int k16n, int q, int c,
                                          f32x4 acc) {
     constexpr int G = 8;

@@ -10,7 +10,7 @@
 // column c) of TWO consecutive 16-row tiles form the B operand of one k32-step of layer l+1 if k-slot (q, j) of step s
 // stands for channel 32 s + 16 (j / 4) + 4 q + j % 4 -- activations chain register to register exactly as in the fp32
 // kernel, the host packs the weights in that order: [tile][k32][hi | lo][lane][8 halves], 2 KiB per fragment
-// (fused._pack_f16).  (The K = 16 instruction this file first used issues at a quarter of the rate)
+// (fused._pack_f16).  (The K = 16 instruction this file first used issues at a quarter of the rate, profiles/round1/microbench_*.txt.)
 #include "sps_common.h"
 #include "sa_mlp_args.h"
 
@@ -21,7 +21,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-// K = 32: the K = 16 form issues at 32 cycles on gfx950, this one at 16 for twice the work
+// K = 32: the K = 16 form issues at 32 cycles on gfx950, this one at 16 for twice the work (profiles/round2/microbench_mfma_gfx950.txt)
 __device__ __forceinline__ f32x4 mfma32h(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 // Split 4 fp32 values into halves OFF..OFF+3 of the hi / lo operand vectors.  The value is clamped to the fp16 range

@@ -165,7 +165,9 @@ def _version_key(pairs, device):
 #           carried as a hi+lo pair of halves (3 MFMAs per block, fp32 accumulate; ~1e-6 relative, csrc/sa_mlp_f16.hip);
 #           narrower scales stay on the fp32 MFMA kernel (their 4-channel input would be padded to 16).
 # "fp32":   every scale on the exact fp32 MFMA kernel.
-PRECISION = "fp16x2"
+PRECISION = __import__("os").environ.get("SPS_MLP_PRECISION", "fp16x2")   # bench.py's headline sets "fp32" explicitly
+if PRECISION not in ("fp32", "fp16x2"):
+    raise ValueError(f"SPS_MLP_PRECISION={PRECISION!r}: expected fp32 or fp16x2")
 # wide split-fp16 scales: the four waves of a workgroup share one weight stream through LDS (csrc/sa_mlp_f16_lds.hip)
 SHARE_WEIGHTS = True
 # exact-fp32 scales whose input features carry a point-major twin run on csrc/sa_mlp_pm.hip (one 16-byte load per four

@@ -555,7 +555,7 @@ def pipelined_bench(step, steps, dev, in_flight=2, scenes=8, fenced=True):
     """Time `steps` complete, independent passes issued round-robin on `in_flight` HIP streams (bench.py's informational
     `pipelined` object; `value` stays the strictly sequential figure) -> dict with elapsed_s.
     fenced: every slot's FPS chain runs on compute units of its own and everything else of every slot is kept off them
-    (CuFence); unfenced, a second pass in flight is SLOWER per pass than one alone."""
+    (CuFence); unfenced, a second pass in flight is SLOWER per pass than one alone (profiles/README.md, round 2)."""
     import time
     if fenced:
         fences = [CuFence(dev, slot=k, slots=in_flight, scenes=scenes) for k in range(in_flight)]
