@@ -311,6 +311,30 @@ int sps_pack_columns(int b, int m, int j0, int jcount, int nsample, const int *i
 int sps_pack_columns2(int b, int m, int j0, int jcount, int nsample_a, const int *idx_a, int *cols_a, unsigned *meta_a,
                       int *ntiles_a, long long tile_cap_a, int nsample_b, const int *idx_b, int *cols_b, unsigned *meta_b,
                       int *ntiles_b, long long tile_cap_b, sps_stream_t stream);
+/* ---- a layer that starts on a partly written cloud (spsnet_amd/sa_stack.py: layer k + 1 samples the first picks of layer
+ * k's D-FPS -- the verified identity prefix -- so its centroids exist long before layer k's last pick does) ---------------
+ * Max-pooling is order-independent and a ball-query row is "the first nsample hits in index order": the row over the points
+ * [0, k) is a prefix of the complete row.  So the columns of the early points go through the grouped MLP while the producer
+ * still runs -- in stages, as the cloud grows -- and behind its last pick only the LAST stage's columns are left:
+ * sps_ball_query_full2_points (rows over a point range), sps_pack_columns2_late (of a stage's rows, the columns the complete
+ * rows would hold, given how many every centroid took before) and sps_sa_group_mlp_packed_merge with mode + 16
+ * (pooled rows merged into `out` by an atomic max on the non-negative bit patterns).  Correct or redo: each of the three takes
+ * the repair predicate -- one device flag OR any of `count` per-scene flags -- and then covers the whole cloud / packs whole
+ * rows / stores plainly, i.e. recomputes the layer from scratch inside the same launches. */
+int sps_ball_query_full2_points(int b, int n, int m, int k0, int kcount, float radius_a, int nsample_a, float radius_b,
+                                int nsample_b, const float *new_xyz, const float *xyz, int *idx_a, int *idx_b,
+                                const int *all_points_if, const int *all_points_if_any, int any_count, sps_stream_t stream);
+int sps_pack_columns2_late(int b, int m, int k_late, int nsample_a, const int *prev_a, const int *idx_a, int *taken_a, int *cols_a,
+                           unsigned *meta_a, int *ntiles_a, long long tile_cap_a, int nsample_b, const int *prev_b,
+                           const int *idx_b, int *taken_b, int *cols_b, unsigned *meta_b, int *ntiles_b, long long tile_cap_b,
+                           const int *full_if, const int *full_if_any, int any_count, sps_stream_t stream);
+int sps_sa_group_mlp_packed_merge(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,
+                                  const float *new_xyz, const float *features, const int *idx, const int *cols,
+                                  const unsigned *meta, const int *ntiles, long long tile_cap, int c1, int c2, int c3,
+                                  int c3_real, const float *w1, const float *b1, const float *w2, const float *b2,
+                                  const float *w3, const float *b3, float *out, int out_c_total, int out_c_off,
+                                  int split_fp16, int *overflow_flag, const int *run_if, const int *full_range_if,
+                                  const int *unless_any, int unless_count, sps_stream_t stream);
 /* sps_sa_group_mlp_ex over either idx + range or (cols != NULL) a packed column stream; split_fp16 + 8: `out` is
  * point-major (b, m, out_c_total).  With packed columns and nsample 64 `out` must be zero-filled as before. */
 int sps_sa_group_mlp_packed(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,

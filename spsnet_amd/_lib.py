@@ -107,6 +107,11 @@ _PROTOS = {
                             _vp, _vp, _i, _i, _i, _vp, _vp],
     "sps_pack_columns": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _vp],
     "sps_pack_columns2": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _vp],
+    "sps_pack_columns2_late": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                               ctypes.c_longlong, _vp, _vp, _i, _vp],
+    "sps_ball_query_full2_points": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "sps_sa_group_mlp_packed_merge": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _i,
+                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "sps_sa_group_mlp_packed": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _i,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sps_fps_redo_where": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],

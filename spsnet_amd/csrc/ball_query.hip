@@ -425,7 +425,12 @@ template <int C, int SEG, int UNR>
 __global__ __launch_bounds__(64 * SEG) void ball_query_wave_multi_kernel(
     int n, int m, float r2a, float r2b, int nsa, int nsb, const float *__restrict__ new_xyz,
     const float *__restrict__ xyz, int *__restrict__ idx_a, int *__restrict__ idx_b, int jbeg,
-    const int *__restrict__ run_if, const int *__restrict__ alt, const int *__restrict__ gather_idx) {
+    const int *__restrict__ run_if, const int *__restrict__ alt, const int *__restrict__ gather_idx,
+    int kfirst = 0, int kcount = -1, const int *__restrict__ all_points_if = nullptr,
+    const int *__restrict__ all_points_if_any = nullptr, int any_count = 0) {
+    // [kfirst, kfirst + kcount): only these points of every scene are scanned (kcount < 0: all n) -- the rows then hold the
+    // first nsample hits AMONG THEM in index order; *all_points_if != 0 widens the scan to the whole scene again
+    // (sps_ball_query_full2_points: a layer whose cloud arrives piecewise queries the early part first and the rest later).
     // gather_idx != NULL: the centroids are xyz[gather_idx[scene][j]] (the sampler's picks, clamped into the cloud) and this
     // launch ALSO writes them to new_xyz -- the gather_operation between sampler and query (pointnet2_modules.py:423-424)
     // fused in, one launch less on the critical chain of a layer
@@ -459,8 +464,10 @@ __global__ __launch_bounds__(64 * SEG) void ball_query_wave_multi_kernel(
         }
     }
     const unsigned long long below = (1ull << lane) - 1ull;
-    const int seg_len = ((n + SEG - 1) / SEG + 63) & ~63;
-    const int kbeg = seg * seg_len, kend = (kbeg + seg_len < n) ? kbeg + seg_len : n;
+    const bool ranged = kcount >= 0 && !flag_or_any(all_points_if, all_points_if_any, any_count);
+    const int k_lo = ranged ? kfirst : 0, k_hi = ranged ? kfirst + kcount : n;
+    const int seg_len = ((k_hi - k_lo + SEG - 1) / SEG + 63) & ~63;
+    const int kbeg = k_lo + seg * seg_len, kend = (kbeg + seg_len < k_hi) ? kbeg + seg_len : k_hi;
     int ca[C], cb[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) ca[c] = cb[c] = 0;
@@ -715,6 +722,36 @@ extern "C" int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcoun
                        radius_a * radius_a, radius_b * radius_b, nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, perm, j0,
                        j0 + jcount, run_if);
     return check_launch("ball_query_dual_kernel");
+}
+
+// Both radii for ALL m centroids of every scene, but only over the points [k0, k0 + kcount) of every scene: row = the first
+// nsample hits among THOSE points in index order, padded with the first of them, zeros when there is none.  When
+// *all_points_if != 0 or any of all_points_if_any[0 .. any_count) != 0 (device ints, may be NULL) the launch scans the whole
+// scene instead -- the self-repair of a caller that queried a partly written cloud (spsnet_amd/sa_stack.py: the next layer's
+// queries start while this layer's FPS still runs).  b * m <= 8192 centroids, m a multiple of 4, n >= 256, nsample <= 64.
+extern "C" int sps_ball_query_full2_points(int b, int n, int m, int k0, int kcount, float radius_a, int nsample_a, float radius_b,
+                                           int nsample_b, const float *new_xyz, const float *xyz, int *idx_a, int *idx_b,
+                                           const int *all_points_if, const int *all_points_if_any, int any_count,
+                                           sps_stream_t stream) {
+    using namespace sps;
+    if (b < 0 || n < 256 || m < 0 || (m % 4) || nsample_a <= 0 || nsample_b <= 0 || nsample_a > BQS_MAX_NS || nsample_b > BQS_MAX_NS ||
+        k0 < 0 || kcount < 0 || k0 + kcount > n || (long long)b * m > BQ_WAVE_MAX_CENTROIDS || b > 65535)
+        return fail(SPS_ERR_INVALID, "ball_query_full2_points: bad shape b=%d n=%d m=%d ns=(%d,%d) points [%d,+%d)", b, n, m,
+                    nsample_a, nsample_b, k0, kcount);
+    if (b == 0 || m == 0) return SPS_OK;
+    if (!new_xyz || !xyz || !idx_a || !idx_b) return fail(SPS_ERR_INVALID, "ball_query_full2_points: null pointer");
+    const float ra2 = radius_a * radius_a, rb2 = radius_b * radius_b;
+    const dim3 grid(m / 4, b);
+    // (the segment count follows the range that is normally scanned; the widened scan of a repair is correct with any)
+    if (kcount >= 2048)
+        hipLaunchKernelGGL((ball_query_wave_multi_kernel<4, 4, 8>), grid, dim3(64 * 4), 0, as_stream(stream), n, m, ra2, rb2,
+                           nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, 0, (const int *)nullptr, (const int *)nullptr,
+                           (const int *)nullptr, k0, kcount, all_points_if, all_points_if_any, any_count);
+    else
+        hipLaunchKernelGGL((ball_query_wave_multi_kernel<4, 4, 4>), grid, dim3(64 * 4), 0, as_stream(stream), n, m, ra2, rb2,
+                           nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, 0, (const int *)nullptr, (const int *)nullptr,
+                           (const int *)nullptr, k0, kcount, all_points_if, all_points_if_any, any_count);
+    return check_launch("ball_query_wave_multi_kernel<points>");
 }
 
 // wave-per-centroid variant of sps_ball_query_full2 (same result; faster when balls fill early, i.e. large radii)

@@ -30,9 +30,20 @@ __global__ __launch_bounds__(256) void pack_columns_kernel(int m, int ns, int j0
                                                            int *__restrict__ ntiles, int tile_cap, int ns2 = 0,
                                                            const int *__restrict__ idx2 = nullptr, int *__restrict__ cols2 = nullptr,
                                                            unsigned *__restrict__ meta2 = nullptr, int *__restrict__ ntiles2 = nullptr,
-                                                           int tile_cap2 = 0) {
+                                                           int tile_cap2 = 0, int staged = 0, const int *__restrict__ prev = nullptr,
+                                                           const int *__restrict__ prev2 = nullptr, int *__restrict__ taken = nullptr,
+                                                           int *__restrict__ taken2 = nullptr, int k_late = 0,
+                                                           const int *__restrict__ full_if = nullptr,
+                                                           const int *__restrict__ full_if_any = nullptr, int any_count = 0) {
+    // STAGED mode (sps_pack_columns2_late): `idx` holds the rows of a query over the points [k_late, k_end) of every scene only;
+    // prev[scene][j] (NULL: zeros) = how many columns of centroid j earlier stages -- over the points below k_late -- have
+    // put through the MLP already.  The complete row of the reference is the earlier hits followed by these, cut at nsample: a
+    // centroid contributes its first min(hits here, nsample - prev) columns, possibly none (then it gets no slot at all);
+    // taken[scene][j] (may be NULL) receives prev + that number for the next stage.  *full_if != 0 or any full_if_any != 0:
+    // `idx` holds COMPLETE rows after all (the query was widened: a repair) and is packed as in the plain mode.
     extern __shared__ int s_idx[];   // [PACK_WINDOW][ns]
-    if (blockIdx.y == 1) { ns = ns2; idx = idx2; cols = cols2; meta = meta2; ntiles = ntiles2; tile_cap = tile_cap2; }
+    if (blockIdx.y == 1) { ns = ns2; idx = idx2; cols = cols2; meta = meta2; ntiles = ntiles2; tile_cap = tile_cap2; prev = prev2; taken = taken2; }
+    const bool late = staged && !flag_or_any(full_if, full_if_any, any_count);
     __shared__ int s_cnt[PACK_WINDOW], s_lg[PACK_WINDOW], s_pos[PACK_WINDOW];
     __shared__ int s_total, s_base;
     const int windows = (jcount + PACK_WINDOW - 1) / PACK_WINDOW;
@@ -51,7 +62,19 @@ __global__ __launch_bounds__(256) void pack_columns_kernel(int m, int ns, int j0
             cnt = 1;
             for (int s = ns - 1; s >= 1; --s)
                 if (r[s] != first) { cnt = s + 1; break; }              // real entries form a prefix; the rest repeats r[0]
-            lg = cnt <= 1 ? 0 : 32 - __builtin_clz(cnt - 1);
+            if (late) {
+                // an empty row of a stage is all zeros -- and 0 lies below the stage's range unless the stage starts at 0,
+                // where point 0 in slot 0 with nothing behind it is told from "empty" by ... nothing: the first stage of a
+                // cloud whose centroids are points of that cloud always finds the centroid itself, so its rows are never
+                // empty (the callers' case); a first-stage row of zeros is packed as one column of point 0, like the
+                // reference's empty ball.
+                if (k_late > 0 && first < k_late) cnt = 0;
+                const int before = prev ? prev[(size_t)scene * m + jw + t] : 0;
+                cnt = cnt < ns - before ? cnt : ns - before;
+                cnt = cnt < 0 ? 0 : cnt;
+                if (taken) taken[(size_t)scene * m + jw + t] = before + cnt;
+            }
+            lg = cnt <= 0 ? -1 : (cnt == 1 ? 0 : 32 - __builtin_clz(cnt - 1));
         }
         // slots by decreasing size: rank inside the class from a ballot, class bases from the class sizes
         int pos = 0, running = 0;
@@ -77,7 +100,7 @@ __global__ __launch_bounds__(256) void pack_columns_kernel(int m, int ns, int j0
     unsigned *om = meta + (size_t)base_tile * 16;
     {
         const int cen = t & 63, part = t >> 6;                          // four threads share a slot
-        if (cen < nw) {
+        if (cen < nw && s_lg[cen] >= 0) {
             const int cnt = s_cnt[cen], lg = s_lg[cen], pos = s_pos[cen];
             const unsigned word = (unsigned)(jw + cen) | ((unsigned)scene << 20) | ((unsigned)lg << 28);
             const int *r = s_idx + cen * ns;
@@ -145,4 +168,31 @@ extern "C" int sps_pack_columns2(int b, int m, int j0, int jcount, int nsample_a
                        as_stream(stream), m, nsample_a, j0, jcount, idx_a, cols_a, meta_a, ntiles_a, (int)tile_cap_a, nsample_b, idx_b,
                        cols_b, meta_b, ntiles_b, (int)tile_cap_b);
     return check_launch("pack_columns_kernel<2>");
+}
+
+// STAGED packing of both scales (see pack_columns_kernel): idx_* = the rows of a query over the points [k_late, k_end) of every
+// scene; prev_* (b, m) ints or NULL = columns of every centroid that earlier stages took (below k_late); taken_* (b, m) or NULL
+// receives the count including this stage.  Only the columns the complete row would hold are packed.  *full_if != 0 or any of
+// full_if_any[0 .. any_count) != 0 (device ints, may be NULL): idx_* hold complete rows and are packed whole.  All m centroids.
+extern "C" int sps_pack_columns2_late(int b, int m, int k_late, int nsample_a, const int *prev_a, const int *idx_a, int *taken_a,
+                                      int *cols_a, unsigned *meta_a, int *ntiles_a, long long tile_cap_a, int nsample_b,
+                                      const int *prev_b, const int *idx_b, int *taken_b, int *cols_b, unsigned *meta_b,
+                                      int *ntiles_b, long long tile_cap_b, const int *full_if, const int *full_if_any,
+                                      int any_count, sps_stream_t stream) {
+    using namespace sps;
+    if (b < 0 || m <= 0 || k_late < 0 || nsample_a <= 0 || nsample_a > 64 || nsample_b <= 0 || nsample_b > 64 || m >= (1 << 20) || b > 256)
+        return fail(SPS_ERR_INVALID, "pack_columns2_late: bad shape (b=%d m=%d k_late=%d nsample=%d/%d)", b, m, k_late, nsample_a, nsample_b);
+    if (b == 0) return SPS_OK;
+    if (!idx_a || !cols_a || !meta_a || !ntiles_a || !idx_b || !cols_b || !meta_b || !ntiles_b)
+        return fail(SPS_ERR_INVALID, "pack_columns2_late: null pointer");
+    if (tile_cap_a < sps_pack_columns_capacity(b, m, nsample_a) || tile_cap_a > 0x7FFFFFF ||
+        tile_cap_b < sps_pack_columns_capacity(b, m, nsample_b) || tile_cap_b > 0x7FFFFFF)
+        return fail(SPS_ERR_INVALID, "pack_columns2_late: tile capacity too small");
+    const int windows = (m + PACK_WINDOW - 1) / PACK_WINDOW;
+    const int nsmax = nsample_a > nsample_b ? nsample_a : nsample_b;
+    hipLaunchKernelGGL(pack_columns_kernel, dim3(b * windows, 2), dim3(256), (size_t)PACK_WINDOW * nsmax * sizeof(int),
+                       as_stream(stream), m, nsample_a, 0, m, idx_a, cols_a, meta_a, ntiles_a, (int)tile_cap_a, nsample_b,
+                       idx_b, cols_b, meta_b, ntiles_b, (int)tile_cap_b, 1, prev_a, prev_b, taken_a, taken_b, k_late, full_if,
+                       full_if_any, any_count);
+    return check_launch("pack_columns_kernel<staged>");
 }

@@ -361,6 +361,20 @@ extern "C" int sps_sa_group_mlp_packed(int b, int n, int m, int j0, int jcount, 
                                        const float *w3, const float *b3, float *out, int out_c_total, int out_c_off,
                                        int split_fp16, int *overflow_flag, const int *run_if, const int *full_range_if,
                                        sps_stream_t stream) {
+    return sps_sa_group_mlp_packed_merge(b, n, m, j0, jcount, c_feat, nsample, xyz, new_xyz, features, idx, cols, meta, ntiles,
+                                         tile_cap, c1, c2, c3, c3_real, w1, b1, w2, b2, w3, b3, out, out_c_total, out_c_off,
+                                         split_fp16, overflow_flag, run_if, full_range_if, nullptr, 0, stream);
+}
+
+// The same with the merge mode's second "plain stores after all" predicate (mode + 16, packed columns): the launch stores
+// instead of merging while *full_range_if != 0 OR any of unless_any[0 .. unless_count) != 0 (device ints, may be NULL).
+extern "C" int sps_sa_group_mlp_packed_merge(int b, int n, int m, int j0, int jcount, int c_feat, int nsample, const float *xyz,
+                                             const float *new_xyz, const float *features, const int *idx, const int *cols,
+                                             const unsigned *meta, const int *ntiles, long long tile_cap, int c1, int c2, int c3,
+                                             int c3_real, const float *w1, const float *b1, const float *w2, const float *b2,
+                                             const float *w3, const float *b3, float *out, int out_c_total, int out_c_off,
+                                             int split_fp16, int *overflow_flag, const int *run_if, const int *full_range_if,
+                                             const int *unless_any, int unless_count, sps_stream_t stream) {
     using namespace sps;
     if (b < 0 || n <= 0 || m < 0 || c_feat < 0 || nsample <= 0 || c3 <= 0 || (c3 % 16) || c3_real > c3 ||
         out_c_off < 0 || out_c_off + c3_real > out_c_total || j0 < 0 || jcount < 0 || j0 + jcount > m)
@@ -388,12 +402,21 @@ extern "C" int sps_sa_group_mlp_packed(int b, int n, int m, int j0, int jcount, 
     a.out_pm = (split_fp16 & 8) ? 1 : 0;
     a.run_if = run_if;
     a.alt = cols ? nullptr : full_range_if;
+    // mode + 16 (packed columns, exact fp32 on point-major features): merge the pooled rows into `out` by atomic max;
+    // full_range_if then means "plain stores after all" (this launch covers every column: a repair)
+    a.merge_max = (cols && (split_fp16 & 16)) ? 1 : 0;
+    a.merge_unless = a.merge_max ? full_range_if : nullptr;
+    a.merge_unless_any = a.merge_max ? unless_any : nullptr;
+    a.merge_unless_count = a.merge_max ? unless_count : 0;
+    if ((split_fp16 & 16) && !(cols && (split_fp16 & 7) == 4))
+        return fail(SPS_ERR_INVALID, "sa_group_mlp: merge mode (16) is served by the packed point-major fp32 kernel only");
     a.alt_j0 = 0; a.alt_ups = 0; a.alt_units = 0;
     a.ks1 = (3 + c_feat + 3) / 4;
     a.c3 = c3; a.c3_real = c3_real; a.out_c_total = out_c_total; a.out_c_off = out_c_off;
     a.xyz = xyz; a.new_xyz = new_xyz; a.feat = features; a.idx = idx;
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.out = out;
     a.overflow = overflow_flag;
+    split_fp16 &= ~16;   // (consumed above)
     const int arith = split_fp16 & 3;
     a.feat_pm = (split_fp16 & 4) ? 1 : 0;
     if (a.feat_pm && (c_feat < 4 || (c_feat % 4)))

@@ -30,6 +30,12 @@ struct SaMlpArgs {
     // without any extra launch when none did.  The unit loops are grid-stride, so the chunk's grid serves either range.
     const int *alt;
     int alt_j0, alt_ups, alt_units;
+    // Packed columns only: the pooled rows are MERGED into `out` with an atomic max (values >= 0 order like ints) instead
+    // of stored -- `out` already holds the maxima over columns that went through an earlier launch (sa_stack: the next
+    // layer's early columns).  While *merge_unless != 0 (a repair: this launch covers every column) plain stores instead.
+    int merge_max;
+    const int *merge_unless, *merge_unless_any;
+    int merge_unless_count;
 };
 
 // the (units, units per scene, first centroid) a launch works on: its range, or the whole layer when *alt is set
@@ -172,7 +178,7 @@ __device__ __forceinline__ void store_pooled_rows(const SaMlpArgs &a, int b, int
 // poison: the unit met an operand it could not represent (split-fp16 kernels): its rows are written as NaN, never clamped.
 template <int NT>
 __device__ __forceinline__ void pool_write_packed(const SaMlpArgs &a, const sps_f32x4 (&acc)[NT], const PackedUnit<NT> &pu,
-                                                  int mt, int q, int c, bool poison = false) {
+                                                  int mt, int q, int c, bool poison = false, bool merge = false) {
     const int lg0 = __builtin_amdgcn_readfirstlane((int)((pu.w[0] >> 28) & 7u));
     const int scene = __builtin_amdgcn_readfirstlane((int)((pu.w[0] >> 20) & 0xFFu));
     const float nan = __int_as_float(0x7fc00000);
@@ -185,7 +191,7 @@ __device__ __forceinline__ void pool_write_packed(const SaMlpArgs &a, const sps_
         const sps_f32x4 p = row_allmax4i(best);
         const float v[4] = {poison ? nan : p[0], poison ? nan : p[1], poison ? nan : p[2], poison ? nan : p[3]};
         // 64 columns = two units: they meet through an atomic max on the zero-filled `out` (values >= 0 order like ints)
-        if (c == 0) store_pooled_rows<true>(a, scene, (int)(pu.w[0] & 0xFFFFFu), mt, q, v, lg0 >= 6);
+        if (c == 0) store_pooled_rows<true>(a, scene, (int)(pu.w[0] & 0xFFFFFu), mt, q, v, lg0 >= 6 || merge);
         return;
     }
 #pragma unroll
@@ -196,7 +202,7 @@ __device__ __forceinline__ void pool_write_packed(const SaMlpArgs &a, const sps_
         const sps_f32x4 p = slot_allmax4(relu, lg);
         const float v[4] = {poison ? nan : p[0], poison ? nan : p[1], poison ? nan : p[2], poison ? nan : p[3]};
         const bool writer = (w >> 31) == 0u && (c & ((1 << lg) - 1)) == 0;   // first lane of a slot, never an unused lane
-        if (writer) store_pooled_rows<true>(a, scene, (int)(w & 0xFFFFFu), mt, q, v, false);
+        if (writer) store_pooled_rows<true>(a, scene, (int)(w & 0xFFFFFu), mt, q, v, merge);
     }
 }
 

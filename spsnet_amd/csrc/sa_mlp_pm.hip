@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_pm_kernel(SaMlpArgs a) {
     const int nwaves = gridDim.x * (blockDim.x >> 6);
     const MlpRange rg = mlp_range(a);
     const int nunits = PACKED ? (*a.ntiles) / NT : rg.units;   // packed: as many units as pack_columns produced tiles for
+    const bool merge = PACKED && a.merge_max && !flag_or_any(a.merge_unless, a.merge_unless_any, a.merge_unless_count);
     const float *w1f = a.w1 + (size_t)T1 * 64;   // layer 1 over the features, behind the coordinate fragments
 
     // a unit's inputs: requested one unit ahead
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_pm_kernel(SaMlpArgs a) {
         chain_layer_rt<C2, MT3, NT>(a.w3, sbias + C1 + C2, lane, q, h2,
             [&](int mt, f32x4 (&acc)[NT]) {
                 if constexpr (PACKED) {
-                    pool_write_packed<NT>(a, acc, pu, mt, q, c);
+                    pool_write_packed<NT>(a, acc, pu, mt, q, c, false, merge);
                     return;
                 }
                 f32x4 best[CPP];

@@ -338,6 +338,33 @@ def pack_columns2(idx_a, idx_b):
     return a, b
 
 
+def pack_columns2_staged(idx_a, idx_b, k_late, prev=None, full_if=None, full_if_any=None):
+    """One STAGE of both scales (csrc/pack_columns.hip, staged mode): idx_* = rows over the points [k_late, k_end) of every
+    scene; prev = (counts_a, counts_b), (B, M) int32 each: the columns every centroid took in earlier stages, or None for the
+    first stage -> (PackedColumns, PackedColumns, (counts_a, counts_b) including this stage).  Only the columns the complete
+    rows would hold are packed; whole rows of idx_* while a repair flag is up."""
+    B, M, _ = idx_a.shape
+    out, taken = [], []
+    for idx in (idx_a, idx_b):
+        p = PackedColumns()
+        p.cap = int(_L.sps_pack_columns_capacity(B, M, idx.shape[2]))
+        p.cols = torch.empty((p.cap * 16,), dtype=torch.int32, device=idx.device)
+        p.meta = torch.empty((p.cap * 16,), dtype=torch.int32, device=idx.device)
+        p.ntiles = _zero_counter(idx.device)
+        out.append(p)
+        taken.append(torch.empty((B, M), dtype=torch.int32, device=idx.device))
+    a, b = out
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+    pa, pb = prev if prev is not None else (None, None)
+    _lib.check(_L.sps_pack_columns2_late(B, M, int(k_late), idx_a.shape[2], ptr(pa), idx_a.data_ptr(), taken[0].data_ptr(),
+                                         a.cols.data_ptr(), a.meta.data_ptr(), a.ntiles.data_ptr(), a.cap, idx_b.shape[2],
+                                         ptr(pb), idx_b.data_ptr(), taken[1].data_ptr(), b.cols.data_ptr(), b.meta.data_ptr(),
+                                         b.ntiles.data_ptr(), b.cap, ptr(full_if), ptr(full_if_any),
+                                         0 if full_if_any is None else full_if_any.numel(),
+                                         torch.cuda.current_stream(idx_a.device).cuda_stream), "pack_columns2_late")
+    return a, b, tuple(taken)
+
+
 def want_packed(idx_shape, packed):
     """Pack a launch over idx of this (B, M, nsample) shape?  Whole-layer launches of the per-wave kernels where dropping
     the padded columns was measured to pay for the extra launch (see PACK_COLUMNS)."""
@@ -365,13 +392,16 @@ def attach_point_major_twin(features):
 
 
 def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=0, jcount=None, columns=None,
-                   out_point_major=False, run_if=None, full_range_if=None):
+                   out_point_major=False, run_if=None, full_range_if=None, merge=False, unless_any=None):
     """One launch: gather the nsample neighbours in `idx` (B,M,ns), run the packed 3-layer MLP, max-pool,
     and write channels [channel_offset, channel_offset + c3_real) of out (B, Ctot, M) -- or (B, M, Ctot) with
     out_point_major; optionally only for the centroids [j0, j0+jcount) of every scene.  A scale packed with point_major
     reads the features' (B, N, C) twin.  columns: a PackedColumns of `idx` (pack_columns): only the distinct neighbours of
     every ball are computed, same result.  run_if (device int32): the launch does nothing while it is zero;
-    full_range_if (device int32): the launch covers all M centroids instead of its range while it is nonzero."""
+    full_range_if (device int32): the launch covers all M centroids instead of its range while it is nonzero.
+    merge (packed columns, exact fp32 on point-major features): the pooled rows are merged into `out` by an atomic max --
+    `out` holds the maxima over columns an earlier launch computed -- unless full_range_if or any of unless_any (device
+    int32 array) is nonzero: then plain stores (the launch covers every column: a repair)."""
     B, N, _ = xyz.shape
     M, ns = idx.shape[1], idx.shape[2]
     jcount = M if jcount is None else jcount
@@ -385,6 +415,10 @@ def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=
         mode |= 4
     if out_point_major:
         mode |= 8
+    if merge:
+        if columns is None or packed.split != 0 or not packed.point_major:
+            raise ValueError("merge mode needs packed columns and the exact-fp32 point-major kernel")
+        mode |= 16
     if 3 + c_feat != packed.cin:
         raise ValueError(f"grouped input has {3 + c_feat} channels, the MLP expects {packed.cin}")
     if features is not None and (features.dtype == torch.float16) != bool(packed.half):
@@ -393,13 +427,14 @@ def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=
     stream = torch.cuda.current_stream(xyz.device).cuda_stream
     cp = (0, 0, 0, 0) if columns is None else (columns.cols.data_ptr(), columns.meta.data_ptr(), columns.ntiles.data_ptr(),
                                                columns.cap)
-    _lib.check(_L.sps_sa_group_mlp_packed(
+    _lib.check(_L.sps_sa_group_mlp_packed_merge(
         B, N, M, j0, jcount, c_feat, ns, xyz.data_ptr(), new_xyz.data_ptr(), 0 if features is None else features.data_ptr(),
         idx.data_ptr(), cp[0], cp[1], cp[2], cp[3], packed.c1, packed.c2, packed.c3, packed.c3_real, packed.w1.data_ptr(),
         packed.b1.data_ptr(), packed.w2.data_ptr(), packed.b2.data_ptr(), packed.w3.data_ptr(), packed.b3.data_ptr(),
         out.data_ptr(), c_total, channel_offset, mode,
         _overflow_flag(xyz.device).data_ptr() if packed.split else 0, 0 if run_if is None else run_if.data_ptr(),
-        0 if full_range_if is None else full_range_if.data_ptr(), stream),
+        0 if full_range_if is None else full_range_if.data_ptr(),
+        0 if unless_any is None else unless_any.data_ptr(), 0 if unless_any is None else unless_any.numel(), stream),
         "sa_group_mlp")
 
 

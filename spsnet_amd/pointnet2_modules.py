@@ -137,6 +137,8 @@ FUSED_FP_TRAINING_MIN = int(os.environ.get("SPS_FUSED_FP_TRAINING_MIN", str(1 <<
 SCALES_ON_STREAMS = os.environ.get("SPS_SCALES_ON_STREAMS", "0") != "0"
 # inference, exact fp32: the smaller grouping scale of a layer on a second stream behind the larger one (see _group_mlp_pool)
 FILL_WITH_SMALL_SCALE = os.environ.get("SPS_FILL_WITH_SMALL_SCALE", "1") != "0"
+# inference, exact fp32: a layer behind a streamed D-FPS layer starts its grouping on the early picks (begin_early_pool)
+EARLY_POOL = os.environ.get("SPS_EARLY_POOL", "1") != "0"
 
 
 def _sync_group(bn):
@@ -406,11 +408,100 @@ class _PointnetSAModuleBase(nn.Module):
             plan.append(packed)
         return plan
 
+    def _run_scales(self, xyz_c, new_c, feats_c, idxs, plan, out, cols, pm, **kw):
+        """The grouped-MLP launches of a layer's scales into `out` (kw: merge / full_range_if / unless_any of
+        fused.group_mlp_pool)."""
+        offsets = [sum(p.c3_real for p in plan[:k]) for k in range(len(plan))]
+        if (len(plan) == 2 and all(c is not None for c in cols) and FILL_WITH_SMALL_SCALE
+                and all(p.split == 0 and p.point_major for p in plan)):
+            # The exact-fp32 kernels run one wave per SIMD, each wave walking its units: a launch ends when the waves with
+            # one unit more than the others do, and for that last round half the chip idles (3640 units on 1024 waves = 4
+            # rounds for 568 of them).  The launch with fewer columns goes to a second stream BEHIND the big one: its
+            # workgroups land on the compute units the big launch's short workgroups free first.
+            k0, k1 = sorted(range(2), key=lambda k: -(idxs[k].shape[2] * plan[k].c3))
+            main = torch.cuda.current_stream(xyz_c.device)
+            side = self._scale_streams(xyz_c)[0]
+            ready = torch.cuda.Event()
+            ready.record(main)
+            _fused.group_mlp_pool(xyz_c, new_c, feats_c, idxs[k0], plan[k0], out, offsets[k0], columns=cols[k0], out_point_major=pm, **kw)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                _fused.group_mlp_pool(xyz_c, new_c, feats_c, idxs[k1], plan[k1], out, offsets[k1], columns=cols[k1],
+                                      out_point_major=pm, **kw)
+                done = torch.cuda.Event()
+                done.record(side)
+            main.wait_event(done)
+            extra = tuple(t for t in kw.values() if isinstance(t, torch.Tensor))
+            for t in (xyz_c, new_c, feats_c, idxs[k1], out, cols[k1].cols, cols[k1].meta, cols[k1].ntiles) + extra + \
+                    ((_fused.point_major_twin(feats_c),) if plan[k1].point_major else ()):
+                if t is not None:
+                    t.record_stream(side)
+        else:
+            for k, (idx, packed) in enumerate(zip(idxs, plan)):
+                _fused.group_mlp_pool(xyz_c, new_c, feats_c, idx, packed, out, offsets[k], columns=cols[k], out_point_major=pm, **kw)
+
+    def early_pool_plan(self, xyz, new_xyz, features):
+        """The packed plan of this layer if its grouping can START on a partly written cloud (begin_early_pool), else None:
+        inference on the fused path, two scales on the exact-fp32 point-major kernel with packed columns, an aggregation
+        kernel that reads point-major rows, at most 8192 centroids."""
+        if len(self.groupers) != 2 or not EARLY_POOL:
+            return None
+        plan = self._fused_plan(xyz, new_xyz, features)
+        B, M = xyz.shape[0], new_xyz.shape[1]
+        if not plan or not all(p.split == 0 and p.point_major for p in plan) or B * M > 8192 or M % 4 or xyz.shape[1] < 256:
+            return None
+        if not all(_fused.want_packed((B, M, g.nsample), p) for g, p in zip(self.groupers, plan)):
+            return None
+        if any(g.nsample > 32 for g in self.groupers) or not self._tail_reads_point_major(xyz, new_xyz):
+            return None
+        return plan
+
+    def begin_early_pool(self, xyz, new_xyz, features, n_early, flag, flags_any):
+        """Start -- or continue -- this layer's grouping while its input cloud is still being written: `xyz` / `features` (and
+        the features' point-major twin) are final for the points [0, n_early) of every scene only, `new_xyz` are the layer's
+        centroids AS GUESSED (sa_stack: the identity prefix of the producing D-FPS).  A ball-query row is the first nsample
+        hits in index order, so the row over [0, n_early) is a prefix of the complete row, and max-pooling does not care in
+        which launch a column was computed: the columns of the points that exist go through the grouped MLP now -- a second
+        call with a larger n_early adds the columns of the points in between, merged by an atomic max -- and
+        `_group_mlp_pool` adds the last ones when the layer is called.  flag (device int32) / flags_any (device int32 array):
+        raised by then if the early inputs or the guessed centroids were wrong -- the last stage then redoes the layer from
+        scratch.  Exact: same kernels, same columns, the same pooled maxima."""
+        pre = getattr(self, "_prepooled", None)
+        cont = pre is not None and pre[0] is xyz and pre[1] is features and pre[7] is new_xyz and pre[4] < n_early
+        plan = self.early_pool_plan(xyz, new_xyz, features)
+        if plan is None:
+            return False
+        ga, gb = self.groupers
+        B, M, width = xyz.shape[0], new_xyz.shape[1], sum(p.c3_real for p in plan)
+        k0 = pre[4] if cont else 0
+        ia, ib = _ext.ball_query_full2_points(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz, new_xyz, k0, n_early - k0)
+        ca, cb, taken = _fused.pack_columns2_staged(ia, ib, k0, prev=pre[3] if cont else None)
+        # (first stage: every centroid holds itself, so plain stores write all rows; later stages merge)
+        out = pre[2] if cont else torch.empty((B, M, width), dtype=torch.float32, device=xyz.device)
+        self._run_scales(xyz, new_xyz, features, (ia, ib), plan, out, [ca, cb], True, **(dict(merge=True) if cont else {}))
+        self._prepooled = (xyz, features, out, taken, int(n_early), flag, flags_any, new_xyz)
+        return True
+
     def _group_mlp_pool(self, xyz, new_xyz, features, point_major_ok=False):
         """-> pooled features (B, sum C_out, M); with point_major_ok (the caller's aggregation kernel reads either layout)
         the fused path may return them point-major, (B, M, sum C_out), tagged `_sps_point_major`: the grouped-MLP kernels
         then write a centroid's pooled rows contiguously."""
+        pre, self._prepooled = getattr(self, "_prepooled", None), None
         plan = self._fused_plan(xyz, new_xyz, features)
+        if plan and pre is not None and pre[0] is xyz and pre[1] is features and point_major_ok and \
+                pre[2].shape[:2] == (xyz.shape[0], new_xyz.shape[1]) and all(p.split == 0 and p.point_major for p in plan):
+            # the early columns are in `out` already (begin_early_pool): query, pack and merge the LATE ones -- or, while a
+            # repair flag is up, everything again with plain stores, inside the same three launches
+            _, _, out, taken, n_early, flag, flags_any, _ = pre
+            ga, gb = self.groupers
+            new_c = new_xyz.contiguous()
+            ia, ib = _ext.ball_query_full2_points(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz, new_c, n_early,
+                                                  xyz.shape[1] - n_early, full_if=flag, full_if_any=flags_any)
+            ca, cb, _ = _fused.pack_columns2_staged(ia, ib, n_early, prev=taken, full_if=flag, full_if_any=flags_any)
+            self._run_scales(xyz, new_c, features, (ia, ib), plan, out, [ca, cb], True, merge=True, full_range_if=flag,
+                             unless_any=flags_any)
+            out._sps_point_major = True
+            return out
         if plan:
             xyz_c, new_c = xyz.contiguous(), new_xyz.contiguous()
             feats_c = features.contiguous() if features is not None else None
@@ -421,7 +512,6 @@ class _PointnetSAModuleBase(nn.Module):
             # a point-major `out` is written by the packed-column and the shared-stream kernels only
             pm = bool(point_major_ok) and all(pk or p.split == 2 for pk, p in zip(pack, plan))
             out = alloc((B, M, width) if pm else (B, width, M), dtype=torch.float32, device=xyz.device)
-            offset = 0
             if len(plan) == 2:  # the usual two-scale layer: both ball queries share one scan
                 ga, gb = self.groupers
                 idxs = _ext.ball_query_full2(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz_c, new_c)
@@ -430,33 +520,7 @@ class _PointnetSAModuleBase(nn.Module):
             both = _fused.pack_columns2(idxs[0], idxs[1]) if (len(plan) == 2 and all(pack)) else None   # one launch for both scales
             cols = [both[k] if both is not None else (_fused.pack_columns(idx) if pk else None)
                     for k, (idx, pk) in enumerate(zip(idxs, pack))]
-            offsets = [sum(p.c3_real for p in plan[:k]) for k in range(len(plan))]
-            if both is not None and FILL_WITH_SMALL_SCALE and all(p.split == 0 and p.point_major for p in plan):
-                # The exact-fp32 kernels run one wave per SIMD, each wave walking its units: a launch ends when the waves with
-                # one unit more than the others do, and for that last round half the chip idles (3640 units on 1024 waves = 4
-                # rounds for 568 of them).  The launch with fewer columns goes to a second stream BEHIND the big one: its
-                # workgroups land on the compute units the big launch's short workgroups free first.
-                order = sorted(range(2), key=lambda k: -(idxs[k].shape[2] * plan[k].c3))
-                main = torch.cuda.current_stream(xyz_c.device)
-                side = self._scale_streams(xyz_c)[0]
-                k0, k1 = order
-                ready = torch.cuda.Event()
-                ready.record(main)
-                _fused.group_mlp_pool(xyz_c, new_c, feats_c, idxs[k0], plan[k0], out, offsets[k0], columns=cols[k0], out_point_major=pm)
-                with torch.cuda.stream(side):
-                    side.wait_event(ready)
-                    _fused.group_mlp_pool(xyz_c, new_c, feats_c, idxs[k1], plan[k1], out, offsets[k1], columns=cols[k1],
-                                          out_point_major=pm)
-                    done = torch.cuda.Event()
-                    done.record(side)
-                main.wait_event(done)
-                for t in (xyz_c, new_c, feats_c, idxs[k1], out, cols[k1].cols, cols[k1].meta, cols[k1].ntiles) + \
-                        ((_fused.point_major_twin(feats_c),) if plan[k1].point_major else ()):
-                    if t is not None:
-                        t.record_stream(side)
-            else:
-                for k, (idx, packed) in enumerate(zip(idxs, plan)):
-                    _fused.group_mlp_pool(xyz_c, new_c, feats_c, idx, packed, out, offsets[k], columns=cols[k], out_point_major=pm)
+            self._run_scales(xyz_c, new_c, feats_c, idxs, plan, out, cols, pm)
             if pm:
                 out._sps_point_major = True
             return out

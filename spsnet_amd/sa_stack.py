@@ -192,8 +192,17 @@ def _can_prefetch(layer, nxt):
 
 # centroid chunks of the streamed first layer, as cumulative fractions of M in 1/16ths: big chunks while FPS still has a
 # long way to go, small ones at the end (what is left to do after the last pick is the last chunk's work; a chunk
-# costs ~70 us however small it is -- one wave scans the whole cloud per centroid -- so finer tails only add launches)
-_CHUNK_ENDS_16 = (4, 8, 12, 14, 15, 16)
+# costs ~70 us however small it is -- one wave scans the whole cloud per centroid -- so finer tails only add launches).
+# (3/16 steps up to 12/16 since round 3: they leave the consumer stream the idle windows the next layer's early stages need,
+#  see EARLY_POOL_AT_16; the pass without those stages takes the same time with either chunking.)
+_CHUNK_ENDS_16 = tuple(int(v) for v in os.environ.get("SPS_CHUNK_ENDS", "3,6,9,12,14,15,16").split(","))
+# the chunk ends (in 1/16ths of M) behind which the NEXT layer starts / continues on the picks that exist (begin_early_pool).
+# The producer needs 0.33 ms per 3/16 of its picks, a 3/16 chunk's own work takes ~0.11 ms of that: the stages' queries and
+# grouped MLPs (~0.12 ms each) fit the idle time behind the chunks that end at 6, 9 and 12 sixteenths.  Measured
+# (tools/tail_events.py, strict fp32, 8 x 16 384): no stage 2.394 ms per pass, stages at (6, 9, 12) 2.305; with the old
+# chunking (4, 8, 12, 14, 15, 16) and stages at (8, 12) 2.355 -- the second stage pushed the last chunks back by 0.05 ms --,
+# and a stage behind the 14/16 chunk costs more than it saves (+0.08 ms).
+EARLY_POOL_AT_16 = tuple(int(v) for v in os.environ.get("SPS_EARLY_POOL_AT", "6,9,12").split(",") if v)
 # the second pass of the next layer's identity-prefix check chunk by chunk beside the producer instead of whole behind it
 EARLY_PREFIX_CHECK = os.environ.get("SPS_EARLY_PREFIX_CHECK", "1") != "0"
 _TIMEOUT_FLAGS = []   # device flags of recent streamed passes (diagnostics only: see check_timeouts)
@@ -302,7 +311,7 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
 
     def consume(j0, j1, wait):
         """gather -> ball query -> grouped MLPs -> aggregation for the centroids [j0, j1) of every scene, on the current stream"""
-        nonlocal xyz_ready, verify, verified_inline
+        nonlocal xyz_ready, verify, verified_inline, guess
         chunk = j1 - j0
         if wait:
             _ext.wait_progress(progress, j1, timed_out, patient=(j1 == M))
@@ -340,6 +349,18 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
             off += packed.c3_real
         if tail is not None:
             tail.run(j0, chunk, full_range_if=repair)
+        if j1 in early_at and verify is not None and verify.begun and tail is not None and side is main:
+            # The NEXT layer starts here: its centroids are the first picks of this layer's D-FPS (the identity prefix that
+            # `verify` confirms -- or flags -- behind the last pick), its cloud are this layer's centroids, of which the first
+            # j1 exist with their features.  Its ball query over those, and the grouped MLP of the columns they give, run now,
+            # beside the producer; behind the last pick only the columns of the remaining M - j1 points are left
+            # (pointnet2_modules.begin_early_pool; exact -- max-pooling does not care which launch computed a column).
+            # Correct or redo: should a wait have given up (timed_out) or the prefix guess fail (verify.flags), the late
+            # launches recompute the layer from scratch.
+            feats_next, _ = tail.result()
+            if guess is None:
+                guess = new_xyz[:, :nxt.npoint_list[0]].contiguous()
+            nxt.begin_early_pool(new_xyz, guess, feats_next, j1, timed_out, verify.flags)
         if verify is not None and j1 < M and EARLY_PREFIX_CHECK and N <= 16384:
             # second pass of the next layer's identity-prefix check for the centroids that exist by now: the stream would
             # otherwise idle in the next chunk's wait (a chunk whose wait gave up checks garbage -- finish() is then told to
@@ -349,6 +370,8 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
             verify.check_upto(j1)
 
     xyz_ready, verified_inline = None, False
+    early_at = tuple(M * e // 16 for e in EARLY_POOL_AT_16) if (nxt is not None and hasattr(nxt, "begin_early_pool") and N <= 16384) else ()
+    guess = None
     # units of one centroid meet through an atomic max when a ball has more than 32 samples: a repair then needs `out`
     # zeroed again, which takes the separate predicated launches of _redo_layer
     self_repair = max(ga.nsample, gb.nsample) <= 32

@@ -2359,6 +2359,143 @@ def test_streamed_first_layer_repairs_timed_out_waits(G, dev, npts, ns, half):
                 assert (ta is None and tb is None) or torch.equal(ta, tb)
 
 
+# ------------------------------------------------------------------ staged grouping: rows over point ranges, staged packing, merged pooling
+@pytest.mark.parametrize("B,N,M,k0,kc", [(2, 4096, 1024, 0, 2048), (2, 4096, 1024, 3072, 1024), (3, 1000, 256, 320, 37),
+                                          (1, 8192, 512, 8000, 192), (2, 4096, 1024, 1024, 0)])
+def test_ball_query_over_a_point_range(ext, G, oracle, B, N, M, k0, kc):
+    """sps_ball_query_full2_points: both radii for all centroids over the points [k0, k0 + kc) only == the oracle's ball query
+    of the sliced cloud (indices shifted back), zeros for empty rows; with the repair flag(s) up: the rows of the whole cloud."""
+    rng = np.random.default_rng(B * N + k0)
+    xyz = cloud(rng, B, N, dup=0.05)
+    ctr = xyz[:, rng.permutation(N)[:M]].copy()
+    ra, nsa, rb, nsb = 0.35, 16, 0.7, 32
+    x, c = G.t(xyz), G.t(ctr)
+    ia, ib = ext.ball_query_full2_points(ra, nsa, rb, nsb, x, c, k0, kc)
+    for got, r, ns in ((ia, ra, nsa), (ib, rb, nsb)):
+        want = np.zeros((B, M, ns), np.int32)
+        if kc > 0:
+            sub = oracle.ball_query(r, ns, np.ascontiguousarray(xyz[:, k0:k0 + kc]), ctr)
+            # the oracle leaves zeros for an empty ball, like the kernel; a non-empty row is shifted by k0
+            empty = (sub == 0).all(-1) & ~_first_point_hit(xyz[:, k0:k0 + kc], ctr, r)
+            want = np.where(empty[..., None], 0, sub + k0).astype(np.int32)
+        np.testing.assert_array_equal(G.n(got), want)
+    one = torch.ones((1,), dtype=torch.int32, device=x.device)
+    flags = torch.zeros((B,), dtype=torch.int32, device=x.device)
+    flags[B - 1] = 1
+    for kw in (dict(full_if=one), dict(full_if_any=flags)):
+        fa, fb = ext.ball_query_full2_points(ra, nsa, rb, nsb, x, c, k0, kc, **kw)
+        np.testing.assert_array_equal(G.n(fa), oracle.ball_query(ra, nsa, xyz, ctr))
+        np.testing.assert_array_equal(G.n(fb), oracle.ball_query(rb, nsb, xyz, ctr))
+
+
+def _first_point_hit(pts, ctr, r):
+    """(B, M) bool: is point 0 of `pts` inside the ball (fp32, the kernels' arithmetic is irrelevant at this margin)?"""
+    d = pts[:, None, 0, :].astype(np.float64) - ctr.astype(np.float64)
+    return (d ** 2).sum(-1) < float(np.float32(r) * np.float32(r)) * (1 - 1e-5)
+
+
+@pytest.mark.parametrize("stages", [(1024,), (512, 1536), (256, 1024, 2048, 3072), (4095,)])
+def test_staged_grouped_mlp_equals_one_launch(ext, G, dev, stages):
+    """The grouped MLP of a layer computed in STAGES over growing point ranges -- rows over [k_i, k_i+1) from
+    sps_ball_query_full2_points, sps_pack_columns2_late with the running per-centroid counts, pooled rows merged by atomic
+    max -- against ONE launch over the complete rows: bit-identical pooled features for both scales; and with the repair
+    flag up in the last stage (complete rows, plain stores) the same again, whatever the earlier stages left in `out`."""
+    from spsnet_amd import fused, pointnet2_modules as M
+    rng = np.random.default_rng(len(stages) * 100 + stages[0])
+    B, N, Mc, cf = 2, 4096, 512, 64
+    xyz = cloud(rng, B, N, dup=0.02)
+    x = G.t(xyz)
+    new_xyz = x[:, :Mc].contiguous()             # centroids are points of the cloud (every first-stage row holds itself)
+    feats = fused.attach_point_major_twin(torch.randn(B, cf, N, device=dev))
+    old = fused.set_precision("fp32")
+    try:
+        mod = M.PointnetSAModuleMSG_WithSampling(
+            npoint_list=[Mc], sample_range_list=[-1], sample_type_list=['D-FPS'], radii=[0.4, 0.8], nsamples=[16, 32],
+            mlps=[[cf, 64, 64, 128], [cf, 64, 96, 128]], use_xyz=True, dilated_group=False, aggregation_mlp=None,
+            confidence_mlp=None, num_class=3).to(dev).eval()
+        with torch.no_grad():
+            plan = mod._fused_plan(x, new_xyz, feats)
+            assert plan and all(p.split == 0 and p.point_major for p in plan)
+            ga, gb = mod.groupers
+            width = sum(p.c3_real for p in plan)
+            ia, ib = ext.ball_query_full2(ga.radius, ga.nsample, gb.radius, gb.nsample, x, new_xyz)
+            ca, cb = fused.pack_columns2(ia, ib)
+            want = torch.empty((B, Mc, width), device=dev)
+            mod._run_scales(x, new_xyz, feats, (ia, ib), plan, want, [ca, cb], True)
+            for repair in (False, True):
+                out = torch.full((B, Mc, width), 7.25 if repair else float("nan"), device=dev)   # (stage 1 overwrites every row)
+                flag = torch.full((1,), int(repair), dtype=torch.int32, device=dev)
+                prev, k0 = None, 0
+                for i, k1 in enumerate(tuple(stages) + (N,)):
+                    last = k1 == N
+                    kw = dict(full_if=flag) if last else {}
+                    sa, sb = ext.ball_query_full2_points(ga.radius, ga.nsample, gb.radius, gb.nsample, x, new_xyz, k0, k1 - k0, **kw)
+                    pa, pb, prev = fused.pack_columns2_staged(sa, sb, k0, prev=prev, **kw)
+                    mkw = {} if i == 0 else (dict(merge=True, full_range_if=flag) if last else dict(merge=True))
+                    mod._run_scales(x, new_xyz, feats, (sa, sb), plan, out, [pa, pb], True, **mkw)
+                    k0 = k1
+                torch.cuda.synchronize()
+                assert torch.equal(out, want), f"repair={repair}"
+    finally:
+        fused.set_precision(old)
+
+
+# ------------------------------------------------------------------ exact fp32: the next layer starts on the early picks
+@pytest.mark.parametrize("case", ["plain", "waits-give-up", "prefix-guess-fails"])
+def test_streamed_first_layer_early_pool_fp32(G, dev, case, monkeypatch):
+    """Strict fp32: behind the chunks that end at 6/16, 9/16 and 12/16 of layer 0's picks, layer 1 queries the centroids that
+    exist and runs the grouped MLP of the columns they give (begin_early_pool, three stages); behind the last pick it adds the
+    last quarter's columns by an atomic max.  Against the plain sequential pass: every output of every layer bit-identical, twice, allocator poisoned --
+    also when every bounded wait is forced to give up (the late launches then redo layer 1 from scratch on the repaired
+    layer 0) and on a lattice cloud whose exact distance ties break the identity-prefix guess of layer 1's D-FPS (flagged
+    scenes: the same redo, on the centroids the real D-FPS picks)."""
+    from spsnet_amd import _lib, fused, pointnet2_modules as M, sa_stack, scenes
+    L = _lib.load()
+    layers = sa_stack.build_sa_layers(M, sa_stack.IASSD_KITTI, seed=21).to(dev)
+    if case == "prefix-guess-fails":
+        rng = np.random.default_rng(77)
+        xyz = cloud(rng, 2, 16384, lattice=True) * 4.0 + rng.integers(0, 2, (2, 16384, 3)).astype(np.float32) * 0.5
+        feats = rng.uniform(0, 1, (2, 1, 16384)).astype(np.float32)
+    else:
+        xyz, feats = scenes.make_batch("kitti-lidar-v1", 2, 16384, seed0=71, dup_fraction=0.01)
+    x, f = G.t(xyz), G.t(feats)
+    monkeypatch.setattr(fused, "PACK_PM32_MIN_COLUMNS", 1024)     # (two scenes: below the size where packing pays)
+    began = []
+    orig = M.PointnetSAModuleMSG_WithSampling.begin_early_pool
+    monkeypatch.setattr(M.PointnetSAModuleMSG_WithSampling, "begin_early_pool",
+                        lambda self, *a, **k: began.append(orig(self, *a, **k)) or began[-1])
+    old = fused.set_precision("fp32")
+    old_spins = L.sps_debug_set_wait_spins(0xFFFFFFFF) if case == "waits-give-up" else None
+    try:
+        with torch.no_grad():
+            if old_spins is not None:
+                L.sps_debug_set_wait_spins(old_spins)
+            want = sa_stack.run_sa_layers(layers, x, f, overlap=False, stream_first_layer=False)
+            torch.cuda.synchronize()
+            sa_stack.check_timeouts()
+            if case == "waits-give-up":
+                L.sps_debug_set_wait_spins(0xFFFFFFFF)
+            for rep in range(2):
+                junk_i = torch.full((32 << 20,), 3 + rep, dtype=torch.int32, device=dev)
+                junk_f = torch.full((32 << 20,), 1.5 + rep, dtype=torch.float32, device=dev)
+                del junk_i, junk_f
+                got = sa_stack.run_sa_layers(layers, x, f)
+                torch.cuda.synchronize()
+                assert sa_stack.check_timeouts() == (case == "waits-give-up")
+                for k, (la, lb) in enumerate(zip(got, want)):
+                    for ta, tb in zip(la, lb):
+                        assert (ta is None and tb is None) or torch.equal(ta, tb), f"repetition {rep}, layer {k}"
+    finally:
+        fused.set_precision(old)
+        if case == "waits-give-up":
+            L.sps_debug_set_wait_spins(old_spins)
+    assert len(began) == 2 * len(sa_stack.EARLY_POOL_AT_16) and all(began), "layer 1 was supposed to start on the early picks"
+    if case == "prefix-guess-fails":
+        idx1 = got[1][3]
+        assert not torch.equal(idx1, torch.arange(idx1.shape[1], device=dev, dtype=idx1.dtype).expand_as(idx1)), \
+            "the lattice cloud was supposed to break the identity-prefix guess"
+
+
 # ------------------------------------------------------------------ training: layer 0's ball queries beside its FPS
 @pytest.mark.parametrize("force_timeouts", [False, True])
 def test_training_streamed_queries_equal_unstreamed(G, dev, force_timeouts, monkeypatch):
