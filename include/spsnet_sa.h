@@ -324,7 +324,7 @@ int sps_pack_columns2(int b, int m, int j0, int jcount, int nsample_a, const int
 int sps_ball_query_full2_points(int b, int n, int m, int k0, int kcount, float radius_a, int nsample_a, float radius_b,
                                 int nsample_b, const float *new_xyz, const float *xyz, int *idx_a, int *idx_b,
                                 const int *all_points_if, const int *all_points_if_any, int any_count, sps_stream_t stream);
-int sps_pack_columns2_late(int b, int m, int k_late, int nsample_a, const int *prev_a, const int *idx_a, int *taken_a, int *cols_a,
+int sps_pack_columns2_late(int b, int m, int last_stage, int nsample_a, const int *prev_a, const int *idx_a, int *taken_a, int *cols_a,
                            unsigned *meta_a, int *ntiles_a, long long tile_cap_a, int nsample_b, const int *prev_b,
                            const int *idx_b, int *taken_b, int *cols_b, unsigned *meta_b, int *ntiles_b, long long tile_cap_b,
                            const int *full_if, const int *full_if_any, int any_count, sps_stream_t stream);

@@ -429,7 +429,8 @@ __global__ __launch_bounds__(64 * SEG) void ball_query_wave_multi_kernel(
     int kfirst = 0, int kcount = -1, const int *__restrict__ all_points_if = nullptr,
     const int *__restrict__ all_points_if_any = nullptr, int any_count = 0) {
     // [kfirst, kfirst + kcount): only these points of every scene are scanned (kcount < 0: all n) -- the rows then hold the
-    // first nsample hits AMONG THEM in index order; *all_points_if != 0 widens the scan to the whole scene again
+    // first nsample hits AMONG THEM in index order, and a row without a hit is filled with -1 (a later range may still hit;
+    // zeros would read as "point 0"); *all_points_if != 0 widens the scan to the whole scene again (rows as always)
     // (sps_ball_query_full2_points: a layer whose cloud arrives piecewise queries the early part first and the rest later).
     // gather_idx != NULL: the centroids are xyz[gather_idx[scene][j]] (the sampler's picks, clamped into the cloud) and this
     // launch ALSO writes them to new_xyz -- the gather_operation between sampler and query (pointnet2_modules.py:423-424)
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(64 * SEG) void ball_query_wave_multi_kernel(
         int cs[SEG], total = 0;
 #pragma unroll
         for (int s2 = 0; s2 < SEG; ++s2) { cs[s2] = cnt[which][c][s2]; total += cs[s2]; }
-        int first = 0;  // empty ball: zeros
+        int first = ranged ? -1 : 0;  // empty ball: zeros like the reference -- over a point RANGE: -1s ("no hit here", not "point 0")
 #pragma unroll
         for (int s2 = SEG - 1; s2 >= 0; --s2) first = cs[s2] > 0 ? hits[which][c][s2][0] : first;
         for (int p = lane; p < ns; p += 64) {
@@ -725,7 +726,7 @@ extern "C" int sps_ball_query_full2_range(int b, int n, int m, int j0, int jcoun
 }
 
 // Both radii for ALL m centroids of every scene, but only over the points [k0, k0 + kcount) of every scene: row = the first
-// nsample hits among THOSE points in index order, padded with the first of them, zeros when there is none.  When
+// nsample hits among THOSE points in index order, padded with the first of them; -1 in every slot when there is none.  When
 // *all_points_if != 0 or any of all_points_if_any[0 .. any_count) != 0 (device ints, may be NULL) the launch scans the whole
 // scene instead -- the self-repair of a caller that queried a partly written cloud (spsnet_amd/sa_stack.py: the next layer's
 // queries start while this layer's FPS still runs).  b * m <= 8192 centroids, m a multiple of 4, n >= 256, nsample <= 64.

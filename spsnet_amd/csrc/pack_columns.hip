@@ -35,9 +35,9 @@ __global__ __launch_bounds__(256) void pack_columns_kernel(int m, int ns, int j0
                                                            int *__restrict__ taken2 = nullptr, int k_late = 0,
                                                            const int *__restrict__ full_if = nullptr,
                                                            const int *__restrict__ full_if_any = nullptr, int any_count = 0) {
-    // STAGED mode (sps_pack_columns2_late): `idx` holds the rows of a query over the points [k_late, k_end) of every scene only;
-    // prev[scene][j] (NULL: zeros) = how many columns of centroid j earlier stages -- over the points below k_late -- have
-    // put through the MLP already.  The complete row of the reference is the earlier hits followed by these, cut at nsample: a
+    // STAGED mode (sps_pack_columns2_late; staged = 1, or 2 for the last stage): `idx` holds the rows of a query over ONE point
+    // range of every scene (-1 rows: no hit there); prev[scene][j] (NULL: zeros) = how many columns of centroid j the stages
+    // over the lower ranges have put through the MLP already.  The complete row of the reference is the earlier hits followed by these, cut at nsample: a
     // centroid contributes its first min(hits here, nsample - prev) columns, possibly none (then it gets no slot at all);
     // taken[scene][j] (may be NULL) receives prev + that number for the next stage.  *full_if != 0 or any full_if_any != 0:
     // `idx` holds COMPLETE rows after all (the query was widened: a repair) and is packed as in the plain mode.
@@ -63,15 +63,13 @@ __global__ __launch_bounds__(256) void pack_columns_kernel(int m, int ns, int j0
             for (int s = ns - 1; s >= 1; --s)
                 if (r[s] != first) { cnt = s + 1; break; }              // real entries form a prefix; the rest repeats r[0]
             if (late) {
-                // an empty row of a stage is all zeros -- and 0 lies below the stage's range unless the stage starts at 0,
-                // where point 0 in slot 0 with nothing behind it is told from "empty" by ... nothing: the first stage of a
-                // cloud whose centroids are points of that cloud always finds the centroid itself, so its rows are never
-                // empty (the callers' case); a first-stage row of zeros is packed as one column of point 0, like the
-                // reference's empty ball.
-                if (k_late > 0 && first < k_late) cnt = 0;
+                if (first < 0) cnt = 0;                                  // a stage's row without a hit is all -1
                 const int before = prev ? prev[(size_t)scene * m + jw + t] : 0;
                 cnt = cnt < ns - before ? cnt : ns - before;
                 cnt = cnt < 0 ? 0 : cnt;
+                // the reference's empty ball groups point 0 (its zeroed idx row): a centroid that no stage found a neighbour
+                // for gets that one column in the LAST stage (k_late < 0 marks it; the column index is clamped below)
+                if (staged == 2 && before + cnt == 0) cnt = 1;
                 if (taken) taken[(size_t)scene * m + jw + t] = before + cnt;
             }
             lg = cnt <= 0 ? -1 : (cnt == 1 ? 0 : 32 - __builtin_clz(cnt - 1));
@@ -105,14 +103,15 @@ __global__ __launch_bounds__(256) void pack_columns_kernel(int m, int ns, int j0
             const unsigned word = (unsigned)(jw + cen) | ((unsigned)scene << 20) | ((unsigned)lg << 28);
             const int *r = s_idx + cen * ns;
             for (int s = part; s < (1 << lg); s += 4) {
-                oc[pos + s] = r[s < cnt ? s : 0];
+                const int v = r[s < cnt ? s : 0];
+                oc[pos + s] = v < 0 ? 0 : v;       // (-1: the empty-ball column of a last stage = point 0)
                 om[pos + s] = word;
             }
         }
     }
     const unsigned idle = (unsigned)jw | ((unsigned)scene << 20) | 0x80000000u;
     for (int e = total + t; e < tiles * 16; e += blockDim.x) {         // the window's tail: valid addresses, never written
-        oc[e] = s_idx[0];
+        oc[e] = s_idx[0] < 0 ? 0 : s_idx[0];
         om[e] = idle;
     }
 }
@@ -170,15 +169,17 @@ extern "C" int sps_pack_columns2(int b, int m, int j0, int jcount, int nsample_a
     return check_launch("pack_columns_kernel<2>");
 }
 
-// STAGED packing of both scales (see pack_columns_kernel): idx_* = the rows of a query over the points [k_late, k_end) of every
-// scene; prev_* (b, m) ints or NULL = columns of every centroid that earlier stages took (below k_late); taken_* (b, m) or NULL
-// receives the count including this stage.  Only the columns the complete row would hold are packed.  *full_if != 0 or any of
+// STAGED packing of both scales (see pack_columns_kernel): idx_* = the rows of sps_ball_query_full2_points over one point range
+// (-1 rows = no hit in the range); prev_* (b, m) ints or NULL = columns of every centroid that the stages over the lower ranges
+// took; taken_* (b, m) or NULL receives the count including this stage.  Only the columns the complete row would hold are
+// packed; last_stage != 0: a centroid that no stage found a neighbour for gets the reference's empty-ball column (point 0).  *full_if != 0 or any of
 // full_if_any[0 .. any_count) != 0 (device ints, may be NULL): idx_* hold complete rows and are packed whole.  All m centroids.
-extern "C" int sps_pack_columns2_late(int b, int m, int k_late, int nsample_a, const int *prev_a, const int *idx_a, int *taken_a,
+extern "C" int sps_pack_columns2_late(int b, int m, int last_stage, int nsample_a, const int *prev_a, const int *idx_a, int *taken_a,
                                       int *cols_a, unsigned *meta_a, int *ntiles_a, long long tile_cap_a, int nsample_b,
                                       const int *prev_b, const int *idx_b, int *taken_b, int *cols_b, unsigned *meta_b,
                                       int *ntiles_b, long long tile_cap_b, const int *full_if, const int *full_if_any,
                                       int any_count, sps_stream_t stream) {
+    const int k_late = 0;
     using namespace sps;
     if (b < 0 || m <= 0 || k_late < 0 || nsample_a <= 0 || nsample_a > 64 || nsample_b <= 0 || nsample_b > 64 || m >= (1 << 20) || b > 256)
         return fail(SPS_ERR_INVALID, "pack_columns2_late: bad shape (b=%d m=%d k_late=%d nsample=%d/%d)", b, m, k_late, nsample_a, nsample_b);
@@ -192,7 +193,7 @@ extern "C" int sps_pack_columns2_late(int b, int m, int k_late, int nsample_a, c
     const int nsmax = nsample_a > nsample_b ? nsample_a : nsample_b;
     hipLaunchKernelGGL(pack_columns_kernel, dim3(b * windows, 2), dim3(256), (size_t)PACK_WINDOW * nsmax * sizeof(int),
                        as_stream(stream), m, nsample_a, 0, m, idx_a, cols_a, meta_a, ntiles_a, (int)tile_cap_a, nsample_b,
-                       idx_b, cols_b, meta_b, ntiles_b, (int)tile_cap_b, 1, prev_a, prev_b, taken_a, taken_b, k_late, full_if,
-                       full_if_any, any_count);
+                       idx_b, cols_b, meta_b, ntiles_b, (int)tile_cap_b, last_stage ? 2 : 1, prev_a, prev_b, taken_a, taken_b, k_late,
+                       full_if, full_if_any, any_count);
     return check_launch("pack_columns_kernel<staged>");
 }

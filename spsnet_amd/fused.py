@@ -338,11 +338,13 @@ def pack_columns2(idx_a, idx_b):
     return a, b
 
 
-def pack_columns2_staged(idx_a, idx_b, k_late, prev=None, full_if=None, full_if_any=None):
-    """One STAGE of both scales (csrc/pack_columns.hip, staged mode): idx_* = rows over the points [k_late, k_end) of every
-    scene; prev = (counts_a, counts_b), (B, M) int32 each: the columns every centroid took in earlier stages, or None for the
-    first stage -> (PackedColumns, PackedColumns, (counts_a, counts_b) including this stage).  Only the columns the complete
-    rows would hold are packed; whole rows of idx_* while a repair flag is up."""
+def pack_columns2_staged(idx_a, idx_b, last, prev=None, full_if=None, full_if_any=None):
+    """One STAGE of both scales (csrc/pack_columns.hip, staged mode): idx_* = the rows of ball_query_full2_points over one point
+    range (-1 rows: no hit there); prev = (counts_a, counts_b), (B, M) int32 each: the columns every centroid took in the
+    stages over the lower ranges, or None for the first stage; last: this is the stage over the top range (a centroid without
+    any neighbour then gets the reference's empty-ball column, point 0) -> (PackedColumns, PackedColumns, (counts_a, counts_b)
+    including this stage).  Only the columns the complete rows would hold are packed; whole rows of idx_* while a repair flag
+    is up."""
     B, M, _ = idx_a.shape
     out, taken = [], []
     for idx in (idx_a, idx_b):
@@ -356,7 +358,7 @@ def pack_columns2_staged(idx_a, idx_b, k_late, prev=None, full_if=None, full_if_
     a, b = out
     ptr = lambda t: 0 if t is None else t.data_ptr()
     pa, pb = prev if prev is not None else (None, None)
-    _lib.check(_L.sps_pack_columns2_late(B, M, int(k_late), idx_a.shape[2], ptr(pa), idx_a.data_ptr(), taken[0].data_ptr(),
+    _lib.check(_L.sps_pack_columns2_late(B, M, 1 if last else 0, idx_a.shape[2], ptr(pa), idx_a.data_ptr(), taken[0].data_ptr(),
                                          a.cols.data_ptr(), a.meta.data_ptr(), a.ntiles.data_ptr(), a.cap, idx_b.shape[2],
                                          ptr(pb), idx_b.data_ptr(), taken[1].data_ptr(), b.cols.data_ptr(), b.meta.data_ptr(),
                                          b.ntiles.data_ptr(), b.cap, ptr(full_if), ptr(full_if_any),

@@ -475,9 +475,9 @@ class _PointnetSAModuleBase(nn.Module):
         B, M, width = xyz.shape[0], new_xyz.shape[1], sum(p.c3_real for p in plan)
         k0 = pre[4] if cont else 0
         ia, ib = _ext.ball_query_full2_points(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz, new_xyz, k0, n_early - k0)
-        ca, cb, taken = _fused.pack_columns2_staged(ia, ib, k0, prev=pre[3] if cont else None)
-        # (first stage: every centroid holds itself, so plain stores write all rows; later stages merge)
-        out = pre[2] if cont else torch.empty((B, M, width), dtype=torch.float32, device=xyz.device)
+        ca, cb, taken = _fused.pack_columns2_staged(ia, ib, False, prev=pre[3] if cont else None)
+        # (zeros: the identity of the merge -- pooled values are >= 0 -- for a centroid the first stage finds no neighbour for)
+        out = pre[2] if cont else torch.zeros((B, M, width), dtype=torch.float32, device=xyz.device)
         self._run_scales(xyz, new_xyz, features, (ia, ib), plan, out, [ca, cb], True, **(dict(merge=True) if cont else {}))
         self._prepooled = (xyz, features, out, taken, int(n_early), flag, flags_any, new_xyz)
         return True
@@ -497,7 +497,7 @@ class _PointnetSAModuleBase(nn.Module):
             new_c = new_xyz.contiguous()
             ia, ib = _ext.ball_query_full2_points(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz, new_c, n_early,
                                                   xyz.shape[1] - n_early, full_if=flag, full_if_any=flags_any)
-            ca, cb, _ = _fused.pack_columns2_staged(ia, ib, n_early, prev=taken, full_if=flag, full_if_any=flags_any)
+            ca, cb, _ = _fused.pack_columns2_staged(ia, ib, True, prev=taken, full_if=flag, full_if_any=flags_any)
             self._run_scales(xyz, new_c, features, (ia, ib), plan, out, [ca, cb], True, merge=True, full_range_if=flag,
                              unless_any=flags_any)
             out._sps_point_major = True

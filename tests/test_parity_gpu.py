@@ -2364,7 +2364,8 @@ def test_streamed_first_layer_repairs_timed_out_waits(G, dev, npts, ns, half):
                                           (1, 8192, 512, 8000, 192), (2, 4096, 1024, 1024, 0)])
 def test_ball_query_over_a_point_range(ext, G, oracle, B, N, M, k0, kc):
     """sps_ball_query_full2_points: both radii for all centroids over the points [k0, k0 + kc) only == the oracle's ball query
-    of the sliced cloud (indices shifted back), zeros for empty rows; with the repair flag(s) up: the rows of the whole cloud."""
+    of the sliced cloud (indices shifted back), -1 in every slot of a row without a hit; with the repair flag(s) up: the rows of
+    the whole cloud (zeros for an empty ball, as always)."""
     rng = np.random.default_rng(B * N + k0)
     xyz = cloud(rng, B, N, dup=0.05)
     ctr = xyz[:, rng.permutation(N)[:M]].copy()
@@ -2372,12 +2373,12 @@ def test_ball_query_over_a_point_range(ext, G, oracle, B, N, M, k0, kc):
     x, c = G.t(xyz), G.t(ctr)
     ia, ib = ext.ball_query_full2_points(ra, nsa, rb, nsb, x, c, k0, kc)
     for got, r, ns in ((ia, ra, nsa), (ib, rb, nsb)):
-        want = np.zeros((B, M, ns), np.int32)
+        want = np.full((B, M, ns), -1, np.int32)
         if kc > 0:
             sub = oracle.ball_query(r, ns, np.ascontiguousarray(xyz[:, k0:k0 + kc]), ctr)
             # the oracle leaves zeros for an empty ball, like the kernel; a non-empty row is shifted by k0
             empty = (sub == 0).all(-1) & ~_first_point_hit(xyz[:, k0:k0 + kc], ctr, r)
-            want = np.where(empty[..., None], 0, sub + k0).astype(np.int32)
+            want = np.where(empty[..., None], -1, sub + k0).astype(np.int32)
         np.testing.assert_array_equal(G.n(got), want)
     one = torch.ones((1,), dtype=torch.int32, device=x.device)
     flags = torch.zeros((B,), dtype=torch.int32, device=x.device)
@@ -2423,14 +2424,14 @@ def test_staged_grouped_mlp_equals_one_launch(ext, G, dev, stages):
             want = torch.empty((B, Mc, width), device=dev)
             mod._run_scales(x, new_xyz, feats, (ia, ib), plan, want, [ca, cb], True)
             for repair in (False, True):
-                out = torch.full((B, Mc, width), 7.25 if repair else float("nan"), device=dev)   # (stage 1 overwrites every row)
+                out = torch.zeros((B, Mc, width), device=dev) if not repair else torch.full((B, Mc, width), 7.25, device=dev)
                 flag = torch.full((1,), int(repair), dtype=torch.int32, device=dev)
                 prev, k0 = None, 0
                 for i, k1 in enumerate(tuple(stages) + (N,)):
                     last = k1 == N
                     kw = dict(full_if=flag) if last else {}
                     sa, sb = ext.ball_query_full2_points(ga.radius, ga.nsample, gb.radius, gb.nsample, x, new_xyz, k0, k1 - k0, **kw)
-                    pa, pb, prev = fused.pack_columns2_staged(sa, sb, k0, prev=prev, **kw)
+                    pa, pb, prev = fused.pack_columns2_staged(sa, sb, last, prev=prev, **kw)
                     mkw = {} if i == 0 else (dict(merge=True, full_range_if=flag) if last else dict(merge=True))
                     mod._run_scales(x, new_xyz, feats, (sa, sb), plan, out, [pa, pb], True, **mkw)
                     k0 = k1
