@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
     const int nwaves = gridDim.x * (blockDim.x >> 6);
 
     constexpr bool packed = PACKED;   // a separate instantiation: the padded form keeps its register budget
+    const bool merge = PACKED && a.merge_max && !flag_or_any(a.merge_unless, a.merge_unless_any, a.merge_unless_count);
     const MlpRange rg = mlp_range(a);
     const int nunits = packed ? (*a.ntiles) / NT : rg.units;   // packed: as many units as pack_columns produced tiles for
     for (int unit = wave; unit < nunits; unit += nwaves) {
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_kernel(SaMlpArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (packed) {
-                    pool_write_packed<NT>(a, acc, pu, mt, q, c);
+                    pool_write_packed<NT>(a, acc, pu, mt, q, c, false, merge);
                     continue;
                 }
                 f32x4 best[CPP];
@@ -402,14 +403,14 @@ extern "C" int sps_sa_group_mlp_packed_merge(int b, int n, int m, int j0, int jc
     a.out_pm = (split_fp16 & 8) ? 1 : 0;
     a.run_if = run_if;
     a.alt = cols ? nullptr : full_range_if;
-    // mode + 16 (packed columns, exact fp32 on point-major features): merge the pooled rows into `out` by atomic max;
+    // mode + 16 (packed columns): merge the pooled rows into `out` by atomic max;
     // full_range_if then means "plain stores after all" (this launch covers every column: a repair)
     a.merge_max = (cols && (split_fp16 & 16)) ? 1 : 0;
     a.merge_unless = a.merge_max ? full_range_if : nullptr;
     a.merge_unless_any = a.merge_max ? unless_any : nullptr;
     a.merge_unless_count = a.merge_max ? unless_count : 0;
-    if ((split_fp16 & 16) && !(cols && (split_fp16 & 7) == 4))
-        return fail(SPS_ERR_INVALID, "sa_group_mlp: merge mode (16) is served by the packed point-major fp32 kernel only");
+    if ((split_fp16 & 16) && !(cols && (split_fp16 & 3) != 2))
+        return fail(SPS_ERR_INVALID, "sa_group_mlp: merge mode (16) needs packed columns (every kernel but the shared-stream one)");
     a.alt_j0 = 0; a.alt_ups = 0; a.alt_units = 0;
     a.ks1 = (3 + c_feat + 3) / 4;
     a.c3 = c3; a.c3_real = c3_real; a.out_c_total = out_c_total; a.out_c_off = out_c_off;

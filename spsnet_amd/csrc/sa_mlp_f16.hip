@@ -145,6 +145,8 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
     const float *b1l = sbias, *b2l = sbias + C1, *b3l = sbias + C1 + C2;
     bool any_bad = false;   // some unit of this wave met an operand beyond the representable range (or NaN / Inf)
     constexpr bool packed = PACKED;   // a separate instantiation: the padded form keeps its register budget
+    // (packed columns: pooled rows merged into `out` by atomic max -- sa_mlp_args.h, the staged grouping of sa_stack)
+    const bool merge = PACKED && a.merge_max && !flag_or_any(a.merge_unless, a.merge_unless_any, a.merge_unless_count);
     const MlpRange rg = mlp_range(a);
     const int nunits = packed ? (*a.ntiles) / NT : rg.units;   // packed: as many units as pack_columns produced tiles for
     for (int unit = wave; unit < nunits; unit += nwaves) {
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(WLDS ? 512 : 256) void sa_group_mlp_f16_kernel(SaMl
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (packed) {
-                    pool_write_packed<NT>(a, acc, pu, mt, q, c, poison);
+                    pool_write_packed<NT>(a, acc, pu, mt, q, c, poison, merge);
                     continue;
                 }
                 f32x4 best[CPP];

@@ -418,8 +418,8 @@ def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=
     if out_point_major:
         mode |= 8
     if merge:
-        if columns is None or packed.split != 0 or not packed.point_major:
-            raise ValueError("merge mode needs packed columns and the exact-fp32 point-major kernel")
+        if columns is None or packed.split == 2:
+            raise ValueError("merge mode needs packed columns (served by every kernel but the shared-stream one)")
         mode |= 16
     if 3 + c_feat != packed.cin:
         raise ValueError(f"grouped input has {3 + c_feat} channels, the MLP expects {packed.cin}")

@@ -442,15 +442,16 @@ class _PointnetSAModuleBase(nn.Module):
 
     def early_pool_plan(self, xyz, new_xyz, features):
         """The packed plan of this layer if its grouping can START on a partly written cloud (begin_early_pool), else None:
-        inference on the fused path, two scales on the exact-fp32 point-major kernel with packed columns, an aggregation
-        kernel that reads point-major rows, at most 8192 centroids."""
+        inference on the fused path, two scales on kernels that take packed columns (all but the shared-stream split-fp16
+        one), an aggregation kernel that reads point-major rows, at most 8192 centroids."""
         if len(self.groupers) != 2 or not EARLY_POOL:
             return None
         plan = self._fused_plan(xyz, new_xyz, features)
         B, M = xyz.shape[0], new_xyz.shape[1]
-        if not plan or not all(p.split == 0 and p.point_major for p in plan) or B * M > 8192 or M % 4 or xyz.shape[1] < 256:
+        # (any kernel that takes packed columns: exact fp32, split-fp16 per wave, fp16 features; not the shared-stream one)
+        if not plan or any(p.split == 2 for p in plan) or B * M > 8192 or M % 4 or xyz.shape[1] < 256:
             return None
-        if not all(_fused.want_packed((B, M, g.nsample), p) for g, p in zip(self.groupers, plan)):
+        if not all(B * M * g.nsample >= _fused.PACK_PM32_MIN_COLUMNS for g in self.groupers):
             return None
         if any(g.nsample > 32 for g in self.groupers) or not self._tail_reads_point_major(xyz, new_xyz):
             return None
@@ -489,7 +490,7 @@ class _PointnetSAModuleBase(nn.Module):
         pre, self._prepooled = getattr(self, "_prepooled", None), None
         plan = self._fused_plan(xyz, new_xyz, features)
         if plan and pre is not None and pre[0] is xyz and pre[1] is features and point_major_ok and \
-                pre[2].shape[:2] == (xyz.shape[0], new_xyz.shape[1]) and all(p.split == 0 and p.point_major for p in plan):
+                pre[2].shape[:2] == (xyz.shape[0], new_xyz.shape[1]) and not any(p.split == 2 for p in plan):
             # the early columns are in `out` already (begin_early_pool): query, pack and merge the LATE ones -- or, while a
             # repair flag is up, everything again with plain stores, inside the same three launches
             _, _, out, taken, n_early, flag, flags_any, _ = pre

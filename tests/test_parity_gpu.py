@@ -2442,9 +2442,10 @@ def test_staged_grouped_mlp_equals_one_launch(ext, G, dev, stages):
 
 
 # ------------------------------------------------------------------ exact fp32: the next layer starts on the early picks
+@pytest.mark.parametrize("precision", ["fp32", "fp16x2"])
 @pytest.mark.parametrize("case", ["plain", "waits-give-up", "prefix-guess-fails"])
-def test_streamed_first_layer_early_pool_fp32(G, dev, case, monkeypatch):
-    """Strict fp32: behind the chunks that end at 6/16, 9/16 and 12/16 of layer 0's picks, layer 1 queries the centroids that
+def test_streamed_first_layer_early_pool(G, dev, case, precision, monkeypatch):
+    """Both arithmetics (strict fp32: the point-major kernel; split-fp16: the per-wave kernel with its weights in LDS): behind the chunks that end at 6/16, 9/16 and 12/16 of layer 0's picks, layer 1 queries the centroids that
     exist and runs the grouped MLP of the columns they give (begin_early_pool, three stages); behind the last pick it adds the
     last quarter's columns by an atomic max.  Against the plain sequential pass: every output of every layer bit-identical, twice, allocator poisoned --
     also when every bounded wait is forced to give up (the late launches then redo layer 1 from scratch on the repaired
@@ -2465,7 +2466,7 @@ def test_streamed_first_layer_early_pool_fp32(G, dev, case, monkeypatch):
     orig = M.PointnetSAModuleMSG_WithSampling.begin_early_pool
     monkeypatch.setattr(M.PointnetSAModuleMSG_WithSampling, "begin_early_pool",
                         lambda self, *a, **k: began.append(orig(self, *a, **k)) or began[-1])
-    old = fused.set_precision("fp32")
+    old = fused.set_precision(precision)
     old_spins = L.sps_debug_set_wait_spins(0xFFFFFFFF) if case == "waits-give-up" else None
     try:
         with torch.no_grad():
