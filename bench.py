@@ -392,6 +392,10 @@ def training_step_leg(modules_pkg, sa_stack, cfg, args, xyz, feats, dev, reps=10
     layer-0 sampling started beside the backward (sa_stack.prefetch_first_layer; here the next batch is the same tensor)."""
     layers = sa_stack.build_sa_layers(modules_pkg, cfg, seed=0).to(dev).train()
     f = feats.float()
+    from spsnet_amd import fused
+    # the training path's own default arithmetic (the fused train-mode kernels, split-fp16 with exact operand scaling:
+    # gradients within 1-3e-6 of float64), whatever the inference legs above were timed with
+    keep = fused.set_precision("fp16x2" if args.mlp_precision != "fp32-train" else "fp32")
 
     def step(prefetch):
         for p in layers.parameters():
@@ -414,9 +418,10 @@ def training_step_leg(modules_pkg, sa_stack, cfg, args, xyz, feats, dev, reps=10
         torch.cuda.synchronize()
         res[key] = 1e3 * (time.perf_counter() - t0) / reps
     layers[0]._presampled = layers[0]._preball = None
+    fused.set_precision(keep)
     res["points_per_s"] = xyz.shape[0] * xyz.shape[1] / (res["ms"] * 1e-3)
     res["grouped_mlp"] = ("fused train-mode kernels (csrc/mlp_train.hip), split-fp16 MFMA with exact power-of-two operand scaling"
-                          if (modules_pkg.FUSED_MLP_TRAINING and args.mlp_precision != "fp32") else "op-by-op fp32 kernels")
+                          if modules_pkg.FUSED_MLP_TRAINING else "op-by-op fp32 kernels")
     res["note"] = "forward + backward of SA layers 0-2 in train() mode on the bench batch; informational, not the headline metric"
     return res
 

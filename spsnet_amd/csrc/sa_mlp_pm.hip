@@ -53,37 +53,52 @@ struct ChainShape {
     static constexpr int Q4 = KCH / 4;
 };
 
-template <int CIN, int MT, int NT, class Pre, class Sink>
+// BRIDGED use (all layers of a kernel with Q4 == 4 and a chunk count that is a multiple of RING): the ring lives in the caller
+// and runs on across layer and unit boundaries -- PRIMED: this layer's first RING - 1 chunks were requested by the layer
+// before it (or the prime in front of the unit loop); NEXT: while this layer multiplies its last chunks it requests the first
+// RING - 1 chunks of the layer behind it (`wnext`: that layer's fragments; the last layer hands on to layer 1 of the next
+// unit).  Without it every layer began with an exposed L2 round trip, three per unit.  The next tile's bias is read from LDS
+// while the current tile multiplies (its lgkmcnt wait otherwise sat in front of every tile's first MFMA).
+typedef f32x4 WeightRing[RING][4];
+
+template <int CIN, int MT, int NT, bool PRIMED, bool NEXT, class Pre, class Sink>
 __device__ __forceinline__ void chain_layer(const float *w, const float *bias, int lane, int q, const f32x4 (&hin)[CIN / 16][NT],
-                                            Pre pre, Sink sink) {
+                                            WeightRing &wb, const float *wnext, int next_chunks, Pre pre, Sink sink) {
     using S = ChainShape<CIN>;
     constexpr int KCH = S::KCH, NCH = S::NCH, Q4 = S::Q4, G = MT * NCH;
+    static_assert(!(PRIMED || NEXT) || (Q4 == 4 && G % RING == 0), "a bridged layer keeps the ring's phase");
     const __amdgpu_buffer_rsrc_t rs = weight_rsrc(w, (unsigned)(MT * S::KS * 64 * 4));
-    f32x4 wb[RING][Q4];
+    const __amdgpu_buffer_rsrc_t rsn = weight_rsrc(wnext, (unsigned)(next_chunks * 4 * 1024));
+    if constexpr (!PRIMED) {
 #pragma unroll
-    for (int p = 0; p < RING - 1; ++p)
-        if (p < G) {
+        for (int p = 0; p < RING - 1; ++p)
+            if (p < G) {
 #pragma unroll
-            for (int u = 0; u < Q4; ++u) wb[p][u] = wload4(rs, lane * 16, (p * Q4 + u) * 1024);
-        }
+                for (int u = 0; u < Q4; ++u) wb[p][u] = wload4(rs, lane * 16, (p * Q4 + u) * 1024);
+            }
+    }
     // A tile's epilogue (ReLU, hand-over) is issued BEHIND the first chunk of the next tile's MFMAs: a wave issues in order, so
     // an epilogue placed right behind its own tile waits for the matrix pipe to drain (its VALU ops read the accumulators)
     // and the pipe then idles until the next tile's first MFMA -- 40 such bubbles per unit at the widest scale.  Two
     // accumulator sets alternate by tile parity.
     f32x4 acc[2][NT];
+    f32x4 bnext = *reinterpret_cast<const f32x4 *>(bias + 4 * q);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int mt = g / NCH, ch = g % NCH, par = mt & 1;
         if (g + RING - 1 < G) {
 #pragma unroll
             for (int u = 0; u < Q4; ++u) wb[(g + RING - 1) % RING][u] = wload4(rs, lane * 16, ((g + RING - 1) * Q4 + u) * 1024);
+        } else if constexpr (NEXT) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wb[(g + RING - 1) % RING][u] = wload4(rsn, lane * 16, ((g + RING - 1 - G) * 4 + u) * 1024);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (ch == 0) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + 16 * mt + 4 * q);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[par][nt] = b4;
+            for (int nt = 0; nt < NT; ++nt) acc[par][nt] = bnext;
             pre(mt, acc[par]);
+            if (mt + 1 < MT) bnext = *reinterpret_cast<const f32x4 *>(bias + 16 * (mt + 1) + 4 * q);
         }
 #pragma unroll
         for (int kk = 0; kk < KCH; ++kk) {
@@ -103,41 +118,53 @@ __device__ __forceinline__ void chain_layer(const float *w, const float *bias, i
 // a no longer constant k-step, land in scratch).  U tiles = U * NCH chunks = a whole number of turns of the ring, so the
 // buffer a chunk lands in is a compile-time constant inside the unrolled group; the requests run RING - 1 chunks ahead across
 // tile and group boundaries (the chunk index is linear in memory).
-template <int CIN, int MT, int NT, class Sink>
+template <int CIN, int MT, int NT, bool PRIMED, bool NEXT, class Sink>
 __device__ __forceinline__ void chain_layer_rt(const float *w, const float *bias, int lane, int q, const f32x4 (&hin)[CIN / 16][NT],
-                                               Sink sink) {
+                                               WeightRing &wb, const float *wnext, int next_chunks, Sink sink) {
     using S = ChainShape<CIN>;
     constexpr int KCH = S::KCH, NCH = S::NCH, Q4 = S::Q4, G = MT * NCH;
     constexpr int U = (NCH % RING == 0) ? 1 : ((2 * NCH) % RING == 0 ? 2 : RING);   // tiles per unrolled group
     static_assert((U * NCH) % RING == 0 && MT % U == 0, "a group of tiles is a whole number of ring turns");
+    static_assert(!(PRIMED || NEXT) || Q4 == 4, "a bridged layer keeps the ring's phase");
     const __amdgpu_buffer_rsrc_t rs = weight_rsrc(w, (unsigned)(MT * S::KS * 64 * 4));
-    f32x4 wb[RING][Q4];
+    const __amdgpu_buffer_rsrc_t rsn = weight_rsrc(wnext, (unsigned)(next_chunks * 4 * 1024));
+    if constexpr (!PRIMED) {
 #pragma unroll
-    for (int p = 0; p < RING - 1; ++p)
-        if (p < G) {
+        for (int p = 0; p < RING - 1; ++p)
+            if (p < G) {
 #pragma unroll
-            for (int u = 0; u < Q4; ++u) wb[p][u] = wload4(rs, lane * 16, (p * Q4 + u) * 1024);
-        }
+                for (int u = 0; u < Q4; ++u) wb[p][u] = wload4(rs, lane * 16, (p * Q4 + u) * 1024);
+            }
+    }
     // (the epilogue of tile mt - 1 -- pool, stores -- is issued behind the first chunk of tile mt's MFMAs, see chain_layer)
     f32x4 accp[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) accp[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 bnext = *reinterpret_cast<const f32x4 *>(bias + 4 * q);
     for (int mt0 = 0; mt0 < MT; mt0 += U) {
         const int c0 = mt0 * NCH;                     // first chunk of the group (wave-uniform)
 #pragma unroll
         for (int tu = 0; tu < U; ++tu) {
             const int mt = mt0 + tu;
-            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + 16 * mt + 4 * q);
             f32x4 acc[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = b4;
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = bnext;
+            {
+                const int mtn = mt + 1 < MT ? mt + 1 : mt;
+                bnext = *reinterpret_cast<const f32x4 *>(bias + 16 * mtn + 4 * q);
+            }
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int cl = tu * NCH + ch;           // chunk within the group: compile-time
-                int cn = c0 + cl + RING - 1;            // the chunk to request now (clamped: the last ones re-read the last chunk)
-                cn = cn < G ? cn : G - 1;
+                int cn = c0 + cl + RING - 1;            // the chunk to request now
+                if (NEXT && cn >= G) {                  // (wave-uniform; the last RING - 1 chunks of the layer only)
 #pragma unroll
-                for (int u = 0; u < Q4; ++u) wb[(cl + RING - 1) % RING][u] = wload4(rs, lane * 16, (cn * Q4 + u) * 1024);
+                    for (int u = 0; u < 4; ++u) wb[(cl + RING - 1) % RING][u] = wload4(rsn, lane * 16, ((cn - G) * 4 + u) * 1024);
+                } else {
+                    cn = cn < G ? cn : G - 1;           // (unbridged: the last ones re-read the last chunk)
+#pragma unroll
+                    for (int u = 0; u < Q4; ++u) wb[(cl + RING - 1) % RING][u] = wload4(rs, lane * 16, (cn * Q4 + u) * 1024);
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kk = 0; kk < KCH; ++kk) {
@@ -242,6 +269,18 @@ __global__ __launch_bounds__(256) void sa_group_mlp_pm_kernel(SaMlpArgs a) {
         load_idx(wave);
         load_inputs(wave);
     }
+    // one weight ring for the whole kernel when every layer keeps its phase (all IA-SSD widths but the 96-wide one)
+    using S0 = ChainShape<CF>; using S1 = ChainShape<C1>; using S2 = ChainShape<C2>;
+    constexpr bool BRIDGE = S0::Q4 == 4 && S1::Q4 == 4 && S2::Q4 == 4 && (T1 * S0::NCH) % RING == 0 && (T2 * S1::NCH) % RING == 0 &&
+                            (MT3 * S2::NCH) % RING == 0;
+    WeightRing wb;
+    if constexpr (BRIDGE) {
+        const __amdgpu_buffer_rsrc_t rs1 = weight_rsrc(w1f, (unsigned)(T1 * S0::KS * 64 * 4));
+#pragma unroll
+        for (int p = 0; p < RING - 1; ++p)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wb[p][u] = wload4(rs1, lane * 16, (p * 4 + u) * 1024);
+    }
     for (int unit = wave; unit < nunits; unit += nwaves) {
         int ub = 0;
         long long col0 = 0;
@@ -255,7 +294,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_pm_kernel(SaMlpArgs a) {
             float wx[T1];
 #pragma unroll
             for (int t = 0; t < T1; ++t) wx[t] = swx[t * 64 + lane];
-            chain_layer<CF, T1, NT>(w1f, sbias, lane, q, xin,
+            chain_layer<CF, T1, NT, BRIDGE, BRIDGE>(w1f, sbias, lane, q, xin, wb, a.w2, T2 * S1::NCH,
                 [&](int mt, f32x4 (&acc)[NT]) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(wx[mt], xq[nt], acc[nt]);
@@ -271,7 +310,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_pm_kernel(SaMlpArgs a) {
         if (more) load_idx(nxt);
         __builtin_amdgcn_sched_barrier(0);
         f32x4 h2[T2][NT];
-        chain_layer<C1, T2, NT>(a.w2, sbias + C1, lane, q, h1, [](int, f32x4 (&)[NT]) {},
+        chain_layer<C1, T2, NT, BRIDGE, BRIDGE>(a.w2, sbias + C1, lane, q, h1, wb, a.w3, MT3 * S2::NCH, [](int, f32x4 (&)[NT]) {},
             [&](int mt, f32x4 (&acc)[NT]) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -284,7 +323,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_pm_kernel(SaMlpArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         // ---------------- layer 3 + max-pool over the unit's columns ----------------
         const long long bj0 = col0 / NS;
-        chain_layer_rt<C2, MT3, NT>(a.w3, sbias + C1 + C2, lane, q, h2,
+        chain_layer_rt<C2, MT3, NT, BRIDGE, BRIDGE>(a.w3, sbias + C1 + C2, lane, q, h2, wb, w1f, T1 * S0::NCH,
             [&](int mt, f32x4 (&acc)[NT]) {
                 if constexpr (PACKED) {
                     pool_write_packed<NT>(a, acc, pu, mt, q, c, false, merge);

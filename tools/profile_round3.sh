@@ -14,6 +14,10 @@ SPS_FPS_PRESORT=0 rocprofv3 --output-format csv --kernel-trace --pmc $PMC -d $O/
 SPS_FPS_PRESORT=0 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o p -- python3 bench.py --steps 3 --warmup 1 --no-fp16x2-leg $QUIET > $O/fetch.log 2>&1 &&
 SPS_FPS_PRESORT=0 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $O/write -o p -- python3 bench.py --steps 3 --warmup 1 --no-fp16x2-leg $QUIET > $O/write.log 2>&1 &&
 python3 bench.py --steps 60 --warmup 10 > $O/bench.log 2> $O/bench.err
+python3 bench.py --config 4 --steps 40 --warmup 10 --no-cpu-baseline --no-training-leg > $O/bench_config4.log 2>> $O/bench.err
+python3 bench.py --config 5 --steps 20 --warmup 5 --no-cpu-baseline --no-training-leg > $O/bench_config5.log 2>> $O/bench.err
+./tools/microbench_mfma_f32 > $O/microbench_mfma_f32_gfx950.txt 2>&1
+python3 tools/tail_events.py > $O/tail_events.txt 2>&1
 python3 tools/pmc_mfma.py $O/pmc32/p_counter_collection.csv fp32 $O/pmc_mfma.json $O/pmc16/p_counter_collection.csv:fp16x2 > $O/pmc_mfma.txt 2>&1
 python3 tools/pmc_traffic.py $O/fetch/p_counter_collection.csv $O/write/p_counter_collection.csv $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
 python3 tools/tail_trace.py $O/kt/kt_kernel_trace.csv > $O/tail_timeline.txt 2>&1
