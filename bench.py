@@ -81,6 +81,9 @@ def parse():
                          "--mlp-precision fp16x2 is the headline)")
     ap.add_argument("--no-exchange", action="store_true",
                     help="N > 1: leave the all-gather of the sampled indices out of the step (config 2 x N instead of configs[2])")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N = 1 only: initialise RCCL with a group of ONE rank and end every step with the same packed all-gather "
+                         "(what the RCCL call itself costs a step; no xGMI is involved and the line says so)")
     ap.add_argument("--no-validate", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pipelined", action="store_true",
                     help="also time the same passes with two batches in flight (informational object)")
@@ -439,6 +442,11 @@ def same_outputs(got, want):
 
 def main():
     args = parse()
+    # stdout carries the ONE JSON line and nothing else: whatever a library prints there (RCCL's version banner at
+    # communicator set-up, for one) goes to stderr for the rest of the run
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -455,6 +463,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    if args.force_exchange:
+        if world != 1:
+            raise SystemExit("--force-exchange is the one-rank exercise of the exchange; at N > 1 the exchange is in the step anyway")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -497,14 +512,14 @@ def main():
     chunk_probe = ChunkProbe(ext)
     # BASELINE configs[2]: at N > 1 every step ends with the ONE exchange the sharded path has -- the global-batch view of each
     # layer's sampled indices, all three layers packed into one all-gather (RCCL over xGMI; latency-bound: 22 KiB per rank)
-    exchange = world > 1 and not args.no_exchange
+    exchange = (world > 1 or args.force_exchange) and not args.no_exchange
     state = {"exchange": exchange, "gathered": None}
 
     def step(**kw):
         with torch.no_grad():
             outs = sa_stack.run_sa_layers(layers, xyz, feats, stds, stream_first_layer=args.stream_first_layer, **kw)
             if state["exchange"]:
-                state["gathered"] = all_gather_sampled_idx([o[3] for o in outs])
+                state["gathered"] = all_gather_sampled_idx([o[3] for o in outs], always_collective=args.force_exchange)
             return outs
 
     def timed(steps, warmup):
@@ -623,11 +638,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_txt,
             "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[2]: batch={world * args.batch} sharded {world}-way ({args.batch}/GPU) x "
-                                    f"{args.points} pts" if exchange else
+                                    f"{args.points} pts" if exchange and world > 1 else
                                     f"BASELINE configs[{args.config - 1}]: batch={args.batch}/GPU x {args.points} pts") +
                                    f" ({args.dataset}), IA-SSD SA L0-L2 ({shape_txt}, layer-2 sampler {args.sampler}), "
                                    f"grouped MLP {args.mlp_precision}" +
-                                   (", one packed RCCL all-gather of the sampled indices per step" if exchange else ""),
+                                   (", one packed RCCL all-gather of the sampled indices per step" if exchange else "") +
+                                   (" (--force-exchange: a group of ONE rank)" if args.force_exchange else ""),
                        "global_batch": world * args.batch, "points_per_scene": args.points,
                        "parallelism": (f"scene-sharded x{world}; per step one all-gather of the layers' sampled indices "
                                        f"(int32 ({args.batch}, sum M) per rank) inside the timed region" if exchange else
@@ -636,13 +652,18 @@ def main():
         if no_exchange is not None:
             line["ms_per_step_no_exchange"] = 1e3 * no_exchange[0] / args.steps
             line["ms_per_step_no_exchange_median"] = float(statistics.median(no_exchange[1]))
-            line["exchange"] = {"collective": "all_gather_into_tensor (RCCL)", "per_step": 1,
+            line["exchange"] = {"collective": "all_gather_into_tensor (RCCL)" + (", group of ONE rank: the cost of the call, no xGMI"
+                                                                               if args.force_exchange else ""),
+                                "ranks": world, "per_step": 1,
                                 "bytes_per_rank": int(4 * args.batch * sum(o[3].shape[1] for o in outs)),
                                 "checked": "every rank's rows found at its offset of the gathered tensors"}
         if rehearsal:
             line["data"] = "synthetic; REHEARSAL: all ranks share one GPU over gloo -- not a measurement"
         if checked is not None:
             line["validated"] = checked
+        from spsnet_amd import streams as _streams   # helper streams are probed for real concurrency with the pass's streams
+        line["helper_streams"] = dict(_streams.stats, note="device-side probes at stream set-up; rejected = streams that shared "
+                                      "a hardware queue with the pass (HIP multiplexes streams onto GPU_MAX_HW_QUEUES queues)")
         if second_leg is not None:
             el2, per2, chk2, mlp2 = second_leg
             line[f"value_{other}"] = total_points / el2
@@ -702,8 +723,9 @@ def main():
                 line["training_step"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(layers, args)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(line_fd, (json.dumps(line) + "\n").encode())
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

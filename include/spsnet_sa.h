@@ -58,6 +58,12 @@ int sps_debug_where(int blocks, int threads, int spin, unsigned *out, sps_stream
  * second pass's whole-chip kernels no longer land on those CUs. */
 int sps_stream_create_cu_mask(int words, const unsigned *mask, sps_stream_t *stream);
 int sps_stream_destroy(sps_stream_t stream);
+/* Do kernels of streams a and b really run side by side?  HIP multiplexes streams onto a few hardware queues
+ * (GPU_MAX_HW_QUEUES, 4 by default) and two streams that share one are serialised; which streams share depends on everything
+ * in the process that created streams (initialising RCCL is enough).  A one-lane kernel on `a` waits, bounded by limit_us of
+ * wall clock, for a word that a kernel launched on `b` right behind it sets: *concurrent = 1 if it saw the word.  scratch =
+ * two device ints.  Synchronises both streams: a set-up call (spsnet_amd/streams.py picks its helper streams with it). */
+int sps_streams_run_concurrently(sps_stream_t a, sps_stream_t b, int *scratch, int limit_us, int *concurrent);
 
 /* ---- the 11 functions of pointnet2_batch_cuda (src/pointnet2_api.cpp:10-26) ---------- */
 

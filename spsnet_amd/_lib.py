@@ -24,6 +24,7 @@ _PROTOS = {
     "sps_debug_where": [_i, _i, _i, _vp, _vp],
     "sps_stream_create_cu_mask": [_i, _vp, _vp],
     "sps_stream_destroy": [_vp],
+    "sps_streams_run_concurrently": [_vp, _vp, _vp, _i, _vp],
     "sps_fps_ordered_prefix": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_fps_ordered_prefix_begin": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_fps_ordered_prefix_finish": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -19,7 +19,7 @@ import copy
 import torch
 import torch.nn as nn
 
-from . import pointnet2_modules, pointnet2_utils, sa_stack, surface_feature
+from . import pointnet2_modules, pointnet2_utils, sa_stack, streams, surface_feature
 
 
 _CHECK_STREAMS = {}
@@ -50,7 +50,7 @@ def equal_counts_check(batch_idx, batch_size):
     key = (dev.type, dev.index)
     side = _CHECK_STREAMS.get(key)
     if side is None:
-        side = _CHECK_STREAMS[key] = torch.cuda.Stream(device=dev)
+        side = _CHECK_STREAMS[key] = streams.helper(dev, torch.cuda.current_stream(dev), "check")
     entry = torch.cuda.Event()
     entry.record(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
@@ -313,7 +313,7 @@ _SURFACE_STREAMS = {}
 def _surface_stream(device):
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _SURFACE_STREAMS:
-        _SURFACE_STREAMS[key] = torch.cuda.Stream(device=device)
+        _SURFACE_STREAMS[key] = streams.helper(device, torch.cuda.current_stream(device), "surface")
     return _SURFACE_STREAMS[key]
 
 

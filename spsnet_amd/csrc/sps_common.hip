@@ -66,3 +66,48 @@ extern "C" int sps_stream_destroy(sps_stream_t stream) {
     if (e != hipSuccess) return fail(SPS_ERR_LAUNCH, "hipStreamDestroy: %s", hipGetErrorString(e));
     return SPS_OK;
 }
+
+// ---- do two streams really run side by side? ------------------------------------------------------------------------
+// HIP multiplexes its streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and kernels of two streams that
+// share one run strictly one after the other -- which stream lands on which queue depends on everything else in the process
+// that created streams (RCCL alone is enough to put the FPS producer and its consumers on one queue: the pass then takes
+// FPS + everything else instead of their maximum).  The probe: a one-lane kernel on `a` waits (bounded by wall clock) for a
+// word that a kernel on `b`, launched right behind it, sets.  On different queues it sees the word within microseconds;
+// on one queue the setter cannot start before the waiter has given up.
+namespace sps {
+__global__ void hq_wait_kernel(int *word, int *seen, unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    int v = 0;
+    do {
+        v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == 0) __builtin_amdgcn_s_sleep(16);
+    } while (v == 0 && wall_clock64() - t0 < ticks);
+    *seen = v;
+}
+__global__ void hq_set_kernel(int *word) { __hip_atomic_store(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}  // namespace sps
+
+// scratch: two device ints.  *concurrent = 1 when a kernel on `b` ran while a kernel on `a` was still running.  Synchronises
+// both streams (a set-up call, not for the data path); at most ~limit_us of GPU time when the streams do share a queue.
+extern "C" int sps_streams_run_concurrently(sps_stream_t a, sps_stream_t b, int *scratch, int limit_us, int *concurrent) {
+    using namespace sps;
+    if (!scratch || !concurrent || limit_us <= 0) return fail(SPS_ERR_INVALID, "streams_run_concurrently: bad arguments");
+    hipStream_t sa = as_stream(a), sb = as_stream(b);
+    *concurrent = 0;
+    if (sa == sb) return SPS_OK;
+    hipError_t e = hipStreamSynchronize(sb);
+    if (e == hipSuccess) e = hipMemsetAsync(scratch, 0, 2 * sizeof(int), sa);
+    if (e == hipSuccess) e = hipStreamSynchronize(sa);
+    if (e != hipSuccess) return fail(SPS_ERR_LAUNCH, "streams_run_concurrently: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(hq_wait_kernel, dim3(1), dim3(1), 0, sa, scratch, scratch + 1, 100ull * (unsigned long long)limit_us);  // 100 MHz
+    hipLaunchKernelGGL(hq_set_kernel, dim3(1), dim3(1), 0, sb, scratch);
+    const int rc = check_launch("hq_wait_kernel / hq_set_kernel");
+    if (rc != SPS_OK) return rc;
+    int seen = 0;
+    e = hipStreamSynchronize(sa);
+    if (e == hipSuccess) e = hipStreamSynchronize(sb);
+    if (e == hipSuccess) e = hipMemcpy(&seen, scratch + 1, sizeof(int), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(SPS_ERR_LAUNCH, "streams_run_concurrently: %s", hipGetErrorString(e));
+    *concurrent = seen != 0;
+    return SPS_OK;
+}

@@ -23,11 +23,13 @@ def shard_range(total_scenes: int, world_size: int, rank: int) -> Tuple[int, int
     return begin, begin + base + (1 if rank < extra else 0)
 
 
-def all_gather_sampled_idx(per_layer_idx: Sequence[torch.Tensor], group=None) -> List[torch.Tensor]:
+def all_gather_sampled_idx(per_layer_idx: Sequence[torch.Tensor], group=None, always_collective: bool = False) -> List[torch.Tensor]:
     """All-gather every layer's (b_local, M_l) int32 sampled indices into (B, M_l) tensors with ONE
     collective: the layers are packed side by side into a (b_local, sum M_l) buffer first.
-    Ranks must hold the same number of scenes (pad the batch otherwise)."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    Ranks must hold the same number of scenes (pad the batch otherwise).
+    always_collective: issue the collective in a group of one rank too (bench.py --force-exchange: the only way to put the
+    RCCL call itself on a one-GPU box); by default a lone rank just copies."""
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always_collective):
         return [t.clone() for t in per_layer_idx]
     world = dist.get_world_size(group)
     widths = [int(t.shape[1]) for t in per_layer_idx]

@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from . import fused as _fused
 from . import pointnet2_batch_cuda as _ext
 from . import pointnet2_utils
+from . import streams
 
 
 # ------------------------------------------------------------------------------------------
@@ -573,7 +574,8 @@ class _PointnetSAModuleBase(nn.Module):
     def _scale_streams(self, like):
         key = (like.device.index, torch.cuda.current_stream(like.device).cuda_stream)
         if key not in _PointnetSAModuleBase._SCALE_STREAMS:
-            _PointnetSAModuleBase._SCALE_STREAMS[key] = [torch.cuda.Stream(device=like.device) for _ in range(2)]
+            main = torch.cuda.current_stream(like.device)
+            _PointnetSAModuleBase._SCALE_STREAMS[key] = [streams.helper(like.device, main, f"scale{i}") for i in range(2)]
         return _PointnetSAModuleBase._SCALE_STREAMS[key]
 
     def _neighbour_indices(self, xyz, new_xyz):

@@ -13,6 +13,8 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
+from . import streams
+
 # the three down-sampling SA layers of BASELINE.json's metric (16 384 -> 4 096 -> 1 024 -> 512)
 IASSD_KITTI = dict(
     npoint_list=[[4096], [1024], [512]],
@@ -149,7 +151,8 @@ def _helper_stream(device, tag="side"):
         return None
     key = (device.type, device.index, main.cuda_stream, tag)
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = fence.new_stream(tag) if fence is not None else torch.cuda.Stream(device=device)
+        _SIDE_STREAMS[key] = (fence.new_stream(tag) if fence is not None else
+                              streams.helper(device, main, tag, exclusive=(tag == "producer")))
     return _SIDE_STREAMS[key]
 
 

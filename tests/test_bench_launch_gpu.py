@@ -40,3 +40,31 @@ def test_two_rank_launch_prints_one_valid_line():
     # whole-job aggregate: both ranks' points over the slowest rank's time
     assert abs(line["value"] - 2 * 8 * 16384 * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-6 * line["value"]
     assert "cpu_baseline" not in line and "training_step" not in line    # N = 1 only
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_exchange_inside_the_step():
+    """--force-exchange: RCCL itself (backend "nccl", a group of one rank) carries the packed all-gather at the end of every
+    timed step -- the collective the N > 1 launch issues, on the library the driver's multi-GPU run will use."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--force-exchange",
+           "--no-fp16x2-leg", "--no-cpu-baseline", "--no-training-leg"]
+    done = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-3000:]
+    lines = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, done.stdout[-3000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["exchange"]["ranks"] == 1 and "RCCL" in line["exchange"]["collective"]
+    assert line["exchange"]["bytes_per_rank"] == 4 * 8 * (4096 + 1024 + 512)
+    assert line["ms_per_step_no_exchange"] > 0 and line["ms_per_step"] > 0
+    assert line["config"]["workload"].startswith("BASELINE configs[1]") and "ONE rank" in line["config"]["workload"]
+    assert line["validated"]["last_step_bit_identical_to_sequential_pass"] is True
+    # RCCL's own streams must not push the FPS producer and its consumers onto one hardware queue (the pass would take
+    # FPS + everything else, 3.2 ms, instead of their maximum, 2.3 ms): the helper streams are probed at set-up
+    assert line["helper_streams"]["probes"] > 0
+    assert line["ms_per_step_no_exchange"] < line["roofline"]["launch_ms"] + 1.0, (line["ms_per_step_no_exchange"], line["roofline"])

@@ -3059,3 +3059,22 @@ def test_fused_train_mode_mlp_under_sync_batchnorm(dev, monkeypatch):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_helper_streams_really_run_beside_the_pass(dev):
+    """HIP maps streams onto a few hardware queues and serialises the ones that share a queue; streams.helper() only hands out
+    streams that passed the device-side probe against the pass's stream and its FPS producer."""
+    from spsnet_amd import streams
+    main = torch.cuda.current_stream(dev)
+    assert not streams.run_concurrently(main, main)                      # one stream: the setter cannot start
+    producer = streams.helper(dev, main, "producer", exclusive=True)
+    scale = streams.helper(dev, main, "scale0")
+    assert streams.helper(dev, main, "producer") is producer             # one per (device, main stream, tag)
+    assert streams.run_concurrently(main, producer) and streams.run_concurrently(producer, main)
+    assert streams.run_concurrently(producer, scale) and streams.run_concurrently(main, scale)
+    x = torch.ones(1 << 20, device=dev)
+    with torch.cuda.stream(producer):                                    # the probe leaves the streams usable
+        y = x * 2
+    producer.synchronize()
+    assert float(y.sum()) == 2.0 * (1 << 20)
