@@ -226,6 +226,15 @@ int sps_sa_group_mlp_supported_stream(int c1, int c2, int c3, int nsample);
 /* 1 if the exact-fp32 kernel for point-major features (sps_sa_group_mlp_ex mode 4) serves c_feat channels and these
  * padded widths. */
 int sps_sa_group_mlp_pm_supported(int c_feat, int c1, int c2, int c3, int nsample);
+/* Layer 1 of that kernel over the FEATURE channels once per point instead of once per grouped point (a point's features
+ * meet the same weights in every ball the point falls into: nsample m / n times, 16 at IA-SSD layer 2; the reference's
+ * SharedMLP, pointnet2_modules.py:114-122 via pcdet's pt_utils, multiplies them every time): out (npts, c1) = b1 + W1f .
+ * features_pm[point] (npts = b n points of the (b, n, c_feat) twin; w1 / b1 as packed for mode 4).  The grouped launch then
+ * takes `out` as its feature tensor with c_feat = c1 and mode bit 32: per grouped point only the coordinate k-step is left
+ * of layer 1.  Sums in a different order than without it (within 1e-4 of torch either way). */
+int sps_sa_layer1_per_point(int npts, int c_feat, int c1, const float *features_pm, const float *w1, const float *b1,
+                            float *out, sps_stream_t stream);
+int sps_sa_layer1_per_point_supported(int c_feat, int c1, int nsample);
 /* Arithmetic of sps_sa_group_mlp: 0 = exact fp32 MFMA (default), 1 = split-fp16: every operand as hi+lo halves,
  * three v_mfma_f32_16x16x16_f16 per product block, fp32 accumulate (~1e-6 relative, csrc/sa_mlp_f16.hip).  The
  * weight buffers passed afterwards must be packed for the selected mode (spsnet_amd/fused.py).  Returns the old mode. */

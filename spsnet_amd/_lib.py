@@ -58,6 +58,8 @@ _PROTOS = {
     "sps_index_add_deterministic": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_sa_group_mlp_supported_stream": [_i, _i, _i, _i],
     "sps_sa_group_mlp_pm_supported": [_i, _i, _i, _i, _i],
+    "sps_sa_layer1_per_point": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sps_sa_layer1_per_point_supported": [_i, _i, _i],
     "sps_fps_with_workspace": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_pointwise_mlp_range": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_pointwise_mlp_ex": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],

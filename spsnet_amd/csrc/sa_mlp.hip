@@ -417,7 +417,11 @@ extern "C" int sps_sa_group_mlp_packed_merge(int b, int n, int m, int j0, int jc
     a.xyz = xyz; a.new_xyz = new_xyz; a.feat = features; a.idx = idx;
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.out = out;
     a.overflow = overflow_flag;
-    split_fp16 &= ~16;   // (consumed above)
+    a.hoist1 = (split_fp16 & 32) ? 1 : 0;   // `features` = layer 1's feature product per point (sps_sa_layer1_per_point)
+    if (a.hoist1 && !((split_fp16 & 7) == 4 && c_feat == c1))
+        return fail(SPS_ERR_INVALID, "sa_group_mlp: mode bit 32 belongs to the exact-fp32 point-major kernel (mode 4) and takes a "
+                                     "(B, N, c1) feature tensor");
+    split_fp16 &= ~(16 | 32);   // (consumed above)
     const int arith = split_fp16 & 3;
     a.feat_pm = (split_fp16 & 4) ? 1 : 0;
     if (a.feat_pm && (c_feat < 4 || (c_feat % 4)))

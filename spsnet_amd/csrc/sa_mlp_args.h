@@ -36,6 +36,10 @@ struct SaMlpArgs {
     int merge_max;
     const int *merge_unless, *merge_unless_any;
     int merge_unless_count;
+    // Exact-fp32 kernel on point-major features (sa_mlp_pm.hip) only: layer 1's product over the FEATURE channels was computed
+    // once per point (sps_sa_layer1_per_point) -- `feat` then holds b1 + W1f . features[point] as (B, N, C1) and layer 1 in
+    // the grouped kernel is the coordinate k-step on top of the gathered row.
+    int hoist1;
 };
 
 // the (units, units per scene, first centroid) a launch works on: its range, or the whole layer when *alt is set

@@ -189,9 +189,15 @@ __device__ __forceinline__ void chain_layer_rt(const float *w, const float *bias
 // the features as [tile][CF/16][lane][4]; a.w2, a.w3 as in sa_mlp.hip (fused._pack_next).
 // PACKED: the columns come from sps_pack_columns (only the distinct neighbours of every ball, in power-of-two slots): a unit is
 // COLS consecutive entries of a.cols / a.meta, the pool is segmented per slot (pool_write_packed) -- same pooled values bit for bit.
-template <int CF, int C1, int C2, int C3, int NT, int NS, bool PACKED>
+// HOIST1: a.feat is (B, N, C1) = b1 + W1f . features[point] (point_layer1_pm_kernel below): per grouped point layer 1 is then
+// ONE k-step (the centred coordinates) on top of the gathered row instead of CF / 4 + 1 -- a grouped MLP multiplies every
+// point's features by the same W1f once per ball the point falls into (nsample M / N times: 16 at IA-SSD layer 2).  The sums
+// are formed in a different order than without it (features first, per point; then the coordinates), like any two fp32 GEMM
+// schedules; both are within 1e-4 of torch.
+template <int CF, int C1, int C2, int C3, int NT, int NS, bool PACKED, bool HOIST1 = false>
 __global__ __launch_bounds__(256) void sa_group_mlp_pm_kernel(SaMlpArgs a) {
     if (a.run_if && *a.run_if == 0) return;
+    static_assert(!HOIST1 || CF == C1, "the hoisted form gathers C1 channels per point into the registers of CF");
     constexpr int T0 = CF / 16, T1 = C1 / 16, T2 = C2 / 16, MT3 = C3 / 16;
     constexpr int COLS = 16 * NT;
     constexpr int CPP = COLS >= NS ? COLS / NS : 1;   // whole centroids per unit ...
@@ -271,11 +277,14 @@ __global__ __launch_bounds__(256) void sa_group_mlp_pm_kernel(SaMlpArgs a) {
     }
     // one weight ring for the whole kernel when every layer keeps its phase (all IA-SSD widths but the 96-wide one)
     using S0 = ChainShape<CF>; using S1 = ChainShape<C1>; using S2 = ChainShape<C2>;
-    constexpr bool BRIDGE = S0::Q4 == 4 && S1::Q4 == 4 && S2::Q4 == 4 && (T1 * S0::NCH) % RING == 0 && (T2 * S1::NCH) % RING == 0 &&
-                            (MT3 * S2::NCH) % RING == 0;
+    constexpr bool BRIDGE = (HOIST1 || (S0::Q4 == 4 && (T1 * S0::NCH) % RING == 0)) && S1::Q4 == 4 && S2::Q4 == 4 &&
+                            (T2 * S1::NCH) % RING == 0 && (MT3 * S2::NCH) % RING == 0;
+    // the layer that follows layer 3 in the ring: layer 1's feature chain, or (HOIST1: there is none) layer 2
+    const float *wfirst = HOIST1 ? a.w2 : w1f;
+    constexpr int FIRST_CHUNKS = HOIST1 ? T2 * S1::NCH : T1 * S0::NCH;
     WeightRing wb;
     if constexpr (BRIDGE) {
-        const __amdgpu_buffer_rsrc_t rs1 = weight_rsrc(w1f, (unsigned)(T1 * S0::KS * 64 * 4));
+        const __amdgpu_buffer_rsrc_t rs1 = weight_rsrc(wfirst, (unsigned)(FIRST_CHUNKS * 4 * 1024));
 #pragma unroll
         for (int p = 0; p < RING - 1; ++p)
 #pragma unroll
@@ -294,6 +303,16 @@ __global__ __launch_bounds__(256) void sa_group_mlp_pm_kernel(SaMlpArgs a) {
             float wx[T1];
 #pragma unroll
             for (int t = 0; t < T1; ++t) wx[t] = swx[t * 64 + lane];
+            if constexpr (HOIST1) {
+#pragma unroll
+                for (int t = 0; t < T1; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const f32x4 acc = mfma16(wx[t], xq[nt], xin[t][nt]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h1[t][nt][r] = relu_keep_nan(acc[r]);
+                    }
+            } else {
             chain_layer<CF, T1, NT, BRIDGE, BRIDGE>(w1f, sbias, lane, q, xin, wb, a.w2, T2 * S1::NCH,
                 [&](int mt, f32x4 (&acc)[NT]) {
 #pragma unroll
@@ -305,6 +324,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_pm_kernel(SaMlpArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) h1[mt][nt][r] = relu_keep_nan(acc[nt][r]);
                 });
+            }
         }
         // the next unit's neighbour indices travel while layer 2 runs ...
         if (more) load_idx(nxt);
@@ -323,7 +343,7 @@ __global__ __launch_bounds__(256) void sa_group_mlp_pm_kernel(SaMlpArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         // ---------------- layer 3 + max-pool over the unit's columns ----------------
         const long long bj0 = col0 / NS;
-        chain_layer_rt<C2, MT3, NT, BRIDGE, BRIDGE>(a.w3, sbias + C1 + C2, lane, q, h2, wb, w1f, T1 * S0::NCH,
+        chain_layer_rt<C2, MT3, NT, BRIDGE, BRIDGE>(a.w3, sbias + C1 + C2, lane, q, h2, wb, wfirst, FIRST_CHUNKS,
             [&](int mt, f32x4 (&acc)[NT]) {
                 if constexpr (PACKED) {
                     pool_write_packed<NT>(a, acc, pu, mt, q, c, false, merge);
@@ -358,6 +378,49 @@ __global__ __launch_bounds__(256) void sa_group_mlp_pm_kernel(SaMlpArgs a) {
                 }
             });
     }
+}
+
+// b1 + W1f . features[point] for every point of the (B, N, CF) twin -> out (B N, C1) point-major: what HOIST1 gathers.  The same
+// chained layer on the same packed fragments, over 16 consecutive points per wave instead of 16 grouped ones.
+template <int CF, int C1>
+__global__ __launch_bounds__(256) void point_layer1_pm_kernel(int npts, const float *__restrict__ feat, const float *__restrict__ w1,
+                                                              const float *__restrict__ b1, float *__restrict__ out) {
+    constexpr int T0 = CF / 16, T1 = C1 / 16;
+    __shared__ __attribute__((aligned(16))) float sbias[C1];
+    for (int i = threadIdx.x; i < C1; i += blockDim.x) sbias[i] = b1[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4, c = lane & 15;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const float *w1f = w1 + (size_t)T1 * 64;   // (behind the coordinate fragments)
+    WeightRing wb;
+    for (int tile = wave; tile * 16 < npts; tile += nwaves) {
+        const int pt = tile * 16 + c;
+        const int ptc = pt < npts ? pt : npts - 1;
+        f32x4 xin[T0][1];
+#pragma unroll
+        for (int t = 0; t < T0; ++t) xin[t][0] = *reinterpret_cast<const f32x4 *>(feat + (size_t)ptc * CF + 16 * t + 4 * q);
+        chain_layer<CF, T1, 1, false, false>(w1f, sbias, lane, q, xin, wb, w1f, 0, [](int, f32x4 (&)[1]) {},
+            [&](int mt, f32x4 (&acc)[1]) {
+                if (pt < npts) *reinterpret_cast<f32x4 *>(out + (size_t)pt * C1 + 16 * mt + 4 * q) = acc[0];
+            });
+    }
+}
+
+int launch_point_layer1_pm(int npts, int c_feat, int c1, const float *feat, const float *w1, const float *b1, float *out, hipStream_t st) {
+    const int tiles = divup(npts, 16);
+    int blocks = divup(tiles, 4);
+    if (blocks > 1024) blocks = 1024;
+#define SPS_PL1_CASE(CF, C1) \
+    if (c_feat == CF && c1 == C1) { \
+        hipLaunchKernelGGL((point_layer1_pm_kernel<CF, C1>), dim3(blocks), dim3(256), 0, st, npts, feat, w1, b1, out); \
+        return check_launch("point_layer1_pm_kernel"); \
+    }
+    SPS_PL1_CASE(64, 64)
+    SPS_PL1_CASE(128, 128)
+#undef SPS_PL1_CASE
+    return fail(SPS_ERR_INVALID, "sa_layer1_per_point: no kernel for %d feature channels -> %d", c_feat, c1);
 }
 
 template <int CF, int C1, int C2, int C3, int NT, int NS>
@@ -397,6 +460,16 @@ static int launch_pm_variant(const SaMlpArgs &a, hipStream_t st) {
         if (v > 0) max_blocks = v;
     }
     if (blocks > max_blocks) blocks = max_blocks;
+    if constexpr (CF == C1 && NS <= 32) {
+        if (a.hoist1) {
+            if (a.cols)
+                hipLaunchKernelGGL((sa_group_mlp_pm_kernel<CF, C1, C2, C3, NT, NS, true, true>), dim3(blocks), dim3(64 * waves_per_block), 0, st, k);
+            else
+                hipLaunchKernelGGL((sa_group_mlp_pm_kernel<CF, C1, C2, C3, NT, NS, false, true>), dim3(blocks), dim3(64 * waves_per_block), 0, st, k);
+            return check_launch("sa_group_mlp_pm_kernel<hoisted layer 1>");
+        }
+    }
+    if (a.hoist1) return fail(SPS_ERR_INVALID, "sa_group_mlp(pm): no per-point layer-1 form for these widths / nsample %d", NS);
     if (a.cols)
         hipLaunchKernelGGL((sa_group_mlp_pm_kernel<CF, C1, C2, C3, NT, NS, true>), dim3(blocks), dim3(64 * waves_per_block), 0, st, k);
     else
@@ -430,4 +503,20 @@ extern "C" int sps_sa_group_mlp_pm_supported(int c_feat, int c1, int c2, int c3,
     for (auto &t : tab)
         if (t[0] == c_feat && t[1] == c1 && t[2] == c2 && t[3] == c3 && t[4] == nsample) return 1;
     return 0;
+}
+
+// b1 + W1f . features[point] of the exact-fp32 point-major kernel's layer 1, once per point: features_pm (npts, c_feat) ->
+// out (npts, c1); w1 / b1 as packed for sps_sa_group_mlp mode 4 (fused._pack_first_pm).  The grouped launch then takes `out` as
+// its feature tensor with mode bit 32.
+extern "C" int sps_sa_layer1_per_point(int npts, int c_feat, int c1, const float *features_pm, const float *w1, const float *b1,
+                                       float *out, sps_stream_t stream) {
+    using namespace sps;
+    if (npts < 0 || !features_pm || !w1 || !b1 || !out) return fail(SPS_ERR_INVALID, "sa_layer1_per_point: bad arguments");
+    if (npts == 0) return SPS_OK;
+    return launch_point_layer1_pm(npts, c_feat, c1, features_pm, w1, b1, out, as_stream(stream));
+}
+
+// 1 if mode bit 32 (layer 1's feature product per point) is served for these widths
+extern "C" int sps_sa_layer1_per_point_supported(int c_feat, int c1, int nsample) {
+    return ((c_feat == 64 && c1 == 64) || (c_feat == 128 && c1 == 128)) && nsample <= 32;
 }

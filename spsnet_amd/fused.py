@@ -393,8 +393,41 @@ def attach_point_major_twin(features):
     return features
 
 
+# Layer 1 of the exact-fp32 point-major kernel over the FEATURE channels once per point instead of once per grouped point
+# (csrc/sa_mlp_pm.hip HOIST1): a point's features meet the same weights in every ball it falls into.  Pays when a layer has
+# several times more grouped points than points (IA-SSD layer 2: 16 x); the sums are formed in a different order (features
+# first, per point; then the coordinates) -- within 1e-4 of torch either way, like any two fp32 GEMM schedules.
+# OPT-IN: measured at the bench shape (MI355X, strict fp32) the grouped launches of layer 2 get 12-18 % shorter (257 -> 227 us,
+# 95 -> 78 us alone; together 256 -> 230), and the two per-point launches in front of them (10 us each, beside the sampler)
+# give back all but ~8 us of it -- 2.307 -> 2.300 ms per pass, inside the box-to-box spread.
+HOIST_LAYER1 = __import__("os").environ.get("SPS_HOIST_LAYER1", "0") != "0"
+HOIST_LAYER1_MIN_RATIO = 4
+
+
+def can_hoist_layer1(packed, B, N, M, nsample):
+    """Would layer 1's per-point form serve this scale (exact fp32 on the twin, supported widths, enough reuse)?"""
+    if not (HOIST_LAYER1 and packed.point_major and packed.split == 0 and not packed.half):
+        return False
+    return bool(_L.sps_sa_layer1_per_point_supported(packed.cin - 3, packed.c1, nsample)) and M * nsample >= HOIST_LAYER1_MIN_RATIO * N
+
+
+def layer1_per_point(features, packed, out=None):
+    """b1 + W1f . features[point] for every point of the features' (B, N, C) twin -> (B, N, c1) fp32 (current stream)."""
+    twin = point_major_twin(features)
+    if twin is None:
+        raise ValueError("layer1_per_point needs the feature tensor's (B, N, C) twin")
+    B, N, C = twin.shape
+    if out is None:
+        out = torch.empty((B, N, packed.c1), dtype=torch.float32, device=twin.device)
+    with torch.cuda.device(twin.device):
+        _lib.check(_L.sps_sa_layer1_per_point(B * N, C, packed.c1, twin.data_ptr(), packed.w1.data_ptr(), packed.b1.data_ptr(),
+                                              out.data_ptr(), torch.cuda.current_stream(twin.device).cuda_stream),
+                   "sa_layer1_per_point")
+    return out
+
+
 def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=0, jcount=None, columns=None,
-                   out_point_major=False, run_if=None, full_range_if=None, merge=False, unless_any=None):
+                   out_point_major=False, run_if=None, full_range_if=None, merge=False, unless_any=None, hoisted=None):
     """One launch: gather the nsample neighbours in `idx` (B,M,ns), run the packed 3-layer MLP, max-pool,
     and write channels [channel_offset, channel_offset + c3_real) of out (B, Ctot, M) -- or (B, M, Ctot) with
     out_point_major; optionally only for the centroids [j0, j0+jcount) of every scene.  A scale packed with point_major
@@ -409,7 +442,15 @@ def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=
     jcount = M if jcount is None else jcount
     c_feat = 0 if features is None else features.shape[1]
     mode = int(packed.split)
-    if packed.point_major:
+    if 3 + c_feat != packed.cin:
+        raise ValueError(f"grouped input has {3 + c_feat} channels, the MLP expects {packed.cin}")
+    if hoisted is not None:
+        # layer 1's feature product per point (layer1_per_point): the kernel gathers its rows instead of the features
+        if not (packed.point_major and packed.split == 0 and hoisted.shape == (B, N, packed.c1) and hoisted.is_contiguous()):
+            raise ValueError("`hoisted` is the (B, N, c1) tensor of layer1_per_point for an exact-fp32 point-major scale")
+        features, c_feat = hoisted, packed.c1
+        mode |= 4 | 32
+    elif packed.point_major:
         twin = point_major_twin(features)
         if twin is None:
             raise ValueError("scale packed for point-major features, but the feature tensor carries no (B, N, C) twin")
@@ -421,8 +462,6 @@ def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=
         if columns is None or packed.split == 2:
             raise ValueError("merge mode needs packed columns (served by every kernel but the shared-stream one)")
         mode |= 16
-    if 3 + c_feat != packed.cin:
-        raise ValueError(f"grouped input has {3 + c_feat} channels, the MLP expects {packed.cin}")
     if features is not None and (features.dtype == torch.float16) != bool(packed.half):
         raise ValueError(f"feature tensor is {features.dtype}, but the scale was packed for {'fp16' if packed.half else 'fp32'}")
     c_total = out.shape[2] if out_point_major else out.shape[1]

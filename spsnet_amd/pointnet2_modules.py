@@ -409,10 +409,78 @@ class _PointnetSAModuleBase(nn.Module):
             plan.append(packed)
         return plan
 
-    def _run_scales(self, xyz_c, new_c, feats_c, idxs, plan, out, cols, pm, **kw):
+    def _layer1_per_point(self, xyz_c, new_c, feats_c, plan):
+        """Layer 1's feature product once per point for every scale of the layer (fused.layer1_per_point), on the scale
+        streams -- beside the ball query and the column packing the caller issues next -- or None where it does not pay.
+        -> [(tensor, event, stream)] per scale."""
+        B, N, M = xyz_c.shape[0], xyz_c.shape[1], new_c.shape[1]
+        pre, self._hoisted = getattr(self, "_hoisted", None), None
+        if pre is not None and pre[0] is feats_c and pre[1] == (B, N, M) and all(a is b for a, b in zip(pre[2], plan)):
+            return pre[3]          # forward() started them before the sampler ran (_start_layer1_per_point)
+        if feats_c is None or not all(_fused.can_hoist_layer1(p, B, N, M, g.nsample) for p, g in zip(plan, self.groupers)):
+            return None
+        # A layer that sa_stack may START on a partly written cloud (begin_early_pool: its centroids are a plain D-FPS of the
+        # layer in front, the identity prefix) keeps the grouped form in BOTH schedules: its staged launches and the one-launch
+        # form must pool the same bits
+        types = getattr(self, "sample_type_list", None) or []
+        plain_dfps = len(types) == 1 and ('D-FPS' in types[0] or 'DFS' in types[0]) and not any(
+            t in types[0] for t in ('cls', 'ctr', 'ss'))
+        if plain_dfps and self.early_pool_plan(xyz_c, new_c, feats_c) is not None:
+            return None
+        main = torch.cuda.current_stream(xyz_c.device)
+        side = self._scale_streams(xyz_c)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        order = sorted(range(len(plan)), key=lambda k: -(self.groupers[k].nsample * plan[k].c3))
+        res = [None] * len(plan)
+        twin = _fused.point_major_twin(feats_c)
+        for rank, k in enumerate(order):
+            st = side[0]     # (both on the stream the small scale's launch runs on: one queue to wake, the big scale's rows first)
+            rows = torch.empty((B, N, plan[k].c1), dtype=torch.float32, device=xyz_c.device)
+            with torch.cuda.stream(st):
+                st.wait_event(fork)
+                _fused.layer1_per_point(feats_c, plan[k], out=rows)
+                done = torch.cuda.Event()
+                done.record(st)
+            rows.record_stream(st)
+            twin.record_stream(st)
+            res[k] = (rows, done, st)
+        return res
+
+    def _start_layer1_per_point(self, xyz, features):
+        """forward(), before the sampler runs: the per-point rows of layer 1 need the input features only, so their launches
+        go out first, on the scale streams, and run beside the sampler, the ball query and the column packing."""
+        self._hoisted = None
+        if not (_fused.HOIST_LAYER1 and features is not None and xyz.is_cuda and not self.training and self.npoint_list
+                and getattr(self, "_prepooled", None) is None and xyz.is_contiguous() and features.is_contiguous()
+                and _fused.point_major_twin(features) is not None):
+            return
+        B, N = xyz.shape[0], xyz.shape[1]
+        M = sum(min(n, N) for n in self.npoint_list if n > 0)
+        shape_only = torch.empty((B, M, 3), device="meta")
+        plan = self._fused_plan(xyz, shape_only, features)
+        if not plan or len(plan) != len(self.groupers):
+            return
+        res = self._layer1_per_point(xyz, shape_only, features, plan)
+        if res is not None:
+            self._hoisted = (features, (B, N, M), plan, res)
+
+    def _run_scales(self, xyz_c, new_c, feats_c, idxs, plan, out, cols, pm, hoist=None, **kw):
         """The grouped-MLP launches of a layer's scales into `out` (kw: merge / full_range_if / unless_any of
-        fused.group_mlp_pool)."""
+        fused.group_mlp_pool).  hoist: _layer1_per_point's result."""
         offsets = [sum(p.c3_real for p in plan[:k]) for k in range(len(plan))]
+
+        def rows_for(k):
+            """layer 1's per-point rows of scale k, ordered before the launch that is about to be issued on the current stream"""
+            if hoist is None:
+                return {}
+            rows, done, st = hoist[k]
+            cur = torch.cuda.current_stream(xyz_c.device)
+            if cur.cuda_stream != st.cuda_stream:
+                cur.wait_event(done)
+                rows.record_stream(cur)
+            return dict(hoisted=rows)
+
         if (len(plan) == 2 and all(c is not None for c in cols) and FILL_WITH_SMALL_SCALE
                 and all(p.split == 0 and p.point_major for p in plan)):
             # The exact-fp32 kernels run one wave per SIMD, each wave walking its units: a launch ends when the waves with
@@ -422,13 +490,15 @@ class _PointnetSAModuleBase(nn.Module):
             k0, k1 = sorted(range(2), key=lambda k: -(idxs[k].shape[2] * plan[k].c3))
             main = torch.cuda.current_stream(xyz_c.device)
             side = self._scale_streams(xyz_c)[0]
+            rows0 = rows_for(k0)         # (its wait, if any, goes in FRONT of `ready`: the small launch must not overtake the big one)
             ready = torch.cuda.Event()
             ready.record(main)
-            _fused.group_mlp_pool(xyz_c, new_c, feats_c, idxs[k0], plan[k0], out, offsets[k0], columns=cols[k0], out_point_major=pm, **kw)
+            _fused.group_mlp_pool(xyz_c, new_c, feats_c, idxs[k0], plan[k0], out, offsets[k0], columns=cols[k0], out_point_major=pm,
+                                  **rows0, **kw)
             with torch.cuda.stream(side):
                 side.wait_event(ready)
                 _fused.group_mlp_pool(xyz_c, new_c, feats_c, idxs[k1], plan[k1], out, offsets[k1], columns=cols[k1],
-                                      out_point_major=pm, **kw)
+                                      out_point_major=pm, **rows_for(k1), **kw)
                 done = torch.cuda.Event()
                 done.record(side)
             main.wait_event(done)
@@ -439,7 +509,8 @@ class _PointnetSAModuleBase(nn.Module):
                     t.record_stream(side)
         else:
             for k, (idx, packed) in enumerate(zip(idxs, plan)):
-                _fused.group_mlp_pool(xyz_c, new_c, feats_c, idx, packed, out, offsets[k], columns=cols[k], out_point_major=pm, **kw)
+                _fused.group_mlp_pool(xyz_c, new_c, feats_c, idx, packed, out, offsets[k], columns=cols[k], out_point_major=pm,
+                                      **rows_for(k), **kw)
 
     def early_pool_plan(self, xyz, new_xyz, features):
         """The packed plan of this layer if its grouping can START on a partly written cloud (begin_early_pool), else None:
@@ -514,6 +585,7 @@ class _PointnetSAModuleBase(nn.Module):
             # a point-major `out` is written by the packed-column and the shared-stream kernels only
             pm = bool(point_major_ok) and all(pk or p.split == 2 for pk, p in zip(pack, plan))
             out = alloc((B, M, width) if pm else (B, width, M), dtype=torch.float32, device=xyz.device)
+            hoist = self._layer1_per_point(xyz_c, new_c, feats_c, plan)   # (beside the ball query and the packing below)
             if len(plan) == 2:  # the usual two-scale layer: both ball queries share one scan
                 ga, gb = self.groupers
                 idxs = _ext.ball_query_full2(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz_c, new_c)
@@ -522,7 +594,7 @@ class _PointnetSAModuleBase(nn.Module):
             both = _fused.pack_columns2(idxs[0], idxs[1]) if (len(plan) == 2 and all(pack)) else None   # one launch for both scales
             cols = [both[k] if both is not None else (_fused.pack_columns(idx) if pk else None)
                     for k, (idx, pk) in enumerate(zip(idxs, pack))]
-            self._run_scales(xyz_c, new_c, feats_c, idxs, plan, out, cols, pm)
+            self._run_scales(xyz_c, new_c, feats_c, idxs, plan, out, cols, pm, hoist=hoist)
             if pm:
                 out._sps_point_major = True
             return out
@@ -949,6 +1021,7 @@ class PointnetSAModuleMSG_WithSampling(_SamplingSAModule):
             stds = stds.view(xyz.shape[0], 1, -1).contiguous()
         sampled_idx_list = []
         if ctr_xyz is None:
+            self._start_layer1_per_point(xyz, features)
             sampled_idx_list, new_xyz, stds = self._sample(xyz, features, cls_features, stds)
         else:
             new_xyz = ctr_xyz

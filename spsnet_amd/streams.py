@@ -64,21 +64,32 @@ def new_stream_beside(device, beside: Sequence[torch.cuda.Stream], priority: int
     return st
 
 
-_HELPERS = {}   # (device index, main stream handle) -> {tag: (stream, exclusive)}
+_HELPERS = {}   # (device index, root stream handle) -> {tag: (stream, exclusive)}
+_ROOT = {}      # handle of a stream handed out by helper() -> (root stream handle, root stream): helpers of helpers join the pass
 
 
 def helper(device, main: torch.cuda.Stream, tag: str, exclusive: bool = False) -> torch.cuda.Stream:
-    """The helper stream `tag` of the pass that runs on `main` (one per (device, main stream, tag)).  Every helper runs
-    beside `main` and beside the pass's EXCLUSIVE helpers; an exclusive helper (the FPS producer: one kernel that occupies
-    its queue for most of the pass) runs beside all of them -- anything queued behind it would wait for the whole FPS."""
+    """The helper stream `tag` of the pass that runs on `main` (one per (device, main stream, tag); asked for while one of the
+    pass's own helpers is current, it joins the same pass).  Every helper runs beside the pass's stream and beside the pass's
+    EXCLUSIVE helpers; an exclusive helper (the FPS producer: one kernel that occupies its queue for most of a pass) runs
+    beside all of the pass's streams -- anything queued behind it would wait for the whole FPS.  Passes on different main
+    streams are not ordered against each other (with four hardware queues they could not be)."""
     device = torch.device(device)
-    reg = _HELPERS.setdefault((device.index, main.cuda_stream), {})
+    root_handle, root = _ROOT.get((device.index, main.cuda_stream), (main.cuda_stream, main))
+    reg = _HELPERS.setdefault((device.index, root_handle), {})
     if tag not in reg:
-        others = [s for s, ex in reg.values() if ex or exclusive]
-        reg[tag] = (new_stream_beside(device, [main] + others), exclusive)
+        beside = [root] + [s for s, ex in reg.values() if ex or exclusive]
+        if main.cuda_stream != root_handle:
+            beside.append(main)
+        uniq = {}
+        for s_ in beside:
+            uniq.setdefault(s_.cuda_stream, s_)
+        st = new_stream_beside(device, list(uniq.values()))
+        reg[tag] = (st, exclusive)
+        _ROOT.setdefault((device.index, st.cuda_stream), (root_handle, root))
     return reg[tag][0]
 
 
 def forget(device, main: torch.cuda.Stream):
-    """Drop the helpers registered for `main` (the CuFence set-up replaces them with CU-masked streams)."""
+    """Drop the helpers registered for the pass on `main`."""
     _HELPERS.pop((torch.device(device).index, main.cuda_stream), None)

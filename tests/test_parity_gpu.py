@@ -3078,3 +3078,68 @@ def test_helper_streams_really_run_beside_the_pass(dev):
         y = x * 2
     producer.synchronize()
     assert float(y.sum()) == 2.0 * (1 << 20)
+
+
+# ------------------------------------------------------------------ exact fp32: layer 1's feature product once per point
+@pytest.mark.parametrize("cf,widths", [(64, ([64, 64, 128], [64, 96, 128])), (128, ([128, 128, 256], [128, 256, 256]))])
+def test_layer1_per_point_form_matches_the_grouped_one(ext, G, dev, cf, widths):
+    """sps_sa_layer1_per_point + mode bit 32 of the exact-fp32 point-major kernel: b1 + W1f . features once per POINT, the
+    coordinate k-step per grouped point.  Against the kernel that multiplies the features per grouped point: the same pooled
+    features up to summation order (<= 2e-6 of the layer's scale), with packed and unpacked columns, and both within 1e-4 of a
+    float64 restatement of group -> SharedMLP -> max-pool (pointnet2_modules.py:114-122, eval-mode BatchNorm folded)."""
+    from spsnet_amd import fused, pointnet2_modules as M
+    rng = np.random.default_rng(cf)
+    B, N, Mc = 2, 1024, 512
+    x = G.t(cloud(rng, B, N, dup=0.02))
+    new_xyz = x[:, :Mc].contiguous()
+    feats = fused.attach_point_major_twin(torch.randn(B, cf, N, device=dev))
+    old, old_hoist = fused.set_precision("fp32"), fused.HOIST_LAYER1
+    fused.HOIST_LAYER1 = True      # (opt-in: SPS_HOIST_LAYER1=1)
+    try:
+        mod = M.PointnetSAModuleMSG_WithSampling(
+            npoint_list=[Mc], sample_range_list=[-1], sample_type_list=['ctr_aware'], radii=[0.8, 1.6], nsamples=[16, 32],
+            mlps=[[cf] + widths[0], [cf] + widths[1]], use_xyz=True, dilated_group=False, aggregation_mlp=None,
+            confidence_mlp=None, num_class=3).to(dev).eval()
+        for mlp in mod.mlps:                       # non-trivial BatchNorm statistics
+            for layer in mlp:
+                if isinstance(layer, torch.nn.BatchNorm2d):
+                    layer.running_mean.uniform_(-0.2, 0.2)
+                    layer.running_var.uniform_(0.5, 1.5)
+                    layer.weight.data.uniform_(0.5, 1.5)
+                    layer.bias.data.uniform_(-0.2, 0.2)
+        with torch.no_grad():
+            plan = mod._fused_plan(x, new_xyz, feats)
+            assert plan and all(p.split == 0 and p.point_major for p in plan)
+            assert all(fused.can_hoist_layer1(p, B, N, Mc, g.nsample) for p, g in zip(plan, mod.groupers))
+            ga, gb = mod.groupers
+            width = sum(p.c3_real for p in plan)
+            idxs = ext.ball_query_full2(ga.radius, ga.nsample, gb.radius, gb.nsample, x, new_xyz)
+            packs = fused.pack_columns2(*idxs)
+            hoist = mod._layer1_per_point(x, new_xyz, feats, plan)
+            assert hoist is not None
+            outs = {}
+            for name, cols, h in (("plain", [None, None], None), ("plain-packed", list(packs), None),
+                                  ("per-point", [None, None], hoist), ("per-point-packed", list(packs), hoist)):
+                pm = cols[0] is not None
+                out = torch.empty((B, Mc, width) if pm else (B, width, Mc), device=dev)
+                mod._run_scales(x, new_xyz, feats, idxs, plan, out, cols, pm, hoist=h)
+                torch.cuda.synchronize()
+                outs[name] = out.transpose(1, 2) if pm else out
+            # float64 restatement
+            want = []
+            for g, mlp, idx in zip(mod.groupers, mod.mlps, idxs):
+                grouped = torch.cat([(x.transpose(1, 2).double()[:, :, None, :].expand(B, 3, Mc, N).gather(
+                                        3, idx.long()[:, None].expand(B, 3, Mc, g.nsample)) - new_xyz.transpose(1, 2).double()[..., None]),
+                                     feats.double()[:, :, None, :].expand(B, cf, Mc, N).gather(
+                                        3, idx.long()[:, None].expand(B, cf, Mc, g.nsample))], dim=1)
+                want.append(mlp.double()(grouped).amax(dim=3))
+                mlp.float()
+            want = torch.cat(want, dim=1)
+        scale = float(want.abs().max())
+        assert torch.equal(outs["plain"], outs["plain-packed"]) and torch.equal(outs["per-point"], outs["per-point-packed"])
+        assert float((outs["per-point"] - outs["plain"]).abs().max()) <= 2e-6 * scale
+        for name in ("plain", "per-point"):
+            assert float((outs[name].double() - want).abs().max()) <= 1e-4 * max(scale, 1.0), name
+    finally:
+        fused.set_precision(old)
+        fused.HOIST_LAYER1 = old_hoist

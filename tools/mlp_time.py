@@ -32,13 +32,25 @@ for widths, ns, radius in SCALES:
         assert plan, "no fused kernel for this scale"
         idx = U.ball_query(radius, ns, xyz, new_xyz)
         out = torch.zeros((B, widths[-1], Mc), device=dev)
+        kw = {}
+        if os.environ.get("MLP_TIME_HOIST", "0") == "1":   # layer 1's feature product once per point (timed separately)
+            rows = fused.layer1_per_point(feats, plan[0])
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(30):
+                fused.layer1_per_point(feats, plan[0], out=rows)
+            e1.record()
+            torch.cuda.synchronize()
+            print(f"   layer1_per_point: {e0.elapsed_time(e1) / 30 * 1e3:.1f} us")
+            kw = dict(hoisted=rows)
         for _ in range(3):
-            fused.group_mlp_pool(xyz, new_xyz, feats, idx, plan[0], out, 0)
+            fused.group_mlp_pool(xyz, new_xyz, feats, idx, plan[0], out, 0, **kw)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(30):
-            fused.group_mlp_pool(xyz, new_xyz, feats, idx, plan[0], out, 0)
+            fused.group_mlp_pool(xyz, new_xyz, feats, idx, plan[0], out, 0, **kw)
         e1.record()
         torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 30 * 1e3
