@@ -58,37 +58,36 @@ class Surface_PW_feature(nn.Module):
             channel_out_list.append(channel_out)
         self.num_point_features = channel_out
 
-    def break_up_pc(self, pc):
-        batch_idx = pc[:, 0]
-        xyz = pc[:, 1:4].contiguous()
-        features = (pc[:, 4:].contiguous() if pc.size(-1) > 4 else None)
-        return batch_idx, xyz, features
+    @staticmethod
+    def _columns(points):
+        """(sum of points, 1 + 3 + C) rows [scene, x, y, z, features ...] -> (scene, xyz, features or None)."""
+        extra = points.shape[-1] - 4
+        return points[:, 0], points[:, 1:4].contiguous(), (points[:, 4:].contiguous() if extra > 0 else None)
+
+    def break_up_pc(self, pc):   # (the reference's name for it, :106-110)
+        return self._columns(pc)
 
     def forward(self, batch_dict):
-        batch_size = batch_dict['batch_size']
-        points = batch_dict['points']
-        batch_idx, xyz, features = self.break_up_pc(points)
-        counts_ok = equal_counts_check(batch_idx, batch_size)   # verdict read once the layers are in the queue
-        xyz = xyz.view(batch_size, -1, 3)
-        features = (features.view(batch_size, -1, features.shape[-1]).permute(0, 2, 1).contiguous()
-                    if features is not None else None)
-        encoder_xyz, encoder_features, sa_ins_preds = [xyz], [features], []
-        encoder_coords = [torch.cat([batch_idx.view(batch_size, -1, 1), xyz], dim=-1)]
-        for i in range(len(self.SA_modules)):
-            xyz_input = encoder_xyz[self.layer_inputs[i]]
-            feature_input = encoder_features[self.layer_inputs[i]]
-            ctr_xyz = encoder_xyz[self.ctr_idx_list[i]] if self.ctr_idx_list[i] != -1 else None
-            li_xyz, li_features, _ = self.SA_modules[i](xyz_input, feature_input, None, ctr_xyz=ctr_xyz)
-            encoder_xyz.append(li_xyz)
-            li_batch_idx = batch_idx.view(batch_size, -1)[:, :li_xyz.shape[1]]
-            encoder_coords.append(torch.cat([li_batch_idx[..., None].float(), li_xyz.view(batch_size, -1, 3)], dim=-1))
-            encoder_features.append(li_features)
-            sa_ins_preds.append([])
+        """Reads `batch_size`, `points`; adds `encoder_xyz`, `encoder_coords`, `sa_ins_preds` and `soc_feature` (B, N, C): the
+        keys the reference's forward leaves in the dict (:112-168)."""
+        B = batch_dict['batch_size']
+        owner, xyz, feats = self._columns(batch_dict['points'])
+        counts_ok = equal_counts_check(owner, B)            # verdict read once the layers are in the queue
+        owner, xyz = owner.view(B, -1), xyz.view(B, -1, 3)
+        if feats is not None:
+            feats = feats.view(B, xyz.shape[1], -1).transpose(1, 2).contiguous()
+        levels = [(xyz, feats)]                             # the input cloud, then every SA layer's (centroids, features)
+        coords = [torch.cat([owner.unsqueeze(-1), xyz], dim=-1)]
+        for layer, src, ctr in zip(self.SA_modules, self.layer_inputs, self.ctr_idx_list):
+            in_xyz, in_feats = levels[src]
+            out_xyz, out_feats, _ = layer(in_xyz, in_feats, None, ctr_xyz=levels[ctr][0] if ctr != -1 else None)
+            levels.append((out_xyz, out_feats))
+            m = out_xyz.shape[1]
+            coords.append(torch.cat([owner[:, :m].unsqueeze(-1).float(), out_xyz.reshape(B, m, 3)], dim=-1))
         counts_ok()
-        batch_dict['encoder_xyz'] = encoder_xyz
-        batch_dict['encoder_coords'] = encoder_coords
-        batch_dict['sa_ins_preds'] = sa_ins_preds
-        batch_dict['soc_feature'] = encoder_features[-1].permute(0, 2, 1).contiguous()
+        batch_dict.update(encoder_xyz=[lv[0] for lv in levels], encoder_coords=coords,
+                          sa_ins_preds=[[] for _ in self.SA_modules],
+                          soc_feature=levels[-1][1].transpose(1, 2).contiguous())
         return batch_dict
 
 
