@@ -339,6 +339,13 @@ int sps_pack_columns2(int b, int m, int j0, int jcount, int nsample_a, const int
 int sps_ball_query_full2_points(int b, int n, int m, int k0, int kcount, float radius_a, int nsample_a, float radius_b,
                                 int nsample_b, const float *new_xyz, const float *xyz, int *idx_a, int *idx_b,
                                 const int *all_points_if, const int *all_points_if_any, int any_count, sps_stream_t stream);
+/* ... with gather_idx (device i32 (b, m), may be NULL): the centroids are xyz[gather_idx[scene][j]] and the launch also writes
+ * them to new_xyz (as sps_ball_query_full2_range does): the last stage takes the sampler's verified picks here instead of a
+ * gather launch in front of it (pointnet2_modules.py:423-424 fused in). */
+int sps_ball_query_full2_points_gather(int b, int n, int m, int k0, int kcount, float radius_a, int nsample_a, float radius_b,
+                                       int nsample_b, const float *new_xyz, const float *xyz, int *idx_a, int *idx_b,
+                                       const int *all_points_if, const int *all_points_if_any, int any_count,
+                                       const int *gather_idx, sps_stream_t stream);
 int sps_pack_columns2_late(int b, int m, int last_stage, int nsample_a, const int *prev_a, const int *idx_a, int *taken_a, int *cols_a,
                            unsigned *meta_a, int *ntiles_a, long long tile_cap_a, int nsample_b, const int *prev_b,
                            const int *idx_b, int *taken_b, int *cols_b, unsigned *meta_b, int *ntiles_b, long long tile_cap_b,

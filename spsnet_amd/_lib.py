@@ -113,6 +113,7 @@ _PROTOS = {
     "sps_pack_columns2_late": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                ctypes.c_longlong, _vp, _vp, _i, _vp],
     "sps_ball_query_full2_points": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "sps_ball_query_full2_points_gather": [_i, _i, _i, _i, _i, _f, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "sps_sa_group_mlp_packed_merge": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _i,
                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "sps_sa_group_mlp_packed": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _i,

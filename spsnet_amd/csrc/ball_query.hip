@@ -734,6 +734,17 @@ extern "C" int sps_ball_query_full2_points(int b, int n, int m, int k0, int kcou
                                            int nsample_b, const float *new_xyz, const float *xyz, int *idx_a, int *idx_b,
                                            const int *all_points_if, const int *all_points_if_any, int any_count,
                                            sps_stream_t stream) {
+    return sps_ball_query_full2_points_gather(b, n, m, k0, kcount, radius_a, nsample_a, radius_b, nsample_b, new_xyz, xyz, idx_a,
+                                              idx_b, all_points_if, all_points_if_any, any_count, nullptr, stream);
+}
+
+// gather_idx (device i32 (b, m), may be NULL): the centroids are xyz[gather_idx[scene][j]] and the launch also WRITES them to
+// new_xyz (as in sps_ball_query_full2_range) -- the last stage of a layer whose centroids were guessed takes the sampler's
+// verified picks here instead of a gather launch in front of it.
+extern "C" int sps_ball_query_full2_points_gather(int b, int n, int m, int k0, int kcount, float radius_a, int nsample_a,
+                                                  float radius_b, int nsample_b, const float *new_xyz, const float *xyz, int *idx_a,
+                                                  int *idx_b, const int *all_points_if, const int *all_points_if_any, int any_count,
+                                                  const int *gather_idx, sps_stream_t stream) {
     using namespace sps;
     if (b < 0 || n < 256 || m < 0 || (m % 4) || nsample_a <= 0 || nsample_b <= 0 || nsample_a > BQS_MAX_NS || nsample_b > BQS_MAX_NS ||
         k0 < 0 || kcount < 0 || k0 + kcount > n || (long long)b * m > BQ_WAVE_MAX_CENTROIDS || b > 65535)
@@ -747,11 +758,11 @@ extern "C" int sps_ball_query_full2_points(int b, int n, int m, int k0, int kcou
     if (kcount >= 2048)
         hipLaunchKernelGGL((ball_query_wave_multi_kernel<4, 4, 8>), grid, dim3(64 * 4), 0, as_stream(stream), n, m, ra2, rb2,
                            nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, 0, (const int *)nullptr, (const int *)nullptr,
-                           (const int *)nullptr, k0, kcount, all_points_if, all_points_if_any, any_count);
+                           gather_idx, k0, kcount, all_points_if, all_points_if_any, any_count);
     else
         hipLaunchKernelGGL((ball_query_wave_multi_kernel<4, 4, 4>), grid, dim3(64 * 4), 0, as_stream(stream), n, m, ra2, rb2,
                            nsample_a, nsample_b, new_xyz, xyz, idx_a, idx_b, 0, (const int *)nullptr, (const int *)nullptr,
-                           (const int *)nullptr, k0, kcount, all_points_if, all_points_if_any, any_count);
+                           gather_idx, k0, kcount, all_points_if, all_points_if_any, any_count);
     return check_launch("ball_query_wave_multi_kernel<points>");
 }
 

@@ -548,20 +548,22 @@ def ball_query_full2_range(radius_a, radius_b, xyz, new_xyz, idx_a, idx_b, j0, j
                                                  _stream(xyz)), "ball_query_full2_range")
 
 
-def ball_query_full2_points(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz, k0, kcount, full_if=None, full_if_any=None):
+def ball_query_full2_points(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz, k0, kcount, full_if=None, full_if_any=None,
+                            gather_idx=None):
     """Both radii for ALL centroids over the points [k0, k0 + kcount) of every scene only -> (idx_a, idx_b), every row written
     (first nsample hits among those points in index order; zeros when there is none).  full_if (device int32) /
-    full_if_any (device int32 array): while either says so the launch scans the whole scene instead (a repair)."""
+    full_if_any (device int32 array): while either says so the launch scans the whole scene instead (a repair).
+    gather_idx (B, M) int32: the centroids are xyz[gather_idx] and the launch writes them into new_xyz (in place)."""
     B, N, _ = xyz.shape
     M = new_xyz.shape[1]
     ia = torch.empty((B, M, nsample_a), dtype=I32, device=xyz.device)
     ib = torch.empty((B, M, nsample_b), dtype=I32, device=xyz.device)
     with _on(xyz):
-        _lib.check(_L.sps_ball_query_full2_points(B, N, M, int(k0), int(kcount), radius_a, nsample_a, radius_b, nsample_b,
-                                                  _ptr(new_xyz, F32, "new_xyz"), _ptr(xyz, F32, "xyz"), ia.data_ptr(), ib.data_ptr(),
-                                                  _flag(full_if), 0 if full_if_any is None else _ptr(full_if_any, I32, "flags"),
-                                                  0 if full_if_any is None else full_if_any.numel(), _stream(xyz)),
-                   "ball_query_full2_points")
+        _lib.check(_L.sps_ball_query_full2_points_gather(
+            B, N, M, int(k0), int(kcount), radius_a, nsample_a, radius_b, nsample_b, _ptr(new_xyz, F32, "new_xyz"),
+            _ptr(xyz, F32, "xyz"), ia.data_ptr(), ib.data_ptr(), _flag(full_if),
+            0 if full_if_any is None else _ptr(full_if_any, I32, "flags"), 0 if full_if_any is None else full_if_any.numel(),
+            0 if gather_idx is None else _ptr(gather_idx, I32, "gather_idx"), _stream(xyz)), "ball_query_full2_points")
     return ia, ib
 
 

@@ -560,16 +560,21 @@ class _PointnetSAModuleBase(nn.Module):
         the fused path may return them point-major, (B, M, sum C_out), tagged `_sps_point_major`: the grouped-MLP kernels
         then write a centroid's pooled rows contiguously."""
         pre, self._prepooled = getattr(self, "_prepooled", None), None
+        picks, self._late_gather_idx = getattr(self, "_late_gather_idx", None), None
         plan = self._fused_plan(xyz, new_xyz, features)
-        if plan and pre is not None and pre[0] is xyz and pre[1] is features and point_major_ok and \
-                pre[2].shape[:2] == (xyz.shape[0], new_xyz.shape[1]) and not any(p.split == 2 for p in plan):
+        late = bool(plan and pre is not None and pre[0] is xyz and pre[1] is features and point_major_ok and
+                    pre[2].shape[:2] == (xyz.shape[0], new_xyz.shape[1]) and not any(p.split == 2 for p in plan))
+        if picks is not None and not (late and pre[7] is new_xyz and new_xyz.is_contiguous()):
+            new_xyz.copy_(_ext.gather_xyz(xyz.contiguous(), picks.contiguous()))   # nobody will gather for us: do it here
+            picks = None
+        if late:
             # the early columns are in `out` already (begin_early_pool): query, pack and merge the LATE ones -- or, while a
             # repair flag is up, everything again with plain stores, inside the same three launches
             _, _, out, taken, n_early, flag, flags_any, _ = pre
             ga, gb = self.groupers
             new_c = new_xyz.contiguous()
             ia, ib = _ext.ball_query_full2_points(ga.radius, ga.nsample, gb.radius, gb.nsample, xyz, new_c, n_early,
-                                                  xyz.shape[1] - n_early, full_if=flag, full_if_any=flags_any)
+                                                  xyz.shape[1] - n_early, full_if=flag, full_if_any=flags_any, gather_idx=picks)
             ca, cb, _ = _fused.pack_columns2_staged(ia, ib, True, prev=taken, full_if=flag, full_if_any=flags_any)
             self._run_scales(xyz, new_c, features, (ia, ib), plan, out, [ca, cb], True, merge=True, full_range_if=flag,
                              unless_any=flags_any)
@@ -769,6 +774,8 @@ def _sample_dfps(mod, ctx):
                 idx.record_stream(main)
             if len(pre) > 3 and ctx.whole:
                 ctx.new_xyz = pre[3]          # the streamed queries gathered the centroids already
+                # ... or guessed them (sa_stack, early stages): the layer's last ball query gathers xyz[idx] into them
+                mod._late_gather_idx = idx if (len(pre) > 4 and pre[4]) else None
             if ctx.stds is not None:
                 _thin_stds(ctx, idx)
             return idx

@@ -206,6 +206,8 @@ _CHUNK_ENDS_16 = tuple(int(v) for v in os.environ.get("SPS_CHUNK_ENDS", "3,6,9,1
 # chunking (4, 8, 12, 14, 15, 16) and stages at (8, 12) 2.355 -- the second stage pushed the last chunks back by 0.05 ms --,
 # and a stage behind the 14/16 chunk costs more than it saves (+0.08 ms).
 EARLY_POOL_AT_16 = tuple(int(v) for v in os.environ.get("SPS_EARLY_POOL_AT", "6,9,12").split(",") if v)
+# the next layer's last stage gathers its verified centroids inside its ball query instead of a launch in front of it
+LATE_GATHER = os.environ.get("SPS_LATE_GATHER", "1") != "0"
 # the second pass of the next layer's identity-prefix check chunk by chunk beside the producer instead of whole behind it
 EARLY_PREFIX_CHECK = os.environ.get("SPS_EARLY_PREFIX_CHECK", "1") != "0"
 _TIMEOUT_FLAGS = []   # device flags of recent streamed passes (diagnostics only: see check_timeouts)
@@ -341,7 +343,14 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
             if verify is not None and verify.checked > 0:
                 # the centroids of the earlier chunks went through the second pass as they arrived (below): what is left is
                 # this chunk's share, ~5 us -- in line, so that the next layer's sampling costs no stream hop at all
-                nxt._presampled = (verify.finish(force_redo=timed_out), None, new_xyz)
+                picks = verify.finish(force_redo=timed_out)
+                if LATE_GATHER and guess is not None and getattr(nxt, "_prepooled", None) is not None \
+                        and getattr(nxt, "_on_new_xyz", None) is None:
+                    # the next layer's centroids: the guess its early stages ran on, corrected IN PLACE by its last ball query,
+                    # which gathers xyz[picks] itself (sps_ball_query_full2_points_gather) -- no gather launch on the chain
+                    nxt._presampled = (picks, None, new_xyz, guess, True)
+                else:
+                    nxt._presampled = (picks, None, new_xyz)
                 verify, verified_inline = None, True
             else:
                 xyz_ready = torch.cuda.Event()
