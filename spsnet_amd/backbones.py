@@ -19,7 +19,7 @@ import copy
 import torch
 import torch.nn as nn
 
-from . import pointnet2_modules, pointnet2_utils, sa_stack, streams, surface_feature
+from . import _lib, pointnet2_modules, pointnet2_utils, sa_stack, streams, surface_feature
 
 
 _CHECK_STREAMS = {}
@@ -311,7 +311,7 @@ _SURFACE_STREAMS = {}
 
 
 def _surface_stream(device):
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.type, device.index, _lib.raw_stream(device))
     if key not in _SURFACE_STREAMS:
         _SURFACE_STREAMS[key] = streams.helper(device, torch.cuda.current_stream(device), "surface")
     return _SURFACE_STREAMS[key]

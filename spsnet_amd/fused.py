@@ -291,7 +291,7 @@ _COUNTERS = {}
 
 def _zero_counter(device):
     """A zeroed int32 on the device without a fill launch per use: slices of a pre-zeroed buffer, refilled every 256 uses."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.type, device.index, _lib.raw_stream(device))
     buf, used = _COUNTERS.get(key, (None, 256))
     if used >= 256:
         buf, used = torch.zeros((256,), dtype=torch.int32, device=device), 0
@@ -314,7 +314,7 @@ def pack_columns(idx, j0=0, jcount=None):
     p.meta = torch.empty((p.cap * 16,), dtype=torch.int32, device=idx.device)
     p.ntiles = _zero_counter(idx.device)
     _lib.check(_L.sps_pack_columns(B, M, j0, jcount, ns, idx.data_ptr(), p.cols.data_ptr(), p.meta.data_ptr(),
-                                   p.ntiles.data_ptr(), p.cap, torch.cuda.current_stream(idx.device).cuda_stream), "pack_columns")
+                                   p.ntiles.data_ptr(), p.cap, _lib.raw_stream(idx.device)), "pack_columns")
     return p
 
 
@@ -334,7 +334,7 @@ def pack_columns2(idx_a, idx_b):
     _lib.check(_L.sps_pack_columns2(B, M, 0, M, idx_a.shape[2], idx_a.data_ptr(), a.cols.data_ptr(), a.meta.data_ptr(),
                                     a.ntiles.data_ptr(), a.cap, idx_b.shape[2], idx_b.data_ptr(), b.cols.data_ptr(),
                                     b.meta.data_ptr(), b.ntiles.data_ptr(), b.cap,
-                                    torch.cuda.current_stream(idx_a.device).cuda_stream), "pack_columns2")
+                                    _lib.raw_stream(idx_a.device)), "pack_columns2")
     return a, b
 
 
@@ -363,7 +363,7 @@ def pack_columns2_staged(idx_a, idx_b, last, prev=None, full_if=None, full_if_an
                                          ptr(pb), idx_b.data_ptr(), taken[1].data_ptr(), b.cols.data_ptr(), b.meta.data_ptr(),
                                          b.ntiles.data_ptr(), b.cap, ptr(full_if), ptr(full_if_any),
                                          0 if full_if_any is None else full_if_any.numel(),
-                                         torch.cuda.current_stream(idx_a.device).cuda_stream), "pack_columns2_late")
+                                         _lib.raw_stream(idx_a.device)), "pack_columns2_late")
     return a, b, tuple(taken)
 
 
@@ -421,7 +421,7 @@ def layer1_per_point(features, packed, out=None):
         out = torch.empty((B, N, packed.c1), dtype=torch.float32, device=twin.device)
     with torch.cuda.device(twin.device):
         _lib.check(_L.sps_sa_layer1_per_point(B * N, C, packed.c1, twin.data_ptr(), packed.w1.data_ptr(), packed.b1.data_ptr(),
-                                              out.data_ptr(), torch.cuda.current_stream(twin.device).cuda_stream),
+                                              out.data_ptr(), _lib.raw_stream(twin.device)),
                    "sa_layer1_per_point")
     return out
 
@@ -465,7 +465,7 @@ def group_mlp_pool(xyz, new_xyz, features, idx, packed, out, channel_offset, j0=
     if features is not None and (features.dtype == torch.float16) != bool(packed.half):
         raise ValueError(f"feature tensor is {features.dtype}, but the scale was packed for {'fp16' if packed.half else 'fp32'}")
     c_total = out.shape[2] if out_point_major else out.shape[1]
-    stream = torch.cuda.current_stream(xyz.device).cuda_stream
+    stream = _lib.raw_stream(xyz.device)
     cp = (0, 0, 0, 0) if columns is None else (columns.cols.data_ptr(), columns.meta.data_ptr(), columns.ntiles.data_ptr(),
                                                columns.cap)
     _lib.check(_L.sps_sa_group_mlp_packed_merge(
@@ -542,7 +542,7 @@ class TailRunner:
                                            (1 if self.half_out else 0) | (2 if self.x_pm else 0),
                                            0 if run_if is None else run_if.data_ptr(),
                                            0 if full_range_if is None else full_range_if.data_ptr(),
-                                           torch.cuda.current_stream(self.x.device).cuda_stream), "pointwise_mlp")
+                                           _lib.raw_stream(self.x.device)), "pointwise_mlp")
 
     def result(self):
         self.y1._sps_nc = self.y1t
@@ -735,7 +735,7 @@ def fp_module_mlp(mlp, known_feats, unknow_feats, idx, weight, dist=None, point_
     _lib.check(_L.sps_fp_module_mlp_ex(B, n, m, c_known, c_skip, c1, c2, kf.data_ptr(), sk.data_ptr() if sk is not None else 0,
                                        ix.data_ptr(), wt.data_ptr(), from_dist, packed.w1.data_ptr(), packed.b1.data_ptr(),
                                        packed.w2.data_ptr() if c2 else 0, packed.b2.data_ptr() if c2 else 0, y.data_ptr(),
-                                       1 if point_major else 0, torch.cuda.current_stream(y.device).cuda_stream), "fp_module_mlp")
+                                       1 if point_major else 0, _lib.raw_stream(y.device)), "fp_module_mlp")
     if point_major:
         y._sps_point_major = True
     return y
@@ -790,7 +790,7 @@ def vote_offsets(mlp, ctr_reg, parts):
     y3 = torch.empty((B, M, classes), dtype=torch.float32, device=x.device)
     _lib.check(_L.sps_pointwise_mlp(B, M, cin_pad, c1, c1, classes, x.data_ptr(), packed.w1.data_ptr(), packed.b1.data_ptr(),
                                     packed.w2.data_ptr(), packed.b2.data_ptr(), packed.w3.data_ptr(), packed.b3.data_ptr(),
-                                    y1.data_ptr(), 0, y3.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream),
+                                    y1.data_ptr(), 0, y3.data_ptr(), _lib.raw_stream(x.device)),
                "pointwise_mlp (vote)")
     return y3
 
@@ -859,7 +859,7 @@ def dense_edge_conv(conv, x, idx):
     _lib.check(_L.sps_dense_edge_conv(B, N, d, idx.shape[2], conv.growth_rate, packed.form, x.data_ptr(),
                                       idx.data_ptr(), packed.w1.data_ptr(), packed.b1.data_ptr(), packed.w2.data_ptr(),
                                       packed.b2.data_ptr(), packed.w3.data_ptr(), packed.b3.data_ptr(), out.data_ptr(),
-                                      torch.cuda.current_stream(x.device).cuda_stream), "dense_edge_conv")
+                                      _lib.raw_stream(x.device)), "dense_edge_conv")
     return out
 
 
@@ -876,7 +876,7 @@ def linear_rows(fc, x):
     out = torch.empty(x.shape[:-1] + (lin.out_features,), dtype=torch.float32, device=x.device)
     _lib.check(_L.sps_linear_rows(rows, lin.in_features, lin.out_features, x.data_ptr(), lin.weight.data_ptr(),
                                   0 if lin.bias is None else lin.bias.data_ptr(), int(isinstance(fc.activation, nn.ReLU)),
-                                  out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream), "linear_rows")
+                                  out.data_ptr(), _lib.raw_stream(x.device)), "linear_rows")
     return out
 
 
@@ -957,7 +957,7 @@ def dense_edge_conv_backward(conv, x, idx, grad_out, packed):
     _lib.check(_L.sps_dense_edge_conv_bwd(B, N, d, 16, conv.growth_rate, int(rel), x.data_ptr(), idx.data_ptr(),
                                           grad_out.data_ptr(), wf.data_ptr(), wt.data_ptr(), b1.data_ptr(), b2.data_ptr(),
                                           b3.data_ptr(), dxc.data_ptr(), dxn.data_ptr(), partial.data_ptr(), gt.data_ptr(),
-                                          torch.cuda.current_stream(dev).cuda_stream), "dense_edge_conv_bwd")
+                                          _lib.raw_stream(dev)), "dense_edge_conv_bwd")
     scat = torch.zeros((B, d, N), dtype=torch.float32, device=dev)
     _ext.group_points_grad_wrapper(B, d, N, N, 16, dxn, idx, scat)
     dx = dxc + scat.transpose(1, 2)
@@ -985,7 +985,7 @@ class DenseEdgeConvTrain(torch.autograd.Function):
         _lib.check(_L.sps_dense_edge_conv(B, N, d, idx.shape[2], conv.growth_rate, 1 if conv.relative_feat_only else 0,
                                           x.data_ptr(), idx.data_ptr(), wf[:ks1].data_ptr(), pb1.data_ptr(),
                                           wf[ks1:ks1 + 10].data_ptr(), pb2.data_ptr(), wf[ks1 + 10:].data_ptr(), pb3.data_ptr(),
-                                          out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream), "dense_edge_conv")
+                                          out.data_ptr(), _lib.raw_stream(x.device)), "dense_edge_conv")
         ctx.save_for_backward(x, idx)
         ctx.packed, ctx.conv = packed, conv
         return out
@@ -1007,7 +1007,7 @@ class LinearRowsTrain(torch.autograd.Function):
         out = torch.empty(x.shape[:-1] + (weight.shape[0],), dtype=torch.float32, device=x.device)
         _lib.check(_L.sps_linear_rows(rows, cin, weight.shape[0], x.data_ptr(), weight.data_ptr(),
                                       0 if bias is None else bias.data_ptr(), int(relu), out.data_ptr(),
-                                      torch.cuda.current_stream(x.device).cuda_stream), "linear_rows")
+                                      _lib.raw_stream(x.device)), "linear_rows")
         ctx.save_for_backward(x, out, weight)
         ctx.relu, ctx.has_bias = bool(relu), bias is not None
         return out
@@ -1024,5 +1024,5 @@ class LinearRowsTrain(torch.autograd.Function):
         gwb = torch.empty((cout * cin + cout,), dtype=torch.float32, device=x.device)
         _lib.check(_L.sps_linear_rows_bwd(rows, cin, cout, x.data_ptr(), y.data_ptr(), dy.data_ptr(), weight.data_ptr(),
                                           int(ctx.relu), dx.data_ptr(), partial.data_ptr(), gwb.data_ptr(),
-                                          torch.cuda.current_stream(x.device).cuda_stream), "linear_rows_bwd")
+                                          _lib.raw_stream(x.device)), "linear_rows_bwd")
         return dx, gwb[:cout * cin].view(cout, cin), (gwb[cout * cin:] if ctx.has_bias else None), None

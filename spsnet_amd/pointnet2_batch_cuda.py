@@ -51,7 +51,7 @@ def _stream(t):
     sc = _TLS.scope
     if sc is not None and sc[0] == t.device.index:     # a tensor of another device never takes the scoped stream
         return sc[1]
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return _lib.raw_stream(t.device)
 
 
 def _bump_versions(*tensors):
@@ -75,7 +75,7 @@ class launch_scope:
     def __enter__(self):
         self.prev = _TLS.scope
         self.guard.__enter__()
-        _TLS.scope = (self.t.device.index, torch.cuda.current_stream(self.t.device).cuda_stream)
+        _TLS.scope = (self.t.device.index, _lib.raw_stream(self.t.device))
 
     def __exit__(self, *exc):
         _TLS.scope = self.prev

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
 from . import fused as _fused
 from . import pointnet2_batch_cuda as _ext
 from . import pointnet2_utils
@@ -649,7 +650,7 @@ class _PointnetSAModuleBase(nn.Module):
     _SCALE_STREAMS = {}
 
     def _scale_streams(self, like):
-        key = (like.device.index, torch.cuda.current_stream(like.device).cuda_stream)
+        key = (like.device.index, _lib.raw_stream(like.device))
         if key not in _PointnetSAModuleBase._SCALE_STREAMS:
             main = torch.cuda.current_stream(like.device)
             _PointnetSAModuleBase._SCALE_STREAMS[key] = [streams.helper(like.device, main, f"scale{i}") for i in range(2)]

@@ -13,7 +13,7 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
-from . import streams
+from . import _lib, streams
 
 # the three down-sampling SA layers of BASELINE.json's metric (16 384 -> 4 096 -> 1 024 -> 512)
 IASSD_KITTI = dict(
@@ -508,7 +508,7 @@ _ZERO_POOL = {}
 def _zeroed_ints(device, count):
     """`count` zeroed int32 that nobody has written yet: slices of a pre-zeroed buffer (one fill launch per 4096 ints handed
     out instead of one per pass, which sat in front of the FPS producer)."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.type, device.index, _lib.raw_stream(device))
     buf, used = _ZERO_POOL.get(key, (None, 1 << 30))
     if buf is None or used + count > buf.numel():
         buf, used = torch.zeros((max(4096, count),), dtype=torch.int32, device=device), 0
