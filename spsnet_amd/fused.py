@@ -397,10 +397,10 @@ def attach_point_major_twin(features):
 # (csrc/sa_mlp_pm.hip HOIST1): a point's features meet the same weights in every ball it falls into.  Pays when a layer has
 # several times more grouped points than points (IA-SSD layer 2: 16 x); the sums are formed in a different order (features
 # first, per point; then the coordinates) -- within 1e-4 of torch either way, like any two fp32 GEMM schedules.
-# OPT-IN: measured at the bench shape (MI355X, strict fp32) the grouped launches of layer 2 get 12-18 % shorter (257 -> 227 us,
-# 95 -> 78 us alone; together 256 -> 230), and the two per-point launches in front of them (10 us each, beside the sampler)
-# give back all but ~8 us of it -- 2.307 -> 2.300 ms per pass, inside the box-to-box spread.
-HOIST_LAYER1 = __import__("os").environ.get("SPS_HOIST_LAYER1", "0") != "0"
+# Measured at the bench shape (MI355X, strict fp32): the grouped launches of layer 2 get 12-18 % shorter (257 -> 227 us, 95 -> 78 us
+# alone; together 256 -> 230); the two per-point launches in front of them (10 us each, on a scale stream beside the sampler, the
+# ball query and the packing) give half of it back: 2.291 -> 2.277 ms per pass.  SPS_HOIST_LAYER1=0 keeps the grouped form.
+HOIST_LAYER1 = __import__("os").environ.get("SPS_HOIST_LAYER1", "1") != "0"
 HOIST_LAYER1_MIN_RATIO = 4
 
 

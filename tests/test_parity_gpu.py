@@ -3094,7 +3094,7 @@ def test_layer1_per_point_form_matches_the_grouped_one(ext, G, dev, cf, widths):
     new_xyz = x[:, :Mc].contiguous()
     feats = fused.attach_point_major_twin(torch.randn(B, cf, N, device=dev))
     old, old_hoist = fused.set_precision("fp32"), fused.HOIST_LAYER1
-    fused.HOIST_LAYER1 = True      # (opt-in: SPS_HOIST_LAYER1=1)
+    fused.HOIST_LAYER1 = True      # (the default; SPS_HOIST_LAYER1=0 turns it off)
     try:
         mod = M.PointnetSAModuleMSG_WithSampling(
             npoint_list=[Mc], sample_range_list=[-1], sample_type_list=['ctr_aware'], radii=[0.8, 1.6], nsamples=[16, 32],
