@@ -53,6 +53,8 @@ import torch.distributed as dist  # noqa: E402
 
 METRIC = "points/sec through SA stack (FPS+ball-query+grouped-MLP), KITTI 16k→512"
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# issue-rate ceiling of the ball query's pair test (see ball_query_roofline): 1024 SIMDs x 2.4 GHz x 64 lanes / 23.1 cycles
+VALU_PAIR_TEST_PEAK = 1024 * 2.4e9 * 64 / (4 * 2.31 + 2 * 2.72 + 2 * 4.20)
 MFMA_PEAK_TF = {"fp32": 157.3, "fp16x2": 2500.0, "fp16": 2500.0}  # dense peaks: fp32 MFMA, fp16 MFMA (no sparsity)
 PROFILE_DIRS = ("round3", "round2", "round1")
 
@@ -186,7 +188,16 @@ class MlpProbe:
         torch.cuda.synchronize()
         ms = [s.elapsed_time(e) for s, e in pairs]
         packed, idx = call[4], call[3]
-        return {"flop": flop, "ms": float(np.median(ms)), "widths": (packed.cin, packed.c1, packed.c2, packed.c3_real),
+        # what the launch really ISSUES to the matrix cores: the packed tile stream's columns (16 per tile, padding of the
+        # power-of-two slots included) instead of the padded nsample columns per centroid, layer 1 reduced to its coordinate
+        # k-step where its feature product is formed once per point, widths as padded for the MFMA tiles
+        cols_alg = int(idx.shape[0] * (idx.shape[1] if call[8] is None else call[8]) * idx.shape[2])
+        cols_issued = int(kw["columns"].ntiles.item()) * 16 if kw.get("columns") is not None else cols_alg
+        k1 = 4 if kw.get("hoisted") is not None else (packed.cin + 3) // 4 * 4
+        c3p = (packed.c3_real + 15) // 16 * 16
+        flop_issued = 2.0 * cols_issued * (k1 * packed.c1 + packed.c1 * packed.c2 + packed.c2 * c3p)
+        return {"flop": flop, "flop_issued": flop_issued, "columns_issued": cols_issued, "layer1_per_point": kw.get("hoisted") is not None,
+                "ms": float(np.median(ms)), "widths": (packed.cin, packed.c1, packed.c2, packed.c3_real),
                 "packed_columns": kw.get("columns") is not None,
                 "nsample": int(idx.shape[2]), "columns": int(flop / (2.0 * (packed.cin * packed.c1 + packed.c1 * packed.c2
                                                                            + packed.c2 * packed.c3_real)))}
@@ -259,15 +270,22 @@ def ball_query_roofline(ext, layers, xyz, outs, chunk_stats):
     rec = (data or {}).get("ball_query_dual_kernel")
     if rec and (rec["batch"], rec["n"], rec["m"]) == (B, N, M):
         traffic = (rec["fetch_kb"] + rec["write_kb"]) * 1024.0
-    out = {"bound": "hbm", "kernel": f"ball_query_dual_kernel (layer 0, both radii in one scan: {M} centroids x {N} points, "
-                                     f"r {ga.radius}/{gb.radius}, nsample {ga.nsample}/{gb.nsample})",
-           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-           "launch_ms": scan_ms, "algorithmic_bytes": algo, "pair_tests": tests, "pair_tests_per_s": tests / (scan_ms * 1e-3),
+    rate = tests / (scan_ms * 1e-3)
+    out = {"bound": "valu", "kernel": f"ball_query_dual_kernel (layer 0, both radii in one scan: {M} centroids x {N} points, "
+                                      f"r {ga.radius}/{gb.radius}, nsample {ga.nsample}/{gb.nsample})",
+           "pair_tests_per_s": rate, "pair_tests": tests, "valu_issue_frac": rate / VALU_PAIR_TEST_PEAK,
+           "valu_issue_peak_pair_tests_per_s": VALU_PAIR_TEST_PEAK, "launch_ms": scan_ms,
+           "hbm": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                   "algorithmic_bytes": algo},
            "grid_variant_ms": grid_ms,
-           "note": "algorithmic bytes = the compulsory 12 (N + M) + 4 M (ns_a + ns_b) per scene; the kernel is VALU-bound on "
-                   "its M N pair tests (3 sub, 1 mul, 2 fma, 2 compares each), not on HBM: the cloud is re-read from the "
-                   "scalar cache / L2, so `frac` is small by construction and pair_tests_per_s is the figure of merit; "
-                   "grid_variant_ms = the same rows through the cell-grid kernels (ball_query_grid.hip)"}
+           "note": "the kernel is VALU-bound on its M N pair tests, not on HBM (the cloud is re-read from the scalar cache / "
+                   "L2; the `hbm` object prices the compulsory 12 (N + M) + 4 M (ns_a + ns_b) bytes per scene and is small by "
+                   "construction).  valu_issue_frac = pair tests per second / the rate at which the chip can ISSUE the "
+                   "eight VALU instructions of one test for 64 pairs (3 v_sub + v_mul at 2.31, 2 v_fma at 2.72, 2 v_cmp at "
+                   "4.20 cycles per instruction and SIMD with >= 2 waves per SIMD: tools/microbench_valu*.hip, "
+                   "profiles/round1/microbench_valu*_gfx950.txt; 23.1 cycles per 64 tests x 1024 SIMDs at 2.4 GHz = 6.8 T "
+                   "tests/s) -- hit-list bookkeeping and the prefix sums come on top; grid_variant_ms = the same rows "
+                   "through the cell-grid kernels (ball_query_grid.hip)"}
     if chunk_stats is not None:
         out["streamed_chunks"] = dict(chunk_stats, kernel="ball_query_wave_multi_kernel / ball_query_wave_seg_kernel "
                                       "(the step's chunked launches, each gathering its own centroids)")
@@ -398,7 +416,7 @@ def training_step_leg(modules_pkg, sa_stack, cfg, args, xyz, feats, dev, reps=10
     from spsnet_amd import fused
     # the training path's own default arithmetic (the fused train-mode kernels, split-fp16 with exact operand scaling:
     # gradients within 1-3e-6 of float64), whatever the inference legs above were timed with
-    keep = fused.set_precision("fp16x2" if args.mlp_precision != "fp32-train" else "fp32")
+    keep = fused.set_train_precision("fp16x2")
 
     def step(prefetch):
         for p in layers.parameters():
@@ -421,7 +439,7 @@ def training_step_leg(modules_pkg, sa_stack, cfg, args, xyz, feats, dev, reps=10
         torch.cuda.synchronize()
         res[key] = 1e3 * (time.perf_counter() - t0) / reps
     layers[0]._presampled = layers[0]._preball = None
-    fused.set_precision(keep)
+    fused.set_train_precision(keep)
     res["points_per_s"] = xyz.shape[0] * xyz.shape[1] / (res["ms"] * 1e-3)
     res["grouped_mlp"] = ("fused train-mode kernels (csrc/mlp_train.hip), split-fp16 MFMA with exact power-of-two operand scaling"
                           if modules_pkg.FUSED_MLP_TRAINING else "op-by-op fp32 kernels")
@@ -571,6 +589,14 @@ def main():
 
     elapsed, per_step, outs = timed(args.steps, args.warmup)
     fps = probe.summary()
+    # the pass's overlap (FPS producer beside its consumers) is only as good as the placement of its helper streams on
+    # hardware queues: every rank reports whether all of them were SHOWN to run beside the pass (streams.py), AND-reduced
+    from spsnet_amd import streams as _streams
+    overlap_ok = bool(_streams.overlap_verified(dev, torch.cuda.current_stream(dev))) if args.stream_first_layer else None
+    if overlap_ok is not None and world > 1:
+        flag = torch.tensor([1 if overlap_ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        overlap_ok = bool(int(flag.item()))
     checked = validate(outs)
     no_exchange = None
     if exchange:
@@ -661,9 +687,19 @@ def main():
             line["data"] = "synthetic; REHEARSAL: all ranks share one GPU over gloo -- not a measurement"
         if checked is not None:
             line["validated"] = checked
-        from spsnet_amd import streams as _streams   # helper streams are probed for real concurrency with the pass's streams
-        line["helper_streams"] = dict(_streams.stats, note="device-side probes at stream set-up; rejected = streams that shared "
-                                      "a hardware queue with the pass (HIP multiplexes streams onto GPU_MAX_HW_QUEUES queues)")
+        # helper streams are probed for real concurrency with the pass's streams
+        line["helper_streams"] = dict(_streams.stats, note="device-side probes at stream set-up; rejected = candidates that shared "
+                                      "a hardware queue with the pass (HIP multiplexes streams onto GPU_MAX_HW_QUEUES queues); "
+                                      "unplaced = roles that got NO queue of their own: the pass then serialises")
+        if overlap_ok is not None:
+            line["overlap_verified"] = overlap_ok       # all ranks: every helper stream shown to run beside the pass
+            base_ms = (1e3 * no_exchange[0] / args.steps) if no_exchange is not None else 1e3 * elapsed / args.steps
+            if fps is not None and (not overlap_ok or base_ms > fps[0] + 0.8):
+                line["overlap_warning"] = (f"a step without the exchange takes {base_ms:.3f} ms against {fps[0]:.3f} ms for its FPS "
+                                           "launch alone (+0.8 ms allowed for the tail behind the last pick)" +
+                                           ("" if overlap_ok else "; helper streams unplaced: " + ", ".join(_streams.unplaced())) +
+                                           " -- the FPS producer and its consumers are probably sharing a hardware queue "
+                                           "(GPU_MAX_HW_QUEUES)")
         if second_leg is not None:
             el2, per2, chk2, mlp2 = second_leg
             line[f"value_{other}"] = total_points / el2
@@ -692,20 +728,27 @@ def main():
                                         "compulsory 16*N+4*m B/scene and the kernel is latency-, not bandwidth-bound"}
         def mlp_roofline(mlp, precision):
             peak = MFMA_PEAK_TF[precision]
-            ach_tf = mlp["flop"] / (mlp["ms"] * 1e-3) / 1e12
+            ach_alg = mlp["flop"] / (mlp["ms"] * 1e-3) / 1e12
+            issue = 3.0 if precision == "fp16x2" else 1.0      # split-fp16: three fp16 MFMAs per product block
+            ach_tf = issue * mlp["flop_issued"] / (mlp["ms"] * 1e-3) / 1e12
             busy, src = pmc_mfma_busy(mlp["widths"], mlp["nsample"], precision)
             return {
                 "bound": "mfma", "kernel": f"grouped MLP {mlp['widths'][0]}->{mlp['widths'][1]}->{mlp['widths'][2]}->"
                                            f"{mlp['widths'][3]}, nsample {mlp['nsample']}, {mlp['columns']} columns",
                 "achieved": ach_tf, "peak": peak, "unit": "TFLOP/s", "frac": ach_tf / peak, "launch_ms": mlp["ms"],
-                "flop": mlp["flop"], "packed_columns": mlp["packed_columns"],
+                "flop_issued": issue * mlp["flop_issued"], "columns_issued": mlp["columns_issued"],
+                "layer1_per_point": mlp["layer1_per_point"],
+                "achieved_algorithmic": ach_alg, "frac_algorithmic": ach_alg / peak, "flop": mlp["flop"],
+                "packed_columns": mlp["packed_columns"],
                 "mfma_busy_frac": None if busy is None else busy.get("mfma_busy_frac"),
                 "mfma_busy_source": src,
-                "note": "achieved = ALGORITHMIC flop 2*columns*sum(Cin*Cout) of the launch (padded duplicate columns "
-                        "included, as the reference computes them) / HIP-event time of that launch repeated on its own "
-                        "arguments after the timed region; peak = dense MFMA peak of the operand type (fp16x2 issues 3 "
-                        "fp16 MFMAs per product block, so its useful ceiling is a third of it); mfma_busy_frac = "
-                        "SQ_VALU_MFMA_BUSY_CYCLES / (kernel duration x 1024 SIMDs x 2.4 GHz) from the committed PMC pass"}
+                "note": "frac = UTILISATION: the MFMA flop the launch issues (packed tile stream x 16 columns, layer 1 without "
+                        "its hoisted per-point feature product, MFMA-tile widths; x3 for split-fp16) / HIP-event time of "
+                        "that launch repeated on its own arguments after the timed region / dense MFMA peak of the operand "
+                        "type; frac_algorithmic = the reference's flop 2*columns*sum(Cin*Cout) (padded duplicate columns "
+                        "included, as the reference computes them) over the same time -- a speed-up figure, not a "
+                        "utilisation; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (kernel duration x 1024 SIMDs x 2.4 GHz) "
+                        "from the committed PMC pass (the counter's view of the same thing)"}
         if mlp is not None:
             line["roofline_mlp"] = mlp_roofline(mlp, args.mlp_precision)
         if second_leg is not None and second_leg[3] is not None:   # the other leg's dominant launch on its own pipe

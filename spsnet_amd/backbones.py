@@ -22,7 +22,6 @@ import torch.nn as nn
 from . import _lib, pointnet2_modules, pointnet2_utils, sa_stack, streams, surface_feature
 
 
-_CHECK_STREAMS = {}
 
 
 def equal_counts_check(batch_idx, batch_size):
@@ -47,10 +46,7 @@ def equal_counts_check(batch_idx, batch_size):
     # the count itself (seven small launches, ~60 us at 8 x 16 384) runs on the side stream too: the caller's stream goes
     # straight to its first layer, whose FPS leaves 248 compute units idle for them
     dev = batch_idx.device
-    key = (dev.type, dev.index)
-    side = _CHECK_STREAMS.get(key)
-    if side is None:
-        side = _CHECK_STREAMS[key] = streams.helper(dev, torch.cuda.current_stream(dev), "check")
+    side = streams.helper(dev, torch.cuda.current_stream(dev), "check")   # (cached per device / pass / role in streams.py)
     entry = torch.cuda.Event()
     entry.record(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
@@ -307,14 +303,8 @@ class _PointBackbone(nn.Module):
         return batch_dict
 
 
-_SURFACE_STREAMS = {}
-
-
 def _surface_stream(device):
-    key = (device.type, device.index, _lib.raw_stream(device))
-    if key not in _SURFACE_STREAMS:
-        _SURFACE_STREAMS[key] = streams.helper(device, torch.cuda.current_stream(device), "surface")
-    return _SURFACE_STREAMS[key]
+    return streams.helper(device, torch.cuda.current_stream(device), "surface")
 
 
 class IASSD_Backbone(_PointBackbone):

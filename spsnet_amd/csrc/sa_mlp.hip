@@ -381,7 +381,10 @@ extern "C" int sps_sa_group_mlp_packed_merge(int b, int n, int m, int j0, int jc
         out_c_off < 0 || out_c_off + c3_real > out_c_total || j0 < 0 || jcount < 0 || j0 + jcount > m)
         return fail(SPS_ERR_INVALID, "sa_group_mlp: bad shape");
     if (b == 0 || (jcount == 0 && !cols)) return SPS_OK;
-    if ((split_fp16 & 3) != 2 && c3 > 256) return fail(SPS_ERR_INVALID, "sa_group_mlp: last layer wider than 256 (%d)", c3);
+    // (the channel-major / split-fp16 per-wave kernels stage at most 256 last-layer biases in LDS; the shared-stream kernel,
+    //  mode 2, and the exact-fp32 point-major kernel, mode 4, serve the 512 / 1024-wide scales of IA-SSD layer 5)
+    if ((split_fp16 & 3) != 2 && (split_fp16 & 7) != 4 && c3 > 256)
+        return fail(SPS_ERR_INVALID, "sa_group_mlp: last layer wider than 256 (%d)", c3);
     if (!xyz || !new_xyz || (!idx && !cols) || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !out || (c_feat > 0 && !features))
         return fail(SPS_ERR_INVALID, "sa_group_mlp: null pointer");
     if (cols && (!meta || !ntiles || tile_cap <= 0 || tile_cap > 0x7FFFFFF || (tile_cap & 3) || m >= (1 << 20) || b > 256))

@@ -271,7 +271,11 @@ __global__ __launch_bounds__(256) void sa_group_mlp_pm_kernel(SaMlpArgs a) {
             xq[nt] = q < 3 ? d : 0.f;
         }
     };
-    if (wave < nunits) {
+    // The widest scales (IA-SSD layer 5: 256 feature channels, up to 512 hidden) hold a unit's activations in 384 of the 512
+    // registers a wave owns, so the next unit's inputs cannot travel beside them; a unit is 8-22 k MFMAs there (120-340 us),
+    // the one exposed gather at its head is noise.
+    constexpr bool PREFETCH = CF <= 128 && C2 <= 256;
+    if (PREFETCH && wave < nunits) {
         load_idx(wave);
         load_inputs(wave);
     }
@@ -294,9 +298,13 @@ __global__ __launch_bounds__(256) void sa_group_mlp_pm_kernel(SaMlpArgs a) {
         int ub = 0;
         long long col0 = 0;
         if constexpr (!PACKED) col0 = col0_of(unit, ub);
+        if constexpr (!PREFETCH) {
+            load_idx(unit);
+            load_inputs(unit);
+        }
         if constexpr (PACKED) pu = pun;
         const int nxt = unit + nwaves;
-        const bool more = nxt < nunits;
+        const bool more = PREFETCH && nxt < nunits;
         // ---------------- layer 1: the coordinate k-step, then the chain over the twin's channels ----------------
         f32x4 h1[T1][NT];
         {
@@ -330,13 +338,23 @@ __global__ __launch_bounds__(256) void sa_group_mlp_pm_kernel(SaMlpArgs a) {
         if (more) load_idx(nxt);
         __builtin_amdgcn_sched_barrier(0);
         f32x4 h2[T2][NT];
-        chain_layer<C1, T2, NT, BRIDGE, BRIDGE>(a.w2, sbias + C1, lane, q, h1, wb, a.w3, MT3 * S2::NCH, [](int, f32x4 (&)[NT]) {},
-            [&](int mt, f32x4 (&acc)[NT]) {
+        // (at most 16 output tiles per fully unrolled call: beyond ~64 tile x chunk blocks the unroller gives up and the
+        // activations, then indexed by a run-time tile, would live in scratch)
+        constexpr int H2 = T2 > 16 ? T2 / 2 : T2;
+        static_assert(T2 == H2 || (T2 == 2 * H2 && (H2 * S1::NCH) % RING == 0), "layer 2 in two halves keeps the ring's phase");
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+        for (int half = 0; half < T2 / H2; ++half) {
+            const bool last = half + 1 == T2 / H2;
+            const float *wh = a.w2 + (size_t)half * H2 * S1::KS * 64;
+            chain_layer<C1, H2, NT, BRIDGE, BRIDGE>(wh, sbias + C1 + 16 * H2 * half, lane, q, h1, wb,
+                last ? a.w3 : wh + (size_t)H2 * S1::KS * 64, last ? MT3 * S2::NCH : H2 * S1::NCH, [](int, f32x4 (&)[NT]) {},
+                [&](int mt, f32x4 (&acc)[NT]) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) h2[mt][nt][r] = relu_keep_nan(acc[nt][r]);
-            });
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h2[half * H2 + mt][nt][r] = relu_keep_nan(acc[nt][r]);
+                });
+        }
         // ... and its inputs while layer 3 does (loads return in order: the first weight wait behind this point also waits
         // for these gathers -- once per unit)
         if (more) load_inputs(nxt);
@@ -419,6 +437,7 @@ int launch_point_layer1_pm(int npts, int c_feat, int c1, const float *feat, cons
     }
     SPS_PL1_CASE(64, 64)
     SPS_PL1_CASE(128, 128)
+    SPS_PL1_CASE(256, 256)
 #undef SPS_PL1_CASE
     return fail(SPS_ERR_INVALID, "sa_layer1_per_point: no kernel for %d feature channels -> %d", c_feat, c1);
 }
@@ -445,16 +464,18 @@ static int launch_pm_variant(const SaMlpArgs &a, hipStream_t st) {
     const int waves_per_block = 4;
     // as many workgroups as the chip holds at this kernel's occupancy, dealt evenly: every wave walks the same number of
     // units (+-1), each of which prefetches the next one's inputs
-    static int occ = 0;     // (per instantiation; the same on every device of the node)
+    static std::atomic<int> occ_cached{0};     // (per instantiation; the same on every device of the node; racing callers
+    int occ = occ_cached.load(std::memory_order_relaxed);   //  compute and store the same value)
     if (occ == 0) {
         int o = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, sa_group_mlp_pm_kernel<CF, C1, C2, C3, NT, NS, false>, 64 * waves_per_block, 0)
                 != hipSuccess || o < 1)
             o = 1;
         occ = o > 4 ? 4 : o;
+        occ_cached.store(occ, std::memory_order_relaxed);
     }
     int blocks = divup(k.units, waves_per_block);
-    int max_blocks = 256 * occ;
+    int max_blocks = device_cu_count() * occ;
     if (const char *e = getenv("SPS_MLP_PM_BLOCKS")) {   // DIAGNOSTIC (tools/mlp_time.py): how the launch scales with the CUs it uses
         const int v = atoi(e);
         if (v > 0) max_blocks = v;
@@ -485,6 +506,8 @@ int launch_sa_mlp_pm(const SaMlpArgs &a, int c1, int c2, int nsample, hipStream_
     SPS_MLPPM_CASE(64, 64, 96, 128, 2, 32)      // L1 [67,64,96,128]
     SPS_MLPPM_CASE(128, 128, 128, 256, 2, 16)   // L2 [131,128,128,256]
     SPS_MLPPM_CASE(128, 128, 256, 256, 2, 32)   // L2 [131,128,256,256]
+    SPS_MLPPM_CASE(256, 256, 256, 512, 2, 16)   // IA-SSD L5 (vote centres) [259,256,256,512]
+    SPS_MLPPM_CASE(256, 256, 512, 1024, 2, 32)  // L5 [259,256,512,1024]
     SPS_MLPPM_CASE(64, 64, 64, 128, 2, 64)      // nsample 64: a centroid spans two units, atomic max onto zeros
     SPS_MLPPM_CASE(64, 64, 96, 128, 2, 64)
     SPS_MLPPM_CASE(128, 128, 128, 256, 2, 64)
@@ -499,6 +522,7 @@ int launch_sa_mlp_pm(const SaMlpArgs &a, int c1, int c2, int nsample, hipStream_
 // 1 if the point-major fp32 kernel (mode 4 of sps_sa_group_mlp_packed) serves these feature channels / padded widths
 extern "C" int sps_sa_group_mlp_pm_supported(int c_feat, int c1, int c2, int c3, int nsample) {
     static const int tab[][5] = {{64, 64, 64, 128, 16}, {64, 64, 96, 128, 32}, {128, 128, 128, 256, 16}, {128, 128, 256, 256, 32},
+                                 {256, 256, 256, 512, 16}, {256, 256, 512, 1024, 32},
                                  {64, 64, 64, 128, 64}, {64, 64, 96, 128, 64}, {128, 128, 128, 256, 64}, {128, 128, 256, 256, 64}};
     for (auto &t : tab)
         if (t[0] == c_feat && t[1] == c1 && t[2] == c2 && t[3] == c3 && t[4] == nsample) return 1;
@@ -518,5 +542,5 @@ extern "C" int sps_sa_layer1_per_point(int npts, int c_feat, int c1, const float
 
 // 1 if mode bit 32 (layer 1's feature product per point) is served for these widths
 extern "C" int sps_sa_layer1_per_point_supported(int c_feat, int c1, int nsample) {
-    return ((c_feat == 64 && c1 == 64) || (c_feat == 128 && c1 == 128)) && nsample <= 32;
+    return ((c_feat == 64 && c1 == 64) || (c_feat == 128 && c1 == 128) || (c_feat == 256 && c1 == 256)) && nsample <= 32;
 }

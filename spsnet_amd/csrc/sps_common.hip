@@ -95,6 +95,9 @@ extern "C" int sps_streams_run_concurrently(sps_stream_t a, sps_stream_t b, int 
     hipStream_t sa = as_stream(a), sb = as_stream(b);
     *concurrent = 0;
     if (sa == sb) return SPS_OK;
+    // a stream gets its hardware queue at its FIRST launch (milliseconds the first time a queue is created): one throw-away
+    // launch on each, so that the timed pair below measures queue sharing and nothing else
+    hipLaunchKernelGGL(hq_set_kernel, dim3(1), dim3(1), 0, sb, scratch);
     hipError_t e = hipStreamSynchronize(sb);
     if (e == hipSuccess) e = hipMemsetAsync(scratch, 0, 2 * sizeof(int), sa);
     if (e == hipSuccess) e = hipStreamSynchronize(sa);

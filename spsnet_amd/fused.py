@@ -161,13 +161,21 @@ def _version_key(pairs, device):
     return tuple(vs)
 
 
-# "fp16x2" (default): scales whose first hidden width is >= 32 run on the fp16 matrix cores with every fp32 operand
-#           carried as a hi+lo pair of halves (3 MFMAs per block, fp32 accumulate; ~1e-6 relative, csrc/sa_mlp_f16.hip);
-#           narrower scales stay on the fp32 MFMA kernel (their 4-channel input would be padded to 16).
-# "fp32":   every scale on the exact fp32 MFMA kernel.
-PRECISION = __import__("os").environ.get("SPS_MLP_PRECISION", "fp16x2")   # bench.py's headline sets "fp32" explicitly
+# Grouped-MLP arithmetic of the INFERENCE path:
+# "fp32" (default): every scale on the exact fp32 MFMA kernels (v_mfma_f32_16x16x4_f32) -- the reference's arithmetic
+#           (fp32 Conv2d / BatchNorm2d / ReLU, pointnet2_modules.py:429-447); what bench.py's headline measures.
+# "fp16x2" (opt-in): scales whose first hidden width is >= 32 run on the fp16 matrix cores with every fp32 operand
+#           carried as a hi+lo pair of halves (3 MFMAs per block, fp32 accumulate; ~22 significant bits, <= 2e-5 relative,
+#           csrc/sa_mlp_f16.hip); narrower scales stay on the fp32 MFMA kernel (their 4-channel input would be padded to 16).
+PRECISION = __import__("os").environ.get("SPS_MLP_PRECISION", "fp32")
 if PRECISION not in ("fp32", "fp16x2"):
     raise ValueError(f"SPS_MLP_PRECISION={PRECISION!r}: expected fp32 or fp16x2")
+# Arithmetic of the fused TRAIN-mode kernels (csrc/mlp_train.hip), independent of the inference switch above:
+# "fp16x2" (default): split-fp16 MFMA with exact power-of-two operand scaling (gradients within 1-3e-6 of float64 torch);
+# "fp32": the exact-fp32 op-by-op kernels (conv1x1_train.hip / bn_relu_train.hip / pool).
+TRAIN_PRECISION = __import__("os").environ.get("SPS_TRAIN_PRECISION", "fp16x2")
+if TRAIN_PRECISION not in ("fp32", "fp16x2"):
+    raise ValueError(f"SPS_TRAIN_PRECISION={TRAIN_PRECISION!r}: expected fp32 or fp16x2")
 # wide split-fp16 scales: the four waves of a workgroup share one weight stream through LDS (csrc/sa_mlp_f16_lds.hip)
 SHARE_WEIGHTS = True
 # exact-fp32 scales whose input features carry a point-major twin run on csrc/sa_mlp_pm.hip (one 16-byte load per four
@@ -177,11 +185,21 @@ _OVERFLOW = {}
 
 
 def set_precision(mode):
-    """Select the grouped-MLP arithmetic ("fp16x2" or "fp32"); returns the previous mode."""
+    """Select the grouped-MLP arithmetic of the inference path ("fp32" or "fp16x2"); returns the previous mode."""
     global PRECISION
     if mode not in ("fp32", "fp16x2"):
         raise ValueError(mode)
     old, PRECISION = PRECISION, mode
+    return old
+
+
+def set_train_precision(mode):
+    """Select the arithmetic of the fused train-mode kernels ("fp16x2" or "fp32" = exact op by op); returns the previous
+    mode."""
+    global TRAIN_PRECISION
+    if mode not in ("fp32", "fp16x2"):
+        raise ValueError(mode)
+    old, TRAIN_PRECISION = TRAIN_PRECISION, mode
     return old
 
 
@@ -214,15 +232,20 @@ def pack_scale(mlp, nsample, point_major=False, half=False):
     (c1m, _), (c2m, _), (c3m, _) = pairs
     pad = _pad32 if half else _pad16
     c1, c2, c3 = pad(c1m.out_channels), pad(c2m.out_channels), _pad16(c3m.out_channels)
-    stream_only = bool(_L.sps_sa_group_mlp_supported_stream(c1, c2, c3, nsample)) and not half
-    if stream_only and not (PRECISION == "fp16x2" and SHARE_WEIGHTS):
-        return None
-    if not stream_only and not _L.sps_sa_group_mlp_supported(c1, c2, nsample):
-        return None
+    # "wide" scales (IA-SSD layer 5: 256 / 512 / 1024 channels): served by the shared-stream split-fp16 kernel (mode 2) and, in
+    # strict fp32, by the point-major kernel (sa_mlp_pm.hip) -- never by the channel-major per-wave kernel (sa_mlp.hip)
+    wide = bool(_L.sps_sa_group_mlp_supported_stream(c1, c2, c3, nsample)) and not half
     device = c1m.weight.device
     c_feat = c1m.in_channels - 3
     pm32 = bool(point_major and not half and PM_FP32 and PRECISION == "fp32" and c_feat % 16 == 0
                 and _L.sps_sa_group_mlp_pm_supported(c_feat, c1, c2, c3, nsample))   # exact fp32 on the twin (sa_mlp_pm.hip)
+    stream_only = wide and not pm32
+    if stream_only and not (PRECISION == "fp16x2" and SHARE_WEIGHTS):
+        return None
+    if not wide and not _L.sps_sa_group_mlp_supported(c1, c2, nsample):
+        return None
+    if not wide and not pm32 and c3 > 256:
+        return None      # (the per-wave kernels stage at most 256 last-layer biases in LDS; the op-by-op path serves the scale)
     point_major = pm32 or bool(point_major and (half or PRECISION == "fp16x2") and c1 >= 32 and c_feat >= 4 and c_feat % 4 == 0)
     key = _version_key(pairs, device) + (PRECISION, SHARE_WEIGHTS, point_major, half, pm32)
     slot = ("_sps_packed_pm" if point_major else "_sps_packed") + ("_h" if half else "")
@@ -257,6 +280,21 @@ def pack_scale(mlp, nsample, point_major=False, half=False):
         p.key = key
     object.__setattr__(mlp, slot, p)  # plain attribute: not a parameter/buffer, not in state_dict
     return p
+
+
+def needs_point_major(mlp, nsample):
+    """True if, in the current arithmetic, only the point-major kernel serves this scale (strict fp32 at IA-SSD layer 5's
+    widths): the caller then gives the feature tensor its (B, N, C) twin (attach_point_major_twin) before planning."""
+    if PRECISION != "fp32" or not PM_FP32:
+        return False
+    pairs = _stack_layers(mlp)
+    if pairs is None:
+        return False
+    (c1m, _), (c2m, _), (c3m, _) = pairs
+    c_feat = c1m.in_channels - 3
+    c1, c2, c3 = _pad16(c1m.out_channels), _pad16(c2m.out_channels), _pad16(c3m.out_channels)
+    return bool(c_feat > 0 and c_feat % 16 == 0 and _L.sps_sa_group_mlp_supported_stream(c1, c2, c3, nsample)
+                and _L.sps_sa_group_mlp_pm_supported(c_feat, c1, c2, c3, nsample))
 
 
 def point_major_twin(features):
@@ -614,17 +652,19 @@ _GENERIC_MAX_CIN = 288      # input channels of a layer that sps_tconv serves (w
 
 def generic_mlp_pool(mlp, grouped):
     """max over the samples of [Conv2d 1x1 + BatchNorm2d(eval) + ReLU] x n on a grouped tensor (B, C0, M, ns) for stacks NO
-    specialised kernel serves (widths outside the IA-SSD / SPSNet table, any depth): the streaming convolution kernels of
-    csrc/mlp_train.hip with the BatchNorm of the running statistics applied in the next layer's operand load and in the
-    pool (split-fp16 MFMA, <= 2e-5 relative) -- n + 1 launches and two HBM crossings per activation instead of torch's
-    3 n + 1 launches and five; a layer with more than 288 input channels runs as a library GEMM on the materialised
-    activation.  -> (B, Cn, M), or None when it does not apply (training, gradients wanted, fp32 mode, nsample outside
-    {4, 8, 16, 32, 64}, M * ns not a multiple of 64)."""
+    specialised kernel serves (widths outside the IA-SSD / SPSNet table, any depth).  "fp16x2": the streaming convolution
+    kernels of csrc/mlp_train.hip with the BatchNorm of the running statistics applied in the next layer's operand load and
+    in the pool (split-fp16 MFMA, <= 2e-5 relative) -- n + 1 launches and two HBM crossings per activation instead of
+    torch's 3 n + 1 launches and five; a layer with more than 288 input channels, and EVERY layer in strict "fp32", runs on
+    the exact-fp32 MFMA convolution kernel (sps_conv1x1_apply) on the materialised activation.  No library GEMM / MIOpen
+    convolution on the inference path in either arithmetic.  -> (B, Cn, M), or None when it does not apply (training,
+    gradients wanted, nsample outside {4, 8, 16, 32, 64}, M * ns not a multiple of 64)."""
     from . import pointnet2_batch_cuda as _ext
     mods = list(mlp)
-    if (PRECISION == "fp32" or len(mods) % 3 or not mods or mlp.training or not grouped.is_cuda or grouped.dtype != torch.float32
+    if (len(mods) % 3 or not mods or mlp.training or not grouped.is_cuda or grouped.dtype != torch.float32
             or grouped.dim() != 4):
         return None
+    exact = PRECISION == "fp32"   # strict fp32: every layer on the exact-fp32 MFMA convolution (sps_conv1x1_apply)
     B, c0, M, ns = grouped.shape
     if ns not in (4, 8, 16, 32, 64) or (M * ns) % 64 or grouped.numel() == 0:
         return None
@@ -661,11 +701,11 @@ def generic_mlp_pool(mlp, grouped):
     operand, pin, mode = grouped.contiguous(), None, _ext.TIN_RAW
     with _ext.launch_scope(operand):
         for k, w in enumerate(packed.ws):
-            if w.shape[1] > _GENERIC_MAX_CIN:
-                # more input channels than the streaming kernel keeps weights for in LDS (PointRCNN's coarsest level: 515 and
-                # 384): a library GEMM (exact fp32) on the materialised activation -- still one or two launches for the layer
+            if exact or w.shape[1] > _GENERIC_MAX_CIN:
+                # strict fp32, or more input channels than the streaming kernel keeps weights for in LDS (PointRCNN's coarsest level: 515 and
+                # 384): the exact-fp32 MFMA convolution of csrc/conv1x1_train.hip on the materialised activation
                 a = operand if pin is None else _ext.tbn_apply_relu(operand, pin)
-                y = torch.matmul(w, a.view(B, w.shape[1], M * ns)).view(B, w.shape[0], M, ns)
+                y = _ext.conv1x1_apply(a, w, False)
             else:
                 y = torch.empty((B, w.shape[0], M, ns), dtype=torch.float32, device=grouped.device)
                 _ext.tconv(w, packed.wamax[k:k + 1], mode, _ext.TEPI_NONE, y, operand=operand, pin=pin, overflow=flag)

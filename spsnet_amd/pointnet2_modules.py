@@ -124,7 +124,7 @@ class _Conv1x1Train(torch.autograd.Function):
 
 FUSED_CONV_TRAINING = True
 # [Conv2d 1x1, BatchNorm2d(batch statistics), ReLU] x n + max-pool as the fused kernels of csrc/mlp_train.hip (split-fp16
-# MFMA arithmetic: active unless fused.set_precision("fp32") asks for the exact op-by-op path)
+# MFMA arithmetic: active unless fused.set_train_precision("fp32") asks for the exact op-by-op path)
 FUSED_MLP_TRAINING = os.environ.get("SPS_FUSED_MLP_TRAINING", "1") != "0"
 # the aggregation / confidence stacks ([Conv1d, BatchNorm1d, ReLU] on (B, C, M)) through the same kernels: built, tested, and
 # measured NOT to pay at the IA-SSD shapes -- these tensors are 2-8 MB, the stack is launch-bound either way, and the fused
@@ -286,7 +286,7 @@ def _fused_stack_train(mods, x, pool: bool):
     # (nn.SyncBatchNorm -- tools/train.py --sync_bn converts every BatchNorm -- takes the same kernels with its sums all-reduced)
     conv_t = nn.Conv2d if pool else (nn.Conv1d, nn.Conv2d)
     bn_t = (nn.BatchNorm2d, nn.SyncBatchNorm) if pool else (nn.BatchNorm1d, nn.BatchNorm2d, nn.SyncBatchNorm)
-    if not (FUSED_MLP_TRAINING and _fused.PRECISION != "fp32" and x.is_cuda and x.dtype == torch.float32
+    if not (FUSED_MLP_TRAINING and _fused.TRAIN_PRECISION != "fp32" and x.is_cuda and x.dtype == torch.float32
             and x.dim() == (4 if pool else 3) and torch.is_grad_enabled()):
         return None
     if len(mods) % 3 or not mods:
@@ -398,6 +398,13 @@ class _PointnetSAModuleBase(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.mlps.parameters()):
             return None
         plan = []
+        if (features is not None and features.is_cuda and features.dtype == torch.float32 and features.dim() == 3
+                and _fused.point_major_twin(features) is None
+                and any(type(g) is pointnet2_utils.QueryAndGroup and _fused.needs_point_major(mlp, g.nsample)
+                        for g, mlp in zip(self.groupers, self.mlps))):
+            # strict fp32 at layer 5's widths runs on the point-major kernel only: a feature tensor that did not come out of an
+            # aggregation kernel (which writes the twin) gets its (B, N, C) copy here -- one transposing copy of N x C floats
+            _fused.attach_point_major_twin(features)
         for grouper, mlp in zip(self.groupers, self.mlps):
             if type(grouper) is not pointnet2_utils.QueryAndGroup or not grouper.use_xyz:
                 return None
@@ -647,14 +654,9 @@ class _PointnetSAModuleBase(nn.Module):
                     t.record_stream(st)
         return torch.cat(scales, dim=1)
 
-    _SCALE_STREAMS = {}
-
     def _scale_streams(self, like):
-        key = (like.device.index, _lib.raw_stream(like.device))
-        if key not in _PointnetSAModuleBase._SCALE_STREAMS:
-            main = torch.cuda.current_stream(like.device)
-            _PointnetSAModuleBase._SCALE_STREAMS[key] = [streams.helper(like.device, main, f"scale{i}") for i in range(2)]
-        return _PointnetSAModuleBase._SCALE_STREAMS[key]
+        main = torch.cuda.current_stream(like.device)
+        return [streams.helper(like.device, main, f"scale{i}") for i in range(2)]   # (cached per pass / role in streams.py)
 
     def _neighbour_indices(self, xyz, new_xyz):
         """Ball-query rows of both scales of a two-radius layer on the op-by-op (training) path, or None: the rows

@@ -141,6 +141,16 @@ def disable_cu_fence(device, main_stream=None):
         del _SIDE_STREAMS[key]
 
 
+def _drop_cached_streams(device_index, root_handle, helper_handles):
+    """streams.forget(): the roles cached here for that pass (asked for from its main stream or from one of its helpers)"""
+    gone = set(helper_handles) | {root_handle}
+    for key in [k for k in _SIDE_STREAMS if k[1] == device_index and k[2] in gone]:
+        del _SIDE_STREAMS[key]
+
+
+streams.on_forget(_drop_cached_streams)
+
+
 def _helper_stream(device, tag="side"):
     """One helper stream per (device, current stream, role): concurrent passes on different streams do not share it.
     With a CuFence registered for the current stream the helper streams are CU-masked; tag "fps" = the stream the FPS
@@ -198,14 +208,38 @@ def _can_prefetch(layer, nxt):
 # costs ~70 us however small it is -- one wave scans the whole cloud per centroid -- so finer tails only add launches).
 # (3/16 steps up to 12/16 since round 3: they leave the consumer stream the idle windows the next layer's early stages need,
 #  see EARLY_POOL_AT_16; the pass without those stages takes the same time with either chunking.)
-_CHUNK_ENDS_16 = tuple(int(v) for v in os.environ.get("SPS_CHUNK_ENDS", "3,6,9,12,14,15,16").split(","))
+def _parse_chunk_ends(text):
+    """SPS_CHUNK_ENDS: strictly ascending sixteenths ending in 16 -- a list that stops short never reaches the last chunk (no
+    repair of timed-out waits, no `verify.finish`, centroids beyond its last entry never computed)."""
+    try:
+        ends = tuple(int(v) for v in text.split(","))
+    except ValueError:
+        raise ValueError(f"SPS_CHUNK_ENDS={text!r}: expected comma-separated integers (sixteenths of the layer's centroids)")
+    if not ends or ends[-1] != 16 or ends[0] < 1 or any(b <= a for a, b in zip(ends, ends[1:])):
+        raise ValueError(f"SPS_CHUNK_ENDS={text!r}: expected strictly ascending values in 1..16 whose last entry is 16")
+    return ends
+
+
+def _parse_early_pool_at(text, ends):
+    """SPS_EARLY_POOL_AT: the chunk ends behind which the next layer's early stages fire -- each must BE a chunk end (a stage
+    only fires where a chunk ends) and lie before the last one (behind the last pick the layer itself runs)."""
+    try:
+        at = tuple(int(v) for v in text.split(",") if v.strip())
+    except ValueError:
+        raise ValueError(f"SPS_EARLY_POOL_AT={text!r}: expected comma-separated integers (sixteenths), or nothing")
+    if any(b <= a for a, b in zip(at, at[1:])) or any(e not in ends[:-1] for e in at):
+        raise ValueError(f"SPS_EARLY_POOL_AT={text!r}: expected ascending values out of the chunk ends {ends[:-1]} (SPS_CHUNK_ENDS)")
+    return at
+
+
+_CHUNK_ENDS_16 = _parse_chunk_ends(os.environ.get("SPS_CHUNK_ENDS", "3,6,9,12,14,15,16"))
 # the chunk ends (in 1/16ths of M) behind which the NEXT layer starts / continues on the picks that exist (begin_early_pool).
 # The producer needs 0.33 ms per 3/16 of its picks, a 3/16 chunk's own work takes ~0.11 ms of that: the stages' queries and
 # grouped MLPs (~0.12 ms each) fit the idle time behind the chunks that end at 6, 9 and 12 sixteenths.  Measured
 # (tools/tail_events.py, strict fp32, 8 x 16 384): no stage 2.394 ms per pass, stages at (6, 9, 12) 2.305; with the old
 # chunking (4, 8, 12, 14, 15, 16) and stages at (8, 12) 2.355 -- the second stage pushed the last chunks back by 0.05 ms --,
 # and a stage behind the 14/16 chunk costs more than it saves (+0.08 ms).
-EARLY_POOL_AT_16 = tuple(int(v) for v in os.environ.get("SPS_EARLY_POOL_AT", "6,9,12").split(",") if v)
+EARLY_POOL_AT_16 = _parse_early_pool_at(os.environ.get("SPS_EARLY_POOL_AT", "6,9,12"), _CHUNK_ENDS_16)
 # the next layer's last stage gathers its verified centroids inside its ball query instead of a launch in front of it
 LATE_GATHER = os.environ.get("SPS_LATE_GATHER", "1") != "0"
 # the second pass of the next layer's identity-prefix check chunk by chunk beside the producer instead of whole behind it

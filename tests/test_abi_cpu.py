@@ -165,3 +165,47 @@ def test_tconv_parts_restatement_matches_library():
         for l in (0, 64, 192, 2048, 16384, 131072):
             for co in (0, 3, 16, 64, 65, 128, 256):
                 assert ns["tconv_parts"](b, l, co) == L.sps_tconv_parts(b, l, co), (b, l, co)
+
+
+def test_chunk_schedule_env_is_validated():
+    """SPS_CHUNK_ENDS / SPS_EARLY_POOL_AT (sa_stack): a chunk list that does not end at 16/16 would never reach the layer's
+    last chunk (no repair, no verify.finish, centroids never computed); an early stage only fires where a chunk ends."""
+    import pytest
+    from spsnet_amd import sa_stack
+    assert sa_stack._parse_chunk_ends("4,8,12,14,15,16") == (4, 8, 12, 14, 15, 16)
+    for bad in ("4,8", "0,16", "8,4,16", "4,4,16", "4,x,16", "17", ""):
+        with pytest.raises(ValueError):
+            sa_stack._parse_chunk_ends(bad)
+    ends = sa_stack._parse_chunk_ends("3,6,9,12,14,15,16")
+    assert sa_stack._parse_early_pool_at("6,9,12", ends) == (6, 9, 12) and sa_stack._parse_early_pool_at("", ends) == ()
+    for bad in ("5", "6,16", "9,6", "a"):
+        with pytest.raises(ValueError):
+            sa_stack._parse_early_pool_at(bad, ends)
+
+
+def test_pack_scale_declines_what_no_kernel_serves():
+    """fused.pack_scale: the per-wave kernels stage at most 256 last-layer biases in LDS -- a scale such as [.., 128, 256, 512]
+    must be DECLINED (None -> the layer takes the op-by-op path), not packed and then rejected by the launcher; the
+    256/512/1024-wide scales of IA-SSD layer 5 are packed for the point-major fp32 kernel in strict fp32 (the default) and
+    for the shared-stream kernel in the split-fp16 arithmetic; without a point-major twin strict fp32 declines them."""
+    import torch
+    from spsnet_amd import fused, pointnet2_modules as M
+    assert fused.PRECISION == "fp32" or "SPS_MLP_PRECISION" in os.environ          # the library default
+    mk = lambda widths: M._conv_bn_relu_stack(list(widths), torch.nn.Conv2d, torch.nn.BatchNorm2d).eval()
+    old = fused.set_precision("fp32")
+    try:
+        assert fused.pack_scale(mk([131, 128, 256, 512]), 32) is None
+        assert fused.pack_scale(mk([131, 128, 256, 512]), 32, point_major=True) is None
+        assert fused.pack_scale(mk([131, 128, 256, 256]), 32) is not None
+        wide = mk([259, 256, 512, 1024])
+        assert fused.needs_point_major(wide, 32) and not fused.needs_point_major(mk([131, 128, 256, 256]), 32)
+        assert fused.pack_scale(wide, 32) is None
+        p = fused.pack_scale(wide, 32, point_major=True)
+        assert p is not None and p.split == 0 and p.point_major and (p.c1, p.c2, p.c3) == (256, 512, 1024)
+        fused.set_precision("fp16x2")
+        assert not fused.needs_point_major(wide, 32)
+        p = fused.pack_scale(wide, 32)
+        assert p is not None and p.split == 2
+        assert fused.pack_scale(mk([131, 128, 256, 512]), 32) is None
+    finally:
+        fused.set_precision(old)

@@ -40,6 +40,13 @@ def test_two_rank_launch_prints_one_valid_line():
     # whole-job aggregate: both ranks' points over the slowest rank's time
     assert abs(line["value"] - 2 * 8 * 16384 * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-6 * line["value"]
     assert "cpu_baseline" not in line and "training_step" not in line    # N = 1 only
+    # a lost overlap is loud: every rank's helper-stream placement is on the line (AND over the ranks), and so is what was
+    # not placed.  (Two ranks SHARE the one GPU here, so the verdict itself is not asserted -- only that it is reported, and
+    # that a lost overlap carries the warning.)
+    assert isinstance(line["overlap_verified"], bool) and isinstance(line["helper_streams"]["unplaced"], list)
+    assert line["overlap_verified"] == (not line["helper_streams"]["unplaced"])
+    if not line["overlap_verified"]:
+        assert "overlap_warning" in line
 
 
 @pytest.mark.gpu
@@ -67,4 +74,5 @@ def test_one_rank_rccl_exchange_inside_the_step():
     # RCCL's own streams must not push the FPS producer and its consumers onto one hardware queue (the pass would take
     # FPS + everything else, 3.2 ms, instead of their maximum, 2.3 ms): the helper streams are probed at set-up
     assert line["helper_streams"]["probes"] > 0
+    assert line["overlap_verified"] is True and line["helper_streams"]["unplaced"] == [] and "overlap_warning" not in line
     assert line["ms_per_step_no_exchange"] < line["roofline"]["launch_ms"] + 1.0, (line["ms_per_step_no_exchange"], line["roofline"])

@@ -27,6 +27,19 @@ def G():
     return gpu_util
 
 
+@pytest.fixture
+def mlp_precision(request):
+    """Runs a test body in the requested grouped-MLP arithmetic (fused.set_precision) and restores the previous one."""
+    from spsnet_amd import fused
+    old = fused.set_precision(request.param)
+    yield request.param
+    fused.check_overflow()
+    fused.set_precision(old)
+
+
+BOTH_PRECISIONS = pytest.mark.parametrize("mlp_precision", ["fp32", "fp16x2"], indirect=True)
+
+
 def gather_xyz(xyz, idx):
     return np.take_along_axis(xyz, idx[..., None].astype(np.int64).repeat(3, axis=2), axis=1)
 
@@ -522,8 +535,9 @@ FUSED_CASES = [  # (c_feat, mlp widths, nsample, radius)
 ]
 
 
+@BOTH_PRECISIONS
 @pytest.mark.parametrize("c_feat,widths,ns,radius", FUSED_CASES)
-def test_fused_group_mlp_matches_unfused(ext, G, dev, c_feat, widths, ns, radius):
+def test_fused_group_mlp_matches_unfused(ext, G, dev, c_feat, widths, ns, radius, mlp_precision):
     """sps_sa_group_mlp (gather + 3 MFMA layers with folded BN + max-pool) against the unfused
     Conv2d/BatchNorm2d/ReLU/max_pool2d path on the same weights (tolerance of BASELINE.json: 1e-4)."""
     from spsnet_amd import pointnet2_modules as M
@@ -548,20 +562,24 @@ def test_fused_group_mlp_matches_unfused(ext, G, dev, c_feat, widths, ns, radius
     with torch.no_grad():
         assert mod._fused_plan(xyz, xyz[:, :256].contiguous(), feats) is not None, "fused path not taken"
         new_xyz, fused, _, idx, _ = mod(xyz, feats)
-        plan = mod._fused_plan
-        mod._fused_plan = lambda *a, **k: None  # force the unfused path
+        from spsnet_amd import fused as fused_mod
+        plan, generic = mod._fused_plan, fused_mod.generic_mlp_pool
+        mod._fused_plan = lambda *a, **k: None  # force the unfused path ...
+        fused_mod.generic_mlp_pool = lambda *a, **k: None   # ... all the way down to the torch modules
         try:
             _, unfused, _, idx2, _ = mod(xyz, feats)
         finally:
-            mod._fused_plan = plan
+            mod._fused_plan, fused_mod.generic_mlp_pool = plan, generic
     assert torch.equal(idx, idx2)
     scale = max(1.0, float(unfused.abs().max()))
     assert float((fused - unfused).abs().max()) <= 1e-4 * scale
     assert fused.shape == unfused.shape
 
 
-def test_fused_full_width_stack_against_cpu_oracle(ext, G, dev):
-    """IA-SSD L0-L2 at full channel widths (fused MFMA path) against the CPU oracle stack."""
+@BOTH_PRECISIONS
+def test_fused_full_width_stack_against_cpu_oracle(ext, G, dev, mlp_precision):
+    """IA-SSD L0-L2 at full channel widths (fused MFMA path) against the CPU oracle stack, in the library's default strict
+    fp32 and in the opt-in split-fp16 arithmetic."""
     from oracle import cpu_stack
     from spsnet_amd import pointnet2_modules as M, sa_stack, scenes
     cfg = sa_stack.scaled_config(npoints=[1024, 256, 128])
@@ -579,19 +597,12 @@ def test_fused_full_width_stack_against_cpu_oracle(ext, G, dev):
     np.testing.assert_allclose(G.n(got[1][2]), want[1][2], rtol=1e-4, atol=1e-4)
 
 
-def test_full_size_stack_against_cpu_oracle(ext, G, dev):
-    """BASELINE config 2 at full size (16 384 points, IA-SSD widths; 2 scenes) against the CPU oracle stack: this is the
-    shape at which the streamed first layer, the multi-pick FPS rounds, the LDS-resident / shared-stream split-fp16
-    MLP kernels, the point-major gathers and the fused tails are all active."""
-    from oracle import cpu_stack
-    from spsnet_amd import fused, pointnet2_modules as M, sa_stack, scenes
-    layers = sa_stack.build_sa_layers(M, sa_stack.IASSD_KITTI, seed=9)
-    xyz, feats = scenes.make_batch("kitti-lidar-v1", 2, 16384, seed0=123, dup_fraction=0.005)
-    want = cpu_stack.sa_stack_cpu(cpu_stack.cpu_copy(layers), xyz, feats)
-    layers = layers.to(dev)
-    with torch.no_grad():
-        got = sa_stack.run_sa_layers(layers, G.t(xyz), G.t(feats))
-    assert not sa_stack.check_timeouts() and not fused.check_overflow()
+def _check_stack_against_cpu_oracle(G, dev, layers, want, got, score_layer_inputs):
+    """Bars of the full-size stack tests: D-FPS layers' indices and centroids bit-exact, features / class scores 1e-4; the
+    score-sampled last layer matched by sampled index on the shared picks, then alone on the ORACLE's previous-layer outputs
+    (identical inputs on both sides): indices bit-exact, every row within 1e-4."""
+    from spsnet_amd import fused
+    from tests.gpu_util import compare_matched_rows
     for k in (0, 1):   # D-FPS layers: indices and centroids exact
         np.testing.assert_array_equal(G.n(got[k][3]), want[k][3])
         np.testing.assert_array_equal(G.n(got[k][0]), want[k][0])
@@ -601,22 +612,60 @@ def test_full_size_stack_against_cpu_oracle(ext, G, dev):
     np.testing.assert_allclose(G.n(got[1][2]), want[1][2], rtol=1e-4, atol=1e-4)
     # layer 2 samples by score: same set up to near-ties of the scores (which carry the 1e-4 feature tolerance); rows are
     # matched by sampled index and compared on the intersection
-    from tests.gpu_util import compare_matched_rows
     overlap = compare_matched_rows(G.n(got[2][3]), want[2][3], [(G.n(got[2][0]), want[2][0], 0.0, 1),
                                                                (G.n(got[2][1]), want[2][1], 1e-4, 2),
                                                                (G.n(got[2][2]), want[2][2], 1e-4, 1)])
     assert overlap >= 0.99
     # ... and layer 2 alone at full size on the ORACLE's layer-1 outputs (identical inputs on both sides): indices
-    # bit-exact, every feature / class-score row within 1e-4 -- the 128-wide shared-stream kernel at M = 512, N = 1024
+    # bit-exact, every feature / class-score row within 1e-4 -- the 128-wide kernels at M = 512, N = 1024
     x1, f1, c1 = G.t(want[1][0]), fused.attach_point_major_twin(G.t(want[1][1])), G.t(want[1][2])
     with torch.no_grad():
-        nx, nf, nc, ni, _ = layers[2](x1, f1, c1)
+        nx, nf, nc, ni, _ = layers[2](x1, f1, c1, **score_layer_inputs)
     np.testing.assert_array_equal(G.n(ni), want[2][3])
     np.testing.assert_array_equal(G.n(nx), want[2][0])
     ref = want[2][1]
     assert float(np.abs(G.n(nf) - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
     np.testing.assert_allclose(G.n(nc), want[2][2], rtol=1e-4, atol=1e-4)
     assert not fused.check_overflow()
+
+
+@BOTH_PRECISIONS
+def test_full_size_stack_against_cpu_oracle(ext, G, dev, mlp_precision):
+    """BASELINE config 2 at full size (16 384 points, IA-SSD widths; 2 scenes) against the CPU oracle stack, in the headline
+    arithmetic (strict fp32: packed columns, layer 1 started on the early picks and merged by atomic max, the per-point
+    layer-1 form at layer 2) and in the opt-in split-fp16 one (LDS-resident / shared-stream kernels): this is the shape at
+    which the streamed first layer, the multi-pick FPS rounds, the point-major gathers and the fused tails are all active."""
+    from oracle import cpu_stack
+    from spsnet_amd import fused, pointnet2_modules as M, sa_stack, scenes
+    layers = sa_stack.build_sa_layers(M, sa_stack.IASSD_KITTI, seed=9)
+    xyz, feats = scenes.make_batch("kitti-lidar-v1", 2, 16384, seed0=123, dup_fraction=0.005)
+    want = cpu_stack.sa_stack_cpu(cpu_stack.cpu_copy(layers), xyz, feats)
+    layers = layers.to(dev)
+    with torch.no_grad():
+        got = sa_stack.run_sa_layers(layers, G.t(xyz), G.t(feats))
+    assert not sa_stack.check_timeouts() and not fused.check_overflow()
+    _check_stack_against_cpu_oracle(G, dev, layers, want, got, {})
+
+
+@BOTH_PRECISIONS
+def test_full_size_stability_stack_against_cpu_oracle(ext, G, dev, mlp_precision):
+    """BASELINE configs[3] at full size (2 x 16 384): SPSNet's stability-score top-k ('sss_aware': sigmoid(max logits) *
+    (1 - sigmoid(stds / 8 - 3)), pointnet2_modules.py:293-305) replacing the ctr-aware sampler of the last layer, the
+    per-point `stds` thinned through the D-FPS layers in front of it -- against the CPU oracle stack, same bars."""
+    from oracle import cpu_stack
+    from spsnet_amd import fused, pointnet2_modules as M, sa_stack, scenes
+    cfg = sa_stack.scaled_config(sample_methods=['D-FPS', 'D-FPS', 'sss_aware'])
+    layers = sa_stack.build_sa_layers(M, cfg, seed=11)
+    xyz, feats = scenes.make_batch("kitti-lidar-v1", 2, 16384, seed0=321, dup_fraction=0.005)
+    stds = np.random.default_rng(17).uniform(0.0, 48.0, (2, 16384)).astype(np.float32)
+    want = cpu_stack.sa_stack_cpu(cpu_stack.cpu_copy(layers), xyz, feats, stds=stds)
+    layers = layers.to(dev)
+    with torch.no_grad():
+        got = sa_stack.run_sa_layers(layers, G.t(xyz), G.t(feats), stds=G.t(stds))
+    assert not sa_stack.check_timeouts() and not fused.check_overflow()
+    # the stds the last layer's sampler sees on the oracle's side: thinned by the two D-FPS layers
+    s1 = np.take_along_axis(np.take_along_axis(stds, want[0][3].astype(np.int64), 1), want[1][3].astype(np.int64), 1)
+    _check_stack_against_cpu_oracle(G, dev, layers, want, got, dict(stds=G.t(np.ascontiguousarray(s1))))
 
 
 # ------------------------------------------------------------------ pruned vs brute-force FPS kernels
@@ -1365,13 +1414,15 @@ def test_deterministic_group_and_gather_grads(ext, G, oracle, B, C, N, M, ns):
 
 
 # ------------------------------------------------------------------ whole backbones (IASSD_backbone.py / PAGNet_backbone.py)
+@BOTH_PRECISIONS
 @pytest.mark.parametrize("tag", ["iassd", "pagnet"])
 @pytest.mark.parametrize("schedule", ["overlapped", "layer_by_layer"])
-def test_golden_backbone(ext, G, dev, tag, schedule):
+def test_golden_backbone(ext, G, dev, tag, schedule, mlp_precision):
     """IASSD_Backbone / PAGNet_Backbone.forward on 2 x 4096 points at the shipped widths against the reference's own
     forward (run over the C oracle, oracle/gen_golden.py:backbones): sampled centres bit-exact at every level, features,
     votes and class scores to 1e-4.  `overlapped` = the inference schedule (streamed layer 0, early FPS, surface features
-    on a side stream), `layer_by_layer` = the reference's order (gradients enabled)."""
+    on a side stream), `layer_by_layer` = the reference's order (gradients enabled).  Both grouped-MLP arithmetics: in
+    strict fp32 (the default) layer 5's 256 / 512 / 1024-wide scales run on the point-major fp32 MFMA kernel."""
     from spsnet_amd import backbones as BB, scenes
     g = np.load(os.path.join(GOLD, f"backbone_{tag}.npz"))
     base = BB.IASSD_KITTI_CFG if tag == "iassd" else BB.SPSNET_KITTI_CFG
@@ -3002,10 +3053,11 @@ def test_fp_module_training_on_fused_kernels_matches_torch(dev, monkeypatch):
 
 @pytest.mark.parametrize("B,M,ns,widths", [(2, 64, 16, [259, 128, 196, 256]), (2, 128, 32, [20, 40, 24]), (1, 32, 8, [7, 100]),
                                            (2, 32, 32, [288, 272, 384]), (2, 64, 16, [515, 256, 256, 512]), (2, 64, 32, [515, 256, 384, 512])])
-def test_generic_eval_mlp_pool_matches_torch(dev, B, M, ns, widths):
+@BOTH_PRECISIONS
+def test_generic_eval_mlp_pool_matches_torch(dev, B, M, ns, widths, mlp_precision):
     """fused.generic_mlp_pool (inference at widths outside the specialised kernels' table: the streaming convolution kernels
-    with the running-statistics BatchNorm applied in the operand loads and the pool) against torch's eval-mode op sequence:
-    1e-4 (the arithmetic is split-fp16, <= 2e-5)."""
+    with the running-statistics BatchNorm applied in the operand loads and the pool; in strict fp32 every layer on the
+    exact-fp32 MFMA convolution kernel -- never a library GEMM) against torch's eval-mode op sequence: 1e-4."""
     from spsnet_amd import fused, pointnet2_modules as PM, scenes
     torch.manual_seed(M + ns)
     mlp = scenes.fill_parameters(PM._conv_bn_relu_stack(list(widths), torch.nn.Conv2d, torch.nn.BatchNorm2d), 6).to(dev).eval()
@@ -3073,11 +3125,35 @@ def test_helper_streams_really_run_beside_the_pass(dev):
     assert streams.helper(dev, main, "producer") is producer             # one per (device, main stream, tag)
     assert streams.run_concurrently(main, producer) and streams.run_concurrently(producer, main)
     assert streams.run_concurrently(producer, scale) and streams.run_concurrently(main, scale)
+    # every role this long-lived process has asked for on the default stream -- scales, chunks, side, check, surface, ...,
+    # whatever the tests before this one needed, in whatever order -- was placed: the producer's queue is reserved FIRST
+    assert streams.overlap_verified(dev, main) and streams.unplaced(dev, main) == []
     x = torch.ones(1 << 20, device=dev)
     with torch.cuda.stream(producer):                                    # the probe leaves the streams usable
         y = x * 2
     producer.synchronize()
     assert float(y.sum()) == 2.0 * (1 << 20)
+
+
+def test_helper_streams_of_a_second_pass_and_forget(dev):
+    """A pass issued from a stream of its own gets its own helpers (placed by the same rules); forget() drops them -- the
+    registry, the helper -> root links and the callers' caches -- and the next request places a fresh set."""
+    from spsnet_amd import sa_stack, streams
+    own = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(own):
+        side = sa_stack._helper_stream(dev, "side")
+        producer = sa_stack._helper_stream(dev, "producer")
+        assert streams.helper(dev, own, "producer") is producer and streams.helper(dev, side, "side") is side
+        assert streams.overlap_verified(dev, own)
+        assert streams.run_concurrently(own, producer) and streams.run_concurrently(producer, side)
+        n_cached = len(sa_stack._SIDE_STREAMS)
+        streams.forget(dev, own)
+        assert len(sa_stack._SIDE_STREAMS) == n_cached - 2
+        assert not streams.overlap_verified(dev, own)                    # nothing registered: nothing verified
+        again = sa_stack._helper_stream(dev, "producer")
+        assert streams.helper(dev, own, "producer") is again and streams.overlap_verified(dev, own)
+        streams.forget(dev, own)
+    torch.cuda.synchronize()
 
 
 # ------------------------------------------------------------------ exact fp32: layer 1's feature product once per point
