@@ -14,8 +14,11 @@
  * Ownership is the reference's: the caller allocates every buffer, including scratch
  * (`temp` pre-filled with 1e10, ball-query `idx` zeroed, gradient buffers zeroed --
  * pointnet2_utils.py:25-26,95,218,246).  Nothing is allocated, freed or synchronised
- * inside these calls, so they are legal inside hipGraph stream capture.  All pointers
- * are DEVICE pointers to contiguous fp32 / int32 arrays.
+ * inside the launchers, so they are legal inside hipGraph stream capture; the two set-up
+ * calls that do allocate or synchronise say so: sps_init() (once per device, OPTIONAL:
+ * it creates the flag pool of the FPS sorting pre-pass; without it the FPS launchers use
+ * the kernel that sorts for itself) and sps_streams_run_concurrently() (a probe).  All
+ * pointers are DEVICE pointers to contiguous fp32 / int32 arrays.
  */
 #ifndef SPSNET_SA_H
 #define SPSNET_SA_H
@@ -37,6 +40,12 @@ enum {
 int sps_abi_version(void);
 /* message of the most recent failing call on this thread ("" if none) */
 const char *sps_last_error(void);
+/* One-time set-up of the library's per-device state (today: the 256 KiB flag pool of the FPS sorting pre-pass); `device`
+ * is made current for the call, `stream` is synchronised.  Idempotent, thread-safe, optional (see above).  Call it before a
+ * stream capture that is meant to record the fast FPS path.  No reference counterpart: the reference's launchers
+ * (sampling_gpu.cu:211-253) own no device state.  sps_is_initialized: 1 once it has succeeded for `device`. */
+int sps_init(int device, sps_stream_t stream);
+int sps_is_initialized(int device);
 /* block size the reference would use for an n-point FPS (cuda_utils.h:10-14) */
 int sps_opt_n_threads(int work_size);
 /* FPS kernel selection: 0 = automatic (spatially pruned kernel where it applies), 1 = brute-force

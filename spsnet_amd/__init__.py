@@ -14,3 +14,13 @@ Layout:
 There is no CPU or PyTorch fallback: importing an op module without the built library raises.
 """
 __version__ = "0.1.0"
+
+
+def init(device=None):
+    """Optional one-time set-up of the library's per-device state (sps_init: the flag pool of the FPS sorting pre-pass).  The op
+    wrappers call it themselves in front of their first FPS launch on a device; call it by hand BEFORE capturing a fresh
+    process's first pass into a HIP graph (the call allocates and synchronises, which a capture must not)."""
+    import torch
+    from . import _lib
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    return _lib.ensure_init(dev)

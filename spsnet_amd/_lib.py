@@ -20,6 +20,8 @@ _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 
 # name -> argument types (every entry point returns int status unless noted)
 _PROTOS = {
+    "sps_init": [_i, _vp],
+    "sps_is_initialized": [_i],
     "sps_set_fps_mode": [_i],
     "sps_debug_where": [_i, _i, _i, _vp, _vp],
     "sps_stream_create_cu_mask": [_i, _vp, _vp],
@@ -201,3 +203,23 @@ def raw_stream(device) -> int:
     if _RAW_STREAM is not None and idx is not None:
         return _RAW_STREAM(idx)
     return torch.cuda.current_stream(device).cuda_stream
+
+
+_INITIALISED = set()
+
+
+def ensure_init(device) -> bool:
+    """sps_init() for `device`, once per process and device: the library's one allocating / synchronising set-up call (the
+    flag pool of the FPS sorting pre-pass).  Called by the wrappers in front of their first FPS launch on a device -- but never
+    while the current stream is being captured into a graph (the call allocates and synchronises): a capture of a fresh
+    process's first pass then records the FPS kernel that sorts for itself; call `spsnet_amd.init(device)` before capturing to
+    record the pre-pass.  -> whether the device is initialised."""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx in _INITIALISED:
+        return True
+    if torch.cuda.is_current_stream_capturing():
+        return bool(load().sps_is_initialized(idx))
+    check(load().sps_init(idx, ctypes.c_void_p(raw_stream(torch.device("cuda", idx)))), "sps_init")
+    _INITIALISED.add(idx)
+    return True

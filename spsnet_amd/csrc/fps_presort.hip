@@ -51,22 +51,34 @@ int fps_cluster_spread();
 // producer cost ~4 us + a launch gap of every pass).  A stale flag carries an older epoch and never matches; more than
 // PS_SLOTS pre-passes in flight on one device would share a slot -- far beyond the 64-workgroup residency rule anyway.
 constexpr int PS_SLOTS = 64, PS_SCENES = 64;
+// The pool is created by sps_init() -- the ONE entry point of the library that allocates and synchronises -- never by a
+// launcher: a launch that finds no pool for its device declines (the caller then takes the kernel that sorts for itself),
+// so that every launcher stays free of allocations and synchronisation (include/spsnet_sa.h: legal under stream capture).
+static std::mutex g_pool_mu;
+static unsigned long long *g_pool[64] = {};
 static unsigned long long *presort_flag_pool(int dev) {
-    static std::mutex mu;
-    static unsigned long long *pool[64] = {};
-    std::lock_guard<std::mutex> lock(mu);
     if (dev < 0 || dev >= 64) return nullptr;
-    if (!pool[dev]) {
-        const size_t bytes = (size_t)PS_SLOTS * PS_SCENES * 2 * PC_MAXK * sizeof(unsigned long long);
-        void *p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-        // (null-stream memset, then a device-wide wait: the first pre-pass is launched on a non-blocking stream and must not
-        //  overtake the zeroes -- once per device and process)
-        if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
-        pool[dev] = static_cast<unsigned long long *>(p);
-    }
-    return pool[dev];
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    return g_pool[dev];
 }
+int presort_pool_create(int dev, hipStream_t st) {
+    if (dev < 0 || dev >= 64) return fail(SPS_ERR_INVALID, "sps_init: device %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    if (g_pool[dev]) return SPS_OK;
+    const size_t bytes = (size_t)PS_SLOTS * PS_SCENES * 2 * PC_MAXK * sizeof(unsigned long long);
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(p, 0, bytes, st);
+    // (the first pre-pass may be launched on any stream and must not overtake the zeroes: wait for them here, once)
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        if (p) (void)hipFree(p);
+        return fail(SPS_ERR_LAUNCH, "sps_init: presort flag pool: %s", hipGetErrorString(e));
+    }
+    g_pool[dev] = static_cast<unsigned long long *>(p);
+    return SPS_OK;
+}
+bool presort_pool_exists(int dev) { return presort_flag_pool(dev) != nullptr; }
 
 // sorted scenes -> work (b * stride floats); temp may be NULL (all running distances 1e10).  *gate: where the FPS kernels
 // behind this launch find out which scenes the pre-pass gave up on (scene s: gate.word + s * gate.stride, raised = its tag
@@ -84,8 +96,12 @@ int launch_fps_presort(int b, int n, const float *dataset, const float *temp, fl
     const int npad = divup(n, 64) * 64;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    // a launch being CAPTURED into a graph declines as well: its flags are told apart by a per-launch epoch, and a replayed
+    // launch would meet its own flags of the previous replay (the kernel that sorts for itself has no such state)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return -1;
     unsigned long long *pool = presort_flag_pool(dev);
-    if (!pool) return -1;   // (the caller falls back to the in-kernel sort)
+    if (!pool) return -1;   // (sps_init() has not run for this device: the caller takes the kernel that sorts for itself)
     static std::atomic<unsigned> counter{0};
     unsigned ticket = counter.fetch_add(1, std::memory_order_relaxed) + 1u;
     if ((ticket << 1) == 0u) ticket = counter.fetch_add(1, std::memory_order_relaxed) + 1u;   // tag 0 = the zeroed pool
@@ -100,6 +116,27 @@ int launch_fps_presort(int b, int n, const float *dataset, const float *temp, fl
 }
 
 }  // namespace sps
+
+// One-time set-up of the library's per-device state on `device` (made current for the call): today the flag pool of the FPS
+// sorting pre-pass.  The ONLY entry point that allocates device memory or synchronises (`stream` is synchronised); idempotent
+// and thread-safe.  A process that never calls it still gets correct results everywhere -- the FPS launchers then use the
+// kernel that sorts for itself (~25 us slower at 8 x 16 384 points) -- so it must be called BEFORE a stream capture that is
+// meant to record the fast path.  No reference counterpart (the reference's launchers own no device state).
+extern "C" int sps_init(int device, sps_stream_t stream) {
+    using namespace sps;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count)
+        return fail(SPS_ERR_INVALID, "sps_init: no device %d", device);
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess) prev = device;
+    if (prev != device && hipSetDevice(device) != hipSuccess) return fail(SPS_ERR_LAUNCH, "sps_init: cannot select device %d", device);
+    const int rc = presort_pool_create(device, as_stream(stream));
+    if (prev != device) (void)hipSetDevice(prev);
+    return rc;
+}
+
+// 1 once sps_init(device, ...) has succeeded in this process
+extern "C" int sps_is_initialized(int device) { return sps::presort_pool_exists(device) ? 1 : 0; }
 
 // DIAGNOSTIC: the spin bound of every cross-workgroup poll of the FPS kernels (the split sort of fps_presort.hip /
 // fps_pruned_cluster.hip and the clustered kernel's record exchange); 0 restores the default, 0xFFFFFFFF makes every poll

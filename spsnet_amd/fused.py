@@ -329,6 +329,8 @@ _COUNTERS = {}
 
 def _zero_counter(device):
     """A zeroed int32 on the device without a fill launch per use: slices of a pre-zeroed buffer, refilled every 256 uses."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros((1,), dtype=torch.int32, device=device)   # (zeroed inside the graph, on every replay)
     key = (device.type, device.index, _lib.raw_stream(device))
     buf, used = _COUNTERS.get(key, (None, 256))
     if used >= 256:

@@ -484,6 +484,7 @@ def fps_publish(xyz, temp, idx, progress, presort=True):
     up to 16 384 points (its workgroups spin on each other and must all be resident: not on a CU-masked stream)."""
     B, N, _ = xyz.shape
     tp = 0 if temp is None else _ptr(temp, F32, "temp")
+    _lib.ensure_init(xyz.device)      # (the sorting pre-pass's flag pool: once per device, never under stream capture)
     with _on(xyz):
         wf = int(_L.sps_fps_workspace_floats(N))
         if wf > 0 and (N > 16384 or (PRESORT and presort)):   # large scenes: sorted points; 6144 .. 16 384: the sorting pre-pass's output

@@ -448,6 +448,10 @@ def _streamed_first_layer(layer, nxt, xyz, features, stds=None, after_producer=N
         nxt._presampled = (nidx, vdone, new_xyz)   # (derived from the repaired centroids; flagged scenes are recomputed)
     elif nxt is not None and _can_prefetch(layer, nxt) and not verified_inline:
         _prefetch_dfps(nxt, new_xyz, True)
+    if fenced and torch.cuda.is_current_stream_capturing():
+        # a stream capture must end with every forked stream joined back; the consumers above are ordered behind the producer
+        # by its published progress, not by an event (in eager mode nothing needs to wait for the kernel's exit)
+        main.wait_stream(fps_stream)
     new_features, cls = tail.result() if tail is not None else layer._tail(out, half)
     if stds is not None:  # the layer's sampler thins the stability scores with its picks (reference :307-310)
         stds = pointnet2_utils.gather_operation(stds.view(B, 1, -1).contiguous(), idx).squeeze()
@@ -542,6 +546,9 @@ _ZERO_POOL = {}
 def _zeroed_ints(device, count):
     """`count` zeroed int32 that nobody has written yet: slices of a pre-zeroed buffer (one fill launch per 4096 ints handed
     out instead of one per pass, which sat in front of the FPS producer)."""
+    if torch.cuda.is_current_stream_capturing():
+        # a graph replays its launches on the SAME memory: the zeroes must be produced inside the graph, every replay
+        return torch.zeros((count,), dtype=torch.int32, device=device)
     key = (device.type, device.index, _lib.raw_stream(device))
     buf, used = _ZERO_POOL.get(key, (None, 1 << 30))
     if buf is None or used + count > buf.numel():

@@ -3135,6 +3135,53 @@ def test_helper_streams_really_run_beside_the_pass(dev):
     assert float(y.sum()) == 2.0 * (1 << 20)
 
 
+@pytest.mark.parametrize("mode", ["streamed", "seq"])
+def test_first_pass_of_a_fresh_process_captures_into_a_graph(dev, mode):
+    """include/spsnet_sa.h promises launchers that neither allocate nor synchronise (legal under stream capture); the one
+    call that does both is sps_init().  A FRESH process (tools/graph_try.py as a subprocess: nothing of the library has run
+    in it) calls spsnet_amd.init(), captures its very first SA-stack pass -- the streamed schedule with its helper streams,
+    bounded waits, packed columns and early stages, or the sequential one -- into a HIP graph and replays it on the captured
+    batch and on a second batch copied into the static inputs: every output bit-identical to an eager sequential pass (stale
+    per-launch state -- progress counters, zero pools, the pre-pass's flag epochs -- would show on the second batch)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRAPH_TRY_B="2")
+    done = subprocess.run([sys.executable, os.path.join(root, "tools", "graph_try.py"), mode, "fp32"], cwd=root, env=env,
+                          capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0 and "GRAPH_TRY_OK" in done.stdout, (done.stdout[-2000:], done.stderr[-3000:])
+    assert done.stdout.count("identical to an eager sequential pass: True; timeouts False") == 2, done.stdout[-2000:]
+
+
+def test_sps_init_is_idempotent_and_launchers_never_allocate(ext, G, oracle, dev):
+    """sps_init / sps_is_initialized (include/spsnet_sa.h): idempotent; the publishing FPS under stream capture declines the
+    sorting pre-pass (its flags carry a per-launch epoch a replay could not renew) and still samples exactly."""
+    import ctypes
+    import spsnet_amd
+    from spsnet_amd import _lib
+    L = _lib.load()
+    assert spsnet_amd.init(dev) and L.sps_is_initialized(dev.index or 0) == 1
+    assert L.sps_init(dev.index or 0, ctypes.c_void_p(_lib.raw_stream(dev))) == 0          # again: a no-op
+    assert L.sps_init(99, None) != 0 and b"no device" in L.sps_last_error()
+    xyz = cloud(np.random.default_rng(3), 2, 8192, dup=0.05)
+    x = G.t(xyz)
+    want = oracle.fps(xyz, 512)
+    idx = torch.zeros((2, 512), dtype=torch.int32, device=dev)
+    progress = torch.zeros((2,), dtype=torch.int32, device=dev)
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        progress.zero_()
+        work = ext.fps_publish(x, None, idx, progress)
+    for _ in range(2):
+        idx.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(G.n(idx), want)
+        assert G.n(progress).tolist() == [512, 512]
+    del work
+
+
 def test_helper_streams_of_a_second_pass_and_forget(dev):
     """A pass issued from a stream of its own gets its own helpers (placed by the same rules); forget() drops them -- the
     registry, the helper -> root links and the callers' caches -- and the next request places a fresh set."""
@@ -3216,6 +3263,46 @@ def test_layer1_per_point_form_matches_the_grouped_one(ext, G, dev, cf, widths):
         assert float((outs["per-point"] - outs["plain"]).abs().max()) <= 2e-6 * scale
         for name in ("plain", "per-point"):
             assert float((outs[name].double() - want).abs().max()) <= 1e-4 * max(scale, 1.0), name
+    finally:
+        fused.set_precision(old)
+        fused.HOIST_LAYER1 = old_hoist
+
+
+@pytest.mark.parametrize("B", [1, 8])
+def test_layer1_form_gating_changes_only_last_bits(ext, G, dev, B):
+    """The exact-fp32 MLP contract is tolerance-based (1e-4), the INDEX contract ends at the layer's sampler: which form of layer
+    1 runs (the grouped one, or its feature product once per point) depends on shape gating -- a point-major twin, M ns >= 4 N,
+    `early_pool_plan` (B M <= 8192, enough columns to pack), whether the layer is a plain D-FPS layer.  Here a plain D-FPS layer
+    at IA-SSD layer 1's widths, at a batch size where `early_pool_plan` is None (B = 1: too few columns) and at the bench's
+    (B = 8: the plan exists, the layer keeps the grouped form): sampled indices identical to the form-forced runs, features
+    within 2e-6 of the layer's scale of each other whatever the gate picked."""
+    from spsnet_amd import fused, pointnet2_modules as M, scenes
+    torch.manual_seed(7)
+    mod = M.PointnetSAModuleMSG_WithSampling(
+        npoint_list=[1024], sample_range_list=[-1], sample_type_list=['D-FPS'], radii=[0.8, 1.6], nsamples=[16, 32],
+        mlps=[[64, 64, 64, 128], [64, 64, 96, 128]], use_xyz=True, dilated_group=False, aggregation_mlp=[128], confidence_mlp=[128],
+        num_class=3)
+    scenes.fill_parameters(mod, 5)
+    mod = mod.to(dev).eval()
+    xyz_np, _ = scenes.make_batch("kitti-lidar-v1", B, 4096, seed0=31)
+    x = G.t(xyz_np)
+    feats = fused.attach_point_major_twin(torch.randn(B, 64, 4096, device=dev))
+    old, old_hoist = fused.set_precision("fp32"), fused.HOIST_LAYER1
+    try:
+        outs = {}
+        with torch.no_grad():
+            plan_exists = mod.early_pool_plan(x, x[:, :1024].contiguous(), feats) is not None
+            assert plan_exists == (B == 8)
+            for name, hoist in (("default", True), ("grouped", False)):
+                fused.HOIST_LAYER1 = hoist
+                nx, nf, cls, idx, _ = mod(x, feats)
+                outs[name] = (idx.clone(), nf.clone(), cls.clone())
+        assert torch.equal(outs["default"][0], outs["grouped"][0])
+        scale = float(outs["grouped"][1].abs().max())
+        assert float((outs["default"][1] - outs["grouped"][1]).abs().max()) <= 2e-6 * max(scale, 1.0)
+        assert float((outs["default"][2] - outs["grouped"][2]).abs().max()) <= 1e-5 * max(1.0, float(outs["grouped"][2].abs().max()))
+        if plan_exists:      # a layer sa_stack may start on a partly written cloud keeps the grouped form in both schedules
+            assert torch.equal(outs["default"][1], outs["grouped"][1])
     finally:
         fused.set_precision(old)
         fused.HOIST_LAYER1 = old_hoist
