@@ -134,6 +134,11 @@ struct TConvArgs {
     float *amax_out;             // TEPI_BWD: atomic max of |out| (device scalar, zeroed by the caller)
     const float *wamax;          // largest |w| (device scalar)
     int *overflow;
+    // K slabs (layers with more than 256 input rows, sps_tconv): this launch multiplies the input rows [k0, k0 + ci) of an
+    // operand that has ci_total rows per scene -- in / in2 / gout / arg / pin already point at row k0, w at column k0 of
+    // its rows (ld = w_ld floats; transposed: at row k0) -- and, behind the first slab, ADDS its product to what `out` holds
+    // (accum; the statistics epilogue runs in the last slab only, on the complete sums).
+    int ci_total, w_ld, accum;
 };
 
 // One 64-column block per wave at a time; the 16 RT output rows of blockIdx.z against all input rows.  Four waves per
@@ -175,10 +180,10 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
         const long long id = first + i * stride;
         const int scene = (int)(id / nb64);
         const long long col0 = (id - (long long)scene * nb64) * 64 + 4 * c;
-        const float *src = a.in + (size_t)scene * a.ci * a.l + col0;
-        const float *src2 = a.in2 + (size_t)scene * a.ci * a.l + col0;
+        const float *src = a.in + (size_t)scene * a.ci_total * a.l + col0;
+        const float *src2 = a.in2 + (size_t)scene * a.ci_total * a.l + col0;
         const long long cen = (IN == TIN_BNBWD_POOL) ? col0 / a.ns : 0;     // the four columns belong to ONE centroid
-        const size_t pool_base = (size_t)scene * a.ci * a.m + cen;
+        const size_t pool_base = (size_t)scene * a.ci_total * a.m + cen;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int row = 32 * s + 8 * q + e;
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
     // workgroup at the widest shapes, longer than the workgroup's whole column range took); the transposed operand walks
     // the rows fastest so that consecutive lanes still read consecutive floats.
     const float sw = tpow2_scale(256.f, *a.wamax);
-    const bool quads = (reinterpret_cast<uintptr_t>(a.w) & 15) == 0 && ((a.trans ? a.co : a.ci) & 3) == 0;
+    const bool quads = (reinterpret_cast<uintptr_t>(a.w) & 15) == 0 && ((a.trans ? a.co : (a.ci | a.w_ld)) & 3) == 0;
     if (quads) {
         // 16-byte loads along the contiguous dimension of w (k for the plain operand, the output row for the transposed one)
         constexpr int WQ = 8;
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
                 const int row = row0 + o;
                 wq[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (idx < 4 * nq && row < a.co && k < a.ci)
-                    wq[u] = *reinterpret_cast<const f32x4 *>(a.trans ? a.w + (size_t)k * a.co + row : a.w + (size_t)row * a.ci + k);
+                    wq[u] = *reinterpret_cast<const f32x4 *>(a.trans ? a.w + (size_t)k * a.co + row : a.w + (size_t)row * a.w_ld + k);
             }
 #pragma unroll
             for (int u = 0; u < WQ; ++u) {
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
                 const int o = a.trans ? idx % rows_wg : idx / cip, k = a.trans ? idx / rows_wg : idx % cip;
                 const int row = row0 + o;
                 wv[u] = 0.f;
-                if (idx < nel && row < a.co && k < a.ci) wv[u] = a.trans ? a.w[(size_t)k * a.co + row] : a.w[(size_t)row * a.ci + k];
+                if (idx < nel && row < a.co && k < a.ci) wv[u] = a.trans ? a.w[(size_t)k * a.co + row] : a.w[(size_t)row * a.w_ld + k];
             }
 #pragma unroll
             for (int u = 0; u < WB; ++u) {
@@ -374,10 +379,14 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
                 const int orow = 16 * t + 4 * q + r, row = row0 + orow;
                 if (row >= a.co) continue;
                 f32x4 o = (f32x4){acc[t][0][r] * inv, acc[t][1][r] * inv, acc[t][2][r] * inv, acc[t][3][r] * inv};
+                const size_t at = ((size_t)scene * a.co + row) * a.l + col0;
+                if (a.accum) {          // (a later K slab: on top of the earlier slabs' sums; a NaN row stays NaN)
+                    const f32x4 prev = *reinterpret_cast<const f32x4 *>(a.out + at);
+                    o = (f32x4){o[0] + prev[0], o[1] + prev[1], o[2] + prev[2], o[3] + prev[3]};
+                }
                 const bool finite = (fabsf(o[0]) + fabsf(o[1])) + (fabsf(o[2]) + fabsf(o[3])) < INFINITY;   // (false for a NaN too)
                 nonfinite |= !finite;
                 if (poison || !finite) o = (f32x4){nanv, nanv, nanv, nanv};
-                const size_t at = ((size_t)scene * a.co + row) * a.l + col0;
                 *reinterpret_cast<f32x4 *>(a.out + at) = o;
                 if (EPI == TEPI_STATS) {
                     st1[t][r] += (o[0] + o[1]) + (o[2] + o[3]);
@@ -442,6 +451,9 @@ struct TWgradArgs {
     float *partial;              // [gridDim.x][cop][cip]  (cop, cip = co, ci rounded up to 16)
     const float *amax_in;        // largest |incoming gradient|
     int *overflow;
+    // blocks of a wide layer (sps_twgrad: more than 256 rows on either side): the operands have co_total / ci_total rows per
+    // scene, this launch takes co / ci of them starting where dA / y / gout / arg / pd and x / px point
+    int co_total, ci_total;
 };
 
 // 8 waves; a stage = 32 NK columns of every row of both operands, transformed and split ONCE into LDS (rows 64 NK + 16 bytes
@@ -502,10 +514,10 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
             pg[p] = 0.f;
             pi[p] = 255;
             if (row < a.co) {
-                const size_t at = ((size_t)scene * a.co + row) * a.l + col;
+                const size_t at = ((size_t)scene * a.co_total + row) * a.l + col;
                 if (a.dmode == TIN_BNBWD_POOL) {
                     const long long cen = col / a.ns;
-                    const size_t pat = ((size_t)scene * a.co + row) * a.m + cen;
+                    const size_t pat = ((size_t)scene * a.co_total + row) * a.m + cen;
                     pg[p] = a.gout[pat];
                     pi[p] = a.arg[pat];
                     psub = (int)(col - cen * a.ns);
@@ -514,7 +526,7 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
                 }
                 pb[p] = *reinterpret_cast<const f32x4 *>(a.y + at);
             }
-            if (row < a.ci) pxv[p] = *reinterpret_cast<const f32x4 *>(a.x + ((size_t)scene * a.ci + row) * a.l + col);
+            if (row < a.ci) pxv[p] = *reinterpret_cast<const f32x4 *>(a.x + ((size_t)scene * a.ci_total + row) * a.l + col);
         }
     };
     auto put = [&](char *hi_base, char *lo_base, int row, const f32x4 v) {
@@ -606,7 +618,7 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
 // order.  (One thread per element walking all partials was 32 dependent round trips: ~12 us per launch whatever the size,
 // eighteen launches per training step.)
 __global__ __launch_bounds__(256) void twgrad_reduce_kernel(int co, int ci, int cip, int cop, int nparts, const float *__restrict__ partial,
-                                                            float *__restrict__ dw) {
+                                                            float *__restrict__ dw, int ld) {
     __shared__ float part[8][32];
     const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + el;
@@ -632,7 +644,7 @@ __global__ __launch_bounds__(256) void twgrad_reduce_kernel(int co, int ci, int 
         float t = part[0][el];
 #pragma unroll
         for (int u = 1; u < 8; ++u) t += part[u][el];
-        dw[e] = t;
+        dw[(size_t)(e / ci) * ld + (e % ci)] = t;      // (ld = ci: the whole matrix; wider: a block of it)
     }
 }
 
@@ -889,7 +901,8 @@ extern "C" int sps_tconv(int b, int ci, int co, long long l, int in_mode, int ep
                          const float *in2, const float *gout, const unsigned char *arg, int nsample, int m, const float *pin,
                          float *out, const float *epi_y, const float *pout, double *partial, const float *amax_in,
                          float *amax_out, const float *wamax, int *overflow, sps_stream_t stream) {
-    if (b < 0 || ci <= 0 || co <= 0 || l < 0 || ci > 288) return fail(SPS_ERR_INVALID, "tconv: bad shape b=%d ci=%d co=%d l=%lld", b, ci, co, l);
+    if (b < 0 || ci <= 0 || co <= 0 || l < 0 || ci > 4096 || co > 4096)
+        return fail(SPS_ERR_INVALID, "tconv: bad shape b=%d ci=%d co=%d l=%lld", b, ci, co, l);
     if (b == 0 || l == 0) return SPS_OK;
     if (l % 64) return fail(SPS_ERR_INVALID, "tconv: l = %lld must be a multiple of 64", l);
     if (in_mode < TIN_RAW || in_mode > TIN_BNBWD_POOL || epi_mode < TEPI_NONE || epi_mode > TEPI_BWD)
@@ -899,16 +912,34 @@ extern "C" int sps_tconv(int b, int ci, int co, long long l, int in_mode, int ep
         return fail(SPS_ERR_INVALID, "tconv: null pointer");
     if (in_mode == TIN_BNBWD_POOL && (!gout || !arg || nsample <= 0 || (nsample % 4) || m <= 0 || (long long)m * nsample != l))
         return fail(SPS_ERR_INVALID, "tconv: the pooled-gradient operand needs gout, arg, nsample %% 4 == 0 and m * nsample == l");
-    TConvArgs a;
-    a.b = b; a.ci = ci; a.co = co; a.S = (ci + 31) / 32; a.l = l; a.trans = trans ? 1 : 0; a.w = w;
-    a.in = in ? in : in2; a.in2 = in2 ? in2 : in; a.gout = gout; a.arg = arg; a.ns = nsample > 0 ? nsample : 4; a.m = m;
-    a.pin = pin; a.out = out; a.epi_y = epi_y; a.pout = pout; a.partial = partial; a.amax_in = amax_in; a.amax_out = amax_out;
-    a.wamax = wamax; a.overflow = overflow;
     hipStream_t st = as_stream(stream);
-    if (co <= 16) return tconv_launch_in<1>(a, in_mode, epi_mode, st);
-    if (co <= 32) return tconv_launch_in<2>(a, in_mode, epi_mode, st);
-    if (co <= 64 || a.S > 8) return tconv_launch_in<4>(a, in_mode, epi_mode, st);   // (nine k-steps: 128 rows of weights would not fit the LDS)
-    return tconv_launch_in<8>(a, in_mode, epi_mode, st);        // 128 rows per workgroup (blockIdx.z walks the rest)
+    // The weights of a workgroup's output rows live in LDS for the whole launch, which holds 288 input rows of them: wider
+    // layers (IA-SSD layer 5: 512 and 1024 channels) run as K SLABS of 256 input rows, one launch each, every slab behind the
+    // first adding to `out`; the statistics / BatchNorm-backward epilogue belongs to the last slab (the complete sums).
+    const int slab = ci <= 288 ? ci : 256;
+    for (int k0 = 0; k0 < ci; k0 += slab) {
+        const int cs = ci - k0 < slab ? ci - k0 : slab;
+        const bool last = k0 + cs >= ci;
+        const size_t rowoff = (size_t)k0 * (size_t)l;
+        TConvArgs a;
+        a.b = b; a.ci = cs; a.co = co; a.S = (cs + 31) / 32; a.l = l; a.trans = trans ? 1 : 0;
+        a.ci_total = ci; a.w_ld = ci; a.accum = k0 > 0 ? 1 : 0;
+        a.w = trans ? w + (size_t)k0 * co : w + k0;
+        const float *in_k = in ? in + rowoff : nullptr, *in2_k = in2 ? in2 + rowoff : nullptr;
+        a.in = in_k ? in_k : in2_k; a.in2 = in2_k ? in2_k : in_k;
+        a.gout = gout ? gout + (size_t)k0 * m : nullptr; a.arg = arg ? arg + (size_t)k0 * m : nullptr;
+        a.ns = nsample > 0 ? nsample : 4; a.m = m;
+        a.pin = pin ? pin + (size_t)k0 * TP : nullptr; a.out = out; a.epi_y = epi_y; a.pout = pout; a.partial = partial;
+        a.amax_in = amax_in; a.amax_out = amax_out; a.wamax = wamax; a.overflow = overflow;
+        const int epi = last ? epi_mode : TEPI_NONE;
+        int rc;
+        if (co <= 16) rc = tconv_launch_in<1>(a, in_mode, epi, st);
+        else if (co <= 32) rc = tconv_launch_in<2>(a, in_mode, epi, st);
+        else if (co <= 64 || a.S > 8) rc = tconv_launch_in<4>(a, in_mode, epi, st);   // (nine k-steps: 128 rows of weights would not fit the LDS)
+        else rc = tconv_launch_in<8>(a, in_mode, epi, st);        // 128 rows per workgroup (blockIdx.z walks the rest)
+        if (rc != SPS_OK) return rc;
+    }
+    return SPS_OK;
 }
 
 // out[k] = max |p_k[0 .. n_k)| for up to four arrays (the weight matrices of one grouped MLP): one launch, one workgroup each
@@ -1049,13 +1080,14 @@ static int twgrad_parts(int b, int co, int ci, long long l) {
 
 extern "C" long long sps_twgrad_workspace_floats(int b, int co, int ci, long long l) {
     if (b <= 0 || co <= 0 || ci <= 0 || l <= 0) return 0;
-    return (long long)twgrad_parts(b, co, ci, l) * (16 * divup(co, 16)) * (16 * divup(ci, 16));
+    const int cb = co < 256 ? co : 256, ib = ci < 256 ? ci : 256;     // (wider layers run block by block through one workspace)
+    return (long long)twgrad_parts(b, cb, ib, l) * (16 * divup(cb, 16)) * (16 * divup(ib, 16));
 }
 
 extern "C" int sps_twgrad(int b, int co, int ci, long long l, int dmode, int xmode, const float *dA, const float *y,
                           const float *gout, const unsigned char *arg, int nsample, int m, const float *pd, const float *x,
                           const float *px, const float *amax_in, float *dw, float *work, int *overflow, sps_stream_t stream) {
-    if (b <= 0 || co <= 0 || ci <= 0 || l <= 0 || co > 256 || ci > 256)
+    if (b <= 0 || co <= 0 || ci <= 0 || l <= 0 || co > 4096 || ci > 4096)
         return fail(SPS_ERR_INVALID, "twgrad: bad shape b=%d co=%d ci=%d l=%lld", b, co, ci, l);
     if (l % 32) return fail(SPS_ERR_INVALID, "twgrad: l = %lld must be a multiple of 32", l);
     if ((dmode != TIN_BNBWD && dmode != TIN_BNBWD_POOL) || (xmode != TIN_RAW && xmode != TIN_BNRELU))
@@ -1064,14 +1096,24 @@ extern "C" int sps_twgrad(int b, int co, int ci, long long l, int dmode, int xmo
         return fail(SPS_ERR_INVALID, "twgrad: null pointer");
     if (dmode == TIN_BNBWD_POOL && (!gout || !arg || nsample <= 0 || (nsample % 4) || m <= 0 || (long long)m * nsample != l))
         return fail(SPS_ERR_INVALID, "twgrad: the pooled-gradient operand needs gout, arg, nsample %% 4 == 0 and m * nsample == l");
-    TWgradArgs a;
-    a.b = b; a.co = co; a.ci = ci; a.l = l; a.dmode = dmode; a.xmode = xmode; a.dA = dA; a.y = y; a.gout = gout; a.arg = arg;
-    a.ns = nsample > 0 ? nsample : 4; a.m = m; a.pd = pd; a.x = x; a.px = px; a.partial = work; a.amax_in = amax_in; a.overflow = overflow;
-    const int cop = 16 * divup(co, 16), cip = 16 * divup(ci, 16), nk = twgrad_nk(co, ci, l), parts = twgrad_parts(b, co, ci, l);
     hipStream_t st = as_stream(stream);
-    const int rc = nk == 8 ? twgrad_launch<8>(a, parts, st)
-                           : (nk == 4 ? twgrad_launch<4>(a, parts, st) : (nk == 2 ? twgrad_launch<2>(a, parts, st) : twgrad_launch<1>(a, parts, st)));
-    if (rc != SPS_OK) return rc;
-    hipLaunchKernelGGL(twgrad_reduce_kernel, dim3(divup(co * ci, 32)), dim3(256), 0, st, co, ci, cip, cop, parts, work, dw);
+    // both operands of a stage live in LDS, which holds 256 rows of each: wider layers (IA-SSD layer 5) run as blocks of at
+    // most 256 x 256 of dW, one launch pair each through the same workspace (the stream orders them), in a fixed order
+    for (int r0 = 0; r0 < co; r0 += 256)
+        for (int c0 = 0; c0 < ci; c0 += 256) {
+            const int cb = co - r0 < 256 ? co - r0 : 256, ib = ci - c0 < 256 ? ci - c0 : 256;
+            TWgradArgs a;
+            a.b = b; a.co = cb; a.ci = ib; a.co_total = co; a.ci_total = ci; a.l = l; a.dmode = dmode; a.xmode = xmode;
+            a.dA = dA ? dA + (size_t)r0 * l : nullptr; a.y = y + (size_t)r0 * l;
+            a.gout = gout ? gout + (size_t)r0 * m : nullptr; a.arg = arg ? arg + (size_t)r0 * m : nullptr;
+            a.ns = nsample > 0 ? nsample : 4; a.m = m; a.pd = pd + (size_t)r0 * TP; a.x = x + (size_t)c0 * l;
+            a.px = px ? px + (size_t)c0 * TP : nullptr; a.partial = work; a.amax_in = amax_in; a.overflow = overflow;
+            const int cop = 16 * divup(cb, 16), cip = 16 * divup(ib, 16), nk = twgrad_nk(cb, ib, l), parts = twgrad_parts(b, cb, ib, l);
+            const int rc = nk == 8 ? twgrad_launch<8>(a, parts, st)
+                                   : (nk == 4 ? twgrad_launch<4>(a, parts, st) : (nk == 2 ? twgrad_launch<2>(a, parts, st) : twgrad_launch<1>(a, parts, st)));
+            if (rc != SPS_OK) return rc;
+            hipLaunchKernelGGL(twgrad_reduce_kernel, dim3(divup(cb * ib, 32)), dim3(256), 0, st, cb, ib, cip, cop, parts, work,
+                               dw + (size_t)r0 * ci + c0, ci);
+        }
     return check_launch("twgrad_kernel");
 }

@@ -649,7 +649,7 @@ class _PackedGeneric:
     __slots__ = ("key", "ws", "wamax", "params")
 
 
-_GENERIC_MAX_CIN = 288      # input channels of a layer that sps_tconv serves (weights resident in LDS as split halves)
+_GENERIC_MAX_CIN = 4096     # input channels of a layer that sps_tconv serves (beyond 288: K slabs of 256 rows, weights in LDS)
 
 
 def generic_mlp_pool(mlp, grouped):

@@ -278,6 +278,9 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
         return (None, None, dx) + tuple(grads)
 
 
+_FUSED_TRAIN_MAX_CHANNELS = int(os.environ.get("SPS_FUSED_TRAIN_MAX_CHANNELS", "1024"))
+
+
 def _fused_stack_train(mods, x, pool: bool):
     """[conv 1x1 (no bias), BatchNorm on batch statistics, ReLU] x n (+ max over the last axis when pool) through
     _GroupedMLPPoolTrain, or None when the modules / shapes do not qualify.  mods: the flat module list."""
@@ -292,14 +295,17 @@ def _fused_stack_train(mods, x, pool: bool):
     if len(mods) % 3 or not mods:
         return None
     cols = x.shape[2] * (x.shape[3] if pool else 1)
-    if (pool and x.shape[3] not in (4, 8, 16, 32, 64)) or cols % 64 or x.shape[1] > 256 or x.numel() == 0:
+    # (up to 1024 channels on either side of a layer: IA-SSD layer 5's 256 / 512 / 1024-wide scales; beyond 256 input rows
+    #  sps_tconv runs K slabs and sps_twgrad 256 x 256 blocks of the weight gradient)
+    if (pool and x.shape[3] not in (4, 8, 16, 32, 64)) or cols % 64 or x.shape[1] > _FUSED_TRAIN_MAX_CHANNELS or x.numel() == 0:
         return None
     bns, wgb = [], []
     for conv, bn, act in zip(mods[0::3], mods[1::3], mods[2::3]):
         if not (isinstance(conv, conv_t) and isinstance(bn, bn_t) and isinstance(act, nn.ReLU) and bn.affine
                 and bn.track_running_stats and bn.momentum is not None and bn.training and all(k == 1 for k in conv.kernel_size)
                 and all(v == 1 for v in conv.stride) and conv.groups == 1 and conv.bias is None
-                and conv.weight.dtype == torch.float32 and bn.weight.dtype == torch.float32 and max(conv.weight.shape[:2]) <= 256):
+                and conv.weight.dtype == torch.float32 and bn.weight.dtype == torch.float32
+                and max(conv.weight.shape[:2]) <= _FUSED_TRAIN_MAX_CHANNELS):
             return None
         bns.append(bn)
         wgb += [conv.weight, bn.weight, bn.bias]

@@ -2027,12 +2027,26 @@ def test_backbone_training_step_runs(ext, G, dev, tag):
     if tag == "pagnet":
         batch["stds"] = G.t(np.random.default_rng(1).uniform(0, 40, (2, 4096)).astype(np.float32))
     before = {k: v.clone() for k, v in net.state_dict().items() if k.endswith("running_mean")}
-    out = net(batch)
-    loss = out["centers_features"].square().mean() + out["ctr_offsets"][:, 1:].square().mean()
-    for t in out["sa_ins_preds"]:
-        if isinstance(t, torch.Tensor):
-            loss = loss + t[..., 1:].square().mean()
-    loss.backward()
+    # every grouped MLP of the step -- layer 5's 256 / 512 / 1024-wide scales included -- runs on the fused train-mode kernels:
+    # no 1x1 convolution of the step reaches a library GEMM (pointnet2_modules._Conv1x1Train's torch.matmul / bmm route)
+    from spsnet_amd import pointnet2_modules as PM
+    gemm_calls, fused_calls = [], []
+    orig_mm, orig_bmm, orig_fused = torch.matmul, torch.bmm, PM._GroupedMLPPoolTrain.apply
+    torch.matmul = lambda *a, **k: gemm_calls.append("matmul") or orig_mm(*a, **k)
+    torch.bmm = lambda *a, **k: gemm_calls.append("bmm") or orig_bmm(*a, **k)
+    PM._GroupedMLPPoolTrain.apply = lambda *a, **k: fused_calls.append(tuple(a[2].shape)) or orig_fused(*a, **k)
+    try:
+        out = net(batch)
+        loss = out["centers_features"].square().mean() + out["ctr_offsets"][:, 1:].square().mean()
+        for t in out["sa_ins_preds"]:
+            if isinstance(t, torch.Tensor):
+                loss = loss + t[..., 1:].square().mean()
+        loss.backward()
+    finally:
+        torch.matmul, torch.bmm = orig_mm, orig_bmm
+        del PM._GroupedMLPPoolTrain.apply                 # (back to the inherited autograd.Function.apply)
+    assert not gemm_calls, gemm_calls
+    assert any(shape[1] == 259 for shape in fused_calls), fused_calls      # layer 5: 256 feature channels + xyz
     grads = [(k, p.grad) for k, p in net.named_parameters() if p.grad is not None]
     assert len(grads) > 40 and all(torch.isfinite(g).all() for _, g in grads)
     assert any(float(g.abs().sum()) > 0 for _, g in grads)
@@ -2613,7 +2627,10 @@ def test_group_concat_matches_query_and_group(ext, G, C, use_xyz):
 # ------------------------------------------------------------------ the fused train-mode grouped MLP (csrc/mlp_train.hip)
 @pytest.mark.parametrize("B,M,ns,widths", [(2, 128, 16, [7, 24, 40, 72]), (2, 64, 32, [131, 128, 256, 256]),
                                            (3, 40, 8, [4, 16, 32]), (1, 16, 4, [19]), (2, 32, 64, [67, 64, 96, 128]),
-                                           (2, 48, 16, [259, 256, 200]), (2, 24, 8, [20, 48, 40]), (1, 8, 8, [5, 16, 16, 16])])
+                                           (2, 48, 16, [259, 256, 200]), (2, 24, 8, [20, 48, 40]), (1, 8, 8, [5, 16, 16, 16]),
+                                           # IA-SSD layer 5 (IA-SSD.yaml:35-55): K slabs in the convolutions, 256 x 256 blocks of dW
+                                           (2, 32, 16, [259, 256, 256, 512]), (2, 16, 32, [259, 256, 512, 1024]),
+                                           (1, 8, 8, [300, 520, 70]), (1, 8, 8, [1030, 16])])
 def test_fused_train_mode_mlp_matches_torch(dev, B, M, ns, widths, monkeypatch):
     """_GroupedMLPPoolTrain (conv + batch statistics in the epilogue, BatchNorm / ReLU / pool routing / BatchNorm backward
     in the operand loads, split-fp16 MFMA) against the plain torch op sequence of the reference (pointnet2_modules.py:432-444)
@@ -2621,7 +2638,9 @@ def test_fused_train_mode_mlp_matches_torch(dev, B, M, ns, widths, monkeypatch):
     parameter, at 2e-4 of the largest reference magnitude (the op-by-op GPU path is held to the same bar).  Shapes cover
     channel counts that are not multiples of 16 / 32, more than 128 output rows (two row chunks), one to three layers,
     every supported nsample, column counts that are odd multiples of 64 (the narrower weight-gradient stage) or a single
-    64-column block, and a first width beyond 256 (declined: falls back to the op-by-op path)."""
+    64-column block, widths of 257 .. 1024 on either side of a layer (K slabs of 256 input rows in sps_tconv, every slab behind
+    the first accumulating into the output; 256 x 256 blocks of the weight gradient in sps_twgrad; channel counts that are
+    no multiple of the slab), and a width beyond 1024 (declined: falls back to the op-by-op path)."""
     import copy
     from spsnet_amd import fused, pointnet2_modules as PM
     torch.manual_seed(B * 1000 + M + ns)
@@ -2646,7 +2665,7 @@ def test_fused_train_mode_mlp_matches_torch(dev, B, M, ns, widths, monkeypatch):
     xg = x0.to(dev).requires_grad_(True)
     monkeypatch.setattr(PM, "FUSED_MLP_TRAINING", True)
     got = PM._fused_mlp_pool_train(mlp, xg, 'max_pool')
-    if max(chain) > 256:
+    if max(chain) > 1024:
         assert got is None
         return
     assert got is not None, "the stack was supposed to qualify"
