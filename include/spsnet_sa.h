@@ -58,6 +58,15 @@ int sps_set_fps_mode(int mode);
 int sps_debug_fps_profile(int b, int n, int m, const float *dataset, float *temp, int *idxs,
                           unsigned long long *dbg, sps_stream_t stream);
 
+/* DIAGNOSTIC ONLY: the same for the four-wave kernel (csrc/fps_pruned4.hip) behind the sorting pre-pass; work = b *
+ * sps_fps_workspace_floats(n) floats; dbg (B, 4 waves, 12) u64; 8192 < n <= 16 384; needs sps_init(). */
+int sps_debug_fps4_profile(int b, int n, int m, const float *dataset, float *temp, int *idxs, float *work,
+                           unsigned long long *dbg, sps_stream_t stream);
+
+/* DIAGNOSTIC / A-B: 4 selects the four-wave register-resident FPS kernel (one wave per SIMD, buckets in AGPRs) behind the sorting
+ * pre-pass for 8192 < n <= 16 384; 8 (default) the eight-wave one.  Bit-identical results; returns the previous setting. */
+int sps_debug_set_fps_waves(int waves);
+
 /* DIAGNOSTIC ONLY: one {XCC_ID, HW_ID} register pair per workgroup -> out (blocks, 2) u32; tools/cumask_probe.py uses it to
  * print which physical compute units a CU-masked stream reaches. */
 int sps_debug_where(int blocks, int threads, int spin, unsigned *out, sps_stream_t stream);

@@ -23,6 +23,7 @@ _PROTOS = {
     "sps_init": [_i, _vp],
     "sps_is_initialized": [_i],
     "sps_set_fps_mode": [_i],
+    "sps_debug_set_fps_waves": [_i],
     "sps_debug_where": [_i, _i, _i, _vp, _vp],
     "sps_stream_create_cu_mask": [_i, _vp, _vp],
     "sps_stream_destroy": [_vp],
@@ -33,6 +34,7 @@ _PROTOS = {
     "sps_fps_ordered_prefix_check_range": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_fps_ordered_prefix_finish_from": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_debug_fps_profile": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sps_debug_fps4_profile": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_farthest_point_sampling_kernel_launcher": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "sps_furthest_point_sampling_with_dist_kernel_launcher": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "sps_gather_points_kernel_launcher_fast": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],

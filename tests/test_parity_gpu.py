@@ -696,6 +696,40 @@ def test_fps_pruned_equals_bruteforce_and_oracle(ext, G, oracle, N, m, kind):
         np.testing.assert_array_equal(got_t, want_t, err_msg=f"fps mode {mode}")
 
 
+@pytest.mark.parametrize("kind,N,m", [("kitti", 16384, 2048), ("lattice", 12288, 700), ("dup", 9000, 900), ("mirror4", 16384, 1500),
+                                      ("stacked", 16384, 600), ("degenerate", 10000, 300)])
+def test_fps_four_wave_variant_matches_oracle(ext, G, oracle, kind, N, m):
+    """csrc/fps_pruned4.hip (one wave per SIMD, 64 bucket slots per wave with coordinates and running distances in AGPRs selected
+    by VGPR-index mode, accepted centres applied two at a time, four records per wave): the opt-in A/B variant of the
+    register-resident FPS kernel -- measured slower than the eight-wave kernel and therefore not the default, but
+    held to the same contract: indices AND final running distances bit-identical to the oracle, ties and degenerate clouds
+    included."""
+    from spsnet_amd import scenes
+    rng = np.random.default_rng(N + m)
+    if kind == "kitti":
+        xyz, _ = scenes.make_batch("kitti-lidar-v1", 3, N, seed0=21, dup_fraction=0.02)
+    elif kind == "lattice":
+        xyz = cloud(rng, 2, N, lattice=True)
+    elif kind == "dup":
+        xyz = cloud(rng, 2, N, dup=0.2)
+    elif kind == "degenerate":
+        xyz = cloud(rng, 3, N)
+        xyz[0] = 2.5                                   # every point identical
+        xyz[1, :, 1:] = 0.0                            # collinear
+        xyz[2, 17] = np.nan
+        xyz[2, 900, 2] = np.inf
+    else:
+        xyz = np.concatenate([_adversarial_cloud(kind, N, s) for s in (1, 2)])
+    want, want_t = oracle.fps(xyz, m, return_temp=True)
+    old = ext.set_fps_waves(4)
+    try:
+        got, got_t = G.fps(ext, xyz, m)
+    finally:
+        ext.set_fps_waves(old)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(got_t, want_t)
+
+
 def _adversarial_cloud(kind, N, seed):
     rng = np.random.default_rng(seed)
     if kind == "mirror4":      # 4-fold mirror symmetry about the first point: exact distance ties in different buckets
