@@ -56,7 +56,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # issue-rate ceiling of the ball query's pair test (see ball_query_roofline): 1024 SIMDs x 2.4 GHz x 64 lanes / 23.1 cycles
 VALU_PAIR_TEST_PEAK = 1024 * 2.4e9 * 64 / (4 * 2.31 + 2 * 2.72 + 2 * 4.20)
 MFMA_PEAK_TF = {"fp32": 157.3, "fp16x2": 2500.0, "fp16": 2500.0}  # dense peaks: fp32 MFMA, fp16 MFMA (no sparsity)
-PROFILE_DIRS = ("round3", "round2", "round1")
+PROFILE_DIRS = ("round4", "round3", "round2", "round1")
 
 
 def parse():
@@ -447,6 +447,37 @@ def training_step_leg(modules_pkg, sa_stack, cfg, args, xyz, feats, dev, reps=10
     return res
 
 
+def backbone_forward_leg(args, dev, reps=20):
+    """Informational, never `value`: the whole IASSD_Backbone forward (SA layers 0-3, the vote layer and layer 5 with its
+    256 / 512 / 1024-wide scales: IASSD_backbone.py:93-168, IA-SSD.yaml:35-55) on a batch of the bench shape, in both grouped-MLP
+    arithmetics.  Strict fp32 runs layer 5 on the point-major fp32 MFMA kernel -- no library GEMM on the inference path."""
+    from spsnet_amd import backbones as BB, fused, scenes
+    xyz, feats = scenes.make_batch(args.dataset, args.batch, args.points, seed0=1)
+    bidx = np.repeat(np.arange(args.batch, dtype=np.float32), args.points)[:, None]
+    points = torch.from_numpy(np.concatenate([bidx, xyz.reshape(-1, 3), feats.transpose(0, 2, 1).reshape(-1, 1)], 1)
+                              .astype(np.float32)).to(dev)
+    net = scenes.fill_parameters(BB.IASSD_Backbone(BB.IASSD_KITTI_CFG, input_channels=4, num_class=3), 5).to(dev).eval()
+    res = {}
+    keep = fused.PRECISION
+    try:
+        for prec in ("fp32", "fp16x2"):
+            fused.set_precision(prec)
+            with torch.no_grad():
+                for _ in range(4):
+                    net(dict(batch_size=args.batch, points=points))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    net(dict(batch_size=args.batch, points=points))
+                torch.cuda.synchronize()
+            res[f"backbone_forward_ms_{prec}"] = 1e3 * (time.perf_counter() - t0) / reps
+    finally:
+        fused.set_precision(keep)
+    res["note"] = (f"IASSD_Backbone.forward, {args.batch} x {args.points} points, wall clock over {reps} back-to-back forwards; "
+                   "informational, not the headline metric")
+    return res
+
+
 def same_outputs(got, want):
     """Bit-for-bit equality of two run_sa_layers results -> (ok, first difference)."""
     for k, (g, w) in enumerate(zip(got, want)):
@@ -764,6 +795,11 @@ def main():
                 line["training_step"] = training_step_leg(M, sa_stack, cfg, args, xyz, feats, dev)
             except Exception as exc:   # informational only: never lose the headline line over it
                 line["training_step"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if world == 1 and not args.no_training_leg and args.config not in (4, 5) and args.mlp_precision != "fp16":
+            try:
+                line["backbone_forward"] = backbone_forward_leg(args, dev)
+            except Exception as exc:   # informational only
+                line["backbone_forward"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(layers, args)
         sys.stdout.flush()
