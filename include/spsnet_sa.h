@@ -658,6 +658,42 @@ int sps_twgrad(int b, int co, int ci, long long l, int dmode, int xmode, const f
                const unsigned char *arg, int nsample, int m, const float *pd, const float *x, const float *px,
                const float *amax_in, float *dw, float *work, int *overflow, sps_stream_t stream);
 
+/* ---- one call per grouped MLP of a TRAINING step (csrc/mlp_train.hip; pointnet2_modules.py:432-444 of the reference in train()
+ * mode: [Conv2d 1x1, BatchNorm2d on batch statistics, ReLU] x n + max-pool, and its backward).  The launch-by-launch entry points
+ * above composed in C: a backbone step issues ~220 of them and is host-bound from Python.  Every buffer is the caller's:
+ *   x (b, c[0], m, ns); w[k] (c[k+1], c[k]); y[k] (b, c[k+1], m ns) pre-BatchNorm outputs; params[k] (c[k+1], 8);
+ *   wamax (n); partial = sps_mlp_train_partial_doubles(desc) doubles; out / yarg (b, c[n], m) floats, arg the same in bytes;
+ *   backward: gout (b, c[n], m); dA[k] (b, c[k], m ns) for k = 1 .. n-1, dA[0] = dx or NULL; dw[k] (c[k+1], c[k]) or NULL;
+ *   dgamma[k], dbeta[k] (c[k+1]); amax (n); work = max_k sps_twgrad_workspace_floats(b, c[k+1], c[k], m ns) floats.
+ * running_mean / running_var / num_batches_tracked are updated as nn.BatchNorm2d does.  Nothing is allocated or synchronised. */
+typedef struct sps_mlp_train_desc {
+    int n, b, m, ns;
+    int c[5];
+    const float *w[4];
+    const float *gamma[4], *beta[4];
+    float eps[4], momentum[4];
+    float *running_mean[4], *running_var[4];
+    long long *num_batches_tracked[4];
+    const float *x;
+    float *y[4];
+    float *params[4];
+    float *wamax;
+    double *partial;
+    float *out;
+    unsigned char *arg;
+    float *yarg;
+    int *overflow;
+    const float *gout;
+    float *dA[4];
+    float *dw[4];
+    float *dgamma[4], *dbeta[4];
+    float *amax;
+    float *work;
+} sps_mlp_train_desc;
+long long sps_mlp_train_partial_doubles(const sps_mlp_train_desc *desc);
+int sps_mlp_train_forward(const sps_mlp_train_desc *desc, sps_stream_t stream);
+int sps_mlp_train_backward(const sps_mlp_train_desc *desc, sps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,8 @@ _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 # name -> argument types (every entry point returns int status unless noted)
 _PROTOS = {
     "sps_init": [_i, _vp],
+    "sps_mlp_train_forward": [_vp, _vp],
+    "sps_mlp_train_backward": [_vp, _vp],
     "sps_is_initialized": [_i],
     "sps_set_fps_mode": [_i],
     "sps_debug_set_fps_waves": [_i],
@@ -135,9 +137,20 @@ _PROTOS = {
 EXPORTS = ["sps_abi_version", "sps_last_error", "sps_opt_n_threads", "sps_fps_workspace_floats",
            "sps_index_add_workspace_ints", "sps_ball_query_grid_workspace_ints", "sps_bn_train_workspace_doubles", "sps_conv1x1_wgrad_workspace_floats",
            "sps_pack_columns_capacity", "sps_debug_set_wait_spins", "sps_debug_set_exchange_spins",
-           "sps_twgrad_workspace_floats"] + list(_PROTOS)
+           "sps_twgrad_workspace_floats", "sps_mlp_train_partial_doubles"] + list(_PROTOS)
 
 _lib = None
+
+
+class MlpTrainDesc(ctypes.Structure):
+    """struct sps_mlp_train_desc of include/spsnet_sa.h (one call per grouped MLP of a training step)"""
+    _fields_ = [("n", _i), ("b", _i), ("m", _i), ("ns", _i), ("c", _i * 5),
+                ("w", _vp * 4), ("gamma", _vp * 4), ("beta", _vp * 4), ("eps", _f * 4), ("momentum", _f * 4),
+                ("running_mean", _vp * 4), ("running_var", _vp * 4), ("num_batches_tracked", _vp * 4),
+                ("x", _vp), ("y", _vp * 4), ("params", _vp * 4), ("wamax", _vp), ("partial", _vp),
+                ("out", _vp), ("arg", _vp), ("yarg", _vp), ("overflow", _vp),
+                ("gout", _vp), ("dA", _vp * 4), ("dw", _vp * 4), ("dgamma", _vp * 4), ("dbeta", _vp * 4),
+                ("amax", _vp), ("work", _vp)]
 
 
 class SpsError(RuntimeError):
@@ -176,6 +189,8 @@ def load():
     lib.sps_debug_set_exchange_spins.restype = ctypes.c_uint
     lib.sps_twgrad_workspace_floats.argtypes = [_i, _i, _i, ctypes.c_longlong]
     lib.sps_twgrad_workspace_floats.restype = ctypes.c_longlong
+    lib.sps_mlp_train_partial_doubles.argtypes = [_vp]
+    lib.sps_mlp_train_partial_doubles.restype = ctypes.c_longlong
     lib.sps_pack_columns_capacity.argtypes = [_i, _i, _i]
     lib.sps_pack_columns_capacity.restype = ctypes.c_longlong
     for name, args in _PROTOS.items():

@@ -1117,3 +1117,105 @@ extern "C" int sps_twgrad(int b, int co, int ci, long long l, int dmode, int xmo
         }
     return check_launch("twgrad_kernel");
 }
+
+// ---- one call per grouped MLP (host side of a training step) ------------------------------------------------------------
+// The launches above, composed in C: a training step of IASSD_Backbone issues ~220 of them from Python (24-argument ctypes
+// calls, a torch.empty per output), ~25 us of host time each, and is host-bound.  The caller allocates every buffer once
+// (sizes: sps_mlp_train_partial_doubles / sps_twgrad_workspace_floats) and makes ONE call for the forward of a grouped MLP
+// with its max-pool, one for its backward.  Same kernels, same order, same results as the launch-by-launch form
+// (pointnet2_modules._GroupedMLPPoolTrain without it; SyncBatchNorm keeps that form: its all-reduces sit between the launches).
+extern "C" long long sps_mlp_train_partial_doubles(const sps_mlp_train_desc *d) {
+    if (!d || d->n < 1 || d->n > 4) return 0;
+    const long long l = (long long)d->m * d->ns;
+    long long need = (long long)d->b * d->c[d->n] * 2;
+    for (int k = 0; k <= d->n; ++k) {
+        const long long v = (long long)sps_tconv_parts(d->b, l, d->c[k]) * d->c[k] * 2;
+        need = v > need ? v : need;
+    }
+    return need;
+}
+
+static int mlp_train_check(const sps_mlp_train_desc *d, const char *what) {
+    if (!d || d->n < 1 || d->n > 4 || d->b <= 0 || d->m <= 0 || d->ns <= 0)
+        return fail(SPS_ERR_INVALID, "%s: bad descriptor (n, b, m, ns)", what);
+    for (int k = 0; k <= d->n; ++k)
+        if (d->c[k] <= 0) return fail(SPS_ERR_INVALID, "%s: c[%d] = %d", what, k, d->c[k]);
+    for (int k = 0; k < d->n; ++k)
+        if (!d->w[k] || !d->y[k] || !d->params[k]) return fail(SPS_ERR_INVALID, "%s: null pointer at layer %d", what, k);
+    if (!d->x || !d->wamax || !d->partial) return fail(SPS_ERR_INVALID, "%s: null pointer", what);
+    return SPS_OK;
+}
+
+extern "C" int sps_mlp_train_forward(const sps_mlp_train_desc *d, sps_stream_t stream) {
+    int rc = mlp_train_check(d, "mlp_train_forward");
+    if (rc != SPS_OK) return rc;
+    if (!d->out || !d->arg || !d->yarg) return fail(SPS_ERR_INVALID, "mlp_train_forward: null output");
+    const int n = d->n;
+    const long long l = (long long)d->m * d->ns;
+    const double count = (double)d->b * (double)l;
+    const float *wp[4] = {nullptr, nullptr, nullptr, nullptr};
+    long long wn[4] = {0, 0, 0, 0};
+    for (int k = 0; k < n; ++k) { wp[k] = d->w[k]; wn[k] = (long long)d->c[k + 1] * d->c[k]; }
+    rc = sps_tamax4(n, wp[0], wn[0], wp[1], wn[1], wp[2], wn[2], wp[3], wn[3], d->wamax, stream);
+    if (rc != SPS_OK) return rc;
+    const float *operand = d->x, *pin = nullptr;
+    for (int k = 0; k < n; ++k) {
+        rc = sps_tconv(d->b, d->c[k], d->c[k + 1], l, k ? TIN_BNRELU : TIN_RAW, TEPI_STATS, 0, d->w[k], operand, nullptr, nullptr,
+                       nullptr, 0, 0, pin, d->y[k], nullptr, nullptr, d->partial, nullptr, nullptr, d->wamax + k, d->overflow, stream);
+        if (rc != SPS_OK) return rc;
+        rc = sps_tbn_finalize_dc(d->c[k + 1], sps_tconv_parts(d->b, l, d->c[k + 1]), count, nullptr, d->partial, d->gamma[k], d->beta[k],
+                                 d->eps[k], d->momentum[k], d->running_mean[k], d->running_var[k], d->params[k],
+                                 d->num_batches_tracked[k], stream);
+        if (rc != SPS_OK) return rc;
+        operand = d->y[k];
+        pin = d->params[k];
+    }
+    return sps_tpool_fwd(d->b, d->c[n], d->m, d->ns, d->y[n - 1], d->params[n - 1], d->out, d->arg, d->yarg, stream);
+}
+
+extern "C" int sps_mlp_train_backward(const sps_mlp_train_desc *d, sps_stream_t stream) {
+    int rc = mlp_train_check(d, "mlp_train_backward");
+    if (rc != SPS_OK) return rc;
+    const int n = d->n;
+    if (!d->gout || !d->arg || !d->yarg || !d->amax) return fail(SPS_ERR_INVALID, "mlp_train_backward: null pointer");
+    for (int k = 0; k < n; ++k) {
+        if (!d->dgamma[k] || !d->dbeta[k] || (k > 0 && !d->dA[k]) || (d->dw[k] && !d->work))
+            return fail(SPS_ERR_INVALID, "mlp_train_backward: null pointer at layer %d", k);
+    }
+    const long long l = (long long)d->m * d->ns;
+    const double count = (double)d->b * (double)l;
+    if (hipMemsetAsync(d->amax, 0, (size_t)n * sizeof(float), as_stream(stream)) != hipSuccess)
+        return fail(SPS_ERR_LAUNCH, "mlp_train_backward: hipMemsetAsync");
+    // the last layer's BatchNorm-backward sums from the pooled gradient alone (its dA is never materialised)
+    rc = sps_tpool_bwd_stats(d->b, d->c[n], d->m, d->yarg, d->gout, d->params[n - 1], d->partial, d->amax + (n - 1), stream);
+    if (rc != SPS_OK) return rc;
+    rc = sps_tbn_bwd_finalize_dc(d->c[n], d->b, count, nullptr, d->partial, d->params[n - 1], d->dgamma[n - 1], d->dbeta[n - 1], stream);
+    if (rc != SPS_OK) return rc;
+    for (int k = n - 1; k >= 0; --k) {
+        const bool routed = k == n - 1;      // the incoming gradient is the pooled one, routed by the arg-max in the operand load
+        const float *dA_in = routed ? nullptr : d->dA[k + 1];
+        const float *g = routed ? d->gout : nullptr;
+        const unsigned char *ar = routed ? d->arg : nullptr;
+        const int ns = routed ? d->ns : 0, mm = routed ? d->m : 0;
+        if (d->dw[k]) {
+            rc = sps_twgrad(d->b, d->c[k + 1], d->c[k], l, routed ? TIN_BNBWD_POOL : TIN_BNBWD, k ? TIN_BNRELU : TIN_RAW, dA_in, d->y[k],
+                            g, ar, ns, mm, d->params[k], k ? d->y[k - 1] : d->x, k ? d->params[k - 1] : nullptr, d->amax + k, d->dw[k],
+                            d->work, d->overflow, stream);
+            if (rc != SPS_OK) return rc;
+        }
+        const int mode = routed ? TIN_BNBWD_POOL : TIN_BNBWD;
+        if (k > 0) {
+            rc = sps_tconv(d->b, d->c[k + 1], d->c[k], l, mode, TEPI_BWD, 1, d->w[k], dA_in, d->y[k], g, ar, ns, mm, d->params[k], d->dA[k],
+                           d->y[k - 1], d->params[k - 1], d->partial, d->amax + k, d->amax + (k - 1), d->wamax + k, d->overflow, stream);
+            if (rc != SPS_OK) return rc;
+            rc = sps_tbn_bwd_finalize_dc(d->c[k], sps_tconv_parts(d->b, l, d->c[k]), count, nullptr, d->partial, d->params[k - 1],
+                                         d->dgamma[k - 1], d->dbeta[k - 1], stream);
+            if (rc != SPS_OK) return rc;
+        } else if (d->dA[0]) {
+            rc = sps_tconv(d->b, d->c[1], d->c[0], l, mode, TEPI_NONE, 1, d->w[0], dA_in, d->y[0], g, ar, ns, mm, d->params[0], d->dA[0],
+                           nullptr, nullptr, nullptr, d->amax, nullptr, d->wamax, d->overflow, stream);
+            if (rc != SPS_OK) return rc;
+        }
+    }
+    return SPS_OK;
+}

@@ -10,6 +10,7 @@ builders, the sampling strategies live in a dispatch table (`_SAMPLERS`, same pr
 reference's if/elif chain at :284-419), score-based sampling is one fused kernel
 (`sps_score_topk`) and grouping uses the fused query+group kernel when no gradient is needed.
 """
+import ctypes
 import os
 from typing import Callable, List, Optional
 
@@ -122,6 +123,13 @@ class _Conv1x1Train(torch.autograd.Function):
         return dx, dw
 
 
+def _L_twgrad_ws(b, co, ci, l):
+    return _lib.load().sps_twgrad_workspace_floats(b, co, ci, l)
+
+
+# the forward / the backward of a fused train-mode grouped MLP as ONE C call each (sps_mlp_train_forward / _backward) instead of
+# ~8 / ~14 ctypes launches with a torch.empty per output: a backbone's training step is host-bound
+ONE_CALL_TRAINING = os.environ.get("SPS_ONE_CALL_TRAINING", "1") != "0"
 FUSED_CONV_TRAINING = True
 # [Conv2d 1x1, BatchNorm2d(batch statistics), ReLU] x n + max-pool as the fused kernels of csrc/mlp_train.hip (split-fp16
 # MFMA arithmetic: active unless fused.set_train_precision("fp32") asks for the exact op-by-op path)
@@ -193,7 +201,117 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
             return _GroupedMLPPoolTrain._backward(ctx, gout)
 
     @staticmethod
+    def _one_call(bns, pool, x):
+        """The whole forward / backward as ONE C call each (sps_mlp_train_forward / _backward) -- what a plain (unsynchronised)
+        grouped MLP with its pool takes; SyncBatchNorm keeps the launch-by-launch form (its all-reduces sit between the
+        launches), and so does a stack without a pool."""
+        return (ONE_CALL_TRAINING and pool and 1 <= len(bns) <= 4 and x.dim() == 4
+                and all(_sync_group(bn)[0] is None for bn in bns))
+
+    @staticmethod
+    def _forward_one_call(ctx, bns, x, *wgb):
+        n = len(bns)
+        x = x.contiguous()
+        B, c0, M, ns = x.shape
+        l = M * ns
+        dev = x.device
+        ws = [wgb[3 * k].detach().reshape(wgb[3 * k].shape[0], wgb[3 * k].shape[1]).contiguous() for k in range(n)]
+        cs = [c0] + [w.shape[0] for w in ws]
+        d = _lib.MlpTrainDesc()
+        d.n, d.b, d.m, d.ns = n, B, M, ns
+        ys, ps = [], []
+        for k in range(n + 1):
+            d.c[k] = cs[k]
+        # one arena for the small float buffers: parameter blocks, wamax
+        small = torch.empty((sum(cs[1:]) * _ext.TRAIN_PARAMS + 4,), dtype=torch.float32, device=dev)
+        off = 0
+        for k, bn in enumerate(bns):
+            y = torch.empty((B, cs[k + 1], M, ns), dtype=torch.float32, device=dev)
+            p = small[off:off + cs[k + 1] * _ext.TRAIN_PARAMS].view(cs[k + 1], _ext.TRAIN_PARAMS)
+            off += cs[k + 1] * _ext.TRAIN_PARAMS
+            ys.append(y); ps.append(p)
+            d.w[k], d.y[k], d.params[k] = ws[k].data_ptr(), y.data_ptr(), p.data_ptr()
+            d.gamma[k], d.beta[k] = wgb[3 * k + 1].data_ptr(), wgb[3 * k + 2].data_ptr()
+            d.eps[k], d.momentum[k] = float(bn.eps), float(bn.momentum)
+            d.running_mean[k], d.running_var[k] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            d.num_batches_tracked[k] = bn.num_batches_tracked.data_ptr()
+        wamax = small[off:off + 4]
+        out = torch.empty((B, cs[n], M), dtype=torch.float32, device=dev)
+        yarg = torch.empty((B, cs[n], M), dtype=torch.float32, device=dev)
+        arg = torch.empty((B, cs[n], M), dtype=torch.uint8, device=dev)
+        need = max([B * cs[n] * 2] + [_ext.tconv_parts(B, l, c) * c * 2 for c in cs])
+        partial = torch.empty((need,), dtype=torch.float64, device=dev)
+        d.x, d.wamax, d.partial = x.data_ptr(), wamax.data_ptr(), partial.data_ptr()
+        d.out, d.arg, d.yarg = out.data_ptr(), arg.data_ptr(), yarg.data_ptr()
+        d.overflow = _fused._overflow_flag(dev).data_ptr()
+        _lib.check(_lib.load().sps_mlp_train_forward(ctypes.byref(d), ctypes.c_void_p(_ext._stream(x))), "mlp_train_forward")
+        for bn in bns:
+            _ext._bump_versions(bn.running_mean, bn.running_var, bn.num_batches_tracked)
+        ctx.n, ctx.ns, ctx.count, ctx.pool = n, ns, B * l, True
+        ctx.one_call = True
+        ctx.cs = cs
+        ctx.wshapes = [tuple(wgb[3 * k].shape) for k in range(n)]
+        ctx.save_for_backward(x, arg, yarg, small, *ys, *ws)
+        return out
+
+    @staticmethod
+    def _backward_one_call(ctx, gout):
+        n, ns, cs = ctx.n, ctx.ns, ctx.cs
+        saved = ctx.saved_tensors
+        x, arg, yarg, small = saved[0], saved[1], saved[2], saved[3]
+        ys, ws = saved[4:4 + n], saved[4 + n:4 + 2 * n]
+        gout = gout.contiguous()
+        B, c0, M, _ = x.shape
+        l = M * ns
+        dev = x.device
+        d = _lib.MlpTrainDesc()
+        d.n, d.b, d.m, d.ns = n, B, M, ns
+        for k in range(n + 1):
+            d.c[k] = cs[k]
+        # the small outputs in one arena: d gamma / d beta per layer, amax
+        sg = torch.empty((2 * sum(cs[1:]) + 4,), dtype=torch.float32, device=dev)
+        grads = [None] * (3 * n)
+        off = po = 0
+        keep = []
+        work_need = 0
+        for k in range(n):
+            c = cs[k + 1]
+            d.w[k], d.y[k] = ws[k].data_ptr(), ys[k].data_ptr()
+            d.params[k] = small[po:po + c * _ext.TRAIN_PARAMS].data_ptr()
+            po += c * _ext.TRAIN_PARAMS
+            dg, db = sg[off:off + c], sg[off + c:off + 2 * c]
+            off += 2 * c
+            d.dgamma[k], d.dbeta[k] = dg.data_ptr(), db.data_ptr()
+            grads[3 * k + 1], grads[3 * k + 2] = dg, db
+            if ctx.needs_input_grad[3 + 3 * k]:
+                dw = torch.empty((c, cs[k]), dtype=torch.float32, device=dev)
+                d.dw[k] = dw.data_ptr()
+                grads[3 * k] = dw.view(ctx.wshapes[k])
+                work_need = max(work_need, int(_L_twgrad_ws(B, c, cs[k], l)))
+            if k > 0:
+                dA = torch.empty((B, cs[k], M, ns), dtype=torch.float32, device=dev)
+                d.dA[k] = dA.data_ptr()
+                keep.append(dA)
+        dx = None
+        if ctx.needs_input_grad[2]:
+            dx = torch.empty_like(x)
+            d.dA[0] = dx.data_ptr()
+        d.wamax = small[po:po + 4].data_ptr()
+        d.amax = sg[off:off + 4].data_ptr()
+        need = max([B * cs[n] * 2] + [_ext.tconv_parts(B, l, c) * c * 2 for c in cs])
+        partial = torch.empty((need,), dtype=torch.float64, device=dev)
+        work = torch.empty((max(work_need, 1),), dtype=torch.float32, device=dev)
+        d.x, d.partial, d.work = x.data_ptr(), partial.data_ptr(), work.data_ptr()
+        d.arg, d.yarg, d.gout = arg.data_ptr(), yarg.data_ptr(), gout.data_ptr()
+        d.overflow = _fused._overflow_flag(dev).data_ptr()
+        _lib.check(_lib.load().sps_mlp_train_backward(ctypes.byref(d), ctypes.c_void_p(_ext._stream(gout))), "mlp_train_backward")
+        return (None, None, dx) + tuple(grads)
+
+    @staticmethod
     def _forward(ctx, bns, pool, x, *wgb):
+        if _GroupedMLPPoolTrain._one_call(bns, pool, x):
+            return _GroupedMLPPoolTrain._forward_one_call(ctx, bns, x, *wgb)
+        ctx.one_call = False
         n = len(bns)
         x = x.contiguous()
         B, tail = x.shape[0], tuple(x.shape[2:])
@@ -231,6 +349,8 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
 
     @staticmethod
     def _backward(ctx, gout):
+        if ctx.one_call:
+            return _GroupedMLPPoolTrain._backward_one_call(ctx, gout)
         n, ns, count, pool = ctx.n, ctx.ns, ctx.count, ctx.pool
         saved = ctx.saved_tensors
         x, arg, yarg = saved[0], saved[1], saved[2]
