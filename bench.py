@@ -2,7 +2,11 @@
 """bench.py -- SA-stack throughput on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+    (N > 1: ONE command per node, like the reference's tools/scripts/dist_train.sh:1-20 -- when no launcher has set
+    WORLD_SIZE, bench.py starts its N ranks itself (`python -m torch.distributed.run --nproc-per-node N bench.py ...`) as
+    child processes BEFORE anything touches the GPU and relays rank 0's line and the exit code; launched by
+    torch.distributed.run it is one of those ranks.  A WORLD_SIZE that differs from --gpus is an error, never a silent
+    one-GPU measurement.)
 
 One "step" = one full pass of the IA-SSD set-abstraction stack L0-L2 (D-FPS 16 384->4 096,
 D-FPS ->1 024, ctr-aware top-k ->512; per layer two ball-query radii, grouping, grouped MLP,
@@ -368,13 +372,68 @@ def pmc_mfma_busy(widths, nsample, precision):
     return rec, f"profiles/{where}/pmc_mfma.json[{key}]"
 
 
-def cpu_baseline(layers, args):
+def oracle_verdict(got, want, samplers, tol):
+    """The timed batch against the CPU oracle's pass over the SAME scenes and weights (run by cpu_baseline, outside every timed
+    region): `got` / `want` = per layer (new_xyz, new_features, cls, sampled_idx) as numpy.  D-FPS layers: indices and
+    centroids bit-exact, features / class scores within `tol` of the layer's largest reference magnitude (>= 1).  A
+    score-sampled layer sits behind features that carry that tolerance, so its picks may swap near-ties: rows are matched by
+    sampled index and compared on the shared picks.  -> (record, list of failures)"""
+    rec = {"scenes": int(want[0][3].shape[0]), "tolerance": tol, "idx_exact": True, "new_xyz_exact": True,
+           "max_abs_err_features": 0.0, "max_rel_err": 0.0, "layers": []}
+    bad = []
+    for k, ((gx, gf, gc, gi), (wx, wf, wc, wi)) in enumerate(zip(got, want)):
+        row = {"layer": k, "sampler": samplers[k], "M": int(wi.shape[1])}
+        scale = max(1.0, float(np.abs(wf).max()))
+        if samplers[k] == "D-FPS" or np.array_equal(gi, wi):
+            row["idx_exact"] = bool(np.array_equal(gi, wi))
+            row["new_xyz_exact"] = bool(np.array_equal(gx, wx))
+            err = float(np.abs(gf - wf).max()) if row["idx_exact"] else float("nan")
+            cerr = float(np.abs(gc - wc).max()) if (row["idx_exact"] and wc is not None) else None
+            if not row["idx_exact"]:
+                rec["idx_exact"] = False
+                bad.append(f"layer {k}: sampled indices differ from the oracle's")
+            if not row["new_xyz_exact"]:
+                rec["new_xyz_exact"] = False
+                bad.append(f"layer {k}: centroids differ from the oracle's")
+        else:
+            err, cerr, shared = 0.0, (0.0 if wc is not None else None), []
+            for b in range(wi.shape[0]):
+                common, gpos, wpos = np.intersect1d(gi[b], wi[b], return_indices=True)
+                shared.append(len(common) / wi.shape[1])
+                if not np.array_equal(gx[b][gpos], wx[b][wpos]):
+                    bad.append(f"layer {k} scene {b}: centroids of shared picks differ")
+                err = max(err, float(np.abs(gf[b][:, gpos] - wf[b][:, wpos]).max()))
+                if wc is not None:
+                    cerr = max(cerr, float(np.abs(gc[b][gpos] - wc[b][wpos]).max()))
+            row["picks_shared_with_oracle"] = float(np.mean(shared))
+            row["compared"] = "rows matched by sampled index (score sampler behind 1e-4 features: near-ties may swap)"
+            if row["picks_shared_with_oracle"] < 0.98:
+                bad.append(f"layer {k}: only {row['picks_shared_with_oracle']:.3f} of the picks shared with the oracle")
+        row.update(max_abs_err_features=err, feature_scale=scale, max_rel_err=err / scale)
+        if cerr is not None:
+            row["max_abs_err_cls"] = cerr
+            if not cerr <= tol * max(1.0, float(np.abs(wc).max())):
+                bad.append(f"layer {k}: class scores off by {cerr}")
+        if not err <= tol * scale:
+            bad.append(f"layer {k}: features off by {err} (scale {scale})")
+        if err == err:
+            rec["max_abs_err_features"] = max(rec["max_abs_err_features"], err)
+            rec["max_rel_err"] = max(rec["max_rel_err"], err / scale)
+        rec["layers"].append(row)
+    rec["ok"] = not bad
+    return rec, bad
+
+
+def cpu_baseline(layers, args, gpu_outs=None, samplers=None):
     """Oracle port of the same stack on the host cores, on a bounded sample: once with all cores, once single-threaded
-    (SURVEY.md 8d asks for both)."""
+    (SURVEY.md 8d asks for both).  The all-core sample IS rank 0's timed batch (same scenes: seeds 0..B-1, same weights), so
+    its first pass doubles as the checker of the GPU outputs the timed region produced (`gpu_outs`, snapshotted to the
+    host right behind the timed steps) -> (baseline object, oracle verdict or None)."""
     from oracle import cpu_stack, oracle as O
     from spsnet_amd import scenes
     cores = os.cpu_count() or 1
     cpu_layers = cpu_stack.cpu_copy(layers)
+    first = {}
 
     def sample(nsc, threads, budget_s, max_reps):
         O.set_threads(threads)
@@ -386,7 +445,9 @@ def cpu_baseline(layers, args):
         t0 = time.perf_counter()
         reps = 0
         while True:
-            cpu_stack.sa_stack_cpu(cpu_layers, xyz, feats, stds)
+            res = cpu_stack.sa_stack_cpu(cpu_layers, xyz, feats, stds)
+            if reps == 0:
+                first[nsc] = res
             reps += 1
             el = time.perf_counter() - t0
             if el > budget_s or reps >= max_reps:
@@ -404,7 +465,14 @@ def cpu_baseline(layers, args):
         out["single_thread"] = {"value": v_one, "unit": "points/s", "cores": 1,
                                 "sample": f"{reps_one} pass(es) over 1 scene x {args.points} pts, 1 thread, {el_one:.1f} s"}
     O.set_threads(cores)
-    return out
+    verdict = None
+    if gpu_outs is not None and nsc == args.batch:
+        verdict, bad = oracle_verdict(gpu_outs, first[nsc], samplers, 2e-3 if args.mlp_precision == "fp16" else 1e-4)
+        verdict["checker"] = ("oracle/cpu_stack.sa_stack_cpu over oracle/sa_oracle.c on the timed batch's own scenes and weights, "
+                              "run after the timed region (its all-core pass is also cpu_baseline's sample)")
+        if bad:
+            raise SystemExit("bench.py: the timed batch does not match the CPU oracle: " + "; ".join(bad) + f" {verdict}")
+    return out, verdict
 
 
 def training_step_leg(modules_pkg, sa_stack, cfg, args, xyz, feats, dev, reps=10):
@@ -489,8 +557,36 @@ def same_outputs(got, want):
     return True, ""
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as children (torch.distributed.run, one per GPU,
+    rendezvous on 127.0.0.1) -- the parent never initialises the GPU -- relay their stdout (rank 0's ONE line) and stderr,
+    and exit with the launcher's code.  Mirrors the reference's one command per node (tools/scripts/dist_train.sh:1-20 ->
+    tools/train.py:64-72 `init_dist_pytorch`)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: the only form this host's driver supports
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: starting", args.gpus, "ranks:", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
+    if int(env_world or "1") != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: the line would report {env_world} GPU(s); "
+                         "launch with --nproc-per-node equal to --gpus (or run `python bench.py --gpus N`, which starts its "
+                         "own ranks)")
     # stdout carries the ONE JSON line and nothing else: whatever a library prints there (RCCL's version banner at
     # communicator set-up, for one) goes to stderr for the rest of the run
     sys.stdout.flush()
@@ -629,6 +725,11 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         overlap_ok = bool(int(flag.item()))
     checked = validate(outs)
+    # the timed batch's outputs, kept on the host for the oracle check that rides on the CPU-baseline leg (N = 1, rank 0)
+    outs_host = None
+    if world == 1 and not args.no_cpu_baseline and not args.no_validate:
+        outs_host = [tuple(None if t is None else t.detach().float().cpu().numpy() if t.is_floating_point()
+                           else t.detach().cpu().numpy() for t in o[:4]) for o in outs]
     no_exchange = None
     if exchange:
         g = state["gathered"]
@@ -801,7 +902,9 @@ def main():
             except Exception as exc:   # informational only
                 line["backbone_forward"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(layers, args)
+            line["cpu_baseline"], verdict = cpu_baseline(layers, args, outs_host, [m[0] for m in cfg["sample_method_list"]])
+            if verdict is not None and "validated" in line:
+                line["validated"]["oracle"] = verdict
         sys.stdout.flush()
         os.write(line_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():

@@ -76,3 +76,32 @@ def test_one_rank_rccl_exchange_inside_the_step():
     assert line["helper_streams"]["probes"] > 0
     assert line["overlap_verified"] is True and line["helper_streams"]["unplaced"] == [] and "overlap_warning" not in line
     assert line["ms_per_step_no_exchange"] < line["roofline"]["launch_ms"] + 1.0, (line["ms_per_step_no_exchange"], line["roofline"])
+
+
+@pytest.mark.gpu
+def test_one_command_launch_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's natural command, and the reference's one command per
+    node: tools/scripts/dist_train.sh) starts two ranks itself and reports them -- not one GPU under the label it was asked for."""
+    env = dict(os.environ, SPS_BENCH_REHEARSAL="one-gpu")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-fp16x2-leg"]
+    done = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-3000:]
+    lines = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, done.stdout[-3000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["exchange"]["ranks"] == 2 and line["config"]["global_batch"] == 16
+    assert line["config"]["workload"].startswith("BASELINE configs[2]")
+    assert line["validated"]["last_step_bit_identical_to_sequential_pass"] is True
+
+
+def test_world_size_that_differs_from_gpus_is_an_error():
+    """A launcher that set WORLD_SIZE=1 under `--gpus 2` (or the reverse) must not produce a line: bench.py exits non-zero before
+    it touches a GPU (runs on CPU)."""
+    for world, gpus in (("1", "2"), ("2", "1")):
+        env = dict(os.environ, WORLD_SIZE=world, RANK="0", LOCAL_RANK="0")
+        done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", gpus, "--steps", "1", "--warmup", "0"],
+                              cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert done.returncode != 0 and "WORLD_SIZE" in done.stderr, (done.returncode, done.stderr[-500:])
+        assert not [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
