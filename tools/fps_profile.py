@@ -5,7 +5,8 @@ import numpy as np, torch
 from spsnet_amd import _lib, scenes
 L = _lib.load()
 B, N, M = 8, int(sys.argv[1]) if len(sys.argv) > 1 else 16384, int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-xyz, _ = scenes.make_batch("kitti-lidar-v1", B, N, seed0=0)
+DATASET = sys.argv[3] if len(sys.argv) > 3 else "kitti-lidar-v1"
+xyz, _ = scenes.make_batch(DATASET, B, N, seed0=0)
 x = torch.from_numpy(xyz).cuda()
 temp = torch.full((B, N), 1e10, device="cuda")
 idx = torch.zeros((B, M), dtype=torch.int32, device="cuda")
@@ -15,7 +16,7 @@ torch.cuda.synchronize()
 d = dbg.cpu().numpy().astype(np.float64)
 names = ["apply", "candidate", "publish", "barrier", "accept"]
 it = M - 1
-print(f"N={N} m={M}: per-ROUND cycles per wave (mean over scenes), stamp cost ~40 included in each segment")
+print(f"{DATASET} N={N} m={M}: per-ROUND cycles per wave (mean over scenes), stamp cost ~40 included in each segment")
 for w in range(8):
     row = d[:, w].mean(0)
     rounds = row[5]
