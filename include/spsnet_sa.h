@@ -35,9 +35,15 @@ enum {
     SPS_ERR_LAUNCH = 2   /* hipGetLastError() != hipSuccess after the launch */
 };
 
-/* library identity: SPS_ABI_VERSION this header was written for */
-#define SPS_ABI_VERSION 1
+/* library identity: SPS_ABI_VERSION this header was written for.  2 (round 5): sps_init / sps_is_initialized, the
+ * sps_mlp_train_* and sps_sa_layer_* descriptor calls and sps_struct_size were added since 1, and the FPS launchers stopped
+ * creating the pre-pass's flag pool themselves (a caller that passes a workspace for 6144 <= n <= 16 384 and never called
+ * sps_init() gets the kernel that sorts for itself: same picks, no pre-pass).
+ * sps_struct_size: sizeof() of the descriptor structs below as THIS library was compiled (which: 0 = sps_mlp_train_desc,
+ * 1 = sps_sa_layer_desc; -1 for anything else) -- a binding that mirrors a struct by hand checks its own size against it. */
+#define SPS_ABI_VERSION 2
 int sps_abi_version(void);
+long long sps_struct_size(int which);
 /* message of the most recent failing call on this thread ("" if none) */
 const char *sps_last_error(void);
 /* One-time set-up of the library's per-device state (today: the 256 KiB flag pool of the FPS sorting pre-pass); `device`
@@ -52,24 +58,6 @@ int sps_opt_n_threads(int work_size);
  * register-resident / streaming kernels only.  Both give bit-identical results; returns the old mode. */
 int sps_set_fps_mode(int mode);
 
-/* DIAGNOSTIC ONLY: s_memtime-instrumented build of the pruned FPS kernel (never on the product path).
- * dbg (B, 8 waves, 12) u64 receives per-wave cycle sums of the loop segments, touched-bucket / tie-path counts and why the
- * accepted prefix of a round ended (lowered, hidden, nothing rejected; picks). */
-int sps_debug_fps_profile(int b, int n, int m, const float *dataset, float *temp, int *idxs,
-                          unsigned long long *dbg, sps_stream_t stream);
-
-/* DIAGNOSTIC ONLY: the same for the four-wave kernel (csrc/fps_pruned4.hip) behind the sorting pre-pass; work = b *
- * sps_fps_workspace_floats(n) floats; dbg (B, 4 waves, 12) u64; 8192 < n <= 16 384; needs sps_init(). */
-int sps_debug_fps4_profile(int b, int n, int m, const float *dataset, float *temp, int *idxs, float *work,
-                           unsigned long long *dbg, sps_stream_t stream);
-
-/* DIAGNOSTIC / A-B: 4 selects the four-wave register-resident FPS kernel (one wave per SIMD, buckets in AGPRs) behind the sorting
- * pre-pass for 8192 < n <= 16 384; 8 (default) the eight-wave one.  Bit-identical results; returns the previous setting. */
-int sps_debug_set_fps_waves(int waves);
-
-/* DIAGNOSTIC ONLY: one {XCC_ID, HW_ID} register pair per workgroup -> out (blocks, 2) u32; tools/cumask_probe.py uses it to
- * print which physical compute units a CU-masked stream reaches. */
-int sps_debug_where(int blocks, int threads, int spin, unsigned *out, sps_stream_t stream);
 /* Stream plumbing for the CU-fenced schedule (no counterpart in the reference, which launches everything on the legacy
  * default stream): a HIP stream restricted to the compute units set in mask[0 .. words) (hipExtStreamCreateWithCUMask);
  * the caller owns it.  A pass's FPS chain occupies one CU per scene for most of the pass; on a stream of its own CUs a
@@ -272,14 +260,9 @@ int sps_set_mlp_precision(int mode);
  * chunk of a streamed layer -- whose wait is patient, so its inputs are final -- passes full_range_if = timed_out: it
  * redoes every chunk when a wait did give up and costs nothing otherwise (one predicated centroid gather is the only extra
  * launch).  force_redo = timed_out goes to sps_fps_ordered_prefix_finish, which then recomputes every scene.
- * sps_debug_set_wait_spins: DIAGNOSTIC, the spin bound of sps_wait_progress (tests force the redo path with it;
- * 0xFFFFFFFF: every wait gives up without looking at the counter; 0 restores the default).
- * sps_debug_set_exchange_spins: DIAGNOSTIC, the spin bound of the cross-workgroup polls inside the FPS kernels (the K-way
- * sort of the pre-pass / clustered kernel and the clustered kernel's record exchange).  A poll that runs out never traps:
- * it raises the scene's give-up word, the scene's workgroups leave, and the launcher's follow-up launch (always enqueued,
- * normally empty) samples the scene with the one-workgroup kernel.  Same encoding as above. */
-unsigned sps_debug_set_wait_spins(unsigned spins);
-unsigned sps_debug_set_exchange_spins(unsigned spins);
+ * (The spin bounds of the waits can be forced from tests: include/spsnet_sa_debug.h.)  A cross-workgroup poll inside the FPS
+ * kernels that runs out never traps: it raises the scene's give-up word, the scene's workgroups leave, and the launcher's
+ * follow-up launch (always enqueued, normally empty) samples the scene with the one-workgroup kernel. */
 /* sps_wait_progress sets timed_out[0 .. b) (one flag per scene, all of them) when it gives up.
  * sps_fps_redo_where: the ordinary FPS for the scenes with redo[scene] != 0 only (temp must be pre-filled with 1e10 for
  * them); the other scenes keep idxs / temp untouched. */
@@ -297,7 +280,7 @@ int sps_fps_publish(int b, int n, int m, const float *dataset, float *temp, int 
 int sps_fps_publish_ws(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress, float *work,
                        sps_stream_t stream);
 int sps_wait_progress(const int *progress, int b, int need, int *timed_out, sps_stream_t stream);
-/* patient != 0: the wait for the producer's last sample -- ~64 x the bound, not affected by sps_debug_set_wait_spins. */
+/* patient != 0: the wait for the producer's last sample -- ~64 x the bound, not affected by the diagnostic spin bound (spsnet_sa_debug.h). */
 int sps_wait_progress_ex(const int *progress, int b, int need, int *timed_out, int patient, sps_stream_t stream);
 int sps_gather_xyz_range(int b, int n, int m, int j0, int jcount, const float *xyz, const int *idx, float *out,
                          const int *run_if, sps_stream_t stream);

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libspsnet_sa.so")
 
 SPS_OK = 0
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 
@@ -25,7 +25,6 @@ _PROTOS = {
     "sps_mlp_train_backward": [_vp, _vp],
     "sps_is_initialized": [_i],
     "sps_set_fps_mode": [_i],
-    "sps_debug_set_fps_waves": [_i],
     "sps_debug_where": [_i, _i, _i, _vp, _vp],
     "sps_stream_create_cu_mask": [_i, _vp, _vp],
     "sps_stream_destroy": [_vp],
@@ -36,7 +35,6 @@ _PROTOS = {
     "sps_fps_ordered_prefix_check_range": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_fps_ordered_prefix_finish_from": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_debug_fps_profile": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
-    "sps_debug_fps4_profile": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sps_farthest_point_sampling_kernel_launcher": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "sps_furthest_point_sampling_with_dist_kernel_launcher": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "sps_gather_points_kernel_launcher_fast": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
@@ -137,7 +135,7 @@ _PROTOS = {
 EXPORTS = ["sps_abi_version", "sps_last_error", "sps_opt_n_threads", "sps_fps_workspace_floats",
            "sps_index_add_workspace_ints", "sps_ball_query_grid_workspace_ints", "sps_bn_train_workspace_doubles", "sps_conv1x1_wgrad_workspace_floats",
            "sps_pack_columns_capacity", "sps_debug_set_wait_spins", "sps_debug_set_exchange_spins",
-           "sps_twgrad_workspace_floats", "sps_mlp_train_partial_doubles"] + list(_PROTOS)
+           "sps_twgrad_workspace_floats", "sps_mlp_train_partial_doubles", "sps_struct_size"] + list(_PROTOS)
 
 _lib = None
 
@@ -151,6 +149,9 @@ class MlpTrainDesc(ctypes.Structure):
                 ("out", _vp), ("arg", _vp), ("yarg", _vp), ("overflow", _vp),
                 ("gout", _vp), ("dA", _vp * 4), ("dw", _vp * 4), ("dgamma", _vp * 4), ("dbeta", _vp * 4),
                 ("amax", _vp), ("work", _vp)]
+
+
+DESC_MIRRORS = [MlpTrainDesc]       # index = `which` of sps_struct_size()
 
 
 class SpsError(RuntimeError):
@@ -191,6 +192,8 @@ def load():
     lib.sps_twgrad_workspace_floats.restype = ctypes.c_longlong
     lib.sps_mlp_train_partial_doubles.argtypes = [_vp]
     lib.sps_mlp_train_partial_doubles.restype = ctypes.c_longlong
+    lib.sps_struct_size.argtypes = [_i]
+    lib.sps_struct_size.restype = ctypes.c_longlong
     lib.sps_pack_columns_capacity.argtypes = [_i, _i, _i]
     lib.sps_pack_columns_capacity.restype = ctypes.c_longlong
     for name, args in _PROTOS.items():
@@ -200,6 +203,10 @@ def load():
     got = lib.sps_abi_version()
     if got != ABI_VERSION:
         raise ImportError(f"libspsnet_sa ABI {got} != expected {ABI_VERSION}; rebuild spsnet_amd/csrc")
+    for which, mirror in enumerate(DESC_MIRRORS):
+        if lib.sps_struct_size(which) != ctypes.sizeof(mirror):
+            raise ImportError(f"{mirror.__name__}: {ctypes.sizeof(mirror)} bytes here, {lib.sps_struct_size(which)} in libspsnet_sa; "
+                              "rebuild spsnet_amd/csrc")
     _lib = lib
     return lib
 

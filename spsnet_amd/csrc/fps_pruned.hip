@@ -526,26 +526,6 @@ int launch_fps_pruned_profile(int b, int n, int m, const float *dataset, float *
 int launch_fps_presort(int b, int n, const float *dataset, const float *temp, float *work, long long stride, hipStream_t st,
                        PresortGate *gate);
 
-// fps_pruned4.hip: the four-wave kernel behind the pre-pass (-1: does not apply)
-int launch_fps_pruned4(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress, const float *work,
-                       long long stride, const PresortGate &gate, hipStream_t st);
-// SPS_FPS_WAVES=4 selects the four-wave kernel where it applies (8192 < n <= 16 384 behind the sorting pre-pass); 8 = this file
-static std::atomic<int> g_fps_waves{0};
-static int fps_waves() {
-    int w = g_fps_waves.load(std::memory_order_relaxed);
-    if (w == 0) {
-        const char *e = getenv("SPS_FPS_WAVES");
-        w = e && atoi(e) == 4 ? 4 : 8;
-        g_fps_waves.store(w, std::memory_order_relaxed);
-    }
-    return w;
-}
-int set_fps_waves(int waves) {
-    const int old = fps_waves();
-    g_fps_waves.store(waves == 4 ? 4 : 8, std::memory_order_relaxed);
-    return old;
-}
-
 int launch_fps_pruned_publish(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress,
                               hipStream_t st, float *work, long long stride) {
     if (n < 6144 || n > 32 * PF_THREADS || m < 2) return -1;
@@ -560,13 +540,6 @@ int launch_fps_pruned_publish(int b, int n, int m, const float *dataset, float *
     if (work && launch_fps_presort(b, n, dataset, temp, work, stride, st, &gate) == SPS_OK) {   // sorted by a pre-pass of K workgroups per scene
         // (behind it: the scenes the pre-pass gave up on -- a bounded poll that ran out, normally none -- through the kernel
         //  that sorts for itself; it publishes the same way)
-        if (fps_waves() == 4 && launch_fps_pruned4(b, n, m, dataset, temp, idxs, progress, work, stride, gate, st) == SPS_OK) {
-            if (gate.word && P <= 32)
-                hipLaunchKernelGGL((fps_pruned_kernel<32, false, false, true>), grid, block, 0, st, n, m, bs, l2, rb, dataset,
-                                   temp, idxs, (unsigned long long *)nullptr, (const int *)nullptr, (const float *)nullptr,
-                                   progress, (const float *)nullptr, 0ll, gate.word, gate.stride, gate.tag);
-            return check_launch("fps_pruned4_kernel<publish>");
-        }
 #define SPS_PFS_CASE(PP)                                                                                         \
         if (P <= PP) {                                                                                           \
             hipLaunchKernelGGL((fps_pruned_kernel<PP, false, false, true, true>), grid, block, 0, st, n, m, bs, l2, rb, dataset, \
@@ -610,13 +583,6 @@ int launch_fps_pruned(int b, int n, int m, const float *dataset, float *temp, in
     dim3 grid(b), block(PF_THREADS);
     PresortGate gate{};
     if (work && !redo && P > 8 && launch_fps_presort(b, n, dataset, temp, work, stride, st, &gate) == SPS_OK) {
-        if (fps_waves() == 4 && launch_fps_pruned4(b, n, m, dataset, temp, idxs, nullptr, work, stride, gate, st) == SPS_OK) {
-            if (gate.word && P <= 32)
-                hipLaunchKernelGGL((fps_pruned_kernel<32, false, false>), grid, block, 0, st, n, m, bs, l2, rb, dataset,
-                                   temp, idxs, (unsigned long long *)nullptr, (const int *)nullptr, (const float *)nullptr,
-                                   (int *)nullptr, (const float *)nullptr, 0ll, gate.word, gate.stride, gate.tag);
-            return check_launch("fps_pruned4_kernel");
-        }
 #define SPS_PFS_CASE(PP)                                                                                       \
         if (P <= PP) {                                                                                         \
             hipLaunchKernelGGL((fps_pruned_kernel<PP, false, false, false, true>), grid, block, 0, st, n, m, bs, l2, rb, dataset, \
@@ -652,8 +618,3 @@ int launch_fps_pruned(int b, int n, int m, const float *dataset, float *temp, in
 }
 
 }  // namespace sps
-
-// DIAGNOSTIC / A-B: which register-resident FPS kernel runs behind the sorting pre-pass for 8192 < n <= 16 384 points --
-// 8 (default: fps_pruned.hip, two waves per SIMD) or 4 (fps_pruned4.hip, one wave per SIMD, buckets in AGPRs; measured slower,
-// DESIGN.md 4.1).  Both give bit-identical results.  Returns the previous setting.
-extern "C" int sps_debug_set_fps_waves(int waves) { return sps::set_fps_waves(waves); }

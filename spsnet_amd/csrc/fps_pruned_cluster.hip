@@ -20,7 +20,8 @@
 // More records per round and less work per wave: 180 000 -> 16 384 in 9.95 ms at K = 8 against 32.8 ms on one CU
 // (fps_pruned_big.hip's launcher holds the measured table and picks K, T).
 // The K workgroups of a scene must be resident together: the launcher uses the cluster only for b K <= 64 workgroups
-// (a CU each; the polls are bounded -- a stuck exchange traps instead of hanging the device).
+// (a CU each; the polls are bounded -- a poll that runs out raises the scene's give-up word, its workgroups leave and the
+// launcher's follow-up launch samples that scene with the one-workgroup kernel: correct or redo, never a trap or a hang).
 #include "fps_sort_split.h"
 
 #include <cstdlib>

@@ -1124,6 +1124,13 @@ extern "C" int sps_twgrad(int b, int co, int ci, long long l, int dmode, int xmo
 // (sizes: sps_mlp_train_partial_doubles / sps_twgrad_workspace_floats) and makes ONE call for the forward of a grouped MLP
 // with its max-pool, one for its backward.  Same kernels, same order, same results as the launch-by-launch form
 // (pointnet2_modules._GroupedMLPPoolTrain without it; SyncBatchNorm keeps that form: its all-reduces sit between the launches).
+extern "C" long long sps_struct_size(int which) {
+    switch (which) {
+    case 0: return (long long)sizeof(sps_mlp_train_desc);
+    default: return -1;
+    }
+}
+
 extern "C" long long sps_mlp_train_partial_doubles(const sps_mlp_train_desc *d) {
     if (!d || d->n < 1 || d->n > 4) return 0;
     const long long l = (long long)d->m * d->ns;

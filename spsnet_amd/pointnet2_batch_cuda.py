@@ -106,18 +106,6 @@ class _on:
 F32, I32 = torch.float32, torch.int32
 
 
-# SPS_FPS_WAVES=4 (csrc/fps_pruned4.hip, the four-wave kernel behind the sorting pre-pass): this wrapper then hands 8192 < n <=
-# 16 384 a workspace too, so that the plain D-FPS takes that kernel as well (A/B and test runs)
-_FPS_WAVES4 = os.environ.get("SPS_FPS_WAVES", "") == "4"
-
-
-def set_fps_waves(waves):
-    """DIAGNOSTIC / A-B: 4 = the four-wave FPS kernel (csrc/fps_pruned4.hip) where it applies, 8 = the default; -> previous"""
-    global _FPS_WAVES4
-    _FPS_WAVES4 = int(waves) == 4
-    return int(_L.sps_debug_set_fps_waves(int(waves)))
-
-
 def farthest_point_sampling_wrapper(b, n, m, points_tensor, temp_tensor, idx_tensor):
     """sampling.cpp:34-43.  points (B,N,3), temp (B,N) pre-filled 1e10, idx (B,M) -> 1."""
     p, t, i = _ptr(points_tensor, F32, "points"), _ptr(temp_tensor, F32, "temp"), _ptr(idx_tensor, I32, "idx")
@@ -126,9 +114,7 @@ def farthest_point_sampling_wrapper(b, n, m, points_tensor, temp_tensor, idx_ten
     # which sorts the points into a workspace (20 B per point) -- torch's caching allocator hands it out
     # (6144 .. 16 384 points: a workspace would select the sorting pre-pass; measured, it pays for the publishing kernel of the
     #  streamed layer only -- 8 x 16 384 -> 4 096 through this wrapper 1.790 ms without, 1.813 ms with)
-    work_floats = int(_L.sps_fps_workspace_floats(n)) if m > 1 and (n > 16384 or (_FPS_WAVES4 and 8192 < n <= 16384)) else 0
-    if work_floats and n <= 16384:
-        _lib.ensure_init(points_tensor.device)     # (the pre-pass's flag pool)
+    work_floats = int(_L.sps_fps_workspace_floats(n)) if m > 1 and n > 16384 else 0
     with _on(points_tensor):
         if work_floats:
             work = torch.empty((b * work_floats,), dtype=F32, device=points_tensor.device)

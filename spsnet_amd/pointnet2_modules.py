@@ -1156,13 +1156,35 @@ class PointnetSAModuleMSG_WithSampling(_SamplingSAModule):
         if stds is not None:
             stds = stds.view(xyz.shape[0], 1, -1).contiguous()
         sampled_idx_list = []
-        if ctr_xyz is None:
-            self._start_layer1_per_point(xyz, features)
-            sampled_idx_list, new_xyz, stds = self._sample(xyz, features, cls_features, stds)
-        else:
-            new_xyz = ctr_xyz
-        new_features, cls_features = self._abstract(xyz, new_xyz, features, sampled_idx_list)
+        try:
+            if ctr_xyz is None:
+                self._start_layer1_per_point(xyz, features)
+                sampled_idx_list, new_xyz, stds = self._sample(xyz, features, cls_features, stds)
+            else:
+                new_xyz = ctr_xyz
+            new_features, cls_features = self._abstract(xyz, new_xyz, features, sampled_idx_list)
+        except BaseException:
+            _drop_schedule_hints(self, everything=True)
+            raise
+        finally:
+            _drop_schedule_hints(self)
         return new_xyz, new_features, cls_features, sampled_idx_list, stds
+
+
+def _drop_schedule_hints(mod, everything=False):
+    """The schedules (sa_stack, backbones, this module's own forward) hand a layer results they started early as attributes
+    keyed by tensor IDENTITY: `_hoisted` (layer 1's per-point rows, started before the sampler), `_prepooled` /
+    `_late_gather_idx` (columns pooled while the cloud was still being written), `_presampled` / `_preball` (an early-started
+    sampler / ball query).  Each is consumed -- read and cleared -- by the forward it was made for; the reference's modules
+    keep no such state ("otherwise stateless").  This runs at the END of every forward: what belongs to the
+    forward that just ran is dropped whether or not a path consumed it, and after a forward that RAISED everything is
+    (nothing stays pinned on the module; a later forward recomputes).  Threading contract: INTEGRATION.md."""
+    mod._hoisted = None
+    mod._late_gather_idx = None
+    mod._prepooled = None
+    if everything:        # (a normal exit keeps a sampling result prefetched for a FUTURE forward: sa_stack.prefetch_first_layer)
+        mod._presampled = None
+        mod._preball = None
 
 
 class Vote_layer(nn.Module):
@@ -1284,9 +1306,15 @@ class PointnetSampling(_SamplingSAModule):
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, cls_features: torch.Tensor = None,
                 new_xyz=None, ctr_xyz=None, **kwargs):
         sampled_idx_list = []
-        if ctr_xyz is None:
-            sampled_idx_list, new_xyz, _ = self._sample(xyz, features, cls_features, None)
-        else:
-            new_xyz = ctr_xyz
-        new_features, _ = self._abstract(xyz, new_xyz, features, sampled_idx_list)
+        try:
+            if ctr_xyz is None:
+                sampled_idx_list, new_xyz, _ = self._sample(xyz, features, cls_features, None)
+            else:
+                new_xyz = ctr_xyz
+            new_features, _ = self._abstract(xyz, new_xyz, features, sampled_idx_list)
+        except BaseException:
+            _drop_schedule_hints(self, everything=True)
+            raise
+        finally:
+            _drop_schedule_hints(self)
         return new_xyz, new_features, sampled_idx_list

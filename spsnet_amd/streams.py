@@ -67,7 +67,9 @@ def new_stream_beside(device, beside: Sequence[torch.cuda.Stream], priority: int
     global _WARNED
     device = torch.device(device)
     if _probing_off():
-        return torch.cuda.Stream(device=device, priority=priority)
+        st = torch.cuda.Stream(device=device, priority=priority)
+        st._sps_unprobed = True       # handed out without a probe (set-up under capture / SPS_STREAM_PROBE=0): verifies nothing
+        return st
     st = None
     for _ in range(max(1, _TRIES)):
         if _PROBES.get(device.index, 0) + len(beside) > _MAX_PROBES_PER_DEVICE:
@@ -93,6 +95,15 @@ def new_stream_beside(device, beside: Sequence[torch.cuda.Stream], priority: int
 _HELPERS = {}   # (device index, root stream handle) -> {tag: (stream, exclusive)}
 _ROOT = {}      # (device index, handle of a stream handed out by helper()) -> (root handle, root stream): helpers of helpers join the pass
 _ON_FORGET = []  # callbacks(device index, root handle, [helper handles]): the callers' own caches of helper streams
+_EXTERNAL_PRODUCER = set()   # (device index, root handle): passes whose FPS producer runs on a stream of the caller's own
+
+
+def declare_external_producer(device, main: torch.cuda.Stream, on: bool = True):
+    """The pass on `main` brings its own producer stream (sa_stack.CuFence: a CU-masked stream): helper() then reserves and
+    probes no "producer" queue for it -- with the default four hardware queues that reservation would cost the pass a queue
+    (and up to SPS_STREAM_TRIES probes) for a stream nobody uses."""
+    key = (torch.device(device).index, main.cuda_stream)
+    (_EXTERNAL_PRODUCER.add if on else _EXTERNAL_PRODUCER.discard)(key)
 
 
 def on_forget(callback):
@@ -109,7 +120,7 @@ def helper(device, main: torch.cuda.Stream, tag: str, exclusive: bool = False) -
     reg = _HELPERS.get(key)
     if reg is None:
         reg = _HELPERS[key] = {}
-        if not _probing_off():
+        if not _probing_off() and key not in _EXTERNAL_PRODUCER:
             # the exclusive helper first: its queue is reserved before any other role can take the last free one
             st = new_stream_beside(device, [root], what=EXCLUSIVE_TAG)
             reg[EXCLUSIVE_TAG] = (st, True)
@@ -145,7 +156,7 @@ def overlap_verified(device, main: torch.cuda.Stream) -> bool:
     reg = _HELPERS.get((device.index, root_handle))
     if not reg or os.environ.get("SPS_STREAM_PROBE", "1") == "0":
         return False
-    return not any(getattr(st, "_sps_unplaced", False) for st, _ in reg.values())
+    return not any(getattr(st, "_sps_unplaced", False) or getattr(st, "_sps_unprobed", False) for st, _ in reg.values())
 
 
 def forget(device, main: torch.cuda.Stream):

@@ -9,10 +9,28 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "spsnet_sa.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(sps_[a-z0-9_]+)\s*\(", text)))
+def declared_functions(headers=("spsnet_sa.h", "spsnet_sa_debug.h")):
+    names = set()
+    for header in headers:
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(sps_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_diagnostics_live_in_their_own_header():
+    """The drop-in header declares no sps_debug_* entry point; the diagnostic header declares nothing else."""
+    assert not [n for n in declared_functions(("spsnet_sa.h",)) if n.startswith("sps_debug_")]
+    assert all(n.startswith("sps_debug_") for n in declared_functions(("spsnet_sa_debug.h",)))
+
+
+def test_descriptor_mirrors_have_the_library_size():
+    import ctypes as C
+    from spsnet_amd import _lib
+    L = _lib.load()
+    for which, mirror in enumerate(_lib.DESC_MIRRORS):
+        assert L.sps_struct_size(which) == C.sizeof(mirror), mirror.__name__
+    assert L.sps_struct_size(len(_lib.DESC_MIRRORS)) == -1
 
 
 def test_header_declares_the_reference_surface():

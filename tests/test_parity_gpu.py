@@ -636,7 +636,7 @@ def _check_stack_against_cpu_oracle(G, dev, layers, want, got, score_layer_input
     np.testing.assert_allclose(G.n(nc), want[2][2], rtol=1e-4, atol=1e-4)
     assert not fused.check_overflow()
     _log_achieved_error(dict(achieved, precision=fused.PRECISION, scenes=int(want[0][3].shape[0]),
-                             points=int(got[0][3].shape[1]), test=os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]))
+                             centroids_layer0=int(got[0][3].shape[1]), test=os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]))
 
 
 def _log_achieved_error(rec):
@@ -716,40 +716,6 @@ def test_fps_pruned_equals_bruteforce_and_oracle(ext, G, oracle, N, m, kind):
             L.sps_set_fps_mode(old)
         np.testing.assert_array_equal(got, want, err_msg=f"fps mode {mode}")
         np.testing.assert_array_equal(got_t, want_t, err_msg=f"fps mode {mode}")
-
-
-@pytest.mark.parametrize("kind,N,m", [("kitti", 16384, 2048), ("lattice", 12288, 700), ("dup", 9000, 900), ("mirror4", 16384, 1500),
-                                      ("stacked", 16384, 600), ("degenerate", 10000, 300)])
-def test_fps_four_wave_variant_matches_oracle(ext, G, oracle, kind, N, m):
-    """csrc/fps_pruned4.hip (one wave per SIMD, 64 bucket slots per wave with coordinates and running distances in AGPRs selected
-    by VGPR-index mode, accepted centres applied two at a time, four records per wave): the opt-in A/B variant of the
-    register-resident FPS kernel -- measured slower than the eight-wave kernel and therefore not the default, but
-    held to the same contract: indices AND final running distances bit-identical to the oracle, ties and degenerate clouds
-    included."""
-    from spsnet_amd import scenes
-    rng = np.random.default_rng(N + m)
-    if kind == "kitti":
-        xyz, _ = scenes.make_batch("kitti-lidar-v1", 3, N, seed0=21, dup_fraction=0.02)
-    elif kind == "lattice":
-        xyz = cloud(rng, 2, N, lattice=True)
-    elif kind == "dup":
-        xyz = cloud(rng, 2, N, dup=0.2)
-    elif kind == "degenerate":
-        xyz = cloud(rng, 3, N)
-        xyz[0] = 2.5                                   # every point identical
-        xyz[1, :, 1:] = 0.0                            # collinear
-        xyz[2, 17] = np.nan
-        xyz[2, 900, 2] = np.inf
-    else:
-        xyz = np.concatenate([_adversarial_cloud(kind, N, s) for s in (1, 2)])
-    want, want_t = oracle.fps(xyz, m, return_temp=True)
-    old = ext.set_fps_waves(4)
-    try:
-        got, got_t = G.fps(ext, xyz, m)
-    finally:
-        ext.set_fps_waves(old)
-    np.testing.assert_array_equal(got, want)
-    np.testing.assert_array_equal(got_t, want_t)
 
 
 def _adversarial_cloud(kind, N, seed):
@@ -2687,7 +2653,8 @@ def test_group_concat_matches_query_and_group(ext, G, C, use_xyz):
                                            # IA-SSD layer 5 (IA-SSD.yaml:35-55): K slabs in the convolutions, 256 x 256 blocks of dW
                                            (2, 32, 16, [259, 256, 256, 512]), (2, 16, 32, [259, 256, 512, 1024]),
                                            (1, 8, 8, [300, 520, 70]), (1, 8, 8, [1030, 16])])
-def test_fused_train_mode_mlp_matches_torch(dev, B, M, ns, widths, monkeypatch):
+@pytest.mark.parametrize("one_call", [True, False], ids=["one-c-call", "launch-by-launch"])
+def test_fused_train_mode_mlp_matches_torch(dev, B, M, ns, widths, one_call, monkeypatch):
     """_GroupedMLPPoolTrain (conv + batch statistics in the epilogue, BatchNorm / ReLU / pool routing / BatchNorm backward
     in the operand loads, split-fp16 MFMA) against the plain torch op sequence of the reference (pointnet2_modules.py:432-444)
     in float64 on the CPU: pooled output, running statistics, and the gradients w.r.t. the grouped input and every
@@ -2720,6 +2687,9 @@ def test_fused_train_mode_mlp_matches_torch(dev, B, M, ns, widths, monkeypatch):
 
     xg = x0.to(dev).requires_grad_(True)
     monkeypatch.setattr(PM, "FUSED_MLP_TRAINING", True)
+    # both host forms of the same kernels: one C call per stack (sps_mlp_train_forward / _backward, the default) and the
+    # launch-by-launch form SyncBatchNorm and SPS_ONE_CALL_TRAINING=0 use
+    monkeypatch.setattr(PM, "ONE_CALL_TRAINING", one_call)
     got = PM._fused_mlp_pool_train(mlp, xg, 'max_pool')
     if max(chain) > 1024:
         assert got is None
