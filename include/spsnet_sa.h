@@ -36,11 +36,11 @@ enum {
 };
 
 /* library identity: SPS_ABI_VERSION this header was written for.  2 (round 5): sps_init / sps_is_initialized, the
- * sps_mlp_train_* and sps_sa_layer_* descriptor calls and sps_struct_size were added since 1, and the FPS launchers stopped
+ * sps_mlp_train_* descriptor calls, sps_set_train_precision and sps_struct_size were added since 1, and the FPS launchers stopped
  * creating the pre-pass's flag pool themselves (a caller that passes a workspace for 6144 <= n <= 16 384 and never called
  * sps_init() gets the kernel that sorts for itself: same picks, no pre-pass).
- * sps_struct_size: sizeof() of the descriptor structs below as THIS library was compiled (which: 0 = sps_mlp_train_desc,
- * 1 = sps_sa_layer_desc; -1 for anything else) -- a binding that mirrors a struct by hand checks its own size against it. */
+ * sps_struct_size: sizeof() of the descriptor structs below as THIS library was compiled (which: 0 = sps_mlp_train_desc;
+ * -1 for anything else) -- a binding that mirrors a struct by hand checks its own size against it. */
 #define SPS_ABI_VERSION 2
 int sps_abi_version(void);
 long long sps_struct_size(int which);
@@ -636,6 +636,13 @@ int sps_tbn_bwd_stats(int b, int c, long long l, const float *y, const float *dA
 /* dw (co, ci) = sum over all columns of dY (x) T(x): dY from (dA, y, pd) as in_mode 2 / 3 of sps_tconv (dmode), T = identity
  * (xmode 0) or relu(fma(x, scale, shift)) with px (xmode 1); co, ci <= 256, l a multiple of 32; work =
  * sps_twgrad_workspace_floats floats. */
+/* Arithmetic of every sps_tconv / sps_twgrad launch and of sps_mlp_train_forward / _backward (process-wide, like
+ * sps_set_mlp_precision): 0 = split-fp16 (every fp32 operand as hi + lo halves behind an exact power-of-two scaling, three
+ * v_mfma_f32_16x16x32_f16 per product block; the library default at this level), 1 = EXACT fp32 on v_mfma_f32_16x16x4_f32 --
+ * the reference's arithmetic (fp32 Conv2d / BatchNorm2d, pointnet2_modules.py:203-211): nothing is scaled, split, range-checked
+ * or poisoned, wamax / amax_in / amax_out may be NULL and the overflow flag is never raised.  Returns the previous mode.
+ * (spsnet_amd.fused.TRAIN_PRECISION, whose default IS "fp32", sets it in front of every launch.) */
+int sps_set_train_precision(int mode);
 long long sps_twgrad_workspace_floats(int b, int co, int ci, long long l);
 int sps_twgrad(int b, int co, int ci, long long l, int dmode, int xmode, const float *dA, const float *y, const float *gout,
                const unsigned char *arg, int nsample, int m, const float *pd, const float *x, const float *px,
@@ -648,6 +655,10 @@ int sps_twgrad(int b, int co, int ci, long long l, int dmode, int xmode, const f
  *   wamax (n); partial = sps_mlp_train_partial_doubles(desc) doubles; out / yarg (b, c[n], m) floats, arg the same in bytes;
  *   backward: gout (b, c[n], m); dA[k] (b, c[k], m ns) for k = 1 .. n-1, dA[0] = dx or NULL; dw[k] (c[k+1], c[k]) or NULL;
  *   dgamma[k], dbeta[k] (c[k+1]); amax (n); work = max_k sps_twgrad_workspace_floats(b, c[k+1], c[k], m ns) floats.
+ * ns = 0: the same stack WITHOUT a pool on (b, c, m) tensors -- an aggregation / confidence / vote stack, [Conv1d, BatchNorm1d,
+ * ReLU] x n (pointnet2_modules.py:213-245, 449-455, 470-478): x (b, c[0], m), y[k] / dA[k] (b, c[k], m), out (b, c[n], m) =
+ * relu(bn_n(...)) dense, gout dense, arg / yarg unused (may be NULL); m a multiple of 64.
+ * Arithmetic: sps_set_train_precision (exact fp32: wamax / amax are not read).
  * running_mean / running_var / num_batches_tracked are updated as nn.BatchNorm2d does.  Nothing is allocated or synchronised. */
 typedef struct sps_mlp_train_desc {
     int n, b, m, ns;

@@ -59,6 +59,7 @@ _PROTOS = {
                          _i, _i, _vp],
     "sps_sa_group_mlp_supported": [_i, _i, _i],
     "sps_set_mlp_precision": [_i],
+    "sps_set_train_precision": [_i],
     "sps_index_add_deterministic": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sps_sa_group_mlp_supported_stream": [_i, _i, _i, _i],
     "sps_sa_group_mlp_pm_supported": [_i, _i, _i, _i, _i],

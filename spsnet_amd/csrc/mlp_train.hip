@@ -40,6 +40,11 @@ enum { TIN_RAW = 0, TIN_BNRELU = 1, TIN_BNBWD = 2, TIN_BNBWD_POOL = 3 };
 enum { TEPI_NONE = 0, TEPI_STATS = 1, TEPI_BWD = 2 };
 
 __device__ __forceinline__ f32x4 tmfma(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+// EXACT fp32 (the reference's arithmetic, fused.set_train_precision("fp32") / sps_set_train_precision(1)): the same kernels with
+// their operands left as they are -- no scaling, no split, no range check -- on v_mfma_f32_16x16x4_f32.  A k-step of 32 input
+// rows is then eight MFMAs of four rows (lane (q, c) holds rows 8 q + e: MFMA e takes row 8 q + e of every q as its k index q,
+// on both operands alike -- a sum over k does not care in which order its terms meet) where the split form issues three of 32.
+__device__ __forceinline__ f32x4 tmfma32(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // relu that keeps a NaN (torch's clamp_min does); the pool compares its results with `>`, hence the float form here
 __device__ __forceinline__ float trelu(float z) { return (z > 0.f || z != z) ? z : 0.f; }
@@ -147,8 +152,9 @@ struct TConvArgs {
 // block boundaries, from a three-deep ring of register buffers.
 //   B operand (activations): lane (q, c) loads rows 32 s + 8 q + e, e = 0..7, as float4 = columns 4c..4c+3; element j of the
 //   float4 feeds column tile j, so loads and stores stay 16 bytes per lane and 256 contiguous bytes per row.
-//   A operand (weights): scaled and split once per workgroup into LDS as [tile][k-step][hi | lo][lane][8 halves].
-template <int RT, int IN, int EPI>
+//   A operand (weights): scaled and split once per workgroup into LDS as [tile][k-step][hi | lo][lane][8 halves]; F32: the
+//   plain floats as [tile][k-step][rows e < 4 | e >= 4][lane][4 floats] -- the same 2 KiB per tile and k-step.
+template <int RT, int IN, int EPI, bool F32>
 __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool GRAD = (IN == TIN_BNBWD || IN == TIN_BNBWD_POOL);
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
     // Weights -> LDS: 16 independent loads per thread and trip (a plain loop waits for every load: 128 round trips to L2 per
     // workgroup at the widest shapes, longer than the workgroup's whole column range took); the transposed operand walks
     // the rows fastest so that consecutive lanes still read consecutive floats.
-    const float sw = tpow2_scale(256.f, *a.wamax);
+    const float sw = F32 ? 1.f : tpow2_scale(256.f, *a.wamax);
     const bool quads = (reinterpret_cast<uintptr_t>(a.w) & 15) == 0 && ((a.trans ? a.co : (a.ci | a.w_ld)) & 3) == 0;
     if (quads) {
         // 16-byte loads along the contiguous dimension of w (k for the plain operand, the output row for the transposed one)
@@ -237,9 +243,13 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int o = a.trans ? f0 + j : slow, k = a.trans ? slow : f0 + j;
+                    const int t = o >> 4, i = o & 15, ss = k >> 5, qq = (k & 31) >> 3, e = k & 7;
+                    if (F32) {
+                        *reinterpret_cast<float *>(wl + ((size_t)(t * S + ss) * 2 + (e >> 2)) * 1024 + (qq * 16 + i) * 16 + (e & 3) * 4) = wq[u][j];
+                        continue;
+                    }
                     _Float16 hi, lo;
                     tsplit(wq[u][j] * sw, hi, lo);
-                    const int t = o >> 4, i = o & 15, ss = k >> 5, qq = (k & 31) >> 3, e = k & 7;
                     char *dst = wl + ((size_t)(t * S + ss) * 2) * 1024 + (qq * 16 + i) * 16 + e * 2;
                     *reinterpret_cast<_Float16 *>(dst) = hi;
                     *reinterpret_cast<_Float16 *>(dst + 1024) = lo;
@@ -264,9 +274,13 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
                 const int idx = base + u * 256 + (int)threadIdx.x;
                 if (idx >= nel) continue;
                 const int o = a.trans ? idx % rows_wg : idx / cip, k = a.trans ? idx / rows_wg : idx % cip;
+                const int t = o >> 4, i = o & 15, ss = k >> 5, qq = (k & 31) >> 3, e = k & 7;
+                if (F32) {
+                    *reinterpret_cast<float *>(wl + ((size_t)(t * S + ss) * 2 + (e >> 2)) * 1024 + (qq * 16 + i) * 16 + (e & 3) * 4) = wv[u];
+                    continue;
+                }
                 _Float16 hi, lo;
                 tsplit(wv[u] * sw, hi, lo);
-                const int t = o >> 4, i = o & 15, ss = k >> 5, qq = (k & 31) >> 3, e = k & 7;
                 char *dst = wl + ((size_t)(t * S + ss) * 2) * 1024 + (qq * 16 + i) * 16 + e * 2;
                 *reinterpret_cast<_Float16 *>(dst) = hi;
                 *reinterpret_cast<_Float16 *>(dst + 1024) = lo;
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
             pin_l[idx] = v;
             if ((idx & (TP - 1)) == 2) smax = fmaxf(smax, fabsf(v));
         }
-        if (GRAD) sx = tpow2_scale(1024.f, tblock_max(smax, scratch, 4) * (*a.amax_in));
+        if (GRAD && !F32) sx = tpow2_scale(1024.f, tblock_max(smax, scratch, 4) * (*a.amax_in));
     }
     if (EPI == TEPI_BWD)
         for (int idx = threadIdx.x; idx < rows_wg * TP; idx += 256)
@@ -321,6 +335,7 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
             }
         }
         TFrag bh[4], bl[4];
+        f32x4 bv[F32 ? 8 : 1];
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) {
             f32x4 v[2];
@@ -346,12 +361,25 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
                     for (int j = 0; j < 4; ++j) v[h][j] = tbwd_apply(rw, g[j], b0.xb[GRAD ? e : 0][j]);
                 }
             }
+            if (F32) {
+                bv[F32 ? 2 * e2 : 0] = v[0];
+                bv[F32 ? 2 * e2 + 1 : 0] = v[1];
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tsplit2(v[0][j], v[1][j], bh[j].u[e2], bl[j].u[e2], mx);
+                for (int j = 0; j < 4; ++j) tsplit2(v[0][j], v[1][j], bh[j].u[e2], bl[j].u[e2], mx);
+            }
         }
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             const char *fr = wl + ((size_t)(t * S + s) * 2) * 1024 + lane * 16;
+            if (F32) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4 *>(fr), a1 = *reinterpret_cast<const f32x4 *>(fr + 1024);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[t][j] = tmfma32(e < 4 ? a0[e & 3] : a1[e & 3], bv[F32 ? e : 0][j], acc[t][j]);
+                continue;
+            }
             const h8 ah = *reinterpret_cast<const h8 *>(fr), al = *reinterpret_cast<const h8 *>(fr + 1024);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -369,7 +397,7 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
         ++blk;
         const int scene = (int)(id / nb64);
         const long long col0 = (id - (long long)scene * nb64) * 64 + 4 * c;
-        const bool poison = __builtin_amdgcn_ballot_w64(mx > 65504.f) != 0ull;   // an unrepresentable operand: NaN, never clamped
+        const bool poison = !F32 && __builtin_amdgcn_ballot_w64(mx > 65504.f) != 0ull;   // an unrepresentable operand: NaN, never clamped
         any_bad |= poison;
         const float nanv = __int_as_float(0x7fc00000);
 #pragma unroll
@@ -385,8 +413,9 @@ __global__ __launch_bounds__(256) void tconv_kernel(TConvArgs a) {
                     o = (f32x4){o[0] + prev[0], o[1] + prev[1], o[2] + prev[2], o[3] + prev[3]};
                 }
                 const bool finite = (fabsf(o[0]) + fabsf(o[1])) + (fabsf(o[2]) + fabsf(o[3])) < INFINITY;   // (false for a NaN too)
-                nonfinite |= !finite;
-                if (poison || !finite) o = (f32x4){nanv, nanv, nanv, nanv};
+                // (exact fp32: an Inf / NaN is whatever the arithmetic made it, as in the reference -- nothing to flag or poison)
+                nonfinite |= !F32 && !finite;
+                if (!F32 && (poison || !finite)) o = (f32x4){nanv, nanv, nanv, nanv};
                 *reinterpret_cast<f32x4 *>(a.out + at) = o;
                 if (EPI == TEPI_STATS) {
                     st1[t][r] += (o[0] + o[1]) + (o[2] + o[3]);
@@ -461,10 +490,13 @@ struct TWgradArgs {
 // tiles (t = wt, wt + 4, ..; u = wu, wu + 2, ..).  The next stage's global loads are in flight during the MFMAs.  NK widens
 // the stage for narrow layers (4 passes of 512 / (8 NK) rows cover 64 NK... rows): a stage then moves enough bytes to hide its
 // two barriers.
-template <int NK, bool DB>
+// F32 (exact fp32, see tmfma32): ONE plane of floats per operand, rows 128 NK + 16 bytes apart (the same 16-bytes-modulo-256
+// walk over the 16 rows of a fragment); a fragment read is the lane's eight columns 8 q .. 8 q + 7 of its row, MFMA e takes
+// column 8 q + e of every q as its k index q.
+template <int NK, bool DB, bool F32>
 __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int RS = 64 * NK + 16;            // LDS bytes per operand row
+    constexpr int RS = F32 ? 128 * NK + 16 : 64 * NK + 16;            // LDS bytes per operand row (and plane)
     constexpr int CG = 8 * NK, RR = 512 / CG;   // float4 groups per row of a stage, rows per pass
     const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, c = lane & 15, wave = tid >> 6;
     const int wt = wave >> 1, wu = wave & 1;
@@ -473,8 +505,8 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
     // DB: two operand buffers, so that the waves that are done with a stage's products write the next stage while the others
     // still multiply -- ONE barrier per stage instead of two (whoever writes buffer p again has passed the barrier of the stage
     // in between, which everybody reaches only after its products on p)
-    const size_t opbytes = (size_t)(cop + cip) * 2 * RS;
-    char *ahi0 = smem, *alo0 = ahi0 + (size_t)cop * RS, *bhi0 = alo0 + (size_t)cop * RS, *blo0 = bhi0 + (size_t)cip * RS;
+    const size_t opbytes = (size_t)(cop + cip) * (F32 ? 1 : 2) * RS;
+    char *ahi0 = smem, *alo0 = ahi0 + (F32 ? 0 : (size_t)cop * RS), *bhi0 = alo0 + (size_t)cop * RS, *blo0 = bhi0 + (F32 ? 0 : (size_t)cip * RS);
     float *pd_l = reinterpret_cast<float *>(smem + (DB ? 2 : 1) * opbytes);
     float *px_l = pd_l + cop * TP;
     float *scratch = px_l + cip * TP;           // 8 floats + the poison flag
@@ -485,7 +517,8 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
         if ((i & (TP - 1)) == 2) smax = fmaxf(smax, fabsf(v));
     }
     for (int i = tid; i < cip * TP; i += 512) px_l[i] = (a.xmode != TIN_RAW && i / TP < a.ci) ? a.px[i] : 0.f;
-    const float sx = tpow2_scale(1024.f, tblock_max(smax, scratch, 8) * (*a.amax_in));   // (ends with a barrier: LDS is ready)
+    const float bmax = tblock_max(smax, scratch, 8);                                       // (ends with a barrier: LDS is ready)
+    const float sx = F32 ? 1.f : tpow2_scale(1024.f, bmax * (*a.amax_in));
 
     const int cg = tid % CG, rr = tid / CG;                      // float4 group within the stage, row within a pass
     const long long per_scene = a.l / (32 * NK);
@@ -530,6 +563,10 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
         }
     };
     auto put = [&](char *hi_base, char *lo_base, int row, const f32x4 v) {
+        if (F32) {
+            *reinterpret_cast<f32x4 *>(hi_base + (size_t)row * RS + cg * 16) = v;
+            return;
+        }
         uint2 hi, lo;
         tsplit2(v[0], v[1], hi.x, lo.x, mx);
         tsplit2(v[2], v[3], hi.y, lo.y, mx);
@@ -573,6 +610,22 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
             for (int i = 0; i < 4; ++i) {
                 const int t = wt + 4 * i;
                 if (t >= T) continue;
+                if (F32) {
+                    const char *ar = ahi + (size_t)(16 * t + c) * RS + kk * 128 + q * 32;
+                    const f32x4 fa0 = *reinterpret_cast<const f32x4 *>(ar), fa1 = *reinterpret_cast<const f32x4 *>(ar + 16);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int u = wu + 2 * j;
+                        if (u >= U) continue;
+                        const char *br = bhi + (size_t)(16 * u + c) * RS + kk * 128 + q * 32;
+                        const f32x4 fb0 = *reinterpret_cast<const f32x4 *>(br), fb1 = *reinterpret_cast<const f32x4 *>(br + 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j] = tmfma32(fa0[e], fb0[e], acc[i][j]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j] = tmfma32(fa1[e], fb1[e], acc[i][j]);
+                    }
+                    continue;
+                }
                 const h8 fah = *reinterpret_cast<const h8 *>(ahi + (size_t)(16 * t + c) * RS + kk * 64 + q * 16);
                 const h8 fal = *reinterpret_cast<const h8 *>(alo + (size_t)(16 * t + c) * RS + kk * 64 + q * 16);
 #pragma unroll
@@ -595,7 +648,7 @@ __global__ __launch_bounds__(512) void twgrad_kernel(TWgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             if (!((fabsf(acc[i][j][0]) + fabsf(acc[i][j][1])) + (fabsf(acc[i][j][2]) + fabsf(acc[i][j][3])) < INFINITY)) accbad = INFINITY;
-    const bool poison = tblock_max(fmaxf(mx, accbad), scratch, 8) > 65504.f;
+    const bool poison = !F32 && tblock_max(fmaxf(mx, accbad), scratch, 8) > 65504.f;
     if (poison && tid == 0 && a.overflow) *a.overflow = 1;
     const float nanv = __int_as_float(0x7fc00000), inv = 1.f / sx;
     float *dst = a.partial + (size_t)blockIdx.x * cop * cip;
@@ -836,7 +889,7 @@ int tconv_grid_x(int b, long long l, int co) {
     return (int)(groups < cap ? groups : cap);
 }
 
-template <int RT, int IN>
+template <int RT, int IN, bool F32>
 int tconv_launch_epi(const TConvArgs &a, int epi, hipStream_t st) {
     const int cip = 32 * a.S, rows_wg = 16 * RT;
     const size_t lds = (size_t)RT * a.S * 2048 + (IN != TIN_RAW ? cip * TP * 4 : 0) + (epi == TEPI_BWD ? rows_wg * TP * 4 : 0) +
@@ -847,10 +900,10 @@ int tconv_launch_epi(const TConvArgs &a, int epi, hipStream_t st) {
     {                                                                                                                   \
         static LdsLimitOnce raised;                                                                                     \
         if (lds > 64 * 1024) {                                                                                          \
-            const int rc = raise_lds_limit((const void *)tconv_kernel<RT, IN, EPI>, 156 * 1024, raised, "tconv");      \
+            const int rc = raise_lds_limit((const void *)tconv_kernel<RT, IN, EPI, F32>, 156 * 1024, raised, "tconv"); \
             if (rc != SPS_OK) return rc;                                                                                \
         }                                                                                                               \
-        hipLaunchKernelGGL((tconv_kernel<RT, IN, EPI>), grid, dim3(256), lds, st, a);                                   \
+        hipLaunchKernelGGL((tconv_kernel<RT, IN, EPI, F32>), grid, dim3(256), lds, st, a);                              \
     }
     if (epi == TEPI_NONE) SPS_TCONV_GO(TEPI_NONE)
     else if (epi == TEPI_STATS) SPS_TCONV_GO(TEPI_STATS)
@@ -859,37 +912,58 @@ int tconv_launch_epi(const TConvArgs &a, int epi, hipStream_t st) {
     return check_launch("tconv_kernel");
 }
 
-template <int RT>
-int tconv_launch_in(const TConvArgs &a, int in_mode, int epi, hipStream_t st) {
+template <int RT, bool F32>
+int tconv_launch_prec(const TConvArgs &a, int in_mode, int epi, hipStream_t st) {
     switch (in_mode) {
-        case TIN_RAW: return tconv_launch_epi<RT, TIN_RAW>(a, epi, st);
-        case TIN_BNRELU: return tconv_launch_epi<RT, TIN_BNRELU>(a, epi, st);
-        case TIN_BNBWD: return tconv_launch_epi<RT, TIN_BNBWD>(a, epi, st);
-        default: return tconv_launch_epi<RT, TIN_BNBWD_POOL>(a, epi, st);
+        case TIN_RAW: return tconv_launch_epi<RT, TIN_RAW, F32>(a, epi, st);
+        case TIN_BNRELU: return tconv_launch_epi<RT, TIN_BNRELU, F32>(a, epi, st);
+        case TIN_BNBWD: return tconv_launch_epi<RT, TIN_BNBWD, F32>(a, epi, st);
+        default: return tconv_launch_epi<RT, TIN_BNBWD_POOL, F32>(a, epi, st);
     }
 }
 
-template <int NK>
-int twgrad_launch(const TWgradArgs &a, int parts, hipStream_t st) {
+// 0 = split-fp16 (hi + lo halves, ~22-bit products), 1 = exact fp32: the arithmetic of every sps_tconv / sps_twgrad launch
+std::atomic<int> g_train_f32{0};
+
+template <int RT>
+int tconv_launch_in(const TConvArgs &a, int in_mode, int epi, hipStream_t st) {
+    return g_train_f32.load(std::memory_order_relaxed) ? tconv_launch_prec<RT, true>(a, in_mode, epi, st)
+                                                       : tconv_launch_prec<RT, false>(a, in_mode, epi, st);
+}
+
+template <int NK, bool F32>
+int twgrad_launch_prec(const TWgradArgs &a, int parts, hipStream_t st) {
     const int cop = 16 * divup(a.co, 16), cip = 16 * divup(a.ci, 16);
-    const size_t op = (size_t)(cop + cip) * 2 * (64 * NK + 16), rest = (size_t)(cop + cip) * TP * 4 + 64;
+    const size_t op = (size_t)(cop + cip) * (F32 ? (128 * NK + 16) : 2 * (64 * NK + 16)), rest = (size_t)(cop + cip) * TP * 4 + 64;
     const bool db = 2 * op + rest <= 150 * 1024;
     const size_t lds = (db ? 2 : 1) * op + rest;
     static LdsLimitOnce raised[2];
     if (lds > 64 * 1024) {
-        const int rc = raise_lds_limit(db ? (const void *)twgrad_kernel<NK, true> : (const void *)twgrad_kernel<NK, false>, 150 * 1024,
-                                       raised[db ? 1 : 0], "twgrad");
+        const int rc = raise_lds_limit(db ? (const void *)twgrad_kernel<NK, true, F32> : (const void *)twgrad_kernel<NK, false, F32>,
+                                       150 * 1024, raised[db ? 1 : 0], "twgrad");
         if (rc != SPS_OK) return rc;
     }
-    if (db) hipLaunchKernelGGL((twgrad_kernel<NK, true>), dim3(parts), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((twgrad_kernel<NK, false>), dim3(parts), dim3(512), lds, st, a);
+    if (db) hipLaunchKernelGGL((twgrad_kernel<NK, true, F32>), dim3(parts), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((twgrad_kernel<NK, false, F32>), dim3(parts), dim3(512), lds, st, a);
     return SPS_OK;
+}
+
+template <int NK>
+int twgrad_launch(const TWgradArgs &a, int parts, hipStream_t st) {
+    return g_train_f32.load(std::memory_order_relaxed) ? twgrad_launch_prec<NK, true>(a, parts, st)
+                                                       : twgrad_launch_prec<NK, false>(a, parts, st);
 }
 
 }  // namespace
 }  // namespace sps
 
 using namespace sps;
+
+// Arithmetic of every sps_tconv / sps_twgrad launch (and of sps_mlp_train_forward / _backward, which compose them):
+// 0 = split-fp16 (default), 1 = exact fp32 on v_mfma_f32_16x16x4_f32 -- the reference's arithmetic.  Returns the old mode.
+extern "C" int sps_set_train_precision(int mode) {
+    return g_train_f32.exchange(mode ? 1 : 0, std::memory_order_relaxed);
+}
 
 // Workgroups along the columns of sps_tconv = first dimension of its `partial` output ([parts][co][2] doubles).
 extern "C" int sps_tconv_parts(int b, long long l, int co) {
@@ -907,8 +981,9 @@ extern "C" int sps_tconv(int b, int ci, int co, long long l, int in_mode, int ep
     if (l % 64) return fail(SPS_ERR_INVALID, "tconv: l = %lld must be a multiple of 64", l);
     if (in_mode < TIN_RAW || in_mode > TIN_BNBWD_POOL || epi_mode < TEPI_NONE || epi_mode > TEPI_BWD)
         return fail(SPS_ERR_INVALID, "tconv: unknown mode");
-    if (!w || !wamax || !out || (in_mode != TIN_BNBWD_POOL && !in) || (in_mode != TIN_RAW && !pin) || (in_mode >= TIN_BNBWD && !in2) ||
-        (epi_mode != TEPI_NONE && !partial) || (epi_mode == TEPI_BWD && (!epi_y || !pout)) || (in_mode >= TIN_BNBWD && !amax_in))
+    const bool f32 = g_train_f32.load(std::memory_order_relaxed) != 0;     // (exact fp32 scales nothing: wamax / amax_in unused)
+    if (!w || (!wamax && !f32) || !out || (in_mode != TIN_BNBWD_POOL && !in) || (in_mode != TIN_RAW && !pin) || (in_mode >= TIN_BNBWD && !in2) ||
+        (epi_mode != TEPI_NONE && !partial) || (epi_mode == TEPI_BWD && (!epi_y || !pout)) || (in_mode >= TIN_BNBWD && !amax_in && !f32))
         return fail(SPS_ERR_INVALID, "tconv: null pointer");
     if (in_mode == TIN_BNBWD_POOL && (!gout || !arg || nsample <= 0 || (nsample % 4) || m <= 0 || (long long)m * nsample != l))
         return fail(SPS_ERR_INVALID, "tconv: the pooled-gradient operand needs gout, arg, nsample %% 4 == 0 and m * nsample == l");
@@ -1092,7 +1167,8 @@ extern "C" int sps_twgrad(int b, int co, int ci, long long l, int dmode, int xmo
     if (l % 32) return fail(SPS_ERR_INVALID, "twgrad: l = %lld must be a multiple of 32", l);
     if ((dmode != TIN_BNBWD && dmode != TIN_BNBWD_POOL) || (xmode != TIN_RAW && xmode != TIN_BNRELU))
         return fail(SPS_ERR_INVALID, "twgrad: unknown mode");
-    if (!y || !pd || !x || !dw || !work || !amax_in || (dmode == TIN_BNBWD && !dA) || (xmode == TIN_BNRELU && !px))
+    if (!y || !pd || !x || !dw || !work || (!amax_in && !g_train_f32.load(std::memory_order_relaxed)) || (dmode == TIN_BNBWD && !dA) ||
+        (xmode == TIN_BNRELU && !px))
         return fail(SPS_ERR_INVALID, "twgrad: null pointer");
     if (dmode == TIN_BNBWD_POOL && (!gout || !arg || nsample <= 0 || (nsample % 4) || m <= 0 || (long long)m * nsample != l))
         return fail(SPS_ERR_INVALID, "twgrad: the pooled-gradient operand needs gout, arg, nsample %% 4 == 0 and m * nsample == l");
@@ -1133,7 +1209,7 @@ extern "C" long long sps_struct_size(int which) {
 
 extern "C" long long sps_mlp_train_partial_doubles(const sps_mlp_train_desc *d) {
     if (!d || d->n < 1 || d->n > 4) return 0;
-    const long long l = (long long)d->m * d->ns;
+    const long long l = (long long)d->m * (d->ns > 0 ? d->ns : 1);
     long long need = (long long)d->b * d->c[d->n] * 2;
     for (int k = 0; k <= d->n; ++k) {
         const long long v = (long long)sps_tconv_parts(d->b, l, d->c[k]) * d->c[k] * 2;
@@ -1143,32 +1219,40 @@ extern "C" long long sps_mlp_train_partial_doubles(const sps_mlp_train_desc *d) 
 }
 
 static int mlp_train_check(const sps_mlp_train_desc *d, const char *what) {
-    if (!d || d->n < 1 || d->n > 4 || d->b <= 0 || d->m <= 0 || d->ns <= 0)
+    if (!d || d->n < 1 || d->n > 4 || d->b <= 0 || d->m <= 0 || d->ns < 0)
         return fail(SPS_ERR_INVALID, "%s: bad descriptor (n, b, m, ns)", what);
     for (int k = 0; k <= d->n; ++k)
         if (d->c[k] <= 0) return fail(SPS_ERR_INVALID, "%s: c[%d] = %d", what, k, d->c[k]);
     for (int k = 0; k < d->n; ++k)
         if (!d->w[k] || !d->y[k] || !d->params[k]) return fail(SPS_ERR_INVALID, "%s: null pointer at layer %d", what, k);
-    if (!d->x || !d->wamax || !d->partial) return fail(SPS_ERR_INVALID, "%s: null pointer", what);
+    if (!d->x || !d->partial || (!d->wamax && !g_train_f32.load(std::memory_order_relaxed)))
+        return fail(SPS_ERR_INVALID, "%s: null pointer", what);
     return SPS_OK;
 }
 
 extern "C" int sps_mlp_train_forward(const sps_mlp_train_desc *d, sps_stream_t stream) {
     int rc = mlp_train_check(d, "mlp_train_forward");
     if (rc != SPS_OK) return rc;
-    if (!d->out || !d->arg || !d->yarg) return fail(SPS_ERR_INVALID, "mlp_train_forward: null output");
+    // nsample = 0: the same stack WITHOUT a pool on (b, c, m) tensors -- an aggregation / confidence / vote stack
+    // ([Conv1d, BatchNorm1d, ReLU] x n, pointnet2_modules.py:213-245): out = relu(bn_n(...)) dense, no arg / yarg
+    const bool pool = d->ns > 0;
+    if (!d->out || (pool && (!d->arg || !d->yarg))) return fail(SPS_ERR_INVALID, "mlp_train_forward: null output");
     const int n = d->n;
-    const long long l = (long long)d->m * d->ns;
+    const long long l = (long long)d->m * (pool ? d->ns : 1);
     const double count = (double)d->b * (double)l;
+    const bool f32 = g_train_f32.load(std::memory_order_relaxed) != 0;
     const float *wp[4] = {nullptr, nullptr, nullptr, nullptr};
     long long wn[4] = {0, 0, 0, 0};
     for (int k = 0; k < n; ++k) { wp[k] = d->w[k]; wn[k] = (long long)d->c[k + 1] * d->c[k]; }
-    rc = sps_tamax4(n, wp[0], wn[0], wp[1], wn[1], wp[2], wn[2], wp[3], wn[3], d->wamax, stream);
-    if (rc != SPS_OK) return rc;
+    if (!f32) {       // (the split form scales the weights by a power of two derived from their largest magnitude)
+        rc = sps_tamax4(n, wp[0], wn[0], wp[1], wn[1], wp[2], wn[2], wp[3], wn[3], d->wamax, stream);
+        if (rc != SPS_OK) return rc;
+    }
     const float *operand = d->x, *pin = nullptr;
     for (int k = 0; k < n; ++k) {
         rc = sps_tconv(d->b, d->c[k], d->c[k + 1], l, k ? TIN_BNRELU : TIN_RAW, TEPI_STATS, 0, d->w[k], operand, nullptr, nullptr,
-                       nullptr, 0, 0, pin, d->y[k], nullptr, nullptr, d->partial, nullptr, nullptr, d->wamax + k, d->overflow, stream);
+                       nullptr, 0, 0, pin, d->y[k], nullptr, nullptr, d->partial, nullptr, nullptr, f32 ? nullptr : d->wamax + k, d->overflow,
+                       stream);
         if (rc != SPS_OK) return rc;
         rc = sps_tbn_finalize_dc(d->c[k + 1], sps_tconv_parts(d->b, l, d->c[k + 1]), count, nullptr, d->partial, d->gamma[k], d->beta[k],
                                  d->eps[k], d->momentum[k], d->running_mean[k], d->running_var[k], d->params[k],
@@ -1177,6 +1261,7 @@ extern "C" int sps_mlp_train_forward(const sps_mlp_train_desc *d, sps_stream_t s
         operand = d->y[k];
         pin = d->params[k];
     }
+    if (!pool) return sps_tbn_apply_relu(d->b, d->c[n], l, d->y[n - 1], d->params[n - 1], d->out, stream);
     return sps_tpool_fwd(d->b, d->c[n], d->m, d->ns, d->y[n - 1], d->params[n - 1], d->out, d->arg, d->yarg, stream);
 }
 
@@ -1184,23 +1269,27 @@ extern "C" int sps_mlp_train_backward(const sps_mlp_train_desc *d, sps_stream_t 
     int rc = mlp_train_check(d, "mlp_train_backward");
     if (rc != SPS_OK) return rc;
     const int n = d->n;
-    if (!d->gout || !d->arg || !d->yarg || !d->amax) return fail(SPS_ERR_INVALID, "mlp_train_backward: null pointer");
+    const bool pool = d->ns > 0;
+    const bool f32 = g_train_f32.load(std::memory_order_relaxed) != 0;
+    if (!d->gout || (pool && (!d->arg || !d->yarg)) || !d->amax) return fail(SPS_ERR_INVALID, "mlp_train_backward: null pointer");
     for (int k = 0; k < n; ++k) {
         if (!d->dgamma[k] || !d->dbeta[k] || (k > 0 && !d->dA[k]) || (d->dw[k] && !d->work))
             return fail(SPS_ERR_INVALID, "mlp_train_backward: null pointer at layer %d", k);
     }
-    const long long l = (long long)d->m * d->ns;
+    const long long l = (long long)d->m * (pool ? d->ns : 1);
     const double count = (double)d->b * (double)l;
     if (hipMemsetAsync(d->amax, 0, (size_t)n * sizeof(float), as_stream(stream)) != hipSuccess)
         return fail(SPS_ERR_LAUNCH, "mlp_train_backward: hipMemsetAsync");
-    // the last layer's BatchNorm-backward sums from the pooled gradient alone (its dA is never materialised)
-    rc = sps_tpool_bwd_stats(d->b, d->c[n], d->m, d->yarg, d->gout, d->params[n - 1], d->partial, d->amax + (n - 1), stream);
+    // the last layer's BatchNorm-backward sums from the pooled gradient alone (its dA is never materialised) -- or, for a
+    // stack without a pool, from the dense incoming gradient
+    rc = pool ? sps_tpool_bwd_stats(d->b, d->c[n], d->m, d->yarg, d->gout, d->params[n - 1], d->partial, d->amax + (n - 1), stream)
+              : sps_tbn_bwd_stats(d->b, d->c[n], l, d->y[n - 1], d->gout, d->params[n - 1], d->partial, d->amax + (n - 1), stream);
     if (rc != SPS_OK) return rc;
     rc = sps_tbn_bwd_finalize_dc(d->c[n], d->b, count, nullptr, d->partial, d->params[n - 1], d->dgamma[n - 1], d->dbeta[n - 1], stream);
     if (rc != SPS_OK) return rc;
     for (int k = n - 1; k >= 0; --k) {
-        const bool routed = k == n - 1;      // the incoming gradient is the pooled one, routed by the arg-max in the operand load
-        const float *dA_in = routed ? nullptr : d->dA[k + 1];
+        const bool routed = pool && k == n - 1;      // the incoming gradient is the pooled one, routed by the arg-max in the operand load
+        const float *dA_in = routed ? nullptr : (k == n - 1 ? d->gout : d->dA[k + 1]);
         const float *g = routed ? d->gout : nullptr;
         const unsigned char *ar = routed ? d->arg : nullptr;
         const int ns = routed ? d->ns : 0, mm = routed ? d->m : 0;
@@ -1213,14 +1302,15 @@ extern "C" int sps_mlp_train_backward(const sps_mlp_train_desc *d, sps_stream_t 
         const int mode = routed ? TIN_BNBWD_POOL : TIN_BNBWD;
         if (k > 0) {
             rc = sps_tconv(d->b, d->c[k + 1], d->c[k], l, mode, TEPI_BWD, 1, d->w[k], dA_in, d->y[k], g, ar, ns, mm, d->params[k], d->dA[k],
-                           d->y[k - 1], d->params[k - 1], d->partial, d->amax + k, d->amax + (k - 1), d->wamax + k, d->overflow, stream);
+                           d->y[k - 1], d->params[k - 1], d->partial, d->amax + k, d->amax + (k - 1), f32 ? nullptr : d->wamax + k, d->overflow,
+                           stream);
             if (rc != SPS_OK) return rc;
             rc = sps_tbn_bwd_finalize_dc(d->c[k], sps_tconv_parts(d->b, l, d->c[k]), count, nullptr, d->partial, d->params[k - 1],
                                          d->dgamma[k - 1], d->dbeta[k - 1], stream);
             if (rc != SPS_OK) return rc;
         } else if (d->dA[0]) {
             rc = sps_tconv(d->b, d->c[1], d->c[0], l, mode, TEPI_NONE, 1, d->w[0], dA_in, d->y[0], g, ar, ns, mm, d->params[0], d->dA[0],
-                           nullptr, nullptr, nullptr, d->amax, nullptr, d->wamax, d->overflow, stream);
+                           nullptr, nullptr, nullptr, d->amax, nullptr, f32 ? nullptr : d->wamax, d->overflow, stream);
             if (rc != SPS_OK) return rc;
         }
     }

@@ -171,9 +171,11 @@ PRECISION = __import__("os").environ.get("SPS_MLP_PRECISION", "fp32")
 if PRECISION not in ("fp32", "fp16x2"):
     raise ValueError(f"SPS_MLP_PRECISION={PRECISION!r}: expected fp32 or fp16x2")
 # Arithmetic of the fused TRAIN-mode kernels (csrc/mlp_train.hip), independent of the inference switch above:
-# "fp16x2" (default): split-fp16 MFMA with exact power-of-two operand scaling (gradients within 1-3e-6 of float64 torch);
-# "fp32": the exact-fp32 op-by-op kernels (conv1x1_train.hip / bn_relu_train.hip / pool).
-TRAIN_PRECISION = __import__("os").environ.get("SPS_TRAIN_PRECISION", "fp16x2")
+# "fp32" (default, round 5): exact fp32 on v_mfma_f32_16x16x4_f32 -- the reference's arithmetic (fp32 Conv2d / BatchNorm2d on
+#           batch statistics, pointnet2_modules.py:203-211, 432-444), same fused kernels, nothing scaled or split;
+# "fp16x2" (opt-in): split-fp16 MFMA with exact power-of-two operand scaling (gradients within 1-3e-6 of float64 torch) --
+#           the GEMMs of a training step then stay memory-bound instead of bound by the fp32 matrix pipe.
+TRAIN_PRECISION = __import__("os").environ.get("SPS_TRAIN_PRECISION", "fp32")
 if TRAIN_PRECISION not in ("fp32", "fp16x2"):
     raise ValueError(f"SPS_TRAIN_PRECISION={TRAIN_PRECISION!r}: expected fp32 or fp16x2")
 # wide split-fp16 scales: the four waves of a workgroup share one weight stream through LDS (csrc/sa_mlp_f16_lds.hip)
@@ -194,8 +196,8 @@ def set_precision(mode):
 
 
 def set_train_precision(mode):
-    """Select the arithmetic of the fused train-mode kernels ("fp16x2" or "fp32" = exact op by op); returns the previous
-    mode."""
+    """Select the arithmetic of the fused train-mode kernels ("fp32" = exact, the reference's, the default; "fp16x2" = split-fp16
+    operands); returns the previous mode.  A forward records its mode and its backward runs in the same one."""
     global TRAIN_PRECISION
     if mode not in ("fp32", "fp16x2"):
         raise ValueError(mode)

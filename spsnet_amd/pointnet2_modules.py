@@ -79,28 +79,17 @@ class _BatchNormReLUTrain(torch.autograd.Function):
         return dx, dweight, dbias, None
 
 
-# 1x1 convolutions whose narrower side has at least this many channels are plain GEMMs big enough for the BLAS library
-# (torch.matmul / bmm -> hipBLASLt, true fp32): measured on IASSD_Backbone's training step, 8 x 16 384, library from
-# 512 / 256 / 128 / 64 / 32 / 16 channels up: 16.4 / 15.6 / 15.3 / 15.0 / 15.2 / 15.3 ms against 17.25 ms with
-# conv1x1_train.hip everywhere (its wide-layer forms re-read their operands per 64-row block).  Below the threshold (the
-# 4..64-channel layers of SA layers 0-1, where the library was 2x slower than MIOpen) conv1x1_train.hip stays.
-_BLAS_MIN = 64
-_BLAS_MIN_WG = 64
-
-
 class _Conv1x1Train(torch.autograd.Function):
-    """Conv2d(kernel 1, no bias) on (B, C, M, ns) with gradients, channel-major throughout: csrc/conv1x1_train.hip
-    (forward, data and weight gradient on fp32 MFMA) for the narrow layers, batched library GEMMs on the same layout for
-    the wide ones -- instead of MIOpen's NHWC implicit-GEMM kernels and their transposes."""
+    """Conv2d / Conv1d(kernel 1, no bias) on (B, C, ...) with gradients, channel-major throughout: csrc/conv1x1_train.hip
+    (forward, data and weight gradient in exact fp32 on the matrix cores) at EVERY width -- no library GEMM, none of MIOpen's
+    NHWC implicit-GEMM kernels and their transposes.  (Round 4 sent layers of >= 64 channels to torch.matmul / bmm; the fused
+    train-mode kernels serve those in exact fp32 now, and this op-by-op form is what is left for stacks they decline.)"""
 
     @staticmethod
     def forward(ctx, x, weight):
         x = x.contiguous()
         w2 = weight.detach().reshape(weight.shape[0], weight.shape[1])
         ctx.save_for_backward(x, weight)
-        if min(w2.shape) >= _BLAS_MIN:
-            B, C, M, S = x.shape
-            return torch.matmul(w2, x.view(B, C, M * S)).view(B, w2.shape[0], M, S)
         return _ext.conv1x1_apply(x, w2, False)
 
     @staticmethod
@@ -108,18 +97,11 @@ class _Conv1x1Train(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
         w2 = weight.detach().reshape(weight.shape[0], weight.shape[1])
-        B, C, M, S = x.shape
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            if min(w2.shape) >= _BLAS_MIN:
-                dx = torch.matmul(w2.t(), dy.view(B, w2.shape[0], M * S)).view(B, C, M, S)
-            else:
-                dx = _ext.conv1x1_apply(dy, w2, True)
+            dx = _ext.conv1x1_apply(dy, w2, True)
         if ctx.needs_input_grad[1]:
-            if min(w2.shape) >= _BLAS_MIN_WG:
-                dw = torch.bmm(dy.view(B, w2.shape[0], M * S), x.view(B, C, M * S).transpose(1, 2)).sum(dim=0).view_as(weight)
-            else:
-                dw = _ext.conv1x1_wgrad(x, dy).view_as(weight)
+            dw = _ext.conv1x1_wgrad(x, dy).view_as(weight)
         return dx, dw
 
 
@@ -131,13 +113,15 @@ def _L_twgrad_ws(b, co, ci, l):
 # ~8 / ~14 ctypes launches with a torch.empty per output: a backbone's training step is host-bound
 ONE_CALL_TRAINING = os.environ.get("SPS_ONE_CALL_TRAINING", "1") != "0"
 FUSED_CONV_TRAINING = True
-# [Conv2d 1x1, BatchNorm2d(batch statistics), ReLU] x n + max-pool as the fused kernels of csrc/mlp_train.hip (split-fp16
-# MFMA arithmetic: active unless fused.set_train_precision("fp32") asks for the exact op-by-op path)
+# [Conv2d 1x1, BatchNorm2d(batch statistics), ReLU] x n + max-pool as the fused kernels of csrc/mlp_train.hip, in the
+# arithmetic fused.TRAIN_PRECISION names (exact fp32 by default, split-fp16 opt-in)
 FUSED_MLP_TRAINING = os.environ.get("SPS_FUSED_MLP_TRAINING", "1") != "0"
-# the aggregation / confidence stacks ([Conv1d, BatchNorm1d, ReLU] on (B, C, M)) through the same kernels: built, tested, and
-# measured NOT to pay at the IA-SSD shapes -- these tensors are 2-8 MB, the stack is launch-bound either way, and the fused
-# form needs more launches than torch's (8.46 vs 8.31 ms per training step of SA layers 0-2).  Opt-in.
-FUSED_POINTWISE_TRAINING = os.environ.get("SPS_FUSED_POINTWISE_TRAINING", "0") != "0"
+# the aggregation / confidence / vote stacks ([Conv1d, BatchNorm1d, ReLU] on (B, C, M), then for the heads a Conv1d with a bias)
+# through the same kernels.  Round 4 measured the launch-by-launch form 2 % slower than torch's (MIOpen implicit-GEMM + its
+# BatchNorm) at the IA-SSD shapes -- these tensors are 2-8 MB and the stack is launch-bound either way -- and left it off;
+# round 5 runs it as ONE C call per stack and direction like the grouped MLPs (sps_mlp_train_forward with nsample = 0) and
+# turns it on: no convolution or BatchNorm of a training step goes through a library any more.
+FUSED_POINTWISE_TRAINING = os.environ.get("SPS_FUSED_POINTWISE_TRAINING", "1") != "0"
 # PointnetFPModule in training: its stack runs on the fused train-mode kernels from this many input elements on (below, the
 # stack is launch-bound either way, as the aggregation stacks are)
 FUSED_FP_TRAINING_MIN = int(os.environ.get("SPS_FUSED_FP_TRAINING_MIN", str(1 << 21)))
@@ -192,28 +176,35 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, bns, pool, x, *wgb):
+        ctx.f32 = _fused.TRAIN_PRECISION == "fp32"
+        _lib.load().sps_set_train_precision(int(ctx.f32))
         with _ext.launch_scope(x):
             return _GroupedMLPPoolTrain._forward(ctx, bns, pool, x, *wgb)
 
     @staticmethod
     def backward(ctx, gout):
+        _lib.load().sps_set_train_precision(int(ctx.f32))      # (the arithmetic its forward ran in)
         with _ext.launch_scope(gout):
             return _GroupedMLPPoolTrain._backward(ctx, gout)
 
     @staticmethod
     def _one_call(bns, pool, x):
         """The whole forward / backward as ONE C call each (sps_mlp_train_forward / _backward) -- what a plain (unsynchronised)
-        grouped MLP with its pool takes; SyncBatchNorm keeps the launch-by-launch form (its all-reduces sit between the
-        launches), and so does a stack without a pool."""
-        return (ONE_CALL_TRAINING and pool and 1 <= len(bns) <= 4 and x.dim() == 4
+        stack takes, with its pool (a grouped MLP) or without (an aggregation / confidence / vote stack: nsample = 0 in the
+        descriptor); SyncBatchNorm keeps the launch-by-launch form (its all-reduces sit between the launches)."""
+        return (ONE_CALL_TRAINING and 1 <= len(bns) <= 4 and x.dim() == (4 if pool else 3)
                 and all(_sync_group(bn)[0] is None for bn in bns))
 
     @staticmethod
-    def _forward_one_call(ctx, bns, x, *wgb):
+    def _forward_one_call(ctx, bns, pool, x, *wgb):
         n = len(bns)
         x = x.contiguous()
-        B, c0, M, ns = x.shape
-        l = M * ns
+        if pool:
+            B, c0, M, ns = x.shape
+        else:
+            (B, c0, M), ns = x.shape, 0
+        tail = (M, ns) if pool else (M,)
+        l = M * max(ns, 1)
         dev = x.device
         ws = [wgb[3 * k].detach().reshape(wgb[3 * k].shape[0], wgb[3 * k].shape[1]).contiguous() for k in range(n)]
         cs = [c0] + [w.shape[0] for w in ws]
@@ -226,7 +217,7 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
         small = torch.empty((sum(cs[1:]) * _ext.TRAIN_PARAMS + 4,), dtype=torch.float32, device=dev)
         off = 0
         for k, bn in enumerate(bns):
-            y = torch.empty((B, cs[k + 1], M, ns), dtype=torch.float32, device=dev)
+            y = torch.empty((B, cs[k + 1]) + tail, dtype=torch.float32, device=dev)
             p = small[off:off + cs[k + 1] * _ext.TRAIN_PARAMS].view(cs[k + 1], _ext.TRAIN_PARAMS)
             off += cs[k + 1] * _ext.TRAIN_PARAMS
             ys.append(y); ps.append(p)
@@ -237,17 +228,22 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
             d.num_batches_tracked[k] = bn.num_batches_tracked.data_ptr()
         wamax = small[off:off + 4]
         out = torch.empty((B, cs[n], M), dtype=torch.float32, device=dev)
-        yarg = torch.empty((B, cs[n], M), dtype=torch.float32, device=dev)
-        arg = torch.empty((B, cs[n], M), dtype=torch.uint8, device=dev)
+        if pool:
+            yarg = torch.empty((B, cs[n], M), dtype=torch.float32, device=dev)
+            arg = torch.empty((B, cs[n], M), dtype=torch.uint8, device=dev)
+        else:
+            yarg = arg = out.new_empty((0,))
         need = max([B * cs[n] * 2] + [_ext.tconv_parts(B, l, c) * c * 2 for c in cs])
         partial = torch.empty((need,), dtype=torch.float64, device=dev)
         d.x, d.wamax, d.partial = x.data_ptr(), wamax.data_ptr(), partial.data_ptr()
-        d.out, d.arg, d.yarg = out.data_ptr(), arg.data_ptr(), yarg.data_ptr()
+        d.out = out.data_ptr()
+        if pool:
+            d.arg, d.yarg = arg.data_ptr(), yarg.data_ptr()
         d.overflow = _fused._overflow_flag(dev).data_ptr()
         _lib.check(_lib.load().sps_mlp_train_forward(ctypes.byref(d), ctypes.c_void_p(_ext._stream(x))), "mlp_train_forward")
         for bn in bns:
             _ext._bump_versions(bn.running_mean, bn.running_var, bn.num_batches_tracked)
-        ctx.n, ctx.ns, ctx.count, ctx.pool = n, ns, B * l, True
+        ctx.n, ctx.ns, ctx.count, ctx.pool = n, ns, B * l, pool
         ctx.one_call = True
         ctx.cs = cs
         ctx.wshapes = [tuple(wgb[3 * k].shape) for k in range(n)]
@@ -261,8 +257,9 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
         x, arg, yarg, small = saved[0], saved[1], saved[2], saved[3]
         ys, ws = saved[4:4 + n], saved[4 + n:4 + 2 * n]
         gout = gout.contiguous()
-        B, c0, M, _ = x.shape
-        l = M * ns
+        B, c0, M = x.shape[:3]
+        l = M * max(ns, 1)
+        tail = (M, ns) if ctx.pool else (M,)
         dev = x.device
         d = _lib.MlpTrainDesc()
         d.n, d.b, d.m, d.ns = n, B, M, ns
@@ -289,7 +286,7 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
                 grads[3 * k] = dw.view(ctx.wshapes[k])
                 work_need = max(work_need, int(_L_twgrad_ws(B, c, cs[k], l)))
             if k > 0:
-                dA = torch.empty((B, cs[k], M, ns), dtype=torch.float32, device=dev)
+                dA = torch.empty((B, cs[k]) + tail, dtype=torch.float32, device=dev)
                 d.dA[k] = dA.data_ptr()
                 keep.append(dA)
         dx = None
@@ -302,7 +299,9 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
         partial = torch.empty((need,), dtype=torch.float64, device=dev)
         work = torch.empty((max(work_need, 1),), dtype=torch.float32, device=dev)
         d.x, d.partial, d.work = x.data_ptr(), partial.data_ptr(), work.data_ptr()
-        d.arg, d.yarg, d.gout = arg.data_ptr(), yarg.data_ptr(), gout.data_ptr()
+        d.gout = gout.data_ptr()
+        if ctx.pool:
+            d.arg, d.yarg = arg.data_ptr(), yarg.data_ptr()
         d.overflow = _fused._overflow_flag(dev).data_ptr()
         _lib.check(_lib.load().sps_mlp_train_backward(ctypes.byref(d), ctypes.c_void_p(_ext._stream(gout))), "mlp_train_backward")
         return (None, None, dx) + tuple(grads)
@@ -310,7 +309,7 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
     @staticmethod
     def _forward(ctx, bns, pool, x, *wgb):
         if _GroupedMLPPoolTrain._one_call(bns, pool, x):
-            return _GroupedMLPPoolTrain._forward_one_call(ctx, bns, x, *wgb)
+            return _GroupedMLPPoolTrain._forward_one_call(ctx, bns, pool, x, *wgb)
         ctx.one_call = False
         n = len(bns)
         x = x.contiguous()
@@ -398,7 +397,9 @@ class _GroupedMLPPoolTrain(torch.autograd.Function):
         return (None, None, dx) + tuple(grads)
 
 
-_FUSED_TRAIN_MAX_CHANNELS = int(os.environ.get("SPS_FUSED_TRAIN_MAX_CHANNELS", "1024"))
+# widest layer side the fused train-mode kernels take (sps_tconv: K slabs of 256 input rows, sps_twgrad: 256 x 256 blocks of dW;
+# IA-SSD's widest is layer 5's aggregation stack, 512 + 1024 = 1536 -> 512 channels, IA-SSD.yaml:55)
+_FUSED_TRAIN_MAX_CHANNELS = int(os.environ.get("SPS_FUSED_TRAIN_MAX_CHANNELS", "2048"))
 
 
 def _fused_stack_train(mods, x, pool: bool):
@@ -409,14 +410,14 @@ def _fused_stack_train(mods, x, pool: bool):
     # (nn.SyncBatchNorm -- tools/train.py --sync_bn converts every BatchNorm -- takes the same kernels with its sums all-reduced)
     conv_t = nn.Conv2d if pool else (nn.Conv1d, nn.Conv2d)
     bn_t = (nn.BatchNorm2d, nn.SyncBatchNorm) if pool else (nn.BatchNorm1d, nn.BatchNorm2d, nn.SyncBatchNorm)
-    if not (FUSED_MLP_TRAINING and _fused.TRAIN_PRECISION != "fp32" and x.is_cuda and x.dtype == torch.float32
+    if not (FUSED_MLP_TRAINING and x.is_cuda and x.dtype == torch.float32
             and x.dim() == (4 if pool else 3) and torch.is_grad_enabled()):
         return None
     if len(mods) % 3 or not mods:
         return None
     cols = x.shape[2] * (x.shape[3] if pool else 1)
-    # (up to 1024 channels on either side of a layer: IA-SSD layer 5's 256 / 512 / 1024-wide scales; beyond 256 input rows
-    #  sps_tconv runs K slabs and sps_twgrad 256 x 256 blocks of the weight gradient)
+    # (up to 2048 channels on either side of a layer: IA-SSD layer 5's 256 / 512 / 1024-wide scales and its 1536 -> 512
+    #  aggregation stack; beyond 256 input rows sps_tconv runs K slabs and sps_twgrad 256 x 256 blocks of the weight gradient)
     if (pool and x.shape[3] not in (4, 8, 16, 32, 64)) or cols % 64 or x.shape[1] > _FUSED_TRAIN_MAX_CHANNELS or x.numel() == 0:
         return None
     bns, wgb = [], []
@@ -463,20 +464,32 @@ def _shared_mlp(mlp: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def _head_conv(conv: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """conv(x) for the last layer of a confidence / vote head -- Conv1d(kernel 1) WITH a bias on (B, C, M) (reference :239-243,
+    :480): with gradients on the GPU the product runs on csrc/conv1x1_train.hip (forward, data and weight gradient in exact
+    fp32 on the matrix cores) and the bias is one broadcast add, instead of MIOpen's implicit-GEMM kernels."""
+    if (FUSED_POINTWISE_TRAINING and isinstance(conv, nn.Conv1d) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3
+            and torch.is_grad_enabled() and conv.kernel_size == (1,) and conv.stride == (1,) and conv.groups == 1
+            and conv.padding == (0,) and conv.weight.dtype == torch.float32 and x.shape[2] % 16 == 0 and x.numel() > 0):
+        y = _Conv1x1Train.apply(x, conv.weight)
+        return y if conv.bias is None else y + conv.bias.view(1, -1, 1)
+    return conv(x)
+
+
 def _pointwise_stack(stack: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
-    """stack(x) for an aggregation / confidence stack on (B, C, M) (reference :213-245): in training its leading
-    [Conv1d, BatchNorm1d, ReLU] triples run on the fused kernels of csrc/mlp_train.hip, whatever follows (the class-score
-    convolution with its bias) through torch."""
+    """stack(x) for an aggregation / confidence / vote stack on (B, C, M) (reference :213-245, :470-480): in training its
+    leading [Conv1d, BatchNorm1d, ReLU] triples run on the fused kernels of csrc/mlp_train.hip, a class-score / offset
+    convolution with its bias behind them on csrc/conv1x1_train.hip (_head_conv); anything else through torch."""
     mods = list(stack)
     lead = 0
     while (lead + 3 <= len(mods) and isinstance(mods[lead], nn.Conv1d) and isinstance(mods[lead + 1], nn.BatchNorm1d)
            and isinstance(mods[lead + 2], nn.ReLU)):
         lead += 3
-    if lead and stack.training and FUSED_POINTWISE_TRAINING:
-        y = _fused_stack_train(mods[:lead], x, False)
+    if stack.training and FUSED_POINTWISE_TRAINING and x.is_cuda and torch.is_grad_enabled():
+        y = _fused_stack_train(mods[:lead], x, False) if lead else x
         if y is not None:
             for mod in mods[lead:]:
-                y = mod(y)
+                y = _head_conv(mod, y) if isinstance(mod, nn.Conv1d) else mod(y)
             return y
     return stack(x)
 
@@ -1227,8 +1240,8 @@ class Vote_layer(nn.Module):
             if self.mlp_modules is not None:
                 if surface is not None:
                     hidden = torch.cat([surface, hidden], dim=1)
-                hidden = self.mlp_modules(hidden)
-            offsets = self.ctr_reg(hidden).transpose(1, 2)      # (B, M, 3)
+                hidden = _pointwise_stack(self.mlp_modules, hidden.contiguous())
+            offsets = (_head_conv(self.ctr_reg, hidden) if self.training else self.ctr_reg(hidden)).transpose(1, 2)   # (B, M, 3)
         new_features = offsets[..., 3:]                      # empty: ctr_reg has exactly 3 outputs
         ctr_offsets = offsets[..., :3]
         if self.max_offset_limit is not None:

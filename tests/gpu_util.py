@@ -78,3 +78,30 @@ def compare_matched_rows(got_idx, want_idx, triples):
                 err = float(np.abs(g - w).max()) if g.size else 0.0
                 assert err <= tol * scale, f"scene {b}: matched rows differ by {err} (scale {scale})"
     return float(np.mean(shared))
+
+
+# substrings of kernel names that come out of a vendor library (rocBLAS / hipBLASLt / Tensile GEMMs, MIOpen convolutions,
+# BatchNorm and layout kernels): none may run inside a step that claims hand-written kernels
+LIBRARY_KERNEL_MARKS = ("Cijk_", "igemm_", "MIOpen", "miopen", "batched_transpose", "SubTensorOp", "gemm", "Gemm", "naive_conv",
+                        "im2col", "Im2Col", "rocblas", "hipblas")
+
+
+def kernel_names(fn):
+    """{kernel name: launches} of ONE call of fn() from torch.profiler's device activity records (roctracer): what the GPU
+    actually ran, whatever Python path led there.  fn() is called once before the trace (one-time set-up: weight packing,
+    stream probes, MIOpen's find pass would otherwise pollute it)."""
+    from torch.profiler import ProfilerActivity, profile
+    fn()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        fn()
+        torch.cuda.synchronize()
+    names = {}
+    for ev in prof.events():
+        if str(getattr(ev, "device_type", "")).endswith("CUDA") and ev.name:
+            names[ev.name] = names.get(ev.name, 0) + 1
+    return names
+
+
+def library_kernels(names):
+    return sorted(k for k in names if any(mark in k for mark in LIBRARY_KERNEL_MARKS))

@@ -41,6 +41,20 @@ def mlp_precision(request):
 BOTH_PRECISIONS = pytest.mark.parametrize("mlp_precision", ["fp32", "fp16x2"], indirect=True)
 
 
+@pytest.fixture
+def train_precision(request):
+    """Runs a test body in the requested arithmetic of the fused TRAIN-mode kernels (fused.set_train_precision: "fp32" =
+    exact, the reference's and the default; "fp16x2" = split-fp16 operands) and restores the previous one."""
+    from spsnet_amd import fused
+    old = fused.set_train_precision(request.param)
+    yield request.param
+    fused.set_train_precision(old)
+
+
+BOTH_TRAIN_PRECISIONS = pytest.mark.parametrize("train_precision", ["fp32", "fp16x2"], indirect=True)
+SPLIT_FP16_TRAINING = pytest.mark.parametrize("train_precision", ["fp16x2"], indirect=True)
+
+
 def gather_xyz(xyz, idx):
     return np.take_along_axis(xyz, idx[..., None].astype(np.int64).repeat(3, axis=2), axis=1)
 
@@ -2033,7 +2047,8 @@ def test_linear_rows_training(ext, dev, cin, relu):
 
 
 @pytest.mark.parametrize("tag", ["iassd", "pagnet"])
-def test_backbone_training_step_runs(ext, G, dev, tag):
+@BOTH_TRAIN_PRECISIONS
+def test_backbone_training_step_runs(ext, G, dev, tag, train_precision):
     """tools/train.py-style use of the backbone mirrors: train() mode, forward + backward through the fused training
     kernels (BatchNorm+ReLU, max-pool, LDS scatter, DenseEdgeConv / FCLayer backward); finite gradients on every parameter
     that takes part, running statistics updated."""
@@ -2049,25 +2064,35 @@ def test_backbone_training_step_runs(ext, G, dev, tag):
     if tag == "pagnet":
         batch["stds"] = G.t(np.random.default_rng(1).uniform(0, 40, (2, 4096)).astype(np.float32))
     before = {k: v.clone() for k, v in net.state_dict().items() if k.endswith("running_mean")}
-    # every grouped MLP of the step -- layer 5's 256 / 512 / 1024-wide scales included -- runs on the fused train-mode kernels:
-    # no 1x1 convolution of the step reaches a library GEMM (pointnet2_modules._Conv1x1Train's torch.matmul / bmm route)
+    # Every convolution and BatchNorm of the step -- the grouped MLPs up to layer 5's 256 / 512 / 1024-wide scales, the
+    # aggregation / confidence / vote stacks up to 1536 -> 512, the class-score and offset heads -- runs on this library's
+    # kernels IN BOTH training arithmetics: asserted on what the GPU ran (the profiler's kernel records of one whole step),
+    # not on which Python function was called.
     from spsnet_amd import pointnet2_modules as PM
-    gemm_calls, fused_calls = [], []
-    orig_mm, orig_bmm, orig_fused = torch.matmul, torch.bmm, PM._GroupedMLPPoolTrain.apply
-    torch.matmul = lambda *a, **k: gemm_calls.append("matmul") or orig_mm(*a, **k)
-    torch.bmm = lambda *a, **k: gemm_calls.append("bmm") or orig_bmm(*a, **k)
+    fused_calls = []
+    orig_fused = PM._GroupedMLPPoolTrain.apply
     PM._GroupedMLPPoolTrain.apply = lambda *a, **k: fused_calls.append(tuple(a[2].shape)) or orig_fused(*a, **k)
-    try:
-        out = net(batch)
+
+    def step():
+        out = net(dict(batch))
         loss = out["centers_features"].square().mean() + out["ctr_offsets"][:, 1:].square().mean()
         for t in out["sa_ins_preds"]:
             if isinstance(t, torch.Tensor):
                 loss = loss + t[..., 1:].square().mean()
+        for p in net.parameters():
+            p.grad = None
         loss.backward()
+
+    try:
+        names = G.kernel_names(step)
     finally:
-        torch.matmul, torch.bmm = orig_mm, orig_bmm
         del PM._GroupedMLPPoolTrain.apply                 # (back to the inherited autograd.Function.apply)
-    assert not gemm_calls, gemm_calls
+    assert sum(names.values()) > 100 and any("tconv_kernel" in k for k in names), "the profiler recorded no kernels of the step"
+    assert not G.library_kernels(names), G.library_kernels(names)
+    f32 = train_precision == "fp32"
+    # (the last template argument of tconv_kernel / twgrad_kernel is the arithmetic: true = exact fp32 MFMA)
+    assert all((", true>(" in k) == f32 for k in names if "tconv_kernel<" in k or "twgrad_kernel<" in k), \
+        sorted(k for k in names if "tconv_kernel<" in k)[:4]
     assert any(shape[1] == 259 for shape in fused_calls), fused_calls      # layer 5: 256 feature channels + xyz
     grads = [(k, p.grad) for k, p in net.named_parameters() if p.grad is not None]
     assert len(grads) > 40 and all(torch.isfinite(g).all() for _, g in grads)
@@ -2652,9 +2677,10 @@ def test_group_concat_matches_query_and_group(ext, G, C, use_xyz):
                                            (2, 48, 16, [259, 256, 200]), (2, 24, 8, [20, 48, 40]), (1, 8, 8, [5, 16, 16, 16]),
                                            # IA-SSD layer 5 (IA-SSD.yaml:35-55): K slabs in the convolutions, 256 x 256 blocks of dW
                                            (2, 32, 16, [259, 256, 256, 512]), (2, 16, 32, [259, 256, 512, 1024]),
-                                           (1, 8, 8, [300, 520, 70]), (1, 8, 8, [1030, 16])])
+                                           (1, 8, 8, [300, 520, 70]), (1, 8, 8, [2100, 16])])
 @pytest.mark.parametrize("one_call", [True, False], ids=["one-c-call", "launch-by-launch"])
-def test_fused_train_mode_mlp_matches_torch(dev, B, M, ns, widths, one_call, monkeypatch):
+@BOTH_TRAIN_PRECISIONS
+def test_fused_train_mode_mlp_matches_torch(dev, B, M, ns, widths, one_call, train_precision, monkeypatch):
     """_GroupedMLPPoolTrain (conv + batch statistics in the epilogue, BatchNorm / ReLU / pool routing / BatchNorm backward
     in the operand loads, split-fp16 MFMA) against the plain torch op sequence of the reference (pointnet2_modules.py:432-444)
     in float64 on the CPU: pooled output, running statistics, and the gradients w.r.t. the grouped input and every
@@ -2663,7 +2689,7 @@ def test_fused_train_mode_mlp_matches_torch(dev, B, M, ns, widths, one_call, mon
     every supported nsample, column counts that are odd multiples of 64 (the narrower weight-gradient stage) or a single
     64-column block, widths of 257 .. 1024 on either side of a layer (K slabs of 256 input rows in sps_tconv, every slab behind
     the first accumulating into the output; 256 x 256 blocks of the weight gradient in sps_twgrad; channel counts that are
-    no multiple of the slab), and a width beyond 1024 (declined: falls back to the op-by-op path)."""
+    no multiple of the slab), and a width beyond 2048 (declined: falls back to the op-by-op path)."""
     import copy
     from spsnet_amd import fused, pointnet2_modules as PM
     torch.manual_seed(B * 1000 + M + ns)
@@ -2691,7 +2717,7 @@ def test_fused_train_mode_mlp_matches_torch(dev, B, M, ns, widths, one_call, mon
     # launch-by-launch form SyncBatchNorm and SPS_ONE_CALL_TRAINING=0 use
     monkeypatch.setattr(PM, "ONE_CALL_TRAINING", one_call)
     got = PM._fused_mlp_pool_train(mlp, xg, 'max_pool')
-    if max(chain) > 1024:
+    if max(chain) > 2048:
         assert got is None
         return
     assert got is not None, "the stack was supposed to qualify"
@@ -2716,9 +2742,10 @@ def test_fused_train_mode_mlp_matches_torch(dev, B, M, ns, widths, one_call, mon
             assert int(bg) == int(br), name
 
 
-def test_fused_train_mode_mlp_poisons_unrepresentable_operands(dev, monkeypatch):
+@SPLIT_FP16_TRAINING
+def test_fused_train_mode_mlp_poisons_unrepresentable_operands(dev, train_precision, monkeypatch):
     """An operand beyond the split-fp16 range is never clamped silently: the outputs that depend on it are NaN and the overflow
-    flag is raised."""
+    flag is raised.  (Exact fp32, the default, has no such range: test_fused_train_mode_mlp_large_operands_in_fp32.)"""
     from spsnet_amd import fused, pointnet2_modules as PM
     torch.manual_seed(0)
     mlp = PM._conv_bn_relu_stack([4, 16, 32], torch.nn.Conv2d, torch.nn.BatchNorm2d).to(dev).train()
@@ -2732,8 +2759,32 @@ def test_fused_train_mode_mlp_poisons_unrepresentable_operands(dev, monkeypatch)
     assert fused.check_overflow()
 
 
-@pytest.mark.parametrize("B,M,widths,tailconv", [(2, 256, [96, 64], False), (3, 128, [256, 128, 128], True), (2, 64, [40, 24], True)])
-def test_fused_train_mode_pointwise_stack_matches_torch(dev, B, M, widths, tailconv, monkeypatch):
+def test_fused_train_mode_mlp_large_operands_in_fp32(dev, monkeypatch):
+    """Exact fp32 (the default training arithmetic): an operand of 1e6 -- beyond what the split form can carry -- is just a
+    number: finite outputs within 2e-4 of float64 torch, no overflow flag."""
+    import copy
+    from spsnet_amd import fused, pointnet2_modules as PM
+    assert fused.TRAIN_PRECISION == "fp32", "the library default is the reference's arithmetic"
+    torch.manual_seed(0)
+    mlp = PM._conv_bn_relu_stack([4, 16, 32], torch.nn.Conv2d, torch.nn.BatchNorm2d)
+    ref = copy.deepcopy(mlp).double().train()
+    mlp = mlp.to(dev).train()
+    x = torch.randn(2, 4, 32, 16)
+    x[1, 2, 5, 3] = 1e6
+    monkeypatch.setattr(PM, "FUSED_MLP_TRAINING", True)
+    fused.check_overflow()
+    out = PM._fused_mlp_pool_train(mlp, x.to(dev).requires_grad_(True), 'max_pool')
+    want = ref(x.double()).max(dim=3)[0]
+    torch.cuda.synchronize()
+    assert out is not None and bool(torch.isfinite(out).all()) and not fused.check_overflow()
+    assert float((out.cpu().double() - want).abs().max()) <= 2e-4 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("B,M,widths,tailconv", [(2, 256, [96, 64], False), (3, 128, [256, 128, 128], True), (2, 64, [40, 24], True),
+                                                 (2, 64, [1536, 512], False)])     # (IA-SSD layer 5's aggregation stack)
+@pytest.mark.parametrize("one_call", [True, False], ids=["one-c-call", "launch-by-launch"])
+@BOTH_TRAIN_PRECISIONS
+def test_fused_train_mode_pointwise_stack_matches_torch(dev, B, M, widths, tailconv, one_call, train_precision, monkeypatch):
     """The aggregation / confidence stacks ([Conv1d, BatchNorm1d, ReLU] x n, optionally a class-score Conv1d with bias behind
     them) in train() mode through _pointwise_stack (fused kernels, no pool) against float64 torch: output, running statistics
     and every gradient."""
@@ -2758,6 +2809,7 @@ def test_fused_train_mode_pointwise_stack_matches_torch(dev, B, M, widths, tailc
     (out_r * wout.double()).sum().backward()
     xg = x0.to(dev).requires_grad_(True)
     monkeypatch.setattr(PM, "FUSED_MLP_TRAINING", True)
+    monkeypatch.setattr(PM, "ONE_CALL_TRAINING", one_call)
     monkeypatch.setattr(PM, "FUSED_POINTWISE_TRAINING", True)
     calls = []
     orig = PM._fused_stack_train
@@ -2904,7 +2956,8 @@ def test_backbone_prefetch_sampling_equals_plain(G, dev):
 
 
 @pytest.mark.parametrize("gscale", [1e-12, 1e-4, 1e4])
-def test_fused_train_mode_mlp_gradient_scale_invariance(dev, gscale, monkeypatch):
+@BOTH_TRAIN_PRECISIONS
+def test_fused_train_mode_mlp_gradient_scale_invariance(dev, gscale, train_precision, monkeypatch):
     """The fp16 halves of the gradient operands carry an exact power-of-two scale (csrc/mlp_train.hip), so the accuracy of the
     backward must not depend on the magnitude of the incoming gradient: 1e-12 .. 1e4 against float64 torch, every gradient
     within 2e-5 of its own largest entry.  (Unscaled, gradients below ~1e-3 lose their low halves to fp16 denormals.)
@@ -2942,9 +2995,11 @@ def test_fused_train_mode_mlp_gradient_scale_invariance(dev, gscale, monkeypatch
             assert err <= 2e-5 * float(w.abs().max()) + 1e-300, (name, err, float(w.abs().max()))
 
 
-def test_fused_train_mode_mlp_nan_input_propagates(dev, monkeypatch):
+@BOTH_TRAIN_PRECISIONS
+def test_fused_train_mode_mlp_nan_input_propagates(dev, train_precision, monkeypatch):
     """A NaN in the grouped input reaches the pooled outputs that depend on it (as through torch's Conv / BatchNorm / ReLU /
-    max_pool2d, where it reaches all of them via the batch statistics) and raises the overflow flag; nothing is clamped."""
+    max_pool2d, where it reaches all of them via the batch statistics); nothing is clamped.  The split form also raises its
+    overflow flag; exact fp32 has no flag to raise -- the NaN is the report."""
     from spsnet_amd import fused, pointnet2_modules as PM
     torch.manual_seed(0)
     mlp = PM._conv_bn_relu_stack([4, 16, 32], torch.nn.Conv2d, torch.nn.BatchNorm2d).to(dev).train()
@@ -2955,7 +3010,7 @@ def test_fused_train_mode_mlp_nan_input_propagates(dev, monkeypatch):
     out = PM._fused_mlp_pool_train(mlp, x.requires_grad_(True), 'max_pool')
     torch.cuda.synchronize()
     assert out is not None and bool(torch.isnan(out).any())
-    assert fused.check_overflow()
+    assert fused.check_overflow() == (train_precision == "fp16x2")
 
 
 @pytest.mark.parametrize("mode", ["inference", "gradients", "train"])
@@ -3064,7 +3119,8 @@ def test_fp_module_fused_kernel_matches_op_sequence(dev, n, m, c_known, c_skip, 
     assert float((given - got).abs().max()) <= 2e-6 * max(1.0, float(got.abs().max()))
 
 
-def test_fp_module_training_on_fused_kernels_matches_torch(dev, monkeypatch):
+@BOTH_TRAIN_PRECISIONS
+def test_fp_module_training_on_fused_kernels_matches_torch(dev, train_precision, monkeypatch):
     """PointnetFPModule in train() mode with its [Conv2d 1x1, BatchNorm2d, ReLU] stack on the fused train-mode kernels
     (no pool) against the module's plain torch op sequence: output, running statistics and every gradient (incl. the
     gradient that flows back through the interpolation into the coarse features)."""
@@ -3116,7 +3172,8 @@ def test_generic_eval_mlp_pool_matches_torch(dev, B, M, ns, widths, mlp_precisio
     assert fused.generic_mlp_pool(mlp, x.clone().requires_grad_(True)) is None      # gradients wanted: declined
 
 
-def test_fused_train_mode_mlp_under_sync_batchnorm(dev, monkeypatch):
+@BOTH_TRAIN_PRECISIONS
+def test_fused_train_mode_mlp_under_sync_batchnorm(dev, train_precision, monkeypatch):
     """tools/train.py --sync_bn converts every BatchNorm to nn.SyncBatchNorm: the fused train-mode stack then all-reduces its
     statistics (forward) and its BatchNorm-backward sums, and returns LOCAL weight / bias gradients, as torch's SyncBatchNorm
     does.  In a one-process group the synchronised path must reproduce the plain one (output, running statistics,
