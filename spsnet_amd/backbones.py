@@ -54,7 +54,15 @@ def equal_counts_check(batch_idx, batch_size):
         ok = count()
     batch_idx.record_stream(side)
 
+    capturing = torch.cuda.is_current_stream_capturing()
+    if capturing:
+        torch.cuda.current_stream(dev).wait_stream(side)     # (a capture ends with every forked stream joined back)
+
     def verdict():
+        if capturing:
+            # a stream capture cannot read device data on the host: the verdict stays on the device (spsnet_amd.graphs puts it
+            # into the replayed batch_dict as 'scene_sizes_equal'); the eager warm-up passes in front of the capture assert
+            return ok
         with torch.cuda.stream(side):
             good = bool(ok)          # (blocks the host until the count kernels are done, nothing else)
         assert good, "scenes of unequal size"
@@ -287,7 +295,9 @@ class _PointBackbone(nn.Module):
             else:
                 sa_ins_preds.append([])
 
-        counts_ok()   # everything is in the queue: blocking here starves nothing
+        sizes_equal = counts_ok()   # everything is in the queue: blocking here starves nothing
+        if isinstance(sizes_equal, torch.Tensor):      # (under stream capture the verdict stays on the device: spsnet_amd.graphs)
+            batch_dict['scene_sizes_equal'] = sizes_equal
         ctr_batch_idx = batch_idx.view(batch_size, -1)[:, :li_xyz.shape[1]].contiguous().view(-1)
         col = ctr_batch_idx[:, None].float()
         batch_dict['ctr_offsets'] = torch.cat((col, ctr_offsets.contiguous().view(-1, 3)), dim=1)

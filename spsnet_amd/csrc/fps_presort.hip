@@ -35,9 +35,9 @@ __global__ __launch_bounds__(PF_THREADS) void fps_presort_kernel(int b, int K, i
     //  The second round of flags is not used by the pre-pass: its first granule is the scene's give-up word -- a poll that gave
     //  up leaves it tagged with this launch's epoch, the FPS kernel behind skips the scene and the launcher's predicated
     //  follow-up launch samples it with the in-kernel sort, see presort_gate)
-    unsigned long long *fl = flags + (size_t)scene * 2 * PC_MAXK;
-    const PcGiveUp gu{fl + PC_MAXK, epoch, spin_limit};
-    (void)pc_sort_split(sh, cu, K, n, npad, bs, l2, rb, xyz, temp, xg, sx, sy, sz, st, srk, false, gu, fl, epoch);
+    unsigned long long *fl = flags + (size_t)scene * 2 * PS_MAXK;
+    const PcGiveUp gu{fl + PS_MAXK, epoch, spin_limit};
+    (void)pc_sort_split<PS_MAXK>(sh, cu, K, n, npad, bs, l2, rb, xyz, temp, xg, sx, sy, sz, st, srk, false, gu, fl, epoch);
 }
 
 static std::atomic<unsigned> g_spin_limit{PC_SPIN_LIMIT};
@@ -65,7 +65,7 @@ int presort_pool_create(int dev, hipStream_t st) {
     if (dev < 0 || dev >= 64) return fail(SPS_ERR_INVALID, "sps_init: device %d out of range", dev);
     std::lock_guard<std::mutex> lock(g_pool_mu);
     if (g_pool[dev]) return SPS_OK;
-    const size_t bytes = (size_t)PS_SLOTS * PS_SCENES * 2 * PC_MAXK * sizeof(unsigned long long);
+    const size_t bytes = (size_t)PS_SLOTS * PS_SCENES * 2 * PS_MAXK * sizeof(unsigned long long);
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
     if (e == hipSuccess) e = hipMemsetAsync(p, 0, bytes, st);
@@ -85,7 +85,7 @@ bool presort_pool_exists(int dev) { return presort_flag_pool(dev) != nullptr; }
 // equals gate.tag).
 int launch_fps_presort(int b, int n, const float *dataset, const float *temp, float *work, long long stride, hipStream_t st,
                        PresortGate *gate) {
-    int K = PC_MAXK;
+    int K = PS_MAXK;
     while (K > 1 && b * K > 64) K >>= 1;   // the K workgroups of a scene spin on each other: all of them resident
     if (b * K > 128 || b > PS_SCENES) return -1;
     const int bs = sps_opt_n_threads(n);
@@ -105,13 +105,13 @@ int launch_fps_presort(int b, int n, const float *dataset, const float *temp, fl
     static std::atomic<unsigned> counter{0};
     unsigned ticket = counter.fetch_add(1, std::memory_order_relaxed) + 1u;
     if ((ticket << 1) == 0u) ticket = counter.fetch_add(1, std::memory_order_relaxed) + 1u;   // tag 0 = the zeroed pool
-    unsigned long long *flags = pool + (size_t)(ticket % PS_SLOTS) * PS_SCENES * 2 * PC_MAXK;
+    unsigned long long *flags = pool + (size_t)(ticket % PS_SLOTS) * PS_SCENES * 2 * PS_MAXK;
     hipLaunchKernelGGL(fps_presort_kernel, dim3(8 * K * divup(b, 8)), dim3(PF_THREADS), 0, st, b, K, n, bs, l2, rb, npad, stride,
                        dataset, temp, work, fps_cluster_spread(), flags, ticket << 1, pc_spin_limit());
     // (SPS_FPS_PRESORT_GATE=0, DIAGNOSTIC / A-B timing only: no gate, no follow-up launch -- a pre-pass that gave up would then
     //  leave its scenes unsampled)
     static const bool gate_on = [] { const char *e = getenv("SPS_FPS_PRESORT_GATE"); return !(e && *e == '0'); }();
-    if (gate) *gate = gate_on ? PresortGate{flags + PC_MAXK, 2 * PC_MAXK, ticket << 1} : PresortGate{nullptr, 0, 0u};
+    if (gate) *gate = gate_on ? PresortGate{flags + PS_MAXK, 2 * PS_MAXK, ticket << 1} : PresortGate{nullptr, 0, 0u};
     return check_launch("fps_presort_kernel");
 }
 

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
     // exchange area), all K workgroups leave, and the launcher's follow-up launch samples the scene with the one-workgroup
     // kernel (fps_pruned_big.hip) -- nothing written so far is used (temp is only written at the very end).
     const PcGiveUp gu{xg, 1u, spin_limit};
-    if (!pc_sort_split(sh.sort, cu, K, n, npad, bs, l2, rb, xyz, temp, xg, sx, sy, sz, st, srk, true, gu)) return;
+    if (!pc_sort_split<PC_MAXK>(sh.sort, cu, K, n, npad, bs, l2, rb, xyz, temp, xg, sx, sy, sz, st, srk, true, gu)) return;
 
     // ------------------------------------------------------------------ bucket metadata
     // bucket g = v * nwaves + gwave is slot v of this wave: row v / 64, lane v % 64

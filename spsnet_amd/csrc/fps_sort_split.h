@@ -17,7 +17,8 @@
 
 namespace sps {
 
-constexpr int PC_MAXK = 8;        // workgroups per scene
+constexpr int PC_MAXK = 16;       // workgroups per scene at most (layout of the flags / histograms of the exchange area; round 5: 16)
+constexpr int PS_MAXK = 8;        // ... of the sorting pre-pass in front of the register-resident kernel (fps_presort.hip)
 constexpr int PC_MAXT = 8;        // records a workgroup publishes per round (fps_pruned_cluster.hip)
 constexpr int PC_MAXR = 32;       // records per round (K T) at most: two lanes per record in the acceptance
 // the exchange area in 8-byte granules: [8 ..): the rounds' records [parity][record][field]; the sort's two rounds of flags
@@ -78,6 +79,8 @@ __device__ __forceinline__ bool pc_bounded_poll(const PcGiveUp &gu, int sleep, R
 // waits until ALL of them have scattered (needed when they go on to read each other's points in the same launch).
 // -> false (to every thread of the workgroup alike) when a poll gave up: the scene's give-up word is raised, nothing this
 // workgroup wrote may be used, the caller returns.
+// KMAX: compile-time bound of K (the histogram exchange keeps KMAX x 4 eight-byte loads in flight per thread)
+template <int KMAX>
 __device__ __forceinline__ bool pc_sort_split(PcSortShared &sh, int cu, int K, int n, int npad, int bs, int l2, int rb,
                                               const float *__restrict__ xyz, const float *__restrict__ temp,
                                               unsigned long long *xg, float *sx, float *sy, float *sz, float *st, int *srk,
@@ -187,9 +190,10 @@ __device__ __forceinline__ bool pc_sort_split(PcSortShared &sh, int cu, int K, i
         if (sh.giveup) return false;   // (the histograms of a sibling that never arrived would be garbage offsets)
         {   // exclusive prefix sum over the cells of the summed histograms, plus what the workgroups before me put in each cell
             int loc[PER], before[PER], sum = 0;
-            unsigned long long h64[PC_MAXK][PER / 2];
+            static_assert(KMAX <= PC_MAXK, "the exchange area holds PC_MAXK histograms");
+            unsigned long long h64[KMAX][PER / 2];
 #pragma unroll
-            for (int c = 0; c < PC_MAXK; ++c)
+            for (int c = 0; c < KMAX; ++c)
 #pragma unroll
                 for (int i = 0; i < PER / 2; ++i)
                     h64[c][i] = c < K ? __hip_atomic_load(&gh64[((size_t)c * PF_BINS + tid * PER) / 2 + i], __ATOMIC_RELAXED,
@@ -199,7 +203,7 @@ __device__ __forceinline__ bool pc_sort_split(PcSortShared &sh, int cu, int K, i
             for (int i = 0; i < PER; ++i) {
                 int tot = 0, bef = 0;
 #pragma unroll
-                for (int c = 0; c < PC_MAXK; ++c) {
+                for (int c = 0; c < KMAX; ++c) {
                     const int h = (int)(unsigned)(h64[c][i / 2] >> (32 * (i & 1)));
                     tot += h;
                     bef += c < cu ? h : 0;

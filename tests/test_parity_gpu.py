@@ -1237,7 +1237,7 @@ def test_ball_query_range_small_launch_kernels(ext, G, oracle, N, M, j0, cnt, ra
 
 
 # ------------------------------------------------------------------ pruned FPS for scenes beyond one CU's registers
-@pytest.mark.parametrize("cluster", ["1", "", "2,8", "4,5", "3,8", "8,1"])
+@pytest.mark.parametrize("cluster", ["1", "", "2,8", "4,5", "3,8", "8,1", "16,2", "12,2"])
 @pytest.mark.parametrize("N,m,kind", [(20000, 700, "lattice"), (40000, 2000, "dup"), (65536, 4096, "kitti"),
                                       (70001, 1500, "uniform"), (180000, 2500, "kitti"), (16385, 16385, "dup"),
                                       (30000, 900, "batch11")])
@@ -3235,6 +3235,43 @@ def test_helper_streams_really_run_beside_the_pass(dev):
         y = x * 2
     producer.synchronize()
     assert float(y.sum()) == 2.0 * (1 << 20)
+
+
+def test_warm_pass_replays_from_a_graph_with_one_host_call(G, dev):
+    """spsnet_amd.graphs: the streamed SA stack and an IASSD_Backbone forward captured WARM (after eager passes: weights packed,
+    helper streams placed) into a HIP graph and replayed -- on the captured batch and on a second one copied into the static
+    inputs: every output bit-identical to the eager pass on the same batch."""
+    from spsnet_amd import backbones as BB, graphs, pointnet2_modules as M, sa_stack, scenes
+    layers = sa_stack.build_sa_layers(M, sa_stack.IASSD_KITTI, seed=3).to(dev)
+    batches = [scenes.make_batch("kitti-lidar-v1", 2, 16384, seed0=s) for s in (5, 50)]
+    x0, f0 = G.t(batches[0][0]), G.t(batches[0][1])
+    g = graphs.graphed_sa_stack(layers, x0, f0)
+    with torch.no_grad():
+        for xa, fa in batches + batches[:1]:
+            x, f = G.t(xa), G.t(fa)
+            got = [tuple(None if t is None else t.clone() for t in o) for o in g(x, f)]
+            want = sa_stack.run_sa_layers(layers, x, f, overlap=False, stream_first_layer=False)
+            torch.cuda.synchronize()
+            assert not sa_stack.check_timeouts()
+            for a, b in zip(got, want):
+                for p, q in zip(a, b):
+                    assert (p is None and q is None) or torch.equal(p, q)
+    net = scenes.fill_parameters(BB.IASSD_Backbone(BB.IASSD_KITTI_CFG, input_channels=4, num_class=3), 5).to(dev).eval()
+
+    def points_of(xa, fa):
+        bidx = np.repeat(np.arange(2, dtype=np.float32), 16384)[:, None]
+        return G.t(np.concatenate([bidx, xa.reshape(-1, 3), fa.transpose(0, 2, 1).reshape(-1, 1)], 1).astype(np.float32))
+    pts = [points_of(*b) for b in batches]
+    gb = graphs.graphed_backbone(net, 2, pts[0])
+    with torch.no_grad():
+        for p in pts + pts[:1]:
+            out = gb(p)
+            got = {k: out[k].clone() for k in ("centers", "centers_features", "ctr_offsets", "encoder_features") if isinstance(out[k], torch.Tensor)}
+            assert bool(out["scene_sizes_equal"])          # (the reference's assert, kept on the device under replay)
+            want = net(dict(batch_size=2, points=p))
+            torch.cuda.synchronize()
+            for k, v in got.items():
+                assert torch.equal(v, want[k]), k
 
 
 @pytest.mark.parametrize("mode", ["streamed", "seq"])

@@ -49,3 +49,34 @@ for tag, cls, cfg in (("IASSD_Backbone", BB.IASSD_Backbone, BB.IASSD_KITTI_CFG),
             lat += time.perf_counter() - t1
     print(f"{tag:16s} {B}x{N}: {ms:7.3f} ms per forward  ({B * N / ms / 1e3:.1f} M points/s); host enqueue "
           f"{1e3 * host / reps:.3f} ms, single-forward latency {1e3 * lat / reps:.3f} ms", flush=True)
+    if os.environ.get("BACKBONE_GRAPH", "1") != "0":
+        # the same forward captured WARM into a HIP graph (spsnet_amd.graphs): one host call per forward
+        from spsnet_amd import graphs
+        try:
+            g = graphs.graphed_backbone(net, B, points, stds if tag.startswith("PAG") else None)
+            args = (points, stds) if tag.startswith("PAG") else (points,)
+            with torch.no_grad():
+                ref = net(batch())
+            out = g(*args)
+            torch.cuda.synchronize()
+            same = all(torch.equal(out[k], ref[k]) for k in ("centers", "centers_features", "ctr_offsets") if k in ref) if "centers" in ref \
+                else torch.equal(out["point_features"], ref["point_features"])
+            for _ in range(3):
+                g(*args)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                g(*args)
+            torch.cuda.synchronize()
+            gms = 1e3 * (time.perf_counter() - t0) / reps
+            ghost = 0.0
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                g(*args)
+                ghost += time.perf_counter() - t1
+            torch.cuda.synchronize()
+            print(f"{'':16s} warm-graph replay: {gms:7.3f} ms per forward, host {1e3 * ghost / reps:.3f} ms per replay call; "
+                  f"outputs identical to the eager forward: {same}", flush=True)
+        except Exception as exc:  # noqa: BLE001
+            print(f"{'':16s} warm-graph replay: FAILED {type(exc).__name__}: {str(exc)[:300]}", flush=True)

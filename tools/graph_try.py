@@ -1,5 +1,8 @@
-"""Capture the FIRST pass of a fresh process into a HIP graph (torch.cuda.graph) and replay it -- on the captured input and on
-another batch copied into the static input tensors -- against eager sequential passes: bit-identical outputs required.
+"""Capture a pass into a HIP graph (torch.cuda.graph) and replay it -- on the captured input and on another batch copied into the
+static input tensors -- against eager sequential passes: bit-identical outputs required.  By default the captured pass is the
+FIRST pass of a fresh process (nothing of the library has run: the capture then also records the one-time weight packing);
+GRAPH_TRY_WARM=1 runs three eager passes first (weights packed, helper streams placed and probed) and captures a WARM pass --
+the honest replay-vs-eager comparison.  GRAPH_TRY_HOST=1 also prints the host time of a replay call and of an eager enqueue.
 usage: python tools/graph_try.py [streamed|seq] [fp32|fp16x2]      (GPU box only; tests/test_parity_gpu.py runs it as a subprocess)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,10 +27,15 @@ def same(a, b):
     return all((p is None and q is None) or torch.equal(p, q) for la, lb in zip(a, b) for p, q in zip(la, lb))
 
 
+WARM = os.environ.get("GRAPH_TRY_WARM", "0") == "1"
 with torch.no_grad():
+    if WARM:
+        for _ in range(3):
+            sa_stack.run_sa_layers(layers, x, f, **kw)
+        torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     torch.cuda.synchronize()
-    with torch.cuda.graph(g):                      # nothing of this library has run in this process yet
+    with torch.cuda.graph(g):                      # (cold: nothing of this library has run in this process yet)
         out = sa_stack.run_sa_layers(layers, x, f, **kw)
     torch.cuda.synchronize()
     ok = True
@@ -49,7 +57,16 @@ with torch.no_grad():
         torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
     for _ in range(3):
         sa_stack.run_sa_layers(layers, x, f, **kw)
-    print(f"[{mode}, {fused.PRECISION}] eager {timeit(lambda: sa_stack.run_sa_layers(layers, x, f, **kw)):.3f} ms/pass, "
-          f"graph replay {timeit(g.replay):.3f} ms/pass")
+    print(f"[{mode}, {fused.PRECISION}, {'warm' if WARM else 'first-pass'} capture, GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}] "
+          f"eager {timeit(lambda: sa_stack.run_sa_layers(layers, x, f, **kw)):.3f} ms/pass, graph replay {timeit(g.replay):.3f} ms/pass")
+    if os.environ.get("GRAPH_TRY_HOST", "0") == "1":
+        def host(fn, n=20):
+            ts = []
+            for _ in range(n):
+                t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+                torch.cuda.synchronize()
+            return sorted(ts)[n // 2] * 1e3
+        print(f"host time per pass (median of 20, device idle at each start): eager enqueue "
+              f"{host(lambda: sa_stack.run_sa_layers(layers, x, f, **kw)):.3f} ms, graph replay call {host(g.replay):.3f} ms")
 print("GRAPH_TRY_OK" if ok else "GRAPH_TRY_MISMATCH")
 sys.exit(0 if ok else 1)
