@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspsnet_sa.so")
+# (SPS_LIBSPSNET_SA: a DIAGNOSTIC build of the same library -- e.g. fps_pruned_cluster.hip with -DSPS_PC_PROFILE, tools/fps_cluster_profile.py)
+LIB_PATH = os.environ.get("SPS_LIBSPSNET_SA") or os.path.join(_HERE, "lib", "libspsnet_sa.so")
 
 SPS_OK = 0
 ABI_VERSION = 2

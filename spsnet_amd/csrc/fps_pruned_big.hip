@@ -409,18 +409,29 @@ size_t fps_big_workspace_elems(int n) {
     return (size_t)5 * ((size_t)divup(n, 64) * 64) + fps_cluster_exchange_floats();
 }
 
-// Workgroups per scene (K) and records each publishes per round (T <= 8, K T <= 32); SPS_FPS_CLUSTER="K,T" overrides
+// Workgroups per scene (K <= 16) and records each publishes per round (T <= 8, K T <= 64); SPS_FPS_CLUSTER="K,T" overrides
 // ("1" = one workgroup, the kernel below).  Measured on MI355X (tools/fps_cluster_probe.py; one workgroup = 1.00):
-//   180 000 -> 16 384, 1 scene    K,T = 2,8  0.71   4,8  0.41   8,3  0.33   8,4  0.30  (32.8 -> 9.95 ms)
+//   round 2-4 (K <= 8, K T <= 32):
+//   180 000 -> 16 384, 1 scene    K,T = 2,8  0.71   4,8  0.41   8,3  0.33   8,4  0.30  (32.8 -> 9.95 ms; 8.19 ms by round 4)
 //    65 536 -> 16 384, 2 scenes         2,8  0.97   4,8  0.56              8,4  0.50  (16.4 -> 8.27 ms)
 //    32 768 ->  8 192, 8 scenes         2,8  1.04   4,8  0.64              8,4  0.59  ( 7.5 -> 4.43 ms)
-// (K = 2 columns measured before the per-bucket application of a round's centres, the others with it.)
+//   round 5 (K <= 16, K T <= 64: one lane per record in the acceptance; profiles/round5/r5g_fps_cluster_64_records.txt):
+//   180 000 -> 16 384, 1 scene    K,T = 8,4  8.56 ms   8,8  7.81   12,5  7.12   16,2  8.86   16,3  7.38   16,4  6.89
+//   180 000 -> 16 384, 4 scenes         8,4  8.99      8,8  8.21                                          16,4  7.36
+//    65 536 -> 16 384, 2 scenes         8,4  7.24      8,8  6.46                             16,3  6.65   16,4  6.04
+//    32 768 ->  8 192, 8 scenes         8,4  3.93      8,6  3.68   8,8  3.68
+// A round is the cross-workgroup hop (poll + barrier: 4.2 k of 12.5 k cycles at 8,4) plus an apply phase that grows with the
+// buckets a workgroup holds (5.0 k at K = 8, 2.9 k at K = 16: tools/fps_cluster_profile.py), so more workgroups AND more
+// records per round both pay: 16,4 runs 1237 rounds of 13.5 k cycles (13.2 picks each) where 8,4 ran 1482 of 12.5 k (11.1
+// picks) -- although the acceptance over 64 record slots, one lane per record and the i-records dealt over the eight waves,
+// costs 2.0 k cycles per round where the 32-slot form cost 1.1 k (profiles/round5/r5h_fps_cluster_phase_profile_64_records.txt).
+// (K = 2 columns of round 2 measured before the per-bucket application of a round's centres, the others with it.)
 // The K workgroups of a scene spin on each other's records, so all b K must be resident at once: at most 64 (a CU each).
 static void fps_cluster_shape(int b, int n, int &K, int &T) {
-    K = 8;
+    K = 16;
     while (K > 1 && b * K > 64) K >>= 1;
     if (K == 2 && n < 65536) K = 1;
-    T = K >= 8 ? 4 : 8;
+    T = K >= 16 ? 4 : 8;
     const char *env = getenv("SPS_FPS_CLUSTER");   // (read per launch: tests switch it)
     if (env && *env) {
         int k = 1, t = 8;

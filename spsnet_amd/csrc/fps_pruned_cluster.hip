@@ -13,11 +13,13 @@
 //   * the exchange is one hop per round: 8-byte {value, round tag} granules written and polled with agent-scope atomics
 //     (MI355X_MICROARCH.md, hand-off price list: ~1 us; no fence, no separate flag), double-buffered by round parity --
 //     a workgroup can publish round r+2 only after everybody has published r+1, i.e. finished reading r;
-//   * a workgroup polls the K T records with one granule per lane (192 lanes at 32 records: one round trip; eight waves
+//   * a workgroup polls the K T records with one granule per lane (384 lanes at 64 records: one round trip; eight waves
 //     each polling everything cost 1 ms of 13 more) into LDS, a second barrier hands them to its waves;
-//   * every wave evaluates the acceptance of all K T records redundantly (identical inputs, identical result), so
-//     nobody waits for a verdict; each wave then applies the accepted centres to its own buckets only.
-// More records per round and less work per wave: 180 000 -> 16 384 in 9.95 ms at K = 8 against 32.8 ms on one CU
+//   * the acceptance over the K T <= 64 records (round 5; 32 before) holds one record per lane, the i-records it is tested
+//     against dealt over the eight waves (eight each), partial counts meeting in LDS behind one more barrier; each wave
+//     then applies the accepted centres (a 64-bit mask per bucket) to its own buckets only.
+// More records per round and less work per wave: 180 000 -> 16 384 in 6.9 ms at K = 16, T = 4 (round 5; 8.2 ms at 8 x 4,
+// 9.95 ms when first built) against 32.8 ms on one CU
 // (fps_pruned_big.hip's launcher holds the measured table and picks K, T).
 // The K workgroups of a scene must be resident together: the launcher uses the cluster only for b K <= 64 workgroups
 // (a CU each; the polls are bounded -- a poll that runs out raises the scene's give-up word, its workgroups leave and the
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
     for (;;) {
         if (younger) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         PC_STAMP(p0);
-        // ---- apply the round's accepted centres (lanes `pend`, always even: bit rr / 2 names a centre) to my buckets.
+        // ---- apply the round's accepted centres (lanes `pend`: lane rr holds record rr, bit rr names a centre) to my buckets.
         // With ~1.5 touched buckets per wave and round the phase is a chain of L2 round trips, so: (1) all box tests first --
         // lane l collects, per row, the centres its bucket cannot rule out; (2) every touched bucket is fetched ONCE
         // (x, y, z, t and the ranks together), takes the minimum over its centres in registers and is refreshed once;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
         if (pend) {
             for_rows([&](auto rc) {
                 constexpr int RW = decltype(rc)::value;
-                unsigned cm = 0u;
+                unsigned long long cm = 0ull;
                 for (unsigned long long pm = pend; pm; pm &= pm - 1) {
                     const int rr = __builtin_ctzll(pm);
                     const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax), rr));
@@ -204,9 +206,9 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
                     const float qz = __builtin_amdgcn_fmed3f(cz, blo_z[RW], bhi_z[RW]);
                     const float lb = sqdist(qx, qy, qz, cx, cy, cz);
                     const bool skip = lb >= __int_as_float(bmax[RW]);  // NaN -> not skipped
-                    cm |= skip ? 0u : (1u << (rr >> 1));
+                    cm |= skip ? 0ull : (1ull << rr);
                 }
-                unsigned long long todo = __ballot(cm != 0u);
+                unsigned long long todo = __ballot(cm != 0ull);
                 if (todo) {
                     struct Bucket { float x, y, z, t; int rk; };
                     auto fetch = [&](int l) -> Bucket {
@@ -226,11 +228,12 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
                         todo &= todo - 1;                       // (0 stays 0)
                         Bucket nxt = cur;
                         if (more) nxt = fetch(ln);              // in flight while this bucket is worked on
-                        unsigned mc = (unsigned)__builtin_amdgcn_readlane((int)cm, l);
+                        unsigned long long mc = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(cm >> 32), l) << 32) |
+                                                (unsigned)__builtin_amdgcn_readlane((int)cm, l);
                         float tn = cur.t;
                         bool moved = false;
                         while (mc) {
-                            const int rr = 2 * __builtin_ctz(mc);
+                            const int rr = __builtin_ctzll(mc);
                             mc &= mc - 1;
                             const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax), rr));
                             const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay), rr));
@@ -368,8 +371,8 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
         __syncthreads();
         if (sh.sort.giveup) return;
         PC_STAMP(p5);
-        // ---- acceptance over the R records: lane (rj, h) evaluates record rj against the i-records of half h
-        const int rj = lane >> 1, h = lane & 1;
+        // ---- acceptance over the R <= 64 records: lane rj holds record rj
+        const int rj = lane;
         const int jd = sh.xr[0][rj], jk = sh.xr[1][rj];
         const float jx = __int_as_float(sh.xr[2][rj]), jy = __int_as_float(sh.xr[3][rj]);
         const float jz = __int_as_float(sh.xr[4][rj]);
@@ -384,17 +387,22 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
             nbad += (before & (lowered | hidden)) ? 1 : 0;
         };
         {
-            // the 16 i-records of a lane's half are dealt over the eight waves, two each (every wave evaluating all of them
-            // was 3.0 k cycles of a 14.9 k round: two waves per SIMD issuing the same ~400 VALU instructions); the partial
-            // counts meet in LDS behind one more barrier, which aligned waves cross in a few hundred cycles
-            static_assert(PC_MAXR == 4 * PF_WAVES, "two i-records per wave and half");
-            const int i0 = h * (PC_MAXR / 2) + wave * 2;
+            // the 64 i-records are dealt over the eight waves, eight each (every wave evaluating all of them was 3.0 k cycles
+            // of a 14.9 k round at 32 records: two waves per SIMD issuing the same VALU instructions); the partial counts
+            // meet in LDS behind one more barrier, which aligned waves cross in a few hundred cycles
+            static_assert(PC_MAXR == 8 * PF_WAVES, "eight i-records per wave");
+            const int i0 = wave * 8;
             // (slots beyond R hold records that are never "before" anything)
-            const int2 id = *(const int2 *)&sh.xr[0][i0], ik = *(const int2 *)&sh.xr[1][i0];
-            const int2 ixv = *(const int2 *)&sh.xr[2][i0], iyv = *(const int2 *)&sh.xr[3][i0];
-            const int2 izv = *(const int2 *)&sh.xr[4][i0], ibv = *(const int2 *)&sh.xr[5][i0];
-            pair(id.x, ik.x, ixv.x, iyv.x, izv.x, ibv.x);
-            pair(id.y, ik.y, ixv.y, iyv.y, izv.y, ibv.y);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int4 id = *(const int4 *)&sh.xr[0][i0 + 4 * u], ik = *(const int4 *)&sh.xr[1][i0 + 4 * u];
+                const int4 ixv = *(const int4 *)&sh.xr[2][i0 + 4 * u], iyv = *(const int4 *)&sh.xr[3][i0 + 4 * u];
+                const int4 izv = *(const int4 *)&sh.xr[4][i0 + 4 * u], ibv = *(const int4 *)&sh.xr[5][i0 + 4 * u];
+                pair(id.x, ik.x, ixv.x, iyv.x, izv.x, ibv.x);
+                pair(id.y, ik.y, ixv.y, iyv.y, izv.y, ibv.y);
+                pair(id.z, ik.z, ixv.z, iyv.z, izv.z, ibv.z);
+                pair(id.w, ik.w, ixv.w, iyv.w, izv.w, ibv.w);
+            }
             sh.part[wave][lane] = nbef | (nbad << 8);
             __syncthreads();
             int sum = 0;
@@ -403,13 +411,11 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
             nbef = sum & 0xFF;
             nbad = sum >> 8;
         }
-        int cnt = nbef | (nbad << 8);
-        cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]: the other half
-        const int pos = cnt & 0xFF;
+        const int pos = nbef;
         const bool real = rj < R;
-        const int firstbad = -wave_max_i32_id((real && (cnt >> 8)) ? -pos : -R);   // nobody bad: all R records
+        const int firstbad = -wave_max_i32_id((real && nbad) ? -pos : -R);   // nobody bad: all R records
         const int L = firstbad < m - j ? firstbad : m - j;
-        const bool taken = h == 0 && real && pos < L;
+        const bool taken = real && pos < L;
         if (cu == 0 && wave == 0) {
             if (taken) {
                 const unsigned rank = 0x0FFFFFFFu - ((unsigned)jk >> 4);

@@ -20,7 +20,7 @@ namespace sps {
 constexpr int PC_MAXK = 16;       // workgroups per scene at most (layout of the flags / histograms of the exchange area; round 5: 16)
 constexpr int PS_MAXK = 8;        // ... of the sorting pre-pass in front of the register-resident kernel (fps_presort.hip)
 constexpr int PC_MAXT = 8;        // records a workgroup publishes per round (fps_pruned_cluster.hip)
-constexpr int PC_MAXR = 32;       // records per round (K T) at most: two lanes per record in the acceptance
+constexpr int PC_MAXR = 64;       // records per round (K T) at most: one lane per record in the acceptance (round 5: 64, was 32)
 // the exchange area in 8-byte granules: [8 ..): the rounds' records [parity][record][field]; the sort's two rounds of flags
 // [2][K]; behind the granules the K cell histograms of the sort (ints).  The launchers zero the granules per launch.
 constexpr int PC_FLAG_AT = 8 + 2 * PC_MAXR * 6;

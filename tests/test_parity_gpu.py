@@ -1237,7 +1237,7 @@ def test_ball_query_range_small_launch_kernels(ext, G, oracle, N, M, j0, cnt, ra
 
 
 # ------------------------------------------------------------------ pruned FPS for scenes beyond one CU's registers
-@pytest.mark.parametrize("cluster", ["1", "", "2,8", "4,5", "3,8", "8,1", "16,2", "12,2"])
+@pytest.mark.parametrize("cluster", ["1", "", "2,8", "4,5", "3,8", "8,1", "16,2", "12,2", "16,4", "8,8", "11,5"])
 @pytest.mark.parametrize("N,m,kind", [(20000, 700, "lattice"), (40000, 2000, "dup"), (65536, 4096, "kitti"),
                                       (70001, 1500, "uniform"), (180000, 2500, "kitti"), (16385, 16385, "dup"),
                                       (30000, 900, "batch11")])

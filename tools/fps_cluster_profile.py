@@ -1,7 +1,8 @@
 """Phase times of the clustered large-scene FPS (fps_pruned_cluster.hip built with -DSPS_PC_PROFILE: per-wave s_memtime sums
 left in the tail of the workspace histogram area).  Prints, per phase, the mean / max over the waves per round.
 usage: python tools/fps_cluster_profile.py [N] [m] [K,T]
-needs the diagnostic build: hipcc ... -DSPS_PC_PROFILE -c fps_pruned_cluster.hip -o _build/fps_pruned_cluster.o, relink"""
+needs the diagnostic build: hipcc ... -DSPS_PC_PROFILE -c fps_pruned_cluster.hip, relinked into a library of its own and named by
+SPS_LIBSPSNET_SA (tools/r5f.sh shows the three commands)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -24,7 +25,7 @@ _lib.check(L.sps_fps_with_workspace(1, N, m, xyz.data_ptr(), temp.data_ptr(), id
                                     torch.cuda.current_stream().cuda_stream), "fps")
 torch.cuda.synchronize()
 npad = (N + 63) // 64 * 64
-PC_MAXK, PF_BINS, PC_MAXR = 8, 4096, 32
+PC_MAXK, PF_BINS, PC_MAXR = 16, 4096, 64      # (csrc/fps_sort_split.h)
 granules = 8 + 2 * PC_MAXR * 6 + 2 * PC_MAXK + 8
 area = work[5 * npad:].view(torch.int64).cpu().numpy()          # the exchange area as 8-byte words
 tail_end = granules + PC_MAXK * PF_BINS // 2
