@@ -440,9 +440,16 @@ static void fps_cluster_shape(int b, int n, int &K, int &T) {
     }
 }
 
+// SPS_FPS_CLUSTER_SMALL=1 (DIAGNOSTIC A/B, read per launch): scenes of 6144 .. 16 384 points that come with a workspace take the
+// clustered kernel (K workgroups per scene, points in the L2-resident workspace) instead of the register-resident one
+static bool fps_cluster_small() {
+    const char *e = getenv("SPS_FPS_CLUSTER_SMALL");
+    return e && *e && *e != '0';
+}
+
 int launch_fps_pruned_big(int b, int n, int m, const float *dataset, float *temp, int *idxs, float *work, hipStream_t st) {
     if (fps_big_workspace_elems(n) == 0 || !work) return -1;
-    if (n <= 32 * PF_THREADS)   // register-resident kernel behind the sorting pre-pass (-1: shape not served, caller falls back)
+    if (n <= 32 * PF_THREADS && !fps_cluster_small())   // register-resident kernel behind the sorting pre-pass (-1: shape not served, caller falls back)
         return launch_fps_pruned(b, n, m, dataset, temp, idxs, st, nullptr, nullptr, work, (long long)fps_big_workspace_elems(n));
     const int bs = sps_opt_n_threads(n);
     int l2 = 0;
@@ -501,7 +508,7 @@ int launch_fps_big_redo_given_up(int b, int n, int m, const float *dataset, floa
 int launch_fps_big_publish(int b, int n, int m, const float *dataset, float *temp, int *idxs, int *progress, float *work,
                            hipStream_t st) {
     if (fps_big_workspace_elems(n) == 0 || !work || m < 2) return -1;
-    if (n <= 32 * PF_THREADS) return -1;
+    if (n <= 32 * PF_THREADS && !fps_cluster_small()) return -1;
     int K, T;
     fps_cluster_shape(b, n, K, T);
     if (K < 2) return -1;
