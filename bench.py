@@ -60,7 +60,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # issue-rate ceiling of the ball query's pair test (see ball_query_roofline): 1024 SIMDs x 2.4 GHz x 64 lanes / 23.1 cycles
 VALU_PAIR_TEST_PEAK = 1024 * 2.4e9 * 64 / (4 * 2.31 + 2 * 2.72 + 2 * 4.20)
 MFMA_PEAK_TF = {"fp32": 157.3, "fp16x2": 2500.0, "fp16": 2500.0}  # dense peaks: fp32 MFMA, fp16 MFMA (no sparsity)
-PROFILE_DIRS = ("round4", "round3", "round2", "round1")
+PROFILE_DIRS = ("round5", "round4", "round3", "round2", "round1")
 
 
 def parse():
