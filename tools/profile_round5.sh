@@ -12,7 +12,7 @@ rocprofv3 --output-format csv --kernel-trace --stats -d $O/kt -o kt -- python3 b
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/kt_uniform -o kt -- python3 bench.py --dataset uniform-v1 --steps 20 --warmup 5 --no-training-leg --no-cpu-baseline > $O/bench_uniform_profiled.log 2>&1 &&
 SPS_FPS_PRESORT=0 rocprofv3 --output-format csv --kernel-trace --pmc $PMC -d $O/pmc32 -o p -- python3 bench.py --steps 4 --warmup 1 --no-fp16x2-leg $QUIET > $O/pmc32.log 2>&1 &&
 SPS_FPS_PRESORT=0 rocprofv3 --output-format csv --kernel-trace --pmc $PMC -d $O/pmc16 -o p -- python3 bench.py --steps 4 --warmup 1 --mlp-precision fp16x2 --no-fp32-leg $QUIET > $O/pmc16.log 2>&1 &&
-rocprofv3 --output-format csv --kernel-trace --pmc $PMC -d $O/pmc5 -o p -- python3 bench.py --config 5 --steps 3 --warmup 1 $QUIET > $O/pmc5.log 2>&1 &&
+rocprofv3 --output-format csv --kernel-trace --pmc $PMC -d $O/pmc5 -o p -- python3 bench.py --config 5 --steps 3 --warmup 1 --no-validate $QUIET > $O/pmc5.log 2>&1 &&
 SPS_FPS_PRESORT=0 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o p -- python3 bench.py --steps 3 --warmup 1 --no-fp16x2-leg $QUIET > $O/fetch.log 2>&1 &&
 SPS_FPS_PRESORT=0 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $O/write -o p -- python3 bench.py --steps 3 --warmup 1 --no-fp16x2-leg $QUIET > $O/write.log 2>&1
 echo "profiled passes rc=$?"
