@@ -1,6 +1,6 @@
 """Phase times of the clustered large-scene FPS (fps_pruned_cluster.hip built with -DSPS_PC_PROFILE: per-wave s_memtime sums
 left in the tail of the workspace histogram area).  Prints, per phase, the mean / max over the waves per round.
-usage: python tools/fps_cluster_profile.py [N] [m] [K,T]
+usage: python tools/fps_cluster_profile.py [N] [m] [K,T] [scenes]
 needs the diagnostic build: hipcc ... -DSPS_PC_PROFILE -c fps_pruned_cluster.hip, relinked into a library of its own and named by
 SPS_LIBSPSNET_SA (tools/r5f.sh shows the three commands)"""
 import os, sys
@@ -16,18 +16,21 @@ os.environ["SPS_FPS_CLUSTER"] = shape
 K = int(shape.split(",")[0])
 L = _lib.load()
 dev = torch.device("cuda:0")
-xyz = torch.from_numpy(scenes.make_batch("kitti-lidar-v1", 1, N, seed0=0)[0]).to(dev)
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 1          # (the profile is read from scene 0's exchange area)
+if N <= 16384:
+    os.environ["SPS_FPS_CLUSTER_SMALL"] = "1"
+xyz = torch.from_numpy(scenes.make_batch("kitti-lidar-v1", B, N, seed0=0)[0]).to(dev)
 wf = int(L.sps_fps_workspace_floats(N))
-work = torch.zeros((wf,), dtype=torch.float32, device=dev)
-temp = torch.full((1, N), 1e10, dtype=torch.float32, device=dev)
-idx = torch.empty((1, m), dtype=torch.int32, device=dev)
-_lib.check(L.sps_fps_with_workspace(1, N, m, xyz.data_ptr(), temp.data_ptr(), idx.data_ptr(), work.data_ptr(),
+work = torch.zeros((B * wf,), dtype=torch.float32, device=dev)
+temp = torch.full((B, N), 1e10, dtype=torch.float32, device=dev)
+idx = torch.empty((B, m), dtype=torch.int32, device=dev)
+_lib.check(L.sps_fps_with_workspace(B, N, m, xyz.data_ptr(), temp.data_ptr(), idx.data_ptr(), work.data_ptr(),
                                     torch.cuda.current_stream().cuda_stream), "fps")
 torch.cuda.synchronize()
 npad = (N + 63) // 64 * 64
 PC_MAXK, PF_BINS, PC_MAXR = 16, 4096, 64      # (csrc/fps_sort_split.h)
 granules = 8 + 2 * PC_MAXR * 6 + 2 * PC_MAXK + 8
-area = work[5 * npad:].view(torch.int64).cpu().numpy()          # the exchange area as 8-byte words
+area = work[5 * npad:wf].view(torch.int64).cpu().numpy()          # the exchange area as 8-byte words
 tail_end = granules + PC_MAXK * PF_BINS // 2
 nw = 8 * K
 rec = area[tail_end - 8 * nw:tail_end].reshape(nw, 8)
