@@ -425,6 +425,10 @@ size_t fps_big_workspace_elems(int n) {
 // records per round both pay: 16,4 runs 1237 rounds of 13.5 k cycles (13.2 picks each) where 8,4 ran 1482 of 12.5 k (11.1
 // picks) -- although the acceptance over 64 record slots, one lane per record and the i-records dealt over the eight waves,
 // costs 2.0 k cycles per round where the 32-slot form cost 1.1 k (profiles/round5/r5h_fps_cluster_phase_profile_64_records.txt).
+// On top (round 5, same table re-measured: r5m_fps_cluster_xcd_local_exchange_ab.txt): the records of a scene whose workgroups share an
+// XCD travel through that XCD's L2 (granule_store_xcd / granule_load_xcd: -0.8 k cycles of hop per round) and a wave reads and writes
+// the running distances of its own buckets with plain accesses instead of agent-scope atomics:
+//   180 000 x 1 at 16,4: 6.62 ms   65 536 x 2 at 16,4: 5.65 ms   32 768 x 8 at 8,8: 3.33 ms   (8.19 / 6.78 / 3.93 in round 4)
 // (K = 2 columns of round 2 measured before the per-bucket application of a round's centres, the others with it.)
 // The K workgroups of a scene spin on each other's records, so all b K must be resident at once: at most 64 (a CU each).
 static void fps_cluster_shape(int b, int n, int &K, int &T) {

@@ -35,6 +35,11 @@ namespace sps {
 namespace {
 
 constexpr int IMIN_C = (int)0x80000000;
+#ifdef SPS_PC_ATOMIC_ST
+constexpr bool PLAIN_ST = false;     // (A/B build: the running distances through agent-scope atomics, as in rounds 2-4)
+#else
+constexpr bool PLAIN_ST = true;
+#endif
 
 struct PcShared {
     PcSortShared sort;
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
                                                                         const float *__restrict__ dataset,
                                                                         float *__restrict__ temp, int *__restrict__ idxs,
                                                                         float *__restrict__ work, int *__restrict__ progress,
-                                                                        int spread, unsigned spin_limit) {
+                                                                        int spread, unsigned spin_limit, int xcd_local) {
     // progress != NULL: consumers on other CUs read idxs while this kernel runs (sa_stack's streamed first layer) -- picks
     // are stored write-through and progress[scene] counts the published ones (every 64 picks; fps_pruned.hip's protocol).
     // temp may then be NULL: all running distances start at 1e10 and are not handed back.
@@ -89,7 +94,17 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
     // exchange area), all K workgroups leave, and the launcher's follow-up launch samples the scene with the one-workgroup
     // kernel (fps_pruned_big.hip) -- nothing written so far is used (temp is only written at the very end).
     const PcGiveUp gu{xg, 1u, spin_limit};
-    if (!pc_sort_split<PC_MAXK>(sh.sort, cu, K, n, npad, bs, l2, rb, xyz, temp, xg, sx, sy, sz, st, srk, true, gu)) return;
+    // (every workgroup publishes its XCC_ID with its sort flag: the K workgroups of a scene that find themselves on ONE XCD
+    //  exchange their records through that XCD's L2 instead of the memory side -- granule_store_xcd / granule_load_xcd)
+    const int my_xcc = (int)(__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xFFu);   // HW_REG_XCC_ID
+    if (!pc_sort_split<PC_MAXK>(sh.sort, cu, K, n, npad, bs, l2, rb, xyz, temp, xg, sx, sy, sz, st, srk, true, gu, nullptr, 2u,
+                                1 + my_xcc))
+        return;
+    bool local = false;
+    if (xcd_local) {
+        const int theirs = lane < K ? (int)(unsigned)granule_load(xg + PC_FLAG_AT + lane) : 1 + my_xcc;
+        local = __ballot(theirs != 1 + my_xcc) == 0ull;      // (every workgroup reads the same K values: the same verdict)
+    }
 
     // ------------------------------------------------------------------ bucket metadata
     // bucket g = v * nwaves + gwave is slot v of this wave: row v / 64, lane v % 64
@@ -215,7 +230,9 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
                         const size_t p = (size_t)((RW * 64 + l) * nwaves + gwave) * 64 + lane;
                         Bucket bk;
                         bk.x = sx[p]; bk.y = sy[p]; bk.z = sz[p];
-                        bk.t = __hip_atomic_load(st + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // (a bucket's running distances are read and written by the ONE wave that owns it: plain accesses, served
+                        //  by this XCD's L2 -- round 2-4 used agent-scope atomics here, i.e. memory-side round trips)
+                        bk.t = PLAIN_ST ? st[p] : __hip_atomic_load(st + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         bk.rk = srk[p];
                         return bk;
                     };
@@ -244,7 +261,8 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
                         }
                         if (moved) {
                             const size_t p = (size_t)((RW * 64 + l) * nwaves + gwave) * 64 + lane;
-                            __hip_atomic_store(st + p, tn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (PLAIN_ST) st[p] = tn;
+                            else __hip_atomic_store(st + p, tn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             refresh(tn, cur.rk, cur.x, cur.y, cur.z);
                             commit(rc, l);
                             const int e = (RW << 6) | l;
@@ -346,12 +364,14 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
                 int bound = sh.soa[buf][5][rj];
                 if (nbef == T - 1) bound = imax(bound, hid);   // whoever comes behind my last record must beat what I hide
                 unsigned long long *dst = xround + (size_t)(cu * T + nbef) * 6;
-                granule_store(dst + 0, jd, tag);
-                granule_store(dst + 1, jk, tag);
-                granule_store(dst + 2, sh.soa[buf][2][rj], tag);
-                granule_store(dst + 3, sh.soa[buf][3][rj], tag);
-                granule_store(dst + 4, sh.soa[buf][4][rj], tag);
-                granule_store(dst + 5, bound, tag);
+                const int f2 = sh.soa[buf][2][rj], f3 = sh.soa[buf][3][rj], f4 = sh.soa[buf][4][rj];
+                if (local) {
+                    granule_store_xcd(dst + 0, jd, tag); granule_store_xcd(dst + 1, jk, tag); granule_store_xcd(dst + 2, f2, tag);
+                    granule_store_xcd(dst + 3, f3, tag); granule_store_xcd(dst + 4, f4, tag); granule_store_xcd(dst + 5, bound, tag);
+                } else {
+                    granule_store(dst + 0, jd, tag); granule_store(dst + 1, jk, tag); granule_store(dst + 2, f2, tag);
+                    granule_store(dst + 3, f3, tag); granule_store(dst + 4, f4, tag); granule_store(dst + 5, bound, tag);
+                }
             }
         }
         PC_STAMP(p4);
@@ -361,7 +381,10 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
             const int ng = R * 6;
             if (tid < ng) {
                 unsigned long long g = 0;
-                if (!pc_bounded_poll(gu, 1, [&] { g = granule_load(xround + tid); return (unsigned)(g >> 32) == tag; })) {
+                if (!pc_bounded_poll(gu, 1, [&] {
+                        g = local ? granule_load_xcd(xround + tid) : granule_load(xround + tid);
+                        return (unsigned)(g >> 32) == tag;
+                    })) {
                     sh.sort.giveup = 1;
                     gu.raise();
                 }
@@ -453,7 +476,7 @@ __global__ __launch_bounds__(PF_THREADS) void fps_pruned_cluster_kernel(int b, i
         if (g >= nb) break;
         const size_t p = (size_t)g * 64 + lane;
         if (p < (size_t)n) {
-            const float tv = __hip_atomic_load(st + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float tv = PLAIN_ST ? st[p] : __hip_atomic_load(st + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             temp[pf_unrank((unsigned)srk[p], l2, rb)] = tv;
         }
     }
@@ -488,10 +511,14 @@ int launch_fps_pruned_cluster(int b, int K, int T, int n, int m, const float *da
                                     (size_t)PC_GRANULES * 8, (size_t)b, st);   // (the granules; the histograms behind them are written before they are read)
     if (e != hipSuccess) return fail(SPS_ERR_LAUNCH, "fps(cluster): hipMemset2DAsync: %s", hipGetErrorString(e));
     dim3 grid(8 * K * divup(b, 8)), block(PF_THREADS);
+    const int spread = fps_cluster_spread();
+    // SPS_FPS_CLUSTER_XCD (read per launch; default 1): record exchange through the XCD's L2 where a scene's workgroups share one
+    const char *xe = getenv("SPS_FPS_CLUSTER_XCD");
+    const int xcd_local = !(xe && *xe == '0');
 #define SPS_PC_CASE(RW)                                                                                                \
     if (rows <= RW) {                                                                                                  \
         hipLaunchKernelGGL((fps_pruned_cluster_kernel<RW>), grid, block, 0, st, b, K, T, n, m, bs, l2, rb, npad, stride, \
-                           dataset, temp, idxs, work, progress, fps_cluster_spread(), pc_spin_limit());                \
+                           dataset, temp, idxs, work, progress, spread, pc_spin_limit(), xcd_local);                  \
         if (check_launch("fps_pruned_cluster_kernel") != SPS_OK) return SPS_ERR_LAUNCH;                               \
         /* the scenes a bounded poll gave up on (normally none: a launch whose workgroups leave at once) */           \
         return launch_fps_big_redo_given_up(b, n, m, dataset, temp, idxs, work, progress, st);                        \

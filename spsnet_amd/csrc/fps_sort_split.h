@@ -42,6 +42,22 @@ __device__ __forceinline__ void granule_store(unsigned long long *p, int value, 
 __device__ __forceinline__ unsigned long long granule_load(const unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The same exchange for workgroups that share an XCD (round 5).  An agent-scope access (sc1) is coherent across the chip's eight L2
+// caches, i.e. it is served from the memory side: ~1 us per hand-off (MI355X_MICROARCH.md).  Workgroups on ONE XCD share ONE L2, and
+// that L2 executes every atomic read-modify-write itself: a swap without scope bits publishes a granule at the L2, an `or 0` WITH
+// return reads it back from there (written as instructions: the compiler folds an idempotent read-modify-write into a plain load,
+// which a CU may serve from its own L1 for ever).  Only legal between workgroups that have checked that they sit on the same XCD
+// (fps_pruned_cluster.hip compares the XCC_ID registers the K workgroups publish with their sort flags).
+__device__ __forceinline__ void granule_store_xcd(unsigned long long *p, int value, unsigned tag) {
+    const unsigned long long v = ((unsigned long long)tag << 32) | (unsigned)value;
+    asm volatile("global_atomic_swap_x2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned long long granule_load_xcd(const unsigned long long *p) {
+    unsigned long long r;
+    const unsigned long long zero = 0ull;
+    asm volatile("global_atomic_or_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p), "v"(zero) : "memory");
+    return r;
+}
 
 // LDS the sort needs (a member of the caller's shared struct)
 struct PcSortShared {
@@ -85,7 +101,7 @@ __device__ __forceinline__ bool pc_sort_split(PcSortShared &sh, int cu, int K, i
                                               const float *__restrict__ xyz, const float *__restrict__ temp,
                                               unsigned long long *xg, float *sx, float *sy, float *sz, float *st, int *srk,
                                               bool hand_over, const PcGiveUp &gu, unsigned long long *xflag = nullptr,
-                                              unsigned tag0 = 2u) {
+                                              unsigned tag0 = 2u, int flag_value = 1) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) sh.giveup = 0;      // (several barriers lie between this store and the first poll)
@@ -180,7 +196,7 @@ __device__ __forceinline__ bool pc_sort_split(PcSortShared &sh, int cu, int K, i
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) granule_store(xflag + cu, 1, tag0);
+        if (tid == 0) granule_store(xflag + cu, flag_value, tag0);   // (flag_value: whatever the caller wants its siblings to read)
         if (wave == 0) {
             bool ok = true;
             if (lane < K) ok = pc_bounded_poll(gu, 2, [&] { return (unsigned)(granule_load(xflag + lane) >> 32) == tag0; });
