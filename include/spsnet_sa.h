@@ -392,7 +392,7 @@ int sps_pointwise_mlp_ex(int b, int m, int j0, int jcount, int cin, int c1, int 
  * b * sps_fps_workspace_floats(n) floats (0 for sizes that need none).  With it, scenes of 16 385 .. 262 144 points
  * take the spatially pruned large-scene kernel (same indices and final `temp`, bit for bit; ~100x faster than the
  * streaming brute-force sweep at Waymo sizes); without it this is sps_farthest_point_sampling_kernel_launcher.
- * Batches of at most 64 / K scenes are spread over K <= 8 workgroups per scene that exchange records every round
+ * Batches of at most 64 / K scenes are spread over K <= 16 workgroups per scene (8 through round 4) that exchange records every round
  * (fps_pruned_cluster.hip; same results): those b * K workgroups spin on each other and must be resident together, so do
  * not issue such a launch on a stream confined to a few compute units by a CU mask (environment SPS_FPS_CLUSTER=1 selects
  * the one-workgroup kernel, "K,T" a shape).  The workspace includes the exchange area, which the launch zeroes itself. */
