@@ -703,6 +703,10 @@ def generic_mlp_pool(mlp, grouped):
         object.__setattr__(mlp, "_sps_generic", packed)
     flag = _overflow_flag(grouped.device)
     operand, pin, mode = grouped.contiguous(), None, _ext.TIN_RAW
+    if not exact:
+        # the streaming kernels below are shared with the training path, whose arithmetic is a process-wide C switch
+        # (sps_set_train_precision; a training forward sets it for itself): this inference mode is the split-fp16 one
+        _lib.load().sps_set_train_precision(0)
     with _ext.launch_scope(operand):
         for k, w in enumerate(packed.ws):
             if exact or w.shape[1] > _GENERIC_MAX_CIN:
