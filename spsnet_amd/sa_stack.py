@@ -128,7 +128,6 @@ def enable_cu_fence(device, main_stream=None, slot=0, slots=1, scenes=8):
     main = torch.cuda.current_stream(device) if main_stream is None else main_stream
     fence = CuFence(device, slot, slots, scenes)
     _FENCES[(device.index, main.cuda_stream)] = fence
-    streams.declare_external_producer(device, main)       # the fence's own CU-masked stream carries the FPS producer
     for key in [k for k in _SIDE_STREAMS if k[1] == device.index and k[2] == main.cuda_stream]:
         del _SIDE_STREAMS[key]
     return fence
@@ -138,7 +137,6 @@ def disable_cu_fence(device, main_stream=None):
     device = torch.device(device)
     main = torch.cuda.current_stream(device) if main_stream is None else main_stream
     _FENCES.pop((device.index, main.cuda_stream), None)
-    streams.declare_external_producer(device, main, on=False)
     for key in [k for k in _SIDE_STREAMS if k[1] == device.index and k[2] == main.cuda_stream]:
         del _SIDE_STREAMS[key]
 
@@ -635,13 +633,11 @@ def pipelined_bench(step, steps, dev, in_flight=2, scenes=8, fenced=True):
     fenced: every slot's FPS chain runs on compute units of its own and everything else of every slot is kept off them
     (CuFence); unfenced, a second pass in flight is SLOWER per pass than one alone (profiles/README.md, round 2)."""
     import time
-    from . import streams as helper_streams
     if fenced:
         fences = [CuFence(dev, slot=k, slots=in_flight, scenes=scenes) for k in range(in_flight)]
         streams = [f.stream(f.rest_bits) for f in fences]
         for f, s_ in zip(fences, streams):
             _FENCES[(dev.index, s_.cuda_stream)] = f
-            helper_streams.declare_external_producer(dev, s_)
     else:
         streams = [torch.cuda.Stream(device=dev) for _ in range(in_flight)]
     for s_ in streams:
@@ -663,7 +659,6 @@ def pipelined_bench(step, steps, dev, in_flight=2, scenes=8, fenced=True):
     if fenced:
         for s_ in streams:
             _FENCES.pop((dev.index, s_.cuda_stream), None)
-            helper_streams.declare_external_producer(dev, s_, on=False)
     return {"batches_in_flight": in_flight, "cu_fenced": bool(fenced), "unit": "points/s", "ms_per_step": 1e3 * el / steps,
             "elapsed_s": el, "last_outputs": keep[-1],
             "note": "same complete, independent passes issued round-robin on several HIP streams" +

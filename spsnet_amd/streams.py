@@ -95,20 +95,11 @@ def new_stream_beside(device, beside: Sequence[torch.cuda.Stream], priority: int
 _HELPERS = {}   # (device index, root stream handle) -> {tag: (stream, exclusive)}
 _ROOT = {}      # (device index, handle of a stream handed out by helper()) -> (root handle, root stream): helpers of helpers join the pass
 _ON_FORGET = []  # callbacks(device index, root handle, [helper handles]): the callers' own caches of helper streams
-_EXTERNAL_PRODUCER = set()   # (device index, root handle): passes whose FPS producer runs on a stream of the caller's own
-
-
-def declare_external_producer(device, main: torch.cuda.Stream, on: bool = True):
-    """The pass on `main` brings its own producer stream (sa_stack.CuFence: a CU-masked stream): helper() then reserves and
-    probes no "producer" queue for it -- with the default four hardware queues that reservation would cost the pass a queue
-    (and up to SPS_STREAM_TRIES probes) for a stream nobody uses."""
-    key = (torch.device(device).index, main.cuda_stream)
-    (_EXTERNAL_PRODUCER.add if on else _EXTERNAL_PRODUCER.discard)(key)
-
-
-def on_forget(callback):
-    """Register a cache of helper streams: callback(device_index, root_handle, helper_handles) is called by forget()."""
-    _ON_FORGET.append(callback)
+# ADVICE r4 suggested not to reserve (and probe) a "producer" queue for passes that bring their own producer stream
+# (sa_stack.CuFence: a CU-masked stream).  Built and measured in round 5 (profiles/round5/r5s_producer_queue_modes.txt, bench.py
+# --pipelined, two CU-fenced passes in flight, same box): no reservation 1.92-2.03 ms per pass, the fence's own stream adopted as the
+# exclusive helper 1.97-2.02, the reservation as it is 1.65-1.71 -- the reserved queue is what keeps the modules' scale streams off the
+# hardware queue the CU-masked producer lands on.  The reservation stays; SPS_RESERVE_PRODUCER=0 switches it off (A/B).
 
 
 def helper(device, main: torch.cuda.Stream, tag: str, exclusive: bool = False) -> torch.cuda.Stream:
@@ -120,7 +111,7 @@ def helper(device, main: torch.cuda.Stream, tag: str, exclusive: bool = False) -
     reg = _HELPERS.get(key)
     if reg is None:
         reg = _HELPERS[key] = {}
-        if not _probing_off() and key not in _EXTERNAL_PRODUCER:
+        if not _probing_off() and os.environ.get("SPS_RESERVE_PRODUCER", "1") != "0":
             # the exclusive helper first: its queue is reserved before any other role can take the last free one
             st = new_stream_beside(device, [root], what=EXCLUSIVE_TAG)
             reg[EXCLUSIVE_TAG] = (st, True)
