@@ -102,6 +102,11 @@ _ON_FORGET = []  # callbacks(device index, root handle, [helper handles]): the c
 # hardware queue the CU-masked producer lands on.  The reservation stays; SPS_RESERVE_PRODUCER=0 switches it off (A/B).
 
 
+def on_forget(callback):
+    """Register a cache of helper streams: callback(device_index, root_handle, helper_handles) is called by forget()."""
+    _ON_FORGET.append(callback)
+
+
 def helper(device, main: torch.cuda.Stream, tag: str, exclusive: bool = False) -> torch.cuda.Stream:
     """The helper stream `tag` of the pass that runs on `main` (one per (device, main stream, tag); asked for while one of the
     pass's own helpers is current, it joins the same pass).  See the module docstring for the placement rules."""
