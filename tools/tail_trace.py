@@ -6,7 +6,7 @@ rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
-prod = [r for r in rows if "fps_pruned_kernel" in r["Kernel_Name"] and (r["e"] - r["s"]) > 1_000_000]
+prod = [r for r in rows if ("fps_pruned_kernel" in r["Kernel_Name"] or "fps_pruned_cluster_kernel" in r["Kernel_Name"]) and (r["e"] - r["s"]) > 1_000_000]
 last = prod[-1]
 t0 = last["e"]
 nxt = [r for r in rows if r["s"] > last["s"]]
